@@ -1,0 +1,444 @@
+"""NumPy restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+All `file:line` citations are relative to /root/reference.  "[TF]" marks semantics that live in
+TensorFlow/Keras (absent here): they are restated from the published behaviour of those ops, and are
+the part of the oracle whose parity is *unpinned* (no reference-produced vector exists for them).
+
+Default dtype is float64 ("ground truth"); pass dtype=np.float32 to mimic the reference's fp32 graph.
+"""
+from collections import defaultdict
+import random as _pyrandom
+
+import numpy as np
+
+EPSILON = 1e-6  # utils.py:12
+
+MODELS = ("DistMult", "TransE", "ComplEx", "HolE")
+LOSSES = ("pointwize_hinge", "pointwize_logistic", "pointwize_square_loss", "pointwize_cross_entropy",
+          "pairwize_hinge", "pairwize_logistic", "pairwize_square_loss")  # utils.py:321-330
+
+
+# ----------------------------------------------------------------------------------------------
+# tables (models.py:87-112)
+# ----------------------------------------------------------------------------------------------
+def glorot_uniform(rows, cols, rs, dtype=np.float32):
+    """[TF] keras GlorotUniform on an Embedding matrix (rows, cols): U(-l, l), l = sqrt(6/(rows+cols))."""
+    lim = np.sqrt(6.0 / (rows + cols))
+    return rs.uniform(-lim, lim, size=(rows, cols)).astype(dtype)
+
+
+def table_dims(model, e_dim, r_dim):
+    """ComplEx doubles both widths (models.py:208-209); everything else keeps them."""
+    if model == "ComplEx":
+        return 2 * e_dim, 2 * r_dim
+    return e_dim, r_dim
+
+
+# ----------------------------------------------------------------------------------------------
+# score functions on gathered rows (models.py `func`)
+# ----------------------------------------------------------------------------------------------
+def func_distmult(s, p, o):
+    """models.py:171-172  reduce_sum(s*p*o, -1)"""
+    return np.sum(s * p * o, axis=-1)
+
+
+def func_transe(s, p, o, norm=1, gamma=12):
+    """models.py:186-190.  [TF] tf.norm ord=1 -> sum|x|, ord=2 -> sqrt(sum x^2).  Sign flips on gamma<=0."""
+    x = s + p - o
+    if norm == 1:
+        n = np.sum(np.abs(x), axis=1)
+    elif norm == 2:
+        n = np.sqrt(np.sum(x * x, axis=1))
+    else:
+        n = np.sum(np.abs(x) ** norm, axis=1) ** (1.0 / norm)
+    return gamma - n if gamma > 0 else n
+
+
+def func_complex(s, p, o):
+    """models.py:212-222.  Rows are [real | imag] halves (tf.split num=2)."""
+    h = s.shape[-1] // 2
+    sr, si = s[..., :h], s[..., h:]
+    pr, pi = p[..., :h], p[..., h:]
+    orr, oi = o[..., :h], o[..., h:]
+    s1 = sr * pr * orr
+    s2 = pr * si * oi
+    s3 = pi * sr * oi
+    s4 = pi * si * orr
+    return np.sum(s1 + s2 + s3 - s4, axis=-1)
+
+
+def ccorr(a, b):
+    """models.py:232-234: real(ifft(conj(fft(a)) * fft(b)))  ==  x_k = sum_i a_i b_{(i+k) mod d}."""
+    return np.real(np.fft.ifft(np.conj(np.fft.fft(a, axis=-1)) * np.fft.fft(b, axis=-1), axis=-1))
+
+
+def func_hole(s, p, o):
+    """models.py:231-237."""
+    return np.sum(p * ccorr(s, o), axis=-1)
+
+
+def score_rows(model, s, p, o, norm=1, gamma=12):
+    if model == "DistMult":
+        return func_distmult(s, p, o)
+    if model == "TransE":
+        return func_transe(s, p, o, norm, gamma)
+    if model == "ComplEx":
+        return func_complex(s, p, o)
+    if model == "HolE":
+        return func_hole(s, p, o).astype(s.dtype)
+    raise KeyError(model)
+
+
+def call(model, E, Rel, triples, norm=1, gamma=12, dtype=np.float64):
+    """EmbeddingModel.call (models.py:134-162) with dropout inactive (predict / dp=0):
+    unstack ids (:140) -> gather E[s], Rel[p], E[o] (:144-150) -> func (:160)."""
+    t = np.asarray(triples).reshape(-1, 3).astype(np.int64)
+    E = np.asarray(E, dtype=dtype)
+    Rel = np.asarray(Rel, dtype=dtype)
+    return score_rows(model, E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]], norm, gamma)
+
+
+def score_row_grads(model, s, p, o, g, norm=1, gamma=12):
+    """d(sum_i g_i * score_i)/d(s,p,o) -- what autodiff hands to the three Embedding gathers [TF]."""
+    g = g[:, None]
+    if model == "DistMult":
+        return g * p * o, g * s * o, g * s * p
+    if model == "TransE":
+        x = s + p - o
+        sgn = -1.0 if gamma > 0 else 1.0
+        if norm == 1:
+            dx = np.sign(x)  # [TF] sign(0) = 0
+        else:
+            n = np.sqrt(np.sum(x * x, axis=1, keepdims=True))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                dx = x / n  # [TF] NaN at x == 0
+        dx = sgn * g * dx
+        return dx, dx, -dx
+    if model == "ComplEx":
+        h = s.shape[-1] // 2
+        sr, si = s[:, :h], s[:, h:]
+        pr, pi = p[:, :h], p[:, h:]
+        orr, oi = o[:, :h], o[:, h:]
+        ds = np.concatenate([pr * orr + pi * oi, pr * oi - pi * orr], 1)
+        dp = np.concatenate([sr * orr + si * oi, sr * oi - si * orr], 1)
+        do = np.concatenate([sr * pr - pi * si, pr * si + pi * sr], 1)
+        return g * ds, g * dp, g * do
+    if model == "HolE":
+        d = s.shape[-1]
+        dp = ccorr(s, o)
+        ds = ccorr(p, o)  # ds_i = sum_k p_k o_{(i+k)}
+        # do_j = sum_k p_k s_{(j-k)}  (circular convolution)
+        do = np.real(np.fft.ifft(np.fft.fft(p, axis=-1) * np.fft.fft(s, axis=-1), axis=-1))
+        assert do.shape[-1] == d
+        return g * ds, g * dp, g * do
+    raise KeyError(model)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (utils.py:288-319): value and d/d(true), d/d(false)
+# ----------------------------------------------------------------------------------------------
+def _unbroadcast(x, shape):
+    while x.ndim > len(shape):
+        x = x.sum(axis=0)
+    for ax, n in enumerate(shape):
+        if n == 1 and x.shape[ax] != 1:
+            x = x.sum(axis=ax, keepdims=True)
+    return x
+
+
+def loss_value_and_grads(name, true, false, margin=1, negative_samples=1):
+    """Returns (loss, dL/dtrue, dL/dfalse) for the reduce_mean=True form the harness uses (tests.py:80-81).
+
+    [TF] relu'(0) = 0; broadcasting is NumPy-style, which is what produces the (m, m) quirk of
+    pairwize_* when negative_samples=1 and `true` is (m,) (utils.py:300-312, tests.py:81)."""
+    t = np.asarray(true)
+    f = np.asarray(false)
+    dt = t.dtype
+    margin = dt.type(margin)
+    eps = dt.type(EPSILON)
+    one = dt.type(1)
+    if name == "pointwize_hinge":  # utils.py:288-289
+        a = margin - t
+        b = margin + f
+        loss = np.mean(np.maximum(a, 0)) + np.mean(np.maximum(b, 0))
+        return loss, -(a > 0).astype(dt) / t.size, (b > 0).astype(dt) / f.size
+    if name == "pointwize_logistic":  # utils.py:291-292
+        ea = np.exp(-t)
+        eb = np.exp(f)
+        loss = np.mean(np.log(eps + one + ea)) + np.mean(np.log(eps + one + eb))
+        return loss, -(ea / (eps + one + ea)) / t.size, (eb / (eps + one + eb)) / f.size
+    if name == "pointwize_square_loss":  # utils.py:294-295
+        a = margin - t
+        b = margin + f
+        loss = np.mean(a * a) + np.mean(b * b)
+        return loss, -2 * a / t.size, 2 * b / f.size
+    if name == "pointwize_cross_entropy":  # utils.py:297-298  [TF] keras BCE clips to [1e-7, 1-1e-7], adds 1e-7 in the log
+        k = dt.type(1e-7)
+        ct = np.clip(t, k, one - k)
+        cf = np.clip(f, k, one - k)
+        loss = -np.mean(np.log(ct + k)) - np.mean(np.log(one - cf + k))
+        gt = np.where((t >= k) & (t <= one - k), -one / (ct + k), 0) / t.size
+        gf = np.where((f >= k) & (f <= one - k), one / (one - cf + k), 0) / f.size
+        return loss, gt.astype(dt), gf.astype(dt)
+    if name in ("pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"):
+        F = f.reshape(-1, negative_samples)  # utils.py:301/308/315
+        z = F - t  # NumPy broadcast == TF broadcast
+        if name == "pairwize_hinge":  # utils.py:300-305
+            y = margin + z
+            tmp = np.maximum(y, 0)
+            dz = (y > 0).astype(dt)
+        elif name == "pairwize_logistic":  # utils.py:307-312 (margin unused)
+            e = np.exp(z)
+            tmp = np.log(eps + one + e)
+            dz = e / (eps + one + e)
+        else:  # utils.py:314-319
+            tmp = -(z * z)
+            dz = -2 * z
+        dz = dz / tmp.size
+        dF = _unbroadcast(dz, F.shape).reshape(f.shape)
+        dT = -_unbroadcast(dz, t.shape if t.ndim == dz.ndim else (1,) * (dz.ndim - t.ndim) + t.shape).reshape(t.shape)
+        return np.mean(tmp), dT.astype(dt), dF.astype(dt)
+    raise KeyError(name)  # utils.py:322-330 dict lookup
+
+
+def loss_value(name, true, false, margin=1, negative_samples=1):
+    return loss_value_and_grads(name, true, false, margin, negative_samples)[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizers [TF] (tests.py:86 compiles with 'adam'; 'sgd' named in the north star)
+# ----------------------------------------------------------------------------------------------
+class AdamTF:
+    """[TF] Keras Adam with IndexedSlices gradients: duplicates summed, then DENSE moment decay and DENSE
+    variable update over every row; epsilon=1e-7 sits outside the bias correction:
+        lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m = b1*m+(1-b1)*g;  v = b2*v+(1-b2)*g^2;  w -= lr_t*m/(sqrt(v)+eps)"""
+
+    def __init__(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        self.t = 0
+        self.slots = {}
+
+    def lr_t(self, t=None):
+        t = self.t if t is None else t
+        return self.lr * np.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+
+    def begin_step(self):
+        self.t += 1
+
+    def apply(self, key, w, g):
+        m, v = self.slots.setdefault(key, (np.zeros_like(w), np.zeros_like(w)))
+        dt = w.dtype.type
+        m *= dt(self.b1)
+        m += dt(1 - self.b1) * g
+        v *= dt(self.b2)
+        v += dt(1 - self.b2) * (g * g)
+        w -= dt(self.lr_t()) * m / (np.sqrt(v) + dt(self.eps))
+
+
+class SGDTF:
+    """[TF] Keras SGD, lr=0.01, no momentum: w[ids] -= lr*g with duplicate ids accumulated."""
+
+    def __init__(self, lr=0.01):
+        self.lr = lr
+        self.t = 0
+
+    def begin_step(self):
+        self.t += 1
+
+    def apply(self, key, w, g):
+        w -= w.dtype.type(self.lr) * g
+
+
+def make_optimizer(name, **kw):
+    return {"adam": AdamTF, "sgd": SGDTF}[name.lower()](**kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# one training batch: the default Keras train_step over add_loss (tests.py:63-89)
+# ----------------------------------------------------------------------------------------------
+def dense_grads(model, E, Rel, pos, neg, loss, margin=1, negative_samples=1, norm=1, gamma=12, regularization=0.0):
+    """Forward on pos and neg with the SAME tables (tests.py:77-78), loss (tests.py:80-81), and the dense
+    equivalents of the IndexedSlices gradients (duplicates summed) [TF].  Returns (loss, scores_pos,
+    scores_neg, gE, gRel).  `regularization` adds w*sum|E|^3 over the whole entity table (models.py:10-11,78-92)."""
+    dt = E.dtype
+    pos = np.asarray(pos).reshape(-1, 3).astype(np.int64)
+    neg = np.asarray(neg).reshape(-1, 3).astype(np.int64)
+    rows = []
+    for t in (pos, neg):
+        rows.append((E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]]))
+    sp = score_rows(model, *rows[0], norm, gamma).astype(dt)
+    sn = score_rows(model, *rows[1], norm, gamma).astype(dt)
+    L, gt, gf = loss_value_and_grads(loss, sp, sn, margin, negative_samples)
+    gE = np.zeros_like(E)
+    gR = np.zeros_like(Rel)
+    for t, (s, p, o), g in ((pos, rows[0], gt), (neg, rows[1], gf)):
+        ds, dp, do = score_row_grads(model, s, p, o, g.astype(dt), norm, gamma)
+        np.add.at(gE, t[:, 0], ds.astype(dt))
+        np.add.at(gR, t[:, 1], dp.astype(dt))
+        np.add.at(gE, t[:, 2], do.astype(dt))
+    if regularization:
+        w = dt.type(regularization)
+        L = L + w * np.sum(np.abs(E) ** 3)
+        gE += 3 * w * E * np.abs(E)
+    return L, sp, sn, gE, gR
+
+
+def train_step(model, E, Rel, opt, pos, neg, loss="pointwize_hinge", margin=1, negative_samples=1,
+               norm=1, gamma=12, regularization=0.0):
+    """In-place update of E and Rel; returns the batch loss (what Keras logs as `loss`)."""
+    L, _, _, gE, gR = dense_grads(model, E, Rel, pos, neg, loss, margin, negative_samples, norm, gamma, regularization)
+    opt.begin_step()
+    opt.apply("E", E, gE)
+    opt.apply("R", Rel, gR)
+    return L
+
+
+# ----------------------------------------------------------------------------------------------
+# batch construction (utils.py:114-153, tests.py:29-61).  NumPy's legacy global RandomState and
+# Python's `random` ARE the reference's dependencies, so the oracle calls them exactly as it does.
+# ----------------------------------------------------------------------------------------------
+def generate_negative(kg, N, negative=2, np_random=np.random):
+    """utils.py:114-121: R = repeat(p, negative); fs = randint(0,N,(negative*len,1)); fo likewise (fs first)."""
+    kg = np.asarray(kg)
+    R = np.repeat(kg[:, 1].reshape((-1, 1)), negative, axis=0)
+    fs = np_random.randint(0, N, size=(negative * len(kg), 1))
+    fo = np_random.randint(0, N, size=(negative * len(kg), 1))
+    return np.stack([fs, R, fo], axis=1)  # (negative*len, 3, 1)
+
+
+def oversample_data(kgs, py_random=_pyrandom):
+    """utils.py:123-147 (the branch the harness uses): every array independently resampled with
+    replacement to the longest length with random.choices, in list order."""
+    kgs = [list(kg) for kg in kgs]
+    m = max(map(len, kgs))
+    out = [py_random.choices(kg, k=m) for kg in kgs]
+    return [np.squeeze(np.asarray(o)) for o in out]
+
+
+def epoch_permutation(n, np_random=np.random):
+    """tests.py:50-53."""
+    idx = np.arange(n)
+    np_random.shuffle(idx)
+    return idx
+
+
+def harness_batch(kg, index, b, B, ns, num_e, np_random=np.random, py_random=_pyrandom):
+    """tests.py:43-61: slice of the epoch permutation -> generate_negative -> oversample_data."""
+    sl = index[b * B:(b + 1) * B]
+    tmp_kg = np.asarray([kg[i] for i in sl])
+    neg = generate_negative(tmp_kg, num_e, ns, np_random)
+    pos_os, neg_os = oversample_data([tmp_kg, neg], py_random)
+    return pos_os, neg_os
+
+
+def pad(kg, bs, py_random=_pyrandom):
+    """utils.py:149-153."""
+    kg = list(kg)
+    while len(kg) % bs != 0:
+        kg.append(py_random.choice(kg))
+    return np.asarray(kg)
+
+
+def load_kg(path):
+    """utils.py:106-112."""
+    out = []
+    with open(path, "r") as f:
+        for l in f:
+            out.append(l.strip().split())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# filtered ranking (utils.py:165-264)
+# ----------------------------------------------------------------------------------------------
+def build_filters(filtering_triples):
+    """utils.py:201-205."""
+    filter_h = defaultdict(set)
+    filter_t = defaultdict(set)
+    for s, p, o in filtering_triples:
+        filter_h[(p, o)].add(s)
+        filter_t[(s, p)].add(o)
+    return filter_h, filter_t
+
+
+def candidate_rows(triple, num_entities, side, filt):
+    """gen_tail_data / gen_head_data (utils.py:165-196): target first, then every entity that is neither the
+    target nor filtered, ascending.  Raises ValueError like list.remove when a filtered id is absent."""
+    s, p, o = triple
+    target, key = (o, (s, p)) if side == "tail" else (s, (p, o))
+    cand = list(range(num_entities))
+    cand.remove(target)
+    for x in filt[key]:
+        cand.remove(x)
+    ids = np.asarray([target] + cand, dtype=np.int64)
+    out = np.empty((len(ids), 3), dtype=np.int64)
+    out[:, 0] = s if side == "tail" else ids
+    out[:, 1] = p
+    out[:, 2] = ids if side == "tail" else o
+    return out
+
+
+def rank_literal(scores):
+    """utils.py:211-215 with scipy's rankdata(.,'max') restated: target is row 0;
+    r0 = #{j : res_j <= res_0};  real_rank = n - r0 + 1  ==  1 + #{j : res_j > res_0}."""
+    res = np.asarray(scores).reshape(-1)
+    r0 = int(np.sum(res <= res[0]))
+    return len(res) - r0 + 1
+
+
+def metrics_from_ranks(tail_ranks, head_ranks):
+    """utils.py:216-262.  hits@k  <=>  real_rank <= k."""
+    def agg(r):
+        r = np.asarray(r, dtype=np.float64)
+        n = float(len(r))
+        return (np.sum(r <= 1) / n, np.sum(r <= 3) / n, np.sum(r <= 10) / n, np.mean(r), np.mean(1.0 / r))
+    t1, t3, t10, tmr, tmrr = agg(tail_ranks)
+    h1, h3, h10, hmr, hmrr = agg(head_ranks)
+    return {'tail_hits@1': t1, 'tail_hits@3': t3, 'tail_hits@10': t10, 'tail_mr': tmr, 'tail_mrr': tmrr,
+            'head_hits@1': h1, 'head_hits@3': h3, 'head_hits@10': h10, 'head_mr': hmr, 'head_mrr': hmrr,
+            'hits@1': (t1 + h1) / 2, 'hits@3': (t3 + h3) / 2, 'hits@10': (t10 + h10) / 2,
+            'mr': (tmr + hmr) / 2, 'mrr': (tmrr + hmrr) / 2}
+
+
+def validate(predict, test_data, num_entities, filtering_triples):
+    """utils.py:199-264 restated literally (Python loop per query; small inputs only)."""
+    filter_h, filter_t = build_filters(filtering_triples)
+    tails = [rank_literal(predict(candidate_rows(t, num_entities, "tail", filter_t))) for t in test_data]
+    heads = [rank_literal(predict(candidate_rows(t, num_entities, "head", filter_h))) for t in test_data]
+    return metrics_from_ranks(tails, heads), np.asarray(tails), np.asarray(heads)
+
+
+def ranks_closed_form(model, E, Rel, test, filtering_triples, norm=1, gamma=12, dtype=np.float64, margin_out=None):
+    """Vectorised 1-vs-all: rank = 1 + #{kept c : score_c > score_target}.  Returns
+    (tail_ranks, head_ranks).  If `margin_out` is a list, appends per query the smallest |score_c -
+    score_target| over kept candidates (to let a float32 checker skip knife-edge ties)."""
+    E = np.asarray(E, dtype=dtype)
+    Rel = np.asarray(Rel, dtype=dtype)
+    N = E.shape[0]
+    filter_h, filter_t = build_filters(filtering_triples)
+    allc = np.arange(N, dtype=np.int64)
+    out = {"tail": [], "head": []}
+    for s, p, o in test:
+        for side in ("tail", "head"):
+            if side == "tail":
+                sc = score_rows(model, E[s][None].repeat(N, 0), Rel[p][None].repeat(N, 0), E, norm, gamma)
+                tgt, fl = o, filter_t.get((s, p), ())
+            else:
+                sc = score_rows(model, E, Rel[p][None].repeat(N, 0), E[o][None].repeat(N, 0), norm, gamma)
+                tgt, fl = s, filter_h.get((p, o), ())
+            keep = np.ones(N, dtype=bool)
+            keep[tgt] = False
+            if len(fl):
+                keep[np.fromiter(fl, dtype=np.int64)] = False
+            out[side].append(1 + int(np.sum(sc[keep] > sc[tgt])))
+            if margin_out is not None:
+                margin_out.append(float(np.min(np.abs(sc[keep] - sc[tgt]))) if keep.any() else np.inf)
+    del allc
+    return np.asarray(out["tail"]), np.asarray(out["head"])
+
+
+def sorted_id_maps(*splits):
+    """Deterministic replacement for tests.py:102-111 (whose ids depend on PYTHONHASHSEED): sorted strings."""
+    ents = sorted({x for sp in splits for (s, _, o) in sp for x in (s, o)})
+    rels = sorted({p for sp in splits for (_, p, _) in sp})
+    return {e: i for i, e in enumerate(ents)}, {r: i for i, r in enumerate(rels)}

@@ -1,0 +1,256 @@
+"""Oracle vs the reference-generated golden vectors, known-answer tests and torch-CPU autograd (CPU only)."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------ sampler restatement vs reference vectors
+def test_generate_negative_golden(golden):
+    g = golden("generate_negative")
+    for c in g["cases"]:
+        np.random.seed(c["seed"])
+        neg = O.generate_negative(np.asarray(c["kg"]), c["N"], c["ns"])
+        assert list(neg.shape) == c["shape"] and str(neg.dtype) == c["dtype"]
+        assert neg.reshape(-1, 3).tolist() == c["neg"]
+        assert np.random.randint(0, 2**31 - 1, size=2).tolist() == c["after"]
+    for c in g["big"]:
+        rs = np.random.RandomState(c["kg_seed"])
+        kg = np.stack([rs.randint(0, c["N"], c["B"]), rs.randint(0, 237, c["B"]), rs.randint(0, c["N"], c["B"])], axis=1)
+        np.random.seed(c["seed"])
+        neg = O.generate_negative(kg, c["N"], c["ns"]).reshape(-1, 3)
+        assert sha(neg.astype(np.int64)) == c["sha256_int64"]
+        assert neg[:8].tolist() == c["head"] and neg[-8:].tolist() == c["tail"]
+
+
+def test_oversample_golden(golden):
+    g = golden("oversample")
+    for c in g["cases"]:
+        random.seed(c["seed"])
+        neg = np.asarray(c["neg"]).reshape(-1, 3, 1)
+        pos_os, neg_os = O.oversample_data([np.asarray(c["kg"]), neg])
+        assert pos_os.tolist() == c["pos_os"] and neg_os.tolist() == c["neg_os"]
+        assert [random.getrandbits(32) for _ in range(2)] == c["after"]
+
+
+def test_shuffle_golden(golden):
+    for c in golden("shuffle")["cases"]:
+        np.random.seed(c["seed"])
+        idx = O.epoch_permutation(c["n"])
+        assert sha(idx.astype(np.int64)) == c["sha256_int64"]
+        if c["perm"] is not None:
+            assert idx.tolist() == c["perm"]
+
+
+def test_batch_stream_golden(golden, datasets):
+    """tests.py:43-61 order: epoch shuffle (numpy) -> generate_negative (numpy) -> oversample (python random)."""
+    g = golden("batch_stream")
+    tr = [tuple(int(x) for x in t) for t in datasets["nations_train"]]
+    np.random.seed(g["np_seed"])
+    random.seed(g["py_seed"])
+    idx = O.epoch_permutation(len(tr))
+    assert len(tr) // g["B"] == g["steps_per_epoch"]
+    for b, ref in enumerate(g["batches"]):
+        assert idx[b * g["B"]:(b + 1) * g["B"]].tolist() == ref["index"]
+        pos_os, neg_os = O.harness_batch(tr, idx, b, g["B"], g["ns"], g["num_e"])
+        assert pos_os.tolist() == ref["pos"] and neg_os.tolist() == ref["neg"]
+
+
+# ------------------------------------------------------------------ evaluator restatement vs reference vectors
+class _DM:
+    def __init__(self, N, R, d, seed, quant):
+        rs = np.random.RandomState(seed)
+        self.E = rs.uniform(-1, 1, (N, d))
+        self.Rel = rs.uniform(-1, 1, (R, d))
+        if quant:
+            self.E = np.round(self.E * quant) / quant
+            self.Rel = np.round(self.Rel * quant) / quant
+
+    def predict(self, t):
+        return O.call("DistMult", self.E, self.Rel, t)
+
+
+def _ids(a):
+    return [tuple(int(x) for x in t) for t in a]
+
+
+def test_validate_golden_literal_and_closed_form(golden, datasets):
+    for c in golden("validate")["cases"]:
+        m = c["model"]
+        fm = _DM(m["N"], m["R"], m["d"], m["seed"], m["quant"])
+        test = [tuple(t) for t in c["test"]]
+        ds = c["dataset"]
+        tes = set(_ids(datasets[ds + "_test"]))
+        filt = [t for t in _ids(datasets[ds + "_train"]) + _ids(datasets[ds + "_valid"]) if t not in tes]
+        assert sha(np.asarray(filt, dtype=np.int64)) == c["filt_sha"]
+        t2, h2 = O.ranks_closed_form("DistMult", fm.E, fm.Rel, test, filt)
+        met2 = O.metrics_from_ranks(t2, h2)
+        for k, v in c["metrics"].items():
+            assert met2[k] == pytest.approx(v, rel=0, abs=1e-12), k
+        if ds != "nations":
+            continue  # the literal O(N)-list restatement is for small N only
+        met, tails, heads = O.validate(fm.predict, test, m["N"], filt)
+        for k, v in c["metrics"].items():
+            assert met[k] == pytest.approx(v, rel=0, abs=1e-12), k
+        assert t2.tolist() == tails.tolist() and h2.tolist() == heads.tolist()
+        ft = O.build_filters(filt)
+        for i, rows in enumerate(c["tails"]):
+            assert O.candidate_rows(test[i], m["N"], "tail", ft[1]).tolist() == rows
+        for i, rows in enumerate(c["heads"]):
+            assert O.candidate_rows(test[i], m["N"], "head", ft[0]).tolist() == rows
+
+
+def test_validate_error_behaviour(golden):
+    errs = golden("misc")["misc"]["errors"]
+    assert errs["validate_filter_contains_test"] == "ValueError"
+    fm = _DM(14, 55, 4, 5, None)
+    with pytest.raises(ValueError):
+        O.validate(fm.predict, [(0, 1, 2)], 14, [(0, 1, 2)])
+    with pytest.raises(KeyError):
+        O.loss_value_and_grads("nope", np.zeros(2), np.zeros(2))
+
+
+# ------------------------------------------------------------------ known-answer tests from the source formulas
+def test_kats():
+    s, p, o = (np.array([[1., 2.]]), np.array([[3., 4.]]), np.array([[5., 6.]]))
+    assert O.func_distmult(s, p, o)[0] == 63.0  # models.py:172
+    assert O.func_transe(np.array([[1., 2.]]), np.array([[1., 1.]]), np.array([[0., 5.]]), 1, 12)[0] == 8.0  # |2|+|-2| -> 12-4
+    assert O.func_transe(np.array([[3., 0.]]), np.array([[0., 4.]]), np.array([[0., 0.]]), 2, 12)[0] == 7.0
+    assert O.func_transe(np.array([[3., 0.]]), np.array([[0., 4.]]), np.array([[0., 0.]]), 2, 0)[0] == 5.0  # sign flip
+    # ComplEx width 2: s=1+2i p=3+4i o=5+6i : Re(s*p*conj(o)) = 35
+    assert O.func_complex(np.array([[1., 2.]]), np.array([[3., 4.]]), np.array([[5., 6.]]))[0] == 35.0
+    z = complex(1, 2) * complex(3, 4) * complex(5, -6)
+    assert z.real == 35.0
+    # ComplEx with zero imaginary halves == DistMult
+    rs = np.random.RandomState(0)
+    a, b, c = (np.concatenate([rs.randn(5, 8), np.zeros((5, 8))], 1) for _ in range(3))
+    np.testing.assert_allclose(O.func_complex(a, b, c), O.func_distmult(a[:, :8], b[:, :8], c[:, :8]))
+    # HolE: direct definition
+    a, b, c = rs.randn(3, 6), rs.randn(3, 6), rs.randn(3, 6)
+    x = np.array([[sum(a[n, i] * c[n, (i + k) % 6] for i in range(6)) for k in range(6)] for n in range(3)])
+    np.testing.assert_allclose(O.func_hole(a, b, c), np.sum(b * x, 1), atol=1e-12)
+
+
+def test_loss_kats():
+    t = np.array([0.5, 2.0])
+    f = np.array([-2.0, 0.0])
+    assert O.loss_value("pointwize_hinge", t, f, 1) == pytest.approx((0.5 + 0) / 2 + (0 + 1) / 2)
+    assert O.loss_value("pointwize_logistic", t, f) == pytest.approx(
+        np.mean(np.log(1e-6 + 1 + np.exp(-t))) + np.mean(np.log(1e-6 + 1 + np.exp(f))))
+    # pairwise with negative_samples=1 is the (m, m) broadcast (tests.py:81)
+    L = O.loss_value("pairwize_hinge", t, f, 1, 1)
+    full = np.maximum(1 + f[:, None] - t[None, :], 0)
+    assert full.shape == (2, 2) and L == pytest.approx(full.mean())
+    # aligned form when ns == len(true)
+    L2 = O.loss_value("pairwize_hinge", t, np.array([0., 1., 2., 3.]), 1, 2)
+    assert L2 == pytest.approx(np.maximum(1 + np.array([[0., 1.], [2., 3.]]) - t, 0).mean())
+
+
+@pytest.mark.parametrize("name", O.LOSSES)
+def test_loss_grads_vs_torch(name):
+    rs = np.random.RandomState(1)
+    t = rs.uniform(0.05, 0.95, 6)
+    f = rs.uniform(0.05, 0.95, 6)
+    ns = 1
+    L, gt, gf = O.loss_value_and_grads(name, t, f, 0.7, ns)
+    tt = torch.tensor(t, requires_grad=True)
+    ff = torch.tensor(f, requires_grad=True)
+    eps = 1e-6
+    if name == "pointwize_hinge":
+        l = torch.relu(0.7 - tt).mean() + torch.relu(0.7 + ff).mean()
+    elif name == "pointwize_logistic":
+        l = torch.log(eps + 1 + torch.exp(-tt)).mean() + torch.log(eps + 1 + torch.exp(ff)).mean()
+    elif name == "pointwize_square_loss":
+        l = ((0.7 - tt) ** 2).mean() + ((0.7 + ff) ** 2).mean()
+    elif name == "pointwize_cross_entropy":
+        l = -(torch.log(tt.clamp(1e-7, 1 - 1e-7) + 1e-7)).mean() - (torch.log(1 - ff.clamp(1e-7, 1 - 1e-7) + 1e-7)).mean()
+    elif name == "pairwize_hinge":
+        l = torch.relu(0.7 + ff.reshape(-1, ns) - tt).mean()
+    elif name == "pairwize_logistic":
+        l = torch.log(eps + 1 + torch.exp(ff.reshape(-1, ns) - tt)).mean()
+    else:
+        l = (-(ff.reshape(-1, ns) - tt) ** 2).mean()
+    l.backward()
+    assert L == pytest.approx(l.item(), rel=1e-12)
+    np.testing.assert_allclose(gt, tt.grad.numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(gf, ff.grad.numpy(), rtol=1e-10, atol=1e-14)
+
+
+def _torch_score(model, s, p, o, norm, gamma):
+    if model == "DistMult":
+        return (s * p * o).sum(-1)
+    if model == "TransE":
+        n = torch.linalg.vector_norm(s + p - o, ord=norm, dim=1)
+        return gamma - n if gamma > 0 else n
+    if model == "ComplEx":
+        h = s.shape[1] // 2
+        sr, si, pr, pi, orr, oi = s[:, :h], s[:, h:], p[:, :h], p[:, h:], o[:, :h], o[:, h:]
+        return (sr * pr * orr + pr * si * oi + pi * sr * oi - pi * si * orr).sum(-1)
+    if model == "HolE":
+        x = torch.fft.ifft(torch.conj(torch.fft.fft(s)) * torch.fft.fft(o)).real
+        return (p * x).sum(-1)
+
+
+@pytest.mark.parametrize("model,norm,gamma", [("DistMult", 1, 12), ("TransE", 1, 12), ("TransE", 2, 12), ("TransE", 2, 0),
+                                              ("ComplEx", 1, 12), ("HolE", 1, 12)])
+@pytest.mark.parametrize("loss", ["pointwize_hinge", "pointwize_logistic", "pairwize_hinge"])
+def test_dense_grads_and_adam_vs_torch(model, norm, gamma, loss):
+    rs = np.random.RandomState(3)
+    N, R, d, m = 11, 4, 6, 40
+    de, dr = O.table_dims(model, d, d)
+    E = rs.uniform(-0.6, 0.6, (N, de))
+    Rel = rs.uniform(-0.6, 0.6, (R, dr))
+    pos = np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)
+    neg = np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)
+    L, sp, sn, gE, gR = O.dense_grads(model, E, Rel, pos, neg, loss, 1.0, 1, norm, gamma, regularization=0.01)
+    Et = torch.tensor(E, requires_grad=True)
+    Rt = torch.tensor(Rel, requires_grad=True)
+    tp = _torch_score(model, Et[pos[:, 0]], Rt[pos[:, 1]], Et[pos[:, 2]], norm, gamma)
+    tn = _torch_score(model, Et[neg[:, 0]], Rt[neg[:, 1]], Et[neg[:, 2]], norm, gamma)
+    if loss == "pointwize_hinge":
+        l = torch.relu(1 - tp).mean() + torch.relu(1 + tn).mean()
+    elif loss == "pointwize_logistic":
+        l = torch.log(1e-6 + 1 + torch.exp(-tp)).mean() + torch.log(1e-6 + 1 + torch.exp(tn)).mean()
+    else:
+        l = torch.relu(1 + tn.reshape(-1, 1) - tp).mean()
+    l = l + 0.01 * (Et.abs() ** 3).sum()
+    l.backward()
+    np.testing.assert_allclose(sp, tp.detach().numpy(), atol=1e-12)
+    assert L == pytest.approx(l.item(), rel=1e-11)
+    np.testing.assert_allclose(gE, Et.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(gR, Rt.grad.numpy(), atol=1e-12)
+
+
+def test_adam_tf_formula():
+    # two steps by hand
+    w = np.array([[1.0, -2.0]])
+    g1 = np.array([[0.5, 0.0]])
+    opt = O.AdamTF()
+    opt.begin_step()
+    opt.apply("w", w, g1)
+    m = 0.1 * g1
+    v = 0.001 * g1 ** 2
+    lr1 = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    exp = np.array([[1.0, -2.0]]) - lr1 * m / (np.sqrt(v) + 1e-7)
+    np.testing.assert_allclose(w, exp, rtol=1e-14)
+    # untouched element still decays its moments on later steps (dense semantics)
+    opt.begin_step()
+    opt.apply("w", w, np.zeros_like(w))
+    m2 = 0.9 * m
+    v2 = 0.999 * v
+    lr2 = 1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    np.testing.assert_allclose(w, exp - lr2 * m2 / (np.sqrt(v2) + 1e-7), rtol=1e-14)
+
+
+def test_glorot_limits():
+    rs = np.random.RandomState(0)
+    E = O.glorot_uniform(14541, 200, rs)
+    assert abs(np.abs(E).max() - np.sqrt(6 / (14541 + 200))) < 1e-4 and E.dtype == np.float32
