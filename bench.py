@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- scored triples/sec of the KGE train step (BASELINE.json metric) on N MI355X.
+
+Workload (BASELINE.json configs[1]): FB15k-237-shaped DistMult d=200, B=2048 positives, 100 negatives ->
+m = 204 800 rows per input array, 409 600 scored triples per step; N=14 541 entities, R=237 relations;
+synthetic uniform-id triples (the train split is a missing blob in the reference), Glorot-uniform tables from
+RandomState(1234); pointwize_hinge (margin 1) + Keras-semantics Adam.  A step = score(pos) + score(neg) + loss +
+gradients + optimizer update on one batch that is already resident in HBM.  Batches come from the bit-exact
+MT19937 builder (np.random.seed(0) / random.seed(0) streams) and are generated before the timed region.
+
+N > 1: data-parallel replicas, one process per GPU (torch.distributed, backend nccl = RCCL): every rank runs the
+gradient half on its own batch, the dense gradient tables are all-reduced (mean) over xGMI, every rank applies
+the same update.  value = triples scored by all ranks / max-over-ranks wall time (weak scaling).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(N=14541, R=237, d=200, B=2048, ns=100, n_train=272115)
+A_FWD = 4 * (2 * CFG["d"] + CFG["d"]) + 12 + 4   # two entity rows, one relation row, 3 ids, 1 score
+A_BWD = 4 * (2 * CFG["d"] + CFG["d"])            # three gradient rows written once
+A_TRAIN = A_FWD + A_BWD                          # 4816 B per scored triple at d=200
+HBM_PEAK = 8.0e12                                # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_batches(n_batches, rank):
+    from kge_keras_amd.sampler import NumpyStream, PythonStream, build_batch
+    rs = np.random.RandomState(1234 + 7919 * rank)
+    train = np.stack([rs.randint(0, CFG["N"], CFG["n_train"]), rs.randint(0, CFG["R"], CFG["n_train"]),
+                      rs.randint(0, CFG["N"], CFG["n_train"])], 1).astype(np.int32)
+    nps, pys = NumpyStream(rank), PythonStream(rank)
+    perm = nps.shuffle(np.arange(CFG["n_train"], dtype=np.int64))
+    out = []
+    for b in range(n_batches):
+        batch = train[perm[b * CFG["B"]:(b + 1) * CFG["B"]]]
+        out.append(build_batch(nps, pys, batch, CFG["ns"], CFG["N"]))
+    return out
+
+
+def cpu_baseline(batches, E0, R0, budget_s=20.0):
+    """The NumPy oracle's train step (fp32) on the same batches, on this host; bounded to ~budget_s."""
+    import oracle as O
+    E, Rl, opt = E0.copy(), R0.copy(), O.AdamTF()
+    t0, n, steps = time.time(), 0, 0
+    for pos, neg in batches:
+        O.train_step("DistMult", E, Rl, opt, pos, neg, "pointwize_hinge", 1.0)
+        n += len(pos) + len(neg)
+        steps += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return dict(value=n / dt, unit="scored triples/s", cores=1, kind="port",
+                sample=f"{steps} full-size steps ({n} triples) of the NumPy fp32 oracle (oracle/kge_oracle.py train_step), single thread, {dt:.1f}s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from kge_keras_amd import _lib
+    from kge_keras_amd.models import DistMult
+    import oracle as O
+
+    rs = np.random.RandomState(1234)
+    E0, R0 = O.glorot_uniform(CFG["N"], CFG["d"], rs), O.glorot_uniform(CFG["R"], CFG["d"], rs)
+    model = DistMult(e_dim=CFG["d"], r_dim=CFG["d"], num_entities=CFG["N"], num_relations=CFG["R"], dp=0.0,
+                     init_entities=E0, init_relations=R0, loss_function="pointwize_hinge", margin=1)
+    model.compile("adam")
+    n_pool = 8
+    host_batches = make_batches(n_pool, rank)
+    dev = [(torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda()) for p, n in host_batches]
+    m = CFG["B"] * CFG["ns"]
+    per_step = 2 * m
+
+    def step(i):
+        pos, neg = dev[i % n_pool]
+        if world == 1:
+            model.train_step([pos, neg])
+        else:
+            model.train_grads([pos, neg])
+            dist.all_reduce(model._gE)
+            dist.all_reduce(model._gR)
+            model.apply_grads(1.0 / world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    _lib.lib.kge_prof_enable(1)  # hipEvents around the dominant kernels, recorded on the launch stream
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.lib.kge_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    model._raise_on_flag()
+    loss = float(model._loss.item())
+    k_ms, k_n = _lib.prof_read("train_grads")
+    o_ms, o_n = _lib.prof_read("opt")
+
+    if rank == 0:
+        value = per_step * world * args.steps / dt
+        k_avg = k_ms / max(1, k_n) * 1e-3
+        achieved = per_step * A_TRAIN / k_avg if k_n else 0.0
+        res = {
+            "metric": "scored triples/sec (train, 100 neg), FB15k-237 d=200", "value": value, "unit": "scored triples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FB15k-237 DistMult d=200, B=2048, 100 negatives (409600 scored triples/step), pointwize_hinge + Adam(TF semantics)",
+                       "N": CFG["N"], "R": CFG["R"], "d": CFG["d"], "B": CFG["B"], "ns": CFG["ns"],
+                       "parallelism": f"dp{world}" if world > 1 else "single", "sampler": "bit-exact MT19937 batches pre-built on host, resident in HBM",
+                       "final_loss": loss},
+            "roofline": {"bound": "hbm", "kernel": "push_kernel (gather+score+loss+grad)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_launch": per_step * A_TRAIN, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
+                         "opt_kernel_avg_ms": o_ms / max(1, o_n)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(host_batches, E0, R0)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

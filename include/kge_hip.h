@@ -1,0 +1,145 @@
+/* kge_hip.h -- C ABI of the MI355X (gfx950) KGE hot path.
+ *
+ * This is the drop-in boundary: the reference (NIVA-Knowledge-Graph/KGE-Keras) has no FFI of its
+ * own -- its hot path is the Python surface KGEkeras.models.* / KGEkeras.utils.* delegating to
+ * TensorFlow ops.  Each entry point below names the reference interface it replaces (file:line,
+ * relative to the reference repository).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain C, no C++ exceptions cross the boundary; every function returns a kge_status
+ *     (0 = ok, negative = error) and kge_last_error() returns a thread-local message.
+ *   - all `float*` / `int32_t*` arguments are DEVICE pointers (HBM) unless the name ends in `_host`;
+ *     the library borrows them (owned by the caller, e.g. torch tensors) and allocates nothing
+ *     persistent: scratch is a caller-provided workspace sized by the *_workspace_bytes() query.
+ *   - every launcher takes the hipStream_t to enqueue on (as void*), is asynchronous and
+ *     graph-capturable (no allocation, no synchronisation inside).  Thread-compatible, not thread-safe.
+ *   - tables are row-major fp32: E is (num_entities, d_e), Rel is (num_relations, d_r).
+ *   - triples are int32 (n, 3) rows of (subject, predicate, object) ids.  Out-of-range ids never fault:
+ *     the row scores NaN, contributes no gradient, and bit 0 of *err_flag (device word) is set.
+ */
+#ifndef KGE_HIP_H
+#define KGE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGE_ABI_VERSION 1
+
+typedef void* kge_stream_t; /* hipStream_t */
+
+typedef enum {
+  KGE_OK = 0,
+  KGE_EINVAL = -1,      /* bad argument (null pointer, negative size, unknown enum) */
+  KGE_ESHAPE = -2,      /* widths that the reference would reject with a broadcast error */
+  KGE_EHIP = -3,        /* a HIP runtime call failed */
+  KGE_EWORKSPACE = -4,  /* workspace too small */
+  KGE_EUNSUPPORTED = -5 /* valid in the reference, not built here yet */
+} kge_status;
+
+/* KGEkeras.models.* classes on the path (models.py:164-237). */
+typedef enum { KGE_DISTMULT = 0, KGE_TRANSE = 1, KGE_COMPLEX = 2, KGE_HOLE = 3 } kge_model;
+
+/* KGEkeras.utils.loss_function_lookup names (utils.py:321-330). */
+typedef enum {
+  KGE_POINTWIZE_HINGE = 0,    /* utils.py:288-289 */
+  KGE_POINTWIZE_LOGISTIC = 1, /* utils.py:291-292 */
+  KGE_PAIRWIZE_HINGE = 2,     /* utils.py:300-305 */
+  KGE_PAIRWIZE_LOGISTIC = 3,  /* utils.py:307-312 */
+  KGE_POINTWIZE_SQUARE = 4,   /* utils.py:294-295 */
+  KGE_PAIRWIZE_SQUARE = 5     /* utils.py:314-319 */
+} kge_loss;
+
+typedef enum { KGE_OPT_SGD = 0, KGE_OPT_ADAM_TF = 1 } kge_opt;
+
+/* EmbeddingModel.__init__ arguments that shape the arithmetic (models.py:14-129, 176-190, 204-209). */
+typedef struct {
+  int32_t model;         /* kge_model */
+  int32_t num_entities;  /* rows of E */
+  int32_t num_relations; /* rows of Rel */
+  int32_t d_e, d_r;      /* row widths in floats (ComplEx: 2*e_dim, models.py:208-209) */
+  int32_t norm;          /* TransE: 1 or 2 (models.py:178,188) */
+  float gamma;           /* TransE (models.py:179,187-190): score = gamma - dist if gamma > 0 else +dist */
+  float dropout;         /* Dropout(dp) on the three gathered rows, training only (models.py:122,144-148) */
+} kge_model_desc;
+
+/* loss_function(true, false, margin, negative_samples) as called at tests.py:80-81. */
+typedef struct {
+  int32_t loss;             /* kge_loss */
+  int32_t negative_samples; /* reshape width of `false` for pairwize_* (utils.py:301) */
+  float margin;
+  float regularization;     /* l3_reg weight on the entity table (models.py:10-11,78-92); 0 = off */
+} kge_loss_desc;
+
+/* Keras optimizer state for both tables.  ADAM_TF: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); dense moment decay and
+ * dense update over every row; eps outside the bias correction (tests.py:86 `optimizer='adam'`). */
+typedef struct {
+  int32_t kind;  /* kge_opt */
+  float lr, beta1, beta2, eps;
+  int64_t step;  /* t of THIS update, 1-based */
+  float *mE, *vE, *mRel, *vRel; /* Adam slots, same shapes as the tables (unused for SGD) */
+} kge_opt_desc;
+
+const char* kge_last_error(void);
+int kge_abi_version(void);
+/* Fills props[0..3] = {compute units, wavefront size, LDS bytes per CU, HBM bytes}; needs a GPU. */
+int kge_device_props(int64_t props[4]);
+
+/* ---- scoring: EmbeddingModel.call with dropout inactive, i.e. model.predict (models.py:134-162;
+ *      utils.py:211,231).  out[i] = func(E[s_i], Rel[p_i], E[o_i]).  */
+int kge_score(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n,
+              float* out, uint32_t* err_flag, kge_stream_t stream);
+
+/* ---- one training batch: the default Keras train_step over the two-input functional wrapper
+ *      (tests.py:63-89,130-134): score(pos), score(neg) on the same tables, loss, sparse gradients of both
+ *      tables with duplicates summed, optimizer update.  pos and neg are (m_pos,3)/(m_neg,3) as produced by
+ *      oversample_data (utils.py:123-147).  gradE/gradRel are dense fp32 accumulators of the tables' shapes
+ *      that must be all-zero on entry and are all-zero again on return.  *loss_out receives the batch loss
+ *      (what Keras logs).  scores_out (optional, may be NULL) receives the m_pos+m_neg forward scores.
+ *      seed feeds the dropout mask generator when md->dropout > 0.  */
+int64_t kge_train_step_workspace_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg);
+int kge_train_step(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel,
+                   float* gradE, float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                   float* loss_out, float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes,
+                   uint32_t* err_flag, kge_stream_t stream);
+
+/* The two halves of kge_train_step, exposed for DP training where a gradient all-reduce sits between them:
+ *   kge_train_grads : forward + loss + gradient accumulation into gradE/gradRel (+= ; caller zeroes once)
+ *   kge_opt_apply   : optimizer update of both tables from gradE/gradRel * grad_scale, then re-zeroes them.
+ * loss_out of kge_train_grads excludes the L3 term, which kge_opt_apply adds (pass the same pointer). */
+int kge_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE,
+                    float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                    float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                    kge_stream_t stream);
+int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel,
+                  float* gradE, float* gradRel, float grad_scale, float* loss_out, void* workspace,
+                  int64_t workspace_bytes, kge_stream_t stream);
+
+/* ---- in-library kernel timing (bench.py's roofline leg): when enabled, every launcher brackets its dominant
+ *      kernel with hipEvents recorded on the launch stream.  kge_prof_read synchronises those events, returns the
+ *      summed duration (ms) and launch count for one label and clears that label.  Off by default. */
+typedef enum { KGE_PROF_TRAIN_GRADS = 0, KGE_PROF_OPT = 1, KGE_PROF_SCORE = 2, KGE_PROF_PAIRWISE = 3, KGE_PROF_RANK = 4,
+               KGE_PROF_SAMPLER = 5, KGE_PROF_NLABELS = 6 } kge_prof_label;
+int kge_prof_enable(int on);
+int kge_prof_read(int label, double* total_ms, int64_t* launches);
+
+/* ---- host-side bit-exact samplers (MT19937), replacing the NumPy / `random` calls of the batch builder:
+ *      np.random.seed / randint (utils.py:118-119), np.random.shuffle (tests.py:50-53),
+ *      random.seed / random.choices (utils.py:136).  State is an opaque 2504-byte blob owned by the caller. */
+#define KGE_MT_STATE_BYTES 2504
+int kge_mt_seed_numpy(void* state_host, uint32_t seed);                       /* np.random.seed(int) = init_genrand */
+int kge_mt_seed_python(void* state_host, const uint32_t* key_host, int n);    /* random.seed(int) = init_by_array(|seed| words) */
+int kge_mt_randint(void* state_host, int64_t low, int64_t high, int64_t* out_host, int64_t n); /* np.random.randint(low, high, n) */
+int kge_mt_shuffle(void* state_host, int64_t* perm_host, int64_t n);          /* np.random.shuffle */
+int kge_mt_choices(void* state_host, int64_t population, int64_t* idx_host, int64_t k); /* random.choices(range(pop), k=k) */
+int kge_mt_raw(void* state_host, uint32_t* out_host, int64_t n);              /* n raw 32-bit outputs */
+/* generate_negative + oversample_data fused on the host (tests.py:55-61): from the (B,3) batch, the NumPy state
+ * and the Python state, writes pos_out (m,3) and neg_out (m,3) int32, m = B*ns. */
+int kge_build_batch_host(void* np_state_host, void* py_state_host, const int32_t* batch_host, int64_t B, int64_t ns,
+                         int64_t num_e, int32_t* pos_out_host, int32_t* neg_out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGE_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libkge_hip.so (include/kge_hip.h).  No fallback: a missing library is an ImportError."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkge_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+lib = C.CDLL(LIB_PATH)
+
+KGE_OK, KGE_EINVAL, KGE_ESHAPE, KGE_EHIP, KGE_EWORKSPACE, KGE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3}
+LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, "pairwize_logistic": 3,
+            "pointwize_square_loss": 4, "pairwize_square_loss": 5}
+OPT_IDS = {"sgd": 0, "adam": 1}
+MT_STATE_BYTES = 2504
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("model", C.c_int32), ("num_entities", C.c_int32), ("num_relations", C.c_int32), ("d_e", C.c_int32),
+                ("d_r", C.c_int32), ("norm", C.c_int32), ("gamma", C.c_float), ("dropout", C.c_float)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("loss", C.c_int32), ("negative_samples", C.c_int32), ("margin", C.c_float), ("regularization", C.c_float)]
+
+
+class OptDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int64), ("mE", C.c_void_p), ("vE", C.c_void_p), ("mRel", C.c_void_p), ("vRel", C.c_void_p)]
+
+
+_P, _I64, _I32, _U64, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float
+_MD, _LD, _OD = C.POINTER(ModelDesc), C.POINTER(LossDesc), C.POINTER(OptDesc)
+
+# every symbol include/kge_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "kge_last_error": (C.c_char_p, []),
+    "kge_abi_version": (C.c_int, []),
+    "kge_device_props": (C.c_int, [_P]),
+    "kge_prof_enable": (C.c_int, [C.c_int]),
+    "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),
+    "kge_score": (C.c_int, [_MD, _P, _P, _P, _I64, _P, _P, _P]),
+    "kge_train_step_workspace_bytes": (_I64, [_MD, _LD, _I64, _I64]),
+    "kge_train_step": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
+    "kge_train_grads": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
+    "kge_opt_apply": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _F, _P, _P, _I64, _P]),
+    "kge_mt_seed_numpy": (C.c_int, [_P, C.c_uint32]),
+    "kge_mt_seed_python": (C.c_int, [_P, _P, C.c_int]),
+    "kge_mt_randint": (C.c_int, [_P, _I64, _I64, _P, _I64]),
+    "kge_mt_shuffle": (C.c_int, [_P, _P, _I64]),
+    "kge_mt_choices": (C.c_int, [_P, _I64, _P, _I64]),
+    "kge_mt_raw": (C.c_int, [_P, _P, _I64]),
+    "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+PROF_LABELS = {"train_grads": 0, "opt": 1, "score": 2, "pairwise": 3, "rank": 4, "sampler": 5}
+
+
+def prof_read(label):
+    """(total_ms, launches) recorded for one kernel label since the last read (kge_prof_read)."""
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    check(lib.kge_prof_read(PROF_LABELS[label], C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
+class KgeError(RuntimeError):
+    pass
+
+
+_EXC = {KGE_EINVAL: ValueError, KGE_ESHAPE: ValueError, KGE_EHIP: KgeError, KGE_EWORKSPACE: KgeError,
+        KGE_EUNSUPPORTED: NotImplementedError}
+
+
+def check(rc):
+    """Raise the Python exception matching a negative kge_status."""
+    if rc < 0:
+        msg = lib.kge_last_error().decode("utf-8", "replace")
+        raise _EXC.get(rc, KgeError)(f"[libkge_hip {rc}] {msg}")
+    return rc
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("kge_keras_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

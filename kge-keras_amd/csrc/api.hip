@@ -1,0 +1,194 @@
+// extern "C" surface of libkge_hip.so: argument validation, error text, dispatch.  See include/kge_hip.h.
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "kge_internal.hpp"
+
+namespace kge {
+
+char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_model(const kge_model_desc* md, const char* who) {
+  if (!md) return fail(KGE_EINVAL, "%s: model descriptor is null", who);
+  if (md->model < KGE_DISTMULT || md->model > KGE_HOLE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
+  if (md->num_entities <= 0 || md->num_relations <= 0 || md->d_e <= 0 || md->d_r <= 0)
+    return fail(KGE_EINVAL, "%s: non-positive table shape (%d,%d) (%d,%d)", who, md->num_entities, md->d_e, md->num_relations, md->d_r);
+  // s*p*o, s+p-o and the ComplEx products broadcast row-against-row: TensorFlow rejects unequal widths
+  if (md->d_e != md->d_r) return fail(KGE_ESHAPE, "%s: e_dim %d and r_dim %d do not broadcast", who, md->d_e, md->d_r);
+  if (md->model == KGE_COMPLEX && (md->d_e & 1)) return fail(KGE_ESHAPE, "%s: ComplEx rows must split in two halves (tf.split), width %d", who, md->d_e);
+  if (md->model == KGE_TRANSE && md->norm != 1 && md->norm != 2) return fail(KGE_EUNSUPPORTED, "%s: TransE norm %d (only 1 and 2 are built)", who, md->norm);
+  if (!(md->dropout >= 0.f && md->dropout < 1.f)) return fail(KGE_EINVAL, "%s: dropout rate %f outside [0,1)", who, md->dropout);
+  return KGE_OK;
+}
+
+// ---- kernel timing hooks
+namespace {
+struct ProfState {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[KGE_PROF_NLABELS];
+  hipEvent_t pending[KGE_PROF_NLABELS] = {};
+};
+ProfState g_prof;
+}  // namespace
+
+void prof_begin(int label, hipStream_t st) {
+  if (!g_prof.on) return;
+  hipEvent_t a;
+  if (hipEventCreate(&a) != hipSuccess) return;
+  (void)hipEventRecord(a, st);
+  g_prof.pending[label] = a;
+}
+
+void prof_end(int label, hipStream_t st) {
+  if (!g_prof.on || !g_prof.pending[label]) return;
+  hipEvent_t b;
+  if (hipEventCreate(&b) != hipSuccess) return;
+  (void)hipEventRecord(b, st);
+  g_prof.ev[label].emplace_back(g_prof.pending[label], b);
+  g_prof.pending[label] = nullptr;
+}
+
+// ---- tuning knobs (env overrides are for experiments on the GPU box; defaults are what ships)
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+int score_group_width(int nchunk) {
+  static const int forced = env_int("KGE_SCORE_G", 0);
+  if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+  int p2 = 1;
+  while (p2 < nchunk) p2 <<= 1;
+  int g = p2 / 4;
+  return g < 4 ? 4 : (g > 64 ? 64 : g);
+}
+
+int push_group_width(int width) {
+  static const int forced = env_int("KGE_PUSH_G", 0);
+  if (forced == 16 || forced == 32 || forced == 64) return forced;
+  return width <= 16 ? 16 : (width <= 32 ? 32 : 64);
+}
+
+int score_dispatch(const kge_model_desc*, const float*, const float*, const int32_t*, int64_t, float*, uint32_t*, hipStream_t);
+int64_t train_workspace_bytes(int64_t, int64_t);
+int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, const int32_t*, int64_t,
+                const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
+int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
+              int64_t, hipStream_t);
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" {
+
+const char* kge_last_error(void) { return err_buf(); }
+int kge_abi_version(void) { return KGE_ABI_VERSION; }
+
+int kge_prof_enable(int on) {
+  g_prof.on = on != 0;
+  return KGE_OK;
+}
+
+int kge_prof_read(int label, double* total_ms, int64_t* launches) {
+  if (label < 0 || label >= KGE_PROF_NLABELS || !total_ms || !launches) return fail(KGE_EINVAL, "kge_prof_read: bad arguments");
+  double tot = 0.0;
+  for (auto& pr : g_prof.ev[label]) {
+    KGE_HIP_TRY(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    KGE_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  *total_ms = tot;
+  *launches = (int64_t)g_prof.ev[label].size();
+  g_prof.ev[label].clear();
+  return KGE_OK;
+}
+
+int kge_device_props(int64_t props[4]) {
+  if (!props) return fail(KGE_EINVAL, "kge_device_props: null output");
+  int dev = 0;
+  KGE_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  KGE_HIP_TRY(hipGetDeviceProperties(&p, dev));
+  props[0] = p.multiProcessorCount;
+  props[1] = p.warpSize;
+  props[2] = (int64_t)p.maxSharedMemoryPerMultiProcessor;
+  props[3] = (int64_t)p.totalGlobalMem;
+  return KGE_OK;
+}
+
+int kge_score(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n, float* out,
+              uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_model(md, "kge_score")) return rc;
+  if (n < 0) return fail(KGE_EINVAL, "kge_score: n = %lld", (long long)n);
+  if (n == 0) return KGE_OK;
+  if (!E || !Rel || !triples || !out || !err_flag) return fail(KGE_EINVAL, "kge_score: null pointer");
+  return score_dispatch(md, E, Rel, triples, n, out, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int64_t kge_train_step_workspace_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg) {
+  (void)ld;
+  if (check_model(md, "kge_train_step_workspace_bytes")) return KGE_EINVAL;
+  if (m_pos < 0 || m_neg < 0) return fail(KGE_EINVAL, "negative batch size");
+  return train_workspace_bytes(m_pos, m_neg);
+}
+
+static int check_train(const char* who, const kge_model_desc* md, const kge_loss_desc* ld, const void* E, const void* Rel,
+                       const void* gE, const void* gR, const void* pos, int64_t m_pos, const void* neg, int64_t m_neg,
+                       const void* loss_out, const void* err) {
+  if (int rc = check_model(md, who)) return rc;
+  if (!ld) return fail(KGE_EINVAL, "%s: loss descriptor is null", who);
+  if (!E || !Rel || !gE || !gR || !pos || !neg || !loss_out || !err) return fail(KGE_EINVAL, "%s: null pointer", who);
+  // reduce_mean over an empty tensor is NaN in TF; a Keras batch is never empty
+  if (m_pos <= 0 || m_neg <= 0) return fail(KGE_EINVAL, "%s: empty batch (m_pos=%lld, m_neg=%lld)", who, (long long)m_pos, (long long)m_neg);
+  if (m_pos + m_neg > 0x7FFFFFFFll) return fail(KGE_EUNSUPPORTED, "%s: batch above 2^31 rows", who);
+  return KGE_OK;
+}
+
+int kge_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE,
+                    float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                    float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                    kge_stream_t stream) {
+  if (int rc = check_train("kge_train_grads", md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, err_flag)) return rc;
+  return train_grads(md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, scores_out, seed, workspace,
+                     workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,
+                  float* gradRel, float grad_scale, float* loss_out, void* workspace, int64_t workspace_bytes,
+                  kge_stream_t stream) {
+  if (int rc = check_model(md, "kge_opt_apply")) return rc;
+  if (!ld || !od || !E || !Rel || !gradE || !gradRel) return fail(KGE_EINVAL, "kge_opt_apply: null pointer");
+  return opt_apply(md, ld, od, E, Rel, gradE, gradRel, grad_scale, loss_out, workspace, workspace_bytes,
+                   static_cast<hipStream_t>(stream));
+}
+
+int kge_train_step(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,
+                   float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                   float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                   kge_stream_t stream) {
+  if (int rc = check_train("kge_train_step", md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, err_flag)) return rc;
+  if (!od) return fail(KGE_EINVAL, "kge_train_step: optimizer descriptor is null");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = train_grads(md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, scores_out, seed, workspace,
+                           workspace_bytes, err_flag, st)) return rc;
+  return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, st);
+}
+
+}  // extern "C"

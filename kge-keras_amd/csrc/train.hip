@@ -1,0 +1,441 @@
+// One training batch on the GPU: forward on pos and neg, loss, sparse gradients (duplicates summed),
+// optimizer update.  Replaces what the default Keras train_step does for the reference's two-input
+// functional wrapper (tests.py:63-89,130-134): EmbeddingModel.call x2 (KGEkeras/models.py:134-162),
+// loss_function (KGEkeras/utils.py:288-319), autodiff of the three Embedding gathers into IndexedSlices
+// and the Keras 'adam' / 'sgd' apply (TensorFlow semantics: SURVEY.md 8(a) rows O1/O2).
+//
+// "push" gradient path: one kernel gathers the three rows of a triple, reduces the score across the
+// wave, turns it into dL/dscore in registers (pointwise losses) and immediately adds the three
+// gradient rows into the dense fp32 accumulators with no-return global_atomic_add_f32, shaped as
+// 256 contiguous bytes per wave-instruction (lane l owns elements l, l+G, ...).  Hinge rows with a
+// zero subgradient issue no atomics at all.
+#include "kge_internal.hpp"
+
+namespace kge {
+
+constexpr float kEps = 1e-6f;  // KGEkeras/utils.py:12
+
+// dL/dscore and the loss term of one row for the pointwise losses (utils.py:288-295).
+// `inv` = 1/len(true) or 1/len(false) (reduce_mean).  [TF] relu'(0) = 0.
+template <int LOSS>
+__device__ __forceinline__ void pointwise(float score, bool is_pos, float margin, float inv, float& g, float& l) {
+  if (LOSS == KGE_POINTWIZE_HINGE) {
+    const float a = is_pos ? margin - score : margin + score;
+    const bool on = a > 0.f;
+    l = on ? a * inv : 0.f;
+    g = on ? (is_pos ? -inv : inv) : 0.f;
+  } else if (LOSS == KGE_POINTWIZE_LOGISTIC) {
+    const float e = expf(is_pos ? -score : score);
+    const float den = kEps + 1.f + e;
+    l = logf(den) * inv;
+    g = (is_pos ? -e : e) / den * inv;
+  } else {  // KGE_POINTWIZE_SQUARE
+    const float a = is_pos ? margin - score : margin + score;
+    l = a * a * inv;
+    g = (is_pos ? -2.f : 2.f) * a * inv;
+  }
+}
+
+// LOSS < 0: dL/dscore comes from gbuf (two-phase pairwise path) and no loss term is produced here.
+template <int MODEL, int NORM, int LOSS, int G>
+__global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
+                                                    float* __restrict__ gE, float* __restrict__ gR,
+                                                    const int32_t* __restrict__ pos, int64_t m_pos,
+                                                    const int32_t* __restrict__ neg, int64_t m_neg, int N, int R, int d_e,
+                                                    int d_r, float gamma, float margin, const float* __restrict__ gbuf,
+                                                    float* __restrict__ scores, float* __restrict__ loss_partials,
+                                                    uint32_t* __restrict__ err) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t group = (int64_t)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+  const int64_t n = m_pos + m_neg;
+  const int h = d_e >> 1;                               // ComplEx half width
+  const int width = MODEL == KGE_COMPLEX ? h : d_e;     // elements each lane strides over
+  const float inv_pos = 1.f / (float)m_pos, inv_neg = 1.f / (float)m_neg;
+  float lsum = 0.f;
+  for (int64_t t = group; t < n; t += ngroups) {
+    const bool is_pos = t < m_pos;
+    const int32_t* tr = is_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+    const int s = tr[0], p = tr[1], o = tr[2];
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+    const float* es = E + (int64_t)(ok ? s : 0) * d_e;
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * d_r;
+    const float* eo = E + (int64_t)(ok ? o : 0) * d_e;
+    // ---- pass 1: score
+    float acc = 0.f;
+    for (int k = lane; k < width; k += G) {
+      if (MODEL == KGE_COMPLEX) {
+        const float sr = es[k], si = es[h + k], pr = rp[k], pi = rp[h + k], orr = eo[k], oi = eo[h + k];
+        acc += sr * pr * orr + pr * si * oi + pi * sr * oi - pi * si * orr;
+      } else {
+        const float sv = es[k], pv = rp[k], ov = eo[k];
+        if (MODEL == KGE_DISTMULT) acc += sv * pv * ov;
+        else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : x * x; }
+      }
+    }
+    acc = group_sum<G>(acc);
+    float score = acc, dist = acc;
+    if (MODEL == KGE_TRANSE) {
+      if (NORM == 2) dist = sqrtf(acc);
+      score = gamma > 0.f ? gamma - dist : dist;
+    }
+    float g, l = 0.f;
+    if (LOSS >= 0) pointwise<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+    else g = gbuf[t];
+    if (!ok) { g = 0.f; l = 0.f; score = __builtin_nanf(""); }
+    if (lane == 0) {
+      lsum += l;
+      if (scores) scores[t] = score;
+      if (!ok) atomicOr(err, 1u);
+    }
+    if (g == 0.f) continue;  // wave-uniform per sub-group: no gradient, no atomics
+    // ---- pass 2: gradient rows (rows are L1/L2-hot from pass 1)
+    float* gs = gE + (int64_t)s * d_e;
+    float* gp = gR + (int64_t)p * d_r;
+    float* go = gE + (int64_t)o * d_e;
+    if (MODEL == KGE_TRANSE) {
+      // d score / d x = -d dist/dx (gamma > 0) or +d dist/dx; L2: x/dist, 0 at dist == 0 (TF yields NaN there)
+      const float sgn = gamma > 0.f ? -g : g;
+      const float rn = (NORM == 2) ? (dist > 0.f ? sgn / dist : 0.f) : sgn;
+      for (int k = lane; k < width; k += G) {
+        const float x = es[k] + rp[k] - eo[k];
+        const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f)) : rn * x;
+        atomicAdd(gs + k, dx);
+        atomicAdd(gp + k, dx);
+        atomicAdd(go + k, -dx);
+      }
+    } else if (MODEL == KGE_DISTMULT) {
+      for (int k = lane; k < width; k += G) {
+        const float sv = es[k], pv = rp[k], ov = eo[k];
+        atomicAdd(gs + k, g * pv * ov);
+        atomicAdd(gp + k, g * sv * ov);
+        atomicAdd(go + k, g * sv * pv);
+      }
+    } else {  // ComplEx
+      for (int k = lane; k < width; k += G) {
+        const float sr = es[k], si = es[h + k], pr = rp[k], pi = rp[h + k], orr = eo[k], oi = eo[h + k];
+        atomicAdd(gs + k, g * (pr * orr + pi * oi));
+        atomicAdd(gs + h + k, g * (pr * oi - pi * orr));
+        atomicAdd(gp + k, g * (sr * orr + si * oi));
+        atomicAdd(gp + h + k, g * (sr * oi - si * orr));
+        atomicAdd(go + k, g * (sr * pr - pi * si));
+        atomicAdd(go + h + k, g * (pr * si + pi * sr));
+      }
+    }
+  }
+  if (LOSS >= 0) {
+    const float b = block_sum(lsum, red);
+    if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
+  }
+}
+
+// ---- pairwise losses, all-pairs broadcast (utils.py:300-319 with negative_samples == 1 as called at
+// tests.py:81, or len(true) == 1): tmp[j][i] = phi(false_j - true_i); mean over m_f*m_t entries.
+// One thread per output element sweeps the other vector through LDS tiles.  O(m_f*m_t) by definition.
+template <int LOSS>
+__device__ __forceinline__ void pair_term(float z, float margin, float& val, float& dz) {
+  if (LOSS == KGE_PAIRWIZE_HINGE) {
+    const float y = margin + z;
+    val = y > 0.f ? y : 0.f;
+    dz = y > 0.f ? 1.f : 0.f;
+  } else if (LOSS == KGE_PAIRWIZE_LOGISTIC) {
+    const float e = expf(z), den = kEps + 1.f + e;
+    val = logf(den);
+    dz = e / den;
+  } else {
+    val = -z * z;
+    dz = -2.f * z;
+  }
+}
+
+// side 0: one thread per false j, sweeps true  -> g_f[j] = +sum_i dz / (m_f m_t), loss partials
+// side 1: one thread per true  i, sweeps false -> g_t[i] = -sum_j dz / (m_f m_t)
+template <int LOSS, int SIDE>
+__global__ __launch_bounds__(256) void pairwise_allpairs_kernel(const float* __restrict__ tscore, int64_t m_t,
+                                                                 const float* __restrict__ fscore, int64_t m_f,
+                                                                 float margin, float* __restrict__ g_t,
+                                                                 float* __restrict__ g_f, float* __restrict__ loss_partials) {
+  __shared__ float tile[256];
+  __shared__ float red[16];
+  const float* mine = SIDE == 0 ? fscore : tscore;
+  const float* other = SIDE == 0 ? tscore : fscore;
+  const int64_t n_mine = SIDE == 0 ? m_f : m_t, n_other = SIDE == 0 ? m_t : m_f;
+  const float inv = 1.f / ((float)m_f * (float)m_t);
+  float lsum = 0.f;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < n_mine; base += (int64_t)gridDim.x * 256) {
+    const int64_t idx = base + threadIdx.x;
+    const float v = idx < n_mine ? mine[idx] : 0.f;
+    float gs = 0.f, ls = 0.f;
+    for (int64_t ob = 0; ob < n_other; ob += 256) {
+      __syncthreads();
+      tile[threadIdx.x] = ob + threadIdx.x < n_other ? other[ob + threadIdx.x] : 0.f;
+      __syncthreads();
+      const int cnt = (int)(n_other - ob < 256 ? n_other - ob : 256);
+      for (int q = 0; q < cnt; ++q) {
+        const float z = SIDE == 0 ? v - tile[q] : tile[q] - v;
+        float val, dz;
+        pair_term<LOSS>(z, margin, val, dz);
+        gs += dz;
+        ls += val;
+      }
+    }
+    if (idx < n_mine) {
+      if (SIDE == 0) { g_f[idx] = gs * inv; lsum += ls * inv; }
+      else g_t[idx] = -gs * inv;
+    }
+  }
+  if (SIDE == 0) {
+    const float b = block_sum(lsum, red);
+    if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
+  }
+}
+
+// ---- optimizer sweeps (dense over the whole table, as Keras does for IndexedSlices + 'adam'; for 'sgd' the dense
+// sweep equals the sparse scatter because untouched rows have g == 0 exactly).  Also re-zeroes the accumulator and,
+// when the L3 regulariser is on (models.py:10-11), adds 3w*x*|x| to the gradient and reduces sum|x|^3 for the loss.
+template <int KIND, bool REG>
+__global__ __launch_bounds__(256) void opt_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
+                                                   float eps, float gscale, float regw, float* __restrict__ reg_partials) {
+  __shared__ float red[16];
+  float rsum = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  float4* w4 = reinterpret_cast<float4*>(w);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  auto upd = [&](float& wx, float gx, float& mx, float& vx) {
+    gx *= gscale;
+    if (REG) {
+      const float a = fabsf(wx);
+      rsum += a * a * a;
+      gx += 3.f * regw * wx * a;
+    }
+    if (KIND == KGE_OPT_ADAM_TF) {
+      mx = b1 * mx + (1.f - b1) * gx;
+      vx = b2 * vx + (1.f - b2) * gx * gx;
+      wx -= lr_t * mx / (sqrtf(vx) + eps);
+    } else {
+      wx -= lr_t * gx;
+    }
+  };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 wv = w4[i], gv = g4[i], mv, vv;
+    if (KIND == KGE_OPT_ADAM_TF) { mv = m4[i]; vv = v4[i]; }
+    upd(wv.x, gv.x, mv.x, vv.x);
+    upd(wv.y, gv.y, mv.y, vv.y);
+    upd(wv.z, gv.z, mv.z, vv.z);
+    upd(wv.w, gv.w, mv.w, vv.w);
+    w4[i] = wv;
+    g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KIND == KGE_OPT_ADAM_TF) { m4[i] = mv; v4[i] = vv; }
+  }
+  // scalar tail (n % 4)
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float wx = w[i], gx = g[i], mx = 0.f, vx = 0.f;
+    if (KIND == KGE_OPT_ADAM_TF) { mx = m[i]; vx = v[i]; }
+    upd(wx, gx, mx, vx);
+    w[i] = wx;
+    g[i] = 0.f;
+    if (KIND == KGE_OPT_ADAM_TF) { m[i] = mx; v[i] = vx; }
+  }
+  if (REG) {
+    const float b = block_sum(rsum, red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = b;
+  }
+}
+
+// loss_out = (accumulate ? loss_out : 0) + scale * sum(partials[0..n)), fixed order -> run-to-run deterministic
+__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ partials, int n, float scale,
+                                                        int accumulate, float* __restrict__ loss_out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+  const float b = block_sum(s, red);
+  if (threadIdx.x == 0) loss_out[0] = (accumulate ? loss_out[0] : 0.f) + scale * b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMaxBlocks = 4096;  // partial-sum slots per kernel
+
+struct Workspace {
+  float* loss_partials;  // kMaxBlocks
+  float* reg_partials;   // kMaxBlocks
+  float* gbuf;           // m_pos + m_neg (pairwise)
+  float* sbuf;           // m_pos + m_neg (pairwise, when scores_out is null)
+};
+
+int64_t train_workspace_bytes(int64_t m_pos, int64_t m_neg) {
+  return (int64_t)sizeof(float) * (2 * kMaxBlocks + 2 * align_up(m_pos + m_neg, 64)) + 256;
+}
+
+static int carve(void* ws, int64_t bytes, int64_t m_pos, int64_t m_neg, Workspace* out) {
+  if (!ws) return fail(KGE_EINVAL, "workspace is null");
+  if (bytes < train_workspace_bytes(m_pos, m_neg))
+    return fail(KGE_EWORKSPACE, "workspace has %lld bytes, needs %lld", (long long)bytes,
+                (long long)train_workspace_bytes(m_pos, m_neg));
+  uintptr_t p = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
+  float* f = reinterpret_cast<float*>(p);
+  out->loss_partials = f;
+  out->reg_partials = f + kMaxBlocks;
+  out->gbuf = f + 2 * kMaxBlocks;
+  out->sbuf = out->gbuf + align_up(m_pos + m_neg, 64);
+  return KGE_OK;
+}
+
+int score_dispatch(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n,
+                   float* out, uint32_t* err, hipStream_t st);
+int push_group_width(int width);  // tuning.cpp
+
+template <int MODEL, int NORM, int LOSS>
+static int launch_push(int G, const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE,
+                       float* gR, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const float* gbuf,
+                       float* scores, float* partials, uint32_t* err, hipStream_t st, int* nblocks) {
+  const int64_t n = m_pos + m_neg;
+  const int64_t want = cdiv(n * G, 256);
+  const int grid = (int)(want < kMaxBlocks ? want : kMaxBlocks);
+  *nblocks = grid;
+  ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
+#define KGE_PUSH(GW)                                                                                                \
+  hipLaunchKernelGGL((push_kernel<MODEL, NORM, LOSS, GW>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, pos, m_pos, \
+                     neg, m_neg, md->num_entities, md->num_relations, md->d_e, md->d_r, md->gamma, ld->margin, gbuf,  \
+                     scores, partials, err)
+  if (G == 16) KGE_PUSH(16);
+  else if (G == 32) KGE_PUSH(32);
+  else KGE_PUSH(64);
+#undef KGE_PUSH
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+template <int LOSS>
+static int push_by_model(int G, const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE,
+                         float* gR, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const float* gbuf,
+                         float* scores, float* partials, uint32_t* err, hipStream_t st, int* nb) {
+  switch (md->model) {
+    case KGE_DISTMULT:
+      return launch_push<KGE_DISTMULT, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
+    case KGE_TRANSE:
+      if (md->norm == 1)
+        return launch_push<KGE_TRANSE, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
+      return launch_push<KGE_TRANSE, 2, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
+    case KGE_COMPLEX:
+      return launch_push<KGE_COMPLEX, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
+    default:
+      return fail(KGE_EUNSUPPORTED, "kge_train_step: model %d has no HIP training kernel yet", md->model);
+  }
+}
+
+template <int LOSS>
+static int launch_pairwise(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float margin, float* g_t, float* g_f,
+                           float* partials, hipStream_t st, int* nb) {
+  const int gf = (int)std::min<int64_t>(cdiv(m_f, 256), kMaxBlocks);
+  const int gt = (int)std::min<int64_t>(cdiv(m_t, 256), kMaxBlocks);
+  *nb = gf;
+  ProfScope prof(KGE_PROF_PAIRWISE, st);
+  hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 0>), dim3(gf), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
+  hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 1>), dim3(gt), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
+                const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out,
+                uint64_t seed, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  (void)seed;
+  if (md->dropout != 0.f) return fail(KGE_EUNSUPPORTED, "dropout > 0 is not built yet (models.py:122); pass dp=0");
+  Workspace ws;
+  if (int rc = carve(workspace, wbytes, m_pos, m_neg, &ws)) return rc;
+  const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
+  const int G = push_group_width(width);
+  int nb = 0;
+  switch (ld->loss) {
+    case KGE_POINTWIZE_HINGE:
+      if (int rc = push_by_model<KGE_POINTWIZE_HINGE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb)) return rc;
+      break;
+    case KGE_POINTWIZE_LOGISTIC:
+      if (int rc = push_by_model<KGE_POINTWIZE_LOGISTIC>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb)) return rc;
+      break;
+    case KGE_POINTWIZE_SQUARE:
+      if (int rc = push_by_model<KGE_POINTWIZE_SQUARE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb)) return rc;
+      break;
+    case KGE_PAIRWIZE_HINGE:
+    case KGE_PAIRWIZE_LOGISTIC:
+    case KGE_PAIRWIZE_SQUARE: {
+      // numpy/TF broadcast of false.reshape(-1, ns) against true (m_t,): all-pairs iff ns == 1 or m_t == 1
+      if (ld->negative_samples < 1 || m_neg % ld->negative_samples)
+        return fail(KGE_ESHAPE, "pairwize loss: len(false)=%lld is not divisible by negative_samples=%d", (long long)m_neg, ld->negative_samples);
+      if (!(ld->negative_samples == 1 || m_pos == 1)) {
+        if (ld->negative_samples == m_pos)
+          return fail(KGE_EUNSUPPORTED, "pairwize loss with negative_samples == len(true) (column-aligned broadcast) is not built yet");
+        return fail(KGE_ESHAPE, "pairwize loss: (%lld,%d) does not broadcast against (%lld,)", (long long)(m_neg / ld->negative_samples),
+                    ld->negative_samples, (long long)m_pos);
+      }
+      float* sc = scores_out ? scores_out : ws.sbuf;
+      // phase 1: scores of pos then neg
+      if (int rc = score_dispatch(md, E, Rel, pos, m_pos, sc, err, st)) return rc;
+      if (int rc = score_dispatch(md, E, Rel, neg, m_neg, sc + m_pos, err, st)) return rc;
+      // phase 2: dL/dscore for every row + loss
+      int rc;
+      if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb);
+      else if (ld->loss == KGE_PAIRWIZE_LOGISTIC) rc = launch_pairwise<KGE_PAIRWIZE_LOGISTIC>(sc, m_pos, sc + m_pos, m_neg, ld->margin, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb);
+      else rc = launch_pairwise<KGE_PAIRWIZE_SQUARE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb);
+      if (rc) return rc;
+      // phase 3: gradient rows
+      int nb2 = 0;
+      if ((rc = push_by_model<-1>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, ws.gbuf, nullptr, nullptr, err, st, &nb2))) return rc;
+      break;
+    }
+    default:
+      return fail(KGE_EINVAL, "unknown loss %d", ld->loss);
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+template <int KIND>
+static int launch_opt(bool reg, float* w, float* g, float* m, float* v, int64_t n, float lr_t, const kge_opt_desc* od,
+                      float gscale, float regw, float* reg_partials, hipStream_t st, int* nb) {
+  const int64_t want = cdiv(cdiv(n, 4), 256);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, kCUs * 8));
+  *nb = grid;
+  if (reg) hipLaunchKernelGGL((opt_kernel<KIND, true>), dim3(grid), dim3(256), 0, st, w, g, m, v, n, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials);
+  else hipLaunchKernelGGL((opt_kernel<KIND, false>), dim3(grid), dim3(256), 0, st, w, g, m, v, n, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gE,
+              float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st) {
+  Workspace ws;
+  if (int rc = carve(workspace, wbytes, 0, 0, &ws)) return rc;
+  const int64_t nE = (int64_t)md->num_entities * md->d_e, nR = (int64_t)md->num_relations * md->d_r;
+  const bool reg = ld->regularization != 0.f;
+  int nb = 0, nb2 = 0;
+  ProfScope prof(KGE_PROF_OPT, st);
+  if (od->kind == KGE_OPT_ADAM_TF) {
+    if (!od->mE || !od->vE || !od->mRel || !od->vRel) return fail(KGE_EINVAL, "adam: moment buffers are null");
+    if (od->step < 1) return fail(KGE_EINVAL, "adam: step must be >= 1");
+    const double t = (double)od->step;
+    const float lr_t = (float)((double)od->lr * std::sqrt(1.0 - std::pow((double)od->beta2, t)) / (1.0 - std::pow((double)od->beta1, t)));
+    if (int rc = launch_opt<KGE_OPT_ADAM_TF>(reg, E, gE, od->mE, od->vE, nE, lr_t, od, gscale, ld->regularization, ws.reg_partials, st, &nb)) return rc;
+    if (int rc = launch_opt<KGE_OPT_ADAM_TF>(false, Rel, gR, od->mRel, od->vRel, nR, lr_t, od, gscale, 0.f, nullptr, st, &nb2)) return rc;
+  } else if (od->kind == KGE_OPT_SGD) {
+    if (int rc = launch_opt<KGE_OPT_SGD>(reg, E, gE, nullptr, nullptr, nE, od->lr, od, gscale, ld->regularization, ws.reg_partials, st, &nb)) return rc;
+    if (int rc = launch_opt<KGE_OPT_SGD>(false, Rel, gR, nullptr, nullptr, nR, od->lr, od, gscale, 0.f, nullptr, st, &nb2)) return rc;
+  } else {
+    return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
+  }
+  if (reg && loss_out) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.reg_partials, nb, ld->regularization, 1, loss_out);
+    KGE_HIP_TRY(hipGetLastError());
+  }
+  return KGE_OK;
+}
+
+}  // namespace kge

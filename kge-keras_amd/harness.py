@@ -1,0 +1,60 @@
+"""Counterpart of the reference's training script pieces (tests.py:29-61 DataGenerator, tests.py:63-89
+build_model): the caller of the hot path.  Batches come out of the host-side bit-exact samplers, and
+are handed to EmbeddingModel.train_step as int32 (m,3) arrays."""
+import numpy as np
+
+from . import models as _models
+from .sampler import NumpyStream, PythonStream, build_batch
+from .utils import loss_function_lookup
+
+models = {'DistMult': _models.DistMult, 'TransE': _models.TransE, 'HolE': _models.HolE, 'ComplEx': _models.ComplEx,
+          'ConvE': _models.ConvE}  # tests.py:18-27, restricted to the path's model families
+
+
+class DataGenerator:
+    """tests.py:29-61.  Consumes NumPy's and Python's *global* generators exactly like the reference
+    (epoch shuffle -> randint heads -> randint tails -> choices positives -> choices negatives), so that
+    `np.random.seed(a); random.seed(b)` gives the same batches as the reference's generator."""
+
+    def __init__(self, kg, ns=10, batch_size=32, shuffle=True):
+        self.batch_size = min(batch_size, len(kg))
+        self.kg = np.ascontiguousarray(np.asarray(kg, dtype=np.int32).reshape(-1, 3))
+        self.ns = ns
+        self.num_e = len(set(self.kg[:, 0].tolist()) | set(self.kg[:, 2].tolist()))  # tests.py:34
+        self.shuffle = shuffle
+        self.indices = np.arange(len(self.kg))
+        self.on_epoch_end()
+
+    def __len__(self):
+        return len(self.kg) // self.batch_size
+
+    def __getitem__(self, index):
+        index = self.index[index * self.batch_size:(index + 1) * self.batch_size]
+        batch = self.kg[self.indices[index]]
+        nps, pys = NumpyStream().adopt_global(), PythonStream().adopt_global()
+        pos, neg = build_batch(nps, pys, batch, self.ns, self.num_e)  # generate_negative + oversample_data
+        nps.release_global()
+        pys.release_global()
+        return [pos, neg], None
+
+    def on_epoch_end(self):
+        self.index = np.arange(len(self.indices), dtype=np.int64)
+        if self.shuffle:
+            st = NumpyStream().adopt_global()
+            st.shuffle(self.index)  # np.random.shuffle (tests.py:53)
+            st.release_global()
+
+
+def build_model(hp):
+    """tests.py:63-89: instantiate the embedding model from the hp dict (all keys passed as kwargs), attach the
+    looked-up loss with `margin or 1` and negative_samples=1, compile with Adam."""
+    params = hp.copy()
+    params['e_dim'] = params['dim']
+    params['r_dim'] = params['dim']
+    params['name'] = 'embedding_model'
+    loss_function_lookup(params['loss_function'])  # KeyError on unknown names, as at tests.py:80
+    model = models[params['embedding_model']](**params)
+    model.margin = params.get('margin') or 1
+    model.loss_negative_samples = 1
+    model.compile(optimizer='adam', loss=None)
+    return model

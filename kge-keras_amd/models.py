@@ -1,0 +1,410 @@
+"""Counterpart of KGEkeras/models.py for the hot path: the same class names, constructor kwargs and
+call / func / predict / compile / fit / train_step surface, with every gather, score, loss, gradient
+and optimizer update running in the HIP kernels of libkge_hip.so.
+
+Reference lines (relative to the reference repo):
+  EmbeddingModel.__init__  KGEkeras/models.py:14-129      call  :134-162      get_config :131-132
+  DistMult :164-172   TransE :175-190   ComplEx :203-222   HolE :224-237   ConvE :239-275
+Keras-inherited behaviour the reference relies on (predict at utils.py:211,231; compile/fit at
+tests.py:86-87,130-134; default train_step over add_loss) is restated on EmbeddingModel itself.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ModelDesc, LossDesc, OptDesc, MODEL_IDS, LOSS_IDS, OPT_IDS
+
+
+def _device():
+    _lib.require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def glorot_uniform(rows, cols, generator=None, device=None):
+    """keras GlorotUniform for an Embedding matrix (models.py:87-88,101-102): U(-l, l), l = sqrt(6/(rows+cols))."""
+    lim = float(np.sqrt(6.0 / (rows + cols)))
+    t = torch.empty((rows, cols), dtype=torch.float32, device=device)
+    t.uniform_(-lim, lim, generator=generator)
+    return t
+
+
+def as_triples(x, device, num_entities=None, num_relations=None):
+    """(n,3) ids as a contiguous int32 device tensor.  Host arrays are range-checked here (TensorFlow's CPU gather
+    raises on out-of-range ids); device tensors are checked by the kernels through the error flag."""
+    if isinstance(x, torch.Tensor):
+        t = x.reshape(-1, 3)
+        if t.device.type != "cuda":
+            return as_triples(t.numpy(), device, num_entities, num_relations)
+        return t.to(dtype=torch.int32).contiguous()
+    a = np.asarray(x)
+    a = a.reshape(-1, 3)
+    if a.dtype.kind == "f":  # Keras Input((3,)) is float32; Embedding casts to int32
+        a = a.astype(np.int64)
+    if a.size and num_entities is not None:
+        if a[:, [0, 2]].min() < 0 or a[:, [0, 2]].max() >= num_entities or a[:, 1].min() < 0 or a[:, 1].max() >= num_relations:
+            raise IndexError("triple ids out of range of the embedding tables (indices[...] is not in [0, N))")
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=False)
+
+
+class EmbeddingTable:
+    """What the reference keeps as a keras Embedding layer (models.py:87-112): the weight matrix, on the GPU."""
+
+    def __init__(self, weights, name):
+        self.weights = weights  # torch.float32 (rows, width), contiguous, device
+        self.name = name
+        self.trainable = True
+
+    def get_weights(self):
+        return [self.weights.detach().cpu().numpy()]
+
+    def set_weights(self, ws):
+        w = torch.as_tensor(np.asarray(ws[0], dtype=np.float32), device=self.weights.device)
+        if w.shape != self.weights.shape:
+            raise ValueError(f"Layer weight shape {tuple(self.weights.shape)} not compatible with provided weight shape {tuple(w.shape)}")
+        self.weights.copy_(w)
+
+
+class _Optimizer:
+    """Keras optimizer as named in compile() (tests.py:86): 'adam' (lr 1e-3, b1 .9, b2 .999, eps 1e-7) or 'sgd' (lr .01)."""
+
+    def __init__(self, kind, **kw):
+        kind = kind.lower()
+        if kind not in OPT_IDS:
+            raise ValueError(f"Unknown optimizer: {kind}")
+        self.kind = kind
+        d = dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7) if kind == "adam" else dict(lr=0.01, beta_1=0.0, beta_2=0.0, epsilon=0.0)
+        if "learning_rate" in kw:
+            kw["lr"] = kw.pop("learning_rate")
+        d.update(kw)
+        self.lr, self.beta_1, self.beta_2, self.epsilon = d["lr"], d["beta_1"], d["beta_2"], d["epsilon"]
+        self.iterations = 0
+        self.slots = None  # (mE, vE, mRel, vRel)
+
+
+def loss_value(name, true, false, margin=1, negative_samples=1):
+    raise NotImplementedError("stand-alone loss evaluation on score vectors is provided through EmbeddingModel.train_step")
+
+
+class EmbeddingModel:
+    MODEL = None
+
+    def __init__(self, e_dim, r_dim, num_entities, num_relations, negative_samples=2, batch_size=16,
+                 loss_function='pointwize_hinge', dp=0.2, margin=1, loss_weight=1, regularization=0.0,
+                 literal_activation=None, literals=None, use_batch_norm=False, entity_embedding_args=None,
+                 relational_embedding_args=None, init_entities=None, init_relations=None, name='embedding_model',
+                 **kwargs):
+        if literal_activation:
+            raise NotImplementedError("the LiteralE input path (models.py:114-120,152-158) is outside the built hot path")
+        dev = _device()
+        self.device = dev
+        self.name = name
+        self.regularization = regularization
+        self.num_entities = int(num_entities)
+        self.num_relations = int(num_relations)
+        seed = kwargs.pop("seed", None)
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(int(seed))
+        if init_entities is not None:  # models.py:94-99
+            E = torch.as_tensor(np.asarray(init_entities, dtype=np.float32), device=dev).contiguous().clone()
+            if tuple(E.shape) != (self.num_entities, e_dim):
+                raise ValueError(f"init_entities has shape {tuple(E.shape)}, expected {(self.num_entities, e_dim)}")
+        else:
+            E = glorot_uniform(self.num_entities, e_dim, gen, dev)
+        if init_relations is not None:  # models.py:107-112
+            Rl = torch.as_tensor(np.asarray(init_relations, dtype=np.float32), device=dev).contiguous().clone()
+            if tuple(Rl.shape) != (self.num_relations, r_dim):
+                raise ValueError(f"init_relations has shape {tuple(Rl.shape)}, expected {(self.num_relations, r_dim)}")
+        else:
+            Rl = glorot_uniform(self.num_relations, r_dim, gen, dev)
+        self.entity_embedding = EmbeddingTable(E, name + '_entity_embedding')
+        self.relational_embedding = EmbeddingTable(Rl, name + '_relational_embedding')
+        self.dp = float(dp)  # the reference keeps a Dropout layer here (models.py:122); the rate is what matters
+        self.e_dim = e_dim
+        self.r_dim = r_dim
+        self.margin = margin
+        self.loss_weight = loss_weight
+        self.loss_function = loss_function.name if hasattr(loss_function, "name") else loss_function
+        self.negative_samples = negative_samples
+        self.batch_size = batch_size
+        self.loss_negative_samples = 1  # what the harness passes to the loss (tests.py:81)
+        self.optimizer = None
+        self.stop_training = False
+        self._gE = None
+        self._ws = None
+        self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._seed = int(seed) if seed is not None else 0
+        self.__dict__.update(kwargs)  # models.py:129: unknown kwargs become attributes
+
+    # ------------------------------------------------------------------ descriptors
+    def _model_desc(self, training=False):
+        return ModelDesc(MODEL_IDS[self.MODEL], self.num_entities, self.num_relations, int(self.e_dim), int(self.r_dim),
+                         int(getattr(self, "norm", 1)), float(getattr(self, "gamma", 0.0)), float(self.dp) if training else 0.0)
+
+    def _loss_desc(self):
+        if self.loss_function not in LOSS_IDS:
+            if self.loss_function == "pointwize_cross_entropy":
+                raise NotImplementedError("pointwize_cross_entropy (utils.py:297-298) is not on the built training path")
+            raise KeyError(self.loss_function)  # utils.py:322-330
+        return LossDesc(LOSS_IDS[self.loss_function], int(self.loss_negative_samples), float(self.margin or 1),
+                        float(self.regularization))
+
+    def get_config(self):
+        return self.__dict__  # models.py:131-132
+
+    @property
+    def E(self):
+        return self.entity_embedding.weights
+
+    @property
+    def Rel(self):
+        return self.relational_embedding.weights
+
+    # ------------------------------------------------------------------ forward (models.py:134-162)
+    def call(self, inputs, training=False):
+        """(n,3) ids -> (n,) scores as a device tensor.  Dropout is only applied inside train_step."""
+        t = as_triples(inputs, self.device, self.num_entities, self.num_relations)
+        n = t.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        md = self._model_desc(False)
+        check(lib.kge_score(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), t.data_ptr(), n, out.data_ptr(),
+                            self._err.data_ptr(), _lib.stream_ptr()))
+        return out
+
+    __call__ = call
+
+    def func(self, s, p, o, training=False):
+        """Score already-gathered rows (models.py:160): rows are staged as temporary tables and scored by the same kernel."""
+        s = torch.as_tensor(s, dtype=torch.float32, device=self.device).reshape(-1, self.e_dim)
+        p = torch.as_tensor(p, dtype=torch.float32, device=self.device).reshape(-1, self.r_dim)
+        o = torch.as_tensor(o, dtype=torch.float32, device=self.device).reshape(-1, self.e_dim)
+        n = s.shape[0]
+        Et = torch.cat([s, o], 0).contiguous()
+        idx = torch.arange(n, dtype=torch.int32, device=self.device)
+        t = torch.stack([idx, idx, idx + n], 1).contiguous()
+        md = self._model_desc(False)
+        md.num_entities, md.num_relations = 2 * n, n
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(lib.kge_score(C.byref(md), Et.data_ptr(), p.contiguous().data_ptr(), t.data_ptr(), n, out.data_ptr(),
+                            self._err.data_ptr(), _lib.stream_ptr()))
+        return out
+
+    def predict(self, x, batch_size=32, verbose=0, **_):
+        """keras Model.predict as used at utils.py:211,231: numpy (n,) scores.  One launch regardless of batch_size."""
+        out = self.call(x).cpu().numpy()
+        self._raise_on_flag()
+        return out
+
+    def _raise_on_flag(self):
+        if int(self._err.item()) != 0:
+            self._err.zero_()
+            raise IndexError("triple ids out of range of the embedding tables (indices[...] is not in [0, N))")
+
+    # ------------------------------------------------------------------ training (tests.py:63-89,130-134)
+    def compile(self, optimizer='adam', loss=None, **kw):
+        self.optimizer = optimizer if isinstance(optimizer, _Optimizer) else _Optimizer(optimizer)
+        return self
+
+    def _ensure_train_state(self, m_pos, m_neg):
+        if self.optimizer is None:
+            raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+        if self._gE is None:
+            self._gE = torch.zeros_like(self.E)
+            self._gR = torch.zeros_like(self.Rel)
+        if self.optimizer.kind == "adam" and self.optimizer.slots is None:
+            self.optimizer.slots = tuple(torch.zeros_like(x) for x in (self.E, self.E, self.Rel, self.Rel))
+        md, ld = self._model_desc(True), self._loss_desc()
+        need = check(lib.kge_train_step_workspace_bytes(C.byref(md), C.byref(ld), m_pos, m_neg))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return md, ld
+
+    def _opt_desc(self):
+        o = self.optimizer
+        sl = [x.data_ptr() for x in o.slots] if o.slots else [None] * 4
+        return OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, o.iterations, *sl)
+
+    def train_step(self, data, scores_out=None):
+        """Default Keras train_step for the two-input wrapper: data = [pos (m,3), neg (m,3)] (optionally (X, y)).
+        Returns {'loss': 0-d device tensor}."""
+        if isinstance(data, tuple) and len(data) == 2 and (data[1] is None or isinstance(data[0], (list, tuple))):
+            data = data[0]
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        m_pos, m_neg = pos.shape[0], neg.shape[0]
+        md, ld = self._ensure_train_state(m_pos, m_neg)
+        self.optimizer.iterations += 1
+        od = self._opt_desc()
+        self._seed += 1
+        check(lib.kge_train_step(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(),
+                                 self._gE.data_ptr(), self._gR.data_ptr(), pos.data_ptr(), m_pos, neg.data_ptr(), m_neg,
+                                 self._loss.data_ptr(), scores_out.data_ptr() if scores_out is not None else None,
+                                 self._seed, self._ws.data_ptr(), self._ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        return {"loss": self._loss[0]}
+
+    def train_grads(self, data):
+        """First half of train_step (forward + loss + gradient accumulation); for data-parallel training an
+        all-reduce of `_gE` / `_gR` goes between this and apply_grads."""
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
+        self._seed += 1
+        check(lib.kge_train_grads(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                  self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0],
+                                  self._loss.data_ptr(), None, self._seed, self._ws.data_ptr(), self._ws.numel(),
+                                  self._err.data_ptr(), _lib.stream_ptr()))
+        return {"loss": self._loss[0]}
+
+    def apply_grads(self, grad_scale=1.0):
+        """Second half of train_step: optimizer update from the (reduced) accumulators * grad_scale; re-zeroes them."""
+        md, ld = self._model_desc(True), self._loss_desc()
+        self.optimizer.iterations += 1
+        od = self._opt_desc()
+        check(lib.kge_opt_apply(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(),
+                                self._gE.data_ptr(), self._gR.data_ptr(), float(grad_scale), self._loss.data_ptr(),
+                                self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()))
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
+            shuffle=True, **_):
+        """keras Model.fit over a Sequence-style generator (tests.py:130-134): len(x) batches per epoch,
+        x[i] -> ([pos, neg], None), x.on_epoch_end() after each epoch.  Returns a History-like object."""
+        import random
+        import time
+        callbacks = callbacks or []
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+        history = {"loss": []}
+        if validation_data is not None:
+            history["val_loss"] = []
+        for epoch in range(epochs):
+            t0 = time.time()
+            order = list(range(len(x)))
+            if shuffle:
+                random.shuffle(order)  # Keras shuffles the batch order of a Sequence with Python's `random`
+            tot = torch.zeros((), dtype=torch.float64, device=self.device)
+            for i in order:
+                X, _y = x[i]
+                tot += self.train_step(X)["loss"].double()
+            logs = {"loss": float(tot.item()) / max(1, len(order))}
+            self._raise_on_flag()
+            if validation_data is not None:
+                logs["val_loss"] = self.evaluate(validation_data)
+            if hasattr(x, "on_epoch_end"):
+                x.on_epoch_end()
+            for cb in callbacks:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+            for k, v in logs.items():
+                history.setdefault(k, []).append(v)
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items() if isinstance(v, float)))
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end({})
+        return type("History", (), {"history": history, "model": self})()
+
+    def evaluate(self, x, **_):
+        """Mean batch loss over a generator without updating the tables (keras Model.evaluate over add_loss)."""
+        tot, n = 0.0, 0
+        for i in range(len(x)):
+            X, _y = x[i]
+            tot += float(self.batch_loss(X).item())
+            n += 1
+        return tot / max(1, n)
+
+    def batch_loss(self, data):
+        """Loss of one [pos, neg] batch, no update: gradients are accumulated and discarded by a zero-lr SGD apply."""
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        if self.optimizer is None:
+            self.compile('sgd')
+        md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
+        md.dropout = 0.0
+        od = OptDesc(OPT_IDS["sgd"], 0.0, 0.0, 0.0, 0.0, 1, None, None, None, None)
+        check(lib.kge_train_step(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(),
+                                 self._gE.data_ptr(), self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(),
+                                 neg.shape[0], self._loss.data_ptr(), None, 0, self._ws.data_ptr(), self._ws.numel(),
+                                 self._err.data_ptr(), _lib.stream_ptr()))
+        return self._loss[0].clone()
+
+    # ------------------------------------------------------------------ weights I/O (checkpointing)
+    def get_weights(self):
+        return self.entity_embedding.get_weights() + self.relational_embedding.get_weights()
+
+    def set_weights(self, ws):
+        self.entity_embedding.set_weights([ws[0]])
+        self.relational_embedding.set_weights([ws[1]])
+
+    def save_weights(self, path):
+        st = {"E": self.E.cpu(), "Rel": self.Rel.cpu(), "model": self.MODEL}
+        if self.optimizer is not None:
+            st["opt"] = dict(kind=self.optimizer.kind, iterations=self.optimizer.iterations,
+                             slots=[s.cpu() for s in self.optimizer.slots] if self.optimizer.slots else None)
+        torch.save(st, path)
+
+    def load_weights(self, path):
+        st = torch.load(path, map_location="cpu")
+        self.E.copy_(st["E"])
+        self.Rel.copy_(st["Rel"])
+        if "opt" in st and self.optimizer is not None and st["opt"]["kind"] == self.optimizer.kind:
+            self.optimizer.iterations = st["opt"]["iterations"]
+            if st["opt"]["slots"] is not None:
+                self.optimizer.slots = tuple(s.to(self.device) for s in st["opt"]["slots"])
+
+
+class DistMult(EmbeddingModel):
+    """models.py:164-172."""
+    MODEL = "DistMult"
+
+    def __init__(self, name='DistMult', **kwargs):
+        super().__init__(name=name, **kwargs)
+
+
+class TransE(EmbeddingModel):
+    """models.py:175-190: score = gamma - ||s+p-o||_norm if gamma > 0 else +||s+p-o||_norm."""
+    MODEL = "TransE"
+
+    def __init__(self, name='TransE', norm=1, gamma=12, **kwargs):
+        super().__init__(name=name, **kwargs)
+        self.gamma = gamma
+        self.norm = norm
+
+
+class ComplEx(EmbeddingModel):
+    """models.py:203-222: both widths are doubled (so e_dim and r_dim must be passed as kwargs, as in the reference)."""
+    MODEL = "ComplEx"
+
+    def __init__(self, name='ComplEx', **kwargs):
+        kwargs['e_dim'] = 2 * kwargs['e_dim']  # KeyError if absent, like models.py:208
+        kwargs['r_dim'] = 2 * kwargs['r_dim']
+        super().__init__(name=name, **kwargs)
+
+
+class HolE(EmbeddingModel):
+    """models.py:224-237 (surface; the circular-correlation kernel is a SURVEY 8(f) 'next' row)."""
+    MODEL = "HolE"
+
+    def __init__(self, name='HolE', **kwargs):
+        super().__init__(name=name, **kwargs)
+
+
+class ConvE(EmbeddingModel):
+    """models.py:239-275 (surface only; conv/BN/Dense kernels are a SURVEY 8(f) 'next' row)."""
+    MODEL = "ConvE"
+
+    def __init__(self, name='ConvE', hidden_dp=0.2, conv_filters=8, conv_size_w=3, conv_size_h=3, **kwargs):
+        super().__init__(name=name, **kwargs)
+        self.dim = kwargs['e_dim']
+        factors = [(int(i), int(self.dim / i)) for i in range(1, int(self.dim ** 0.5) + 1) if self.dim % i == 0]
+        self.w, self.h = factors.pop(-1)
+        assert self.w > 1 or self.h > 1  # models.py:252
+
+    def _model_desc(self, training=False):
+        raise NotImplementedError("ConvE scoring (models.py:265-275) has no HIP kernel yet")

@@ -1,0 +1,113 @@
+"""Host-side MT19937 streams that reproduce NumPy's legacy global RandomState and CPython's `random`
+bit for bit (csrc/sampler.cpp).  A stream can adopt the live global state and hand it back, so that
+`generate_negative` / `oversample_data` here consume exactly the draws the reference's calls would
+(KGEkeras/utils.py:118-119,136; tests.py:50-53) and leave the global generators where the reference
+would have left them."""
+import ctypes as C
+import random as _pyrandom
+
+import numpy as np
+
+from ._lib import lib, check, MT_STATE_BYTES
+
+
+class _Stream:
+    def __init__(self):
+        self._buf = np.zeros(MT_STATE_BYTES // 4, dtype=np.uint32)  # 624 words + pos + pad
+
+    @property
+    def ptr(self):
+        return self._buf.ctypes.data
+
+    def raw(self, n):
+        out = np.empty(int(n), dtype=np.uint32)
+        check(lib.kge_mt_raw(self.ptr, out.ctypes.data, int(n)))
+        return out
+
+
+class NumpyStream(_Stream):
+    """Twin of `np.random` (legacy RandomState, MT19937 seeded by init_genrand)."""
+
+    def __init__(self, seed=None):
+        super().__init__()
+        if seed is not None:
+            self.seed(seed)
+
+    def seed(self, seed):
+        seed = int(seed)
+        if not 0 <= seed <= 0xFFFFFFFF:
+            raise ValueError("Seed must be between 0 and 2**32 - 1")  # numpy's message
+        check(lib.kge_mt_seed_numpy(self.ptr, C.c_uint32(seed)))
+        return self
+
+    def adopt_global(self):
+        """Copy the state of NumPy's global generator."""
+        kind, key, pos, _, _ = np.random.get_state()
+        assert kind == "MT19937"
+        self._buf[:624] = key
+        self._buf[624] = pos
+        return self
+
+    def release_global(self):
+        """Write this stream's state back into NumPy's global generator."""
+        np.random.set_state(("MT19937", self._buf[:624].copy(), int(self._buf[624]), 0, 0.0))
+
+    def randint(self, low, high, size):
+        n = int(np.prod(size))
+        out = np.empty(n, dtype=np.int64)
+        check(lib.kge_mt_randint(self.ptr, int(low), int(high), out.ctypes.data, n))
+        return out.reshape(size)
+
+    def shuffle(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.int64)
+        check(lib.kge_mt_shuffle(self.ptr, a.ctypes.data, a.shape[0]))
+        if a is not arr:
+            arr[...] = a
+        return arr
+
+
+class PythonStream(_Stream):
+    """Twin of the module-level `random` generator (MT19937 seeded by init_by_array)."""
+
+    def __init__(self, seed=None):
+        super().__init__()
+        if seed is not None:
+            self.seed(seed)
+
+    def seed(self, seed):
+        a = abs(int(seed))  # random.seed(int) hashes nothing: key = 32-bit words of |seed|, little-endian
+        words = []
+        while True:
+            words.append(a & 0xFFFFFFFF)
+            a >>= 32
+            if not a:
+                break
+        key = np.asarray(words, dtype=np.uint32)
+        check(lib.kge_mt_seed_python(self.ptr, key.ctypes.data, len(words)))
+        return self
+
+    def adopt_global(self):
+        ver, st, _ = _pyrandom.getstate()
+        assert ver == 3
+        self._buf[:625] = np.asarray(st, dtype=np.uint32)
+        return self
+
+    def release_global(self):
+        _pyrandom.setstate((3, tuple(int(x) for x in self._buf[:625]), None))
+
+    def choices_idx(self, population, k):
+        out = np.empty(int(k), dtype=np.int64)
+        check(lib.kge_mt_choices(self.ptr, int(population), out.ctypes.data, int(k)))
+        return out
+
+
+def build_batch(np_stream, py_stream, batch, ns, num_e):
+    """generate_negative + oversample_data of one (B,3) batch in one host call (tests.py:55-61).
+    Returns int32 (m,3) pos and neg, m = B*ns."""
+    b = np.ascontiguousarray(batch, dtype=np.int32).reshape(-1, 3)
+    m = b.shape[0] * int(ns)
+    pos = np.empty((m, 3), dtype=np.int32)
+    neg = np.empty((m, 3), dtype=np.int32)
+    check(lib.kge_build_batch_host(np_stream.ptr, py_stream.ptr, b.ctypes.data, b.shape[0], int(ns), int(num_e),
+                                   pos.ctypes.data, neg.ctypes.data))
+    return pos, neg

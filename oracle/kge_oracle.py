@@ -256,6 +256,17 @@ def make_optimizer(name, **kw):
 # ----------------------------------------------------------------------------------------------
 # one training batch: the default Keras train_step over add_loss (tests.py:63-89)
 # ----------------------------------------------------------------------------------------------
+def _scatter_add(G, idx, rows):
+    """G[idx] += rows with duplicates summed ([TF] IndexedSlices dedup).  Sparse mat-vec for big batches."""
+    if len(idx) < 4096:
+        np.add.at(G, idx, rows)
+        return
+    from scipy.sparse import csr_matrix
+    m = len(idx)
+    S = csr_matrix((np.ones(m, dtype=rows.dtype), (idx, np.arange(m))), shape=(G.shape[0], m))
+    G += S @ rows
+
+
 def dense_grads(model, E, Rel, pos, neg, loss, margin=1, negative_samples=1, norm=1, gamma=12, regularization=0.0):
     """Forward on pos and neg with the SAME tables (tests.py:77-78), loss (tests.py:80-81), and the dense
     equivalents of the IndexedSlices gradients (duplicates summed) [TF].  Returns (loss, scores_pos,
@@ -273,9 +284,9 @@ def dense_grads(model, E, Rel, pos, neg, loss, margin=1, negative_samples=1, nor
     gR = np.zeros_like(Rel)
     for t, (s, p, o), g in ((pos, rows[0], gt), (neg, rows[1], gf)):
         ds, dp, do = score_row_grads(model, s, p, o, g.astype(dt), norm, gamma)
-        np.add.at(gE, t[:, 0], ds.astype(dt))
-        np.add.at(gR, t[:, 1], dp.astype(dt))
-        np.add.at(gE, t[:, 2], do.astype(dt))
+        _scatter_add(gE, t[:, 0], ds.astype(dt))
+        _scatter_add(gR, t[:, 1], dp.astype(dt))
+        _scatter_add(gE, t[:, 2], do.astype(dt))
     if regularization:
         w = dt.type(regularization)
         L = L + w * np.sum(np.abs(E) ** 3)

@@ -1,0 +1,223 @@
+"""GPU parity tests (run with -m gpu on the MI355X): every call goes through the C ABI of libkge_hip.so and is
+compared with the oracle on identical inputs.  Tolerance: 1e-4 absolute on fp32 scores / losses / weights
+(BASELINE.json north_star); index work is bit-exact and is covered by the CPU suite."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _mk(model, N, R, d, seed=0, **kw):
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(seed)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    cls = getattr(M, model)
+    mdl = cls(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0, **kw)
+    return mdl, E0, R0, rs
+
+
+def _triples(rs, n, N, R):
+    return np.stack([rs.randint(0, N, n), rs.randint(0, R, n), rs.randint(0, N, n)], 1)
+
+
+CASES = [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)),
+         ("TransE", dict(norm=2, gamma=0)), ("ComplEx", {})]
+
+
+@pytest.mark.parametrize("model,kw", CASES)
+@pytest.mark.parametrize("d", [32, 200, 30, 3])
+@pytest.mark.parametrize("n", [1, 63, 5000])
+def test_score_parity(model, kw, d, n):
+    mdl, E0, R0, rs = _mk(model, 97, 11, d, **kw)
+    t = _triples(rs, n, 97, 11)
+    got = mdl.predict(t)
+    ref = O.call(model, E0, R0, t, kw.get("norm", 1), kw.get("gamma", 12))
+    assert got.shape == (n,) and got.dtype == np.float32
+    np.testing.assert_allclose(got, ref, atol=TOL, rtol=1e-5)
+    # func() on pre-gathered rows goes through the same kernel
+    if n == 63:
+        de = E0.shape[1]
+        f = mdl.func(E0[t[:, 0]], R0[t[:, 1]], E0[t[:, 2]]).cpu().numpy()
+        np.testing.assert_allclose(f, ref, atol=TOL, rtol=1e-5)
+        assert de == mdl.e_dim
+
+
+def test_score_kats():
+    from kge_keras_amd.models import DistMult, TransE, ComplEx
+    E = np.array([[1., 2.], [5., 6.], [0., 5.], [1., 1.]], dtype=np.float32)
+    Rl = np.array([[3., 4.], [1., 1.]], dtype=np.float32)
+    dm = DistMult(e_dim=2, r_dim=2, num_entities=4, num_relations=2, dp=0, init_entities=E, init_relations=Rl)
+    assert dm.predict([[0, 0, 1]])[0] == 63.0  # models.py:172
+    te = TransE(e_dim=2, r_dim=2, num_entities=4, num_relations=2, dp=0, init_entities=E, init_relations=Rl)
+    assert te.predict([[0, 1, 2]])[0] == 8.0  # 12 - (|2| + |-2|)
+    cx = ComplEx(e_dim=1, r_dim=1, num_entities=4, num_relations=2, dp=0, init_entities=E, init_relations=Rl)
+    assert cx.predict([[0, 0, 1]])[0] == 35.0  # Re((1+2i)(3+4i)conj(5+6i))
+
+
+def test_score_fb15k237_real_batches(datasets):
+    """Config 2/3 of BASELINE.json on the real valid+test triples that exist (38 001 rows), d=200."""
+    from kge_keras_amd.models import DistMult, TransE
+    N, R = (int(x) for x in datasets["fb15k237_dims"])
+    t = np.concatenate([datasets["fb15k237_valid"], datasets["fb15k237_test"]])
+    rs = np.random.RandomState(1234)
+    E0, R0 = O.glorot_uniform(N, 200, rs), O.glorot_uniform(R, 200, rs)
+    for cls, name, kw in ((DistMult, "DistMult", {}), (TransE, "TransE", dict(norm=2, gamma=12))):
+        mdl = cls(e_dim=200, r_dim=200, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0, **kw)
+        got = mdl.predict(t)
+        ref = O.call(name, E0, R0, t, kw.get("norm", 1), kw.get("gamma", 12))
+        np.testing.assert_allclose(got, ref, atol=TOL, rtol=1e-5)
+
+
+def test_out_of_range_ids():
+    mdl, E0, R0, rs = _mk("DistMult", 10, 3, 8)
+    with pytest.raises(IndexError):  # host arrays are checked before upload
+        mdl.predict([[0, 0, 10]])
+    bad = torch.tensor([[0, 0, 1], [0, 3, 1], [-1, 0, 1]], dtype=torch.int32, device="cuda")
+    sc = mdl.call(bad).cpu().numpy()
+    assert np.isfinite(sc[0]) and np.isnan(sc[1]) and np.isnan(sc[2])
+    with pytest.raises(IndexError):  # device arrays are checked by the kernel through the error flag
+        mdl._raise_on_flag()
+    assert mdl.predict(np.zeros((0, 3), dtype=np.int64)).shape == (0,)  # empty input
+
+
+LOSSES = ["pointwize_hinge", "pointwize_logistic", "pointwize_square_loss", "pairwize_hinge", "pairwize_logistic",
+          "pairwize_square_loss"]
+
+
+@pytest.mark.parametrize("model,kw", CASES)
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_train_step_parity(model, kw, loss, opt):
+    N, R, d, m = 40, 6, 32, 300
+    mdl, E0, R0, rs = _mk(model, N, R, d, loss_function=loss, margin=0.5, **kw)
+    mdl.compile(opt)
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.make_optimizer(opt)
+    for step in range(3):
+        pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
+        sc = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        L = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+        sp = O.call(model, Eo, Ro, pos, kw.get("norm", 1), kw.get("gamma", 12))
+        sn = O.call(model, Eo, Ro, neg, kw.get("norm", 1), kw.get("gamma", 12))
+        np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12))
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0  # accumulators re-zeroed
+
+
+def test_train_gradients_exact_semantics():
+    """SGD with lr=1 turns the weight delta into the summed sparse gradient: duplicates must accumulate."""
+    from kge_keras_amd.models import DistMult, _Optimizer
+    N, R, d = 5, 2, 8
+    rs = np.random.RandomState(3)
+    E0 = rs.uniform(-1, 1, (N, d)).astype(np.float32)
+    R0 = rs.uniform(-1, 1, (R, d)).astype(np.float32)
+    mdl = DistMult(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0,
+                   loss_function="pointwize_square_loss")
+    mdl.compile(_Optimizer("sgd", lr=1.0))
+    pos = np.array([[0, 0, 1]] * 7 + [[1, 1, 1]])  # same triple seven times + a self-loop (s == o)
+    neg = np.array([[2, 0, 3]] * 4)
+    mdl.train_step([pos, neg])
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    L, _, _, gE, gR = O.dense_grads("DistMult", Eo, Ro, pos, neg, "pointwize_square_loss", 1.0)
+    np.testing.assert_allclose(E0 - mdl.E.cpu().numpy(), gE, atol=2e-5)
+    np.testing.assert_allclose(R0 - mdl.Rel.cpu().numpy(), gR, atol=2e-5)
+    assert np.all(gE[4] == 0) and np.array_equal(mdl.E.cpu().numpy()[4], E0[4])  # untouched row: bit-identical
+
+
+def test_l3_regulariser():
+    mdl, E0, R0, rs = _mk("DistMult", 30, 4, 16, regularization=0.01)
+    mdl.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.AdamTF()
+    for _ in range(2):
+        pos, neg = _triples(rs, 100, 30, 4), _triples(rs, 100, 30, 4)
+        L = float(mdl.train_step([pos, neg])["loss"].item())
+        Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1.0, regularization=0.01)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+
+
+def test_nations_harness_fit_matches_oracle(datasets):
+    """Config 1 of BASELINE.json: nations, DistMult d=32, 10 negatives, B=32, the harness's pairwise hinge with the
+    (m,m) broadcast AND pointwise hinge, Adam, dp=0 -- batches from the bit-exact generator, 12 steps."""
+    from kge_keras_amd.harness import DataGenerator, build_model
+    tr = datasets["nations_train"]
+    N, R = 14, 55
+    for loss in ("pairwize_hinge", "pointwize_hinge"):
+        rs = np.random.RandomState(1234)
+        E0, R0 = O.glorot_uniform(N, 32, rs), O.glorot_uniform(R, 32, rs)
+        mdl = build_model(dict(num_entities=N, num_relations=R, dim=32, embedding_model="DistMult", loss_function=loss,
+                               margin=1, dp=0.0, init_entities=E0, init_relations=R0))
+        np.random.seed(0)
+        random.seed(0)
+        gen = DataGenerator(tr, ns=10, batch_size=32)
+        Eo, Ro, oo = E0.astype(np.float64), R0.astype(np.float64), O.AdamTF()
+        np.random.seed(0)
+        random.seed(0)
+        idx = O.epoch_permutation(len(tr))
+        trl = [tuple(int(v) for v in t) for t in tr]
+        for b in range(12):
+            (pos, neg), _ = gen[b]
+            np_state, py_state = np.random.get_state(), random.getstate()
+            # the oracle consumes the same global streams: rewind to where the generator started this batch
+            L = float(mdl.train_step([pos, neg])["loss"].item())
+            Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, loss, 1.0, 1)
+            assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (loss, b)
+            np.random.set_state(np_state)
+            random.setstate(py_state)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        del idx, trl
+
+
+def test_fit_runs_and_learns(datasets):
+    from kge_keras_amd.harness import DataGenerator, build_model
+    np.random.seed(1)
+    random.seed(1)
+    mdl = build_model(dict(num_entities=14, num_relations=55, dim=32, embedding_model="DistMult",
+                           loss_function="pointwize_logistic", margin=1, dp=0.0, seed=3))
+    gen = DataGenerator(datasets["nations_train"], ns=10, batch_size=32)
+    h = mdl.fit(gen, epochs=4, verbose=0, validation_data=DataGenerator(datasets["nations_valid"], ns=10, batch_size=32))
+    assert len(h.history["loss"]) == 4 and h.history["loss"][-1] < h.history["loss"][0]
+    assert len(h.history["val_loss"]) == 4
+
+
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=2, gamma=12))])
+def test_full_size_fb15k237_step(model, kw):
+    """BASELINE configs 2 and 3 at full size: N=14541, R=237, d=200, B=2048, ns=100 -> 409 600 scored triples."""
+    from kge_keras_amd.sampler import NumpyStream, PythonStream, build_batch
+    from kge_keras_amd import models as M
+    N, R, d, B, ns = 14541, 237, 200, 2048, 100
+    rs = np.random.RandomState(1234)
+    E0, R0 = O.glorot_uniform(N, d, rs), O.glorot_uniform(R, d, rs)
+    if model == "TransE":  # keep scores in the active hinge region
+        E0, R0 = E0 * 20, R0 * 2
+    batch = _triples(rs, B, N, R)
+    pos, neg = build_batch(NumpyStream(0), PythonStream(0), batch, ns, N)
+    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0,
+                            loss_function="pointwize_logistic", **kw)
+    mdl.compile("adam")
+    L = float(mdl.train_step([pos, neg])["loss"].item())
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    Lo = O.train_step(model, Eo, Ro, O.AdamTF(), pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    # size-independent property: the update is a function of the multiset of rows, not of their order
+    mdl2 = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0,
+                             loss_function="pointwize_logistic", **kw)
+    mdl2.compile("adam")
+    perm = np.random.RandomState(5).permutation(len(pos))
+    mdl2.train_step([pos[perm], neg[perm[::-1]]])
+    np.testing.assert_allclose(mdl2.E.cpu().numpy(), mdl.E.cpu().numpy(), atol=2e-5)
