@@ -63,6 +63,62 @@ def cpu_baseline(batches, E0, R0, budget_s=20.0):
                 sample=f"{steps} full-size steps ({n} triples) of the NumPy fp32 oracle (oracle/kge_oracle.py train_step), single thread, {dt:.1f}s")
 
 
+def eval_leg(torch, dist, model, rank, world, reps=3):
+    """1-vs-all ranks/sec on the same FB15k-237-shaped tables: 40 932 queries (20 466 test triples x head/tail),
+    filters = 3 random ids per query.  N > 1: every rank holds a row shard of E, the shards are all-gathered over
+    RCCL into a full table, and the queries are split across ranks (SURVEY 8(e) schedule i)."""
+    import numpy as np
+    from kge_keras_amd import _lib
+    rs = np.random.RandomState(99)
+    nt = 20466
+    test = np.stack([rs.randint(0, CFG["N"], nt), rs.randint(0, CFG["R"], nt), rs.randint(0, CFG["N"], nt)], 1).astype(np.int32)
+    mine = test[rank::world]
+    nq = len(mine)
+    fq = np.repeat(np.arange(nq, dtype=np.int32), 3)
+    fi = rs.randint(0, CFG["N"], 3 * nq).astype(np.int32)
+    keep = (fi != np.repeat(mine[:, 2], 3)) & (fi != np.repeat(mine[:, 0], 3))
+    fq, fi = fq[keep], fi[keep]
+    tq = torch.from_numpy(mine).cuda()
+
+    def sweep():
+        if world > 1:  # all-gather of the row shards into the full table
+            N = CFG["N"]
+            per = (N + world - 1) // world
+            pad = torch.zeros((per * world, CFG["d"]), dtype=torch.float32, device="cuda")
+            shard = model.E[rank * per:min(N, (rank + 1) * per)]
+            mine_pad = torch.zeros((per, CFG["d"]), dtype=torch.float32, device="cuda")
+            mine_pad[:shard.shape[0]] = shard
+            dist.all_gather_into_tensor(pad, mine_pad)
+            model.E.copy_(pad[:N])
+        c0 = model.rank_counts(tq, 0, fq, fi)
+        c1 = model.rank_counts(tq, 1, fq, fi)
+        return c0, c1
+
+    sweep()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.lib.kge_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c0, c1 = sweep()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    _lib.lib.kge_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms, n = _lib.prof_read("rank")
+    total_q = 2 * nt
+    flops = 2.0 * CFG["d"] * CFG["N"]  # SURVEY 8(d): 2*d_e*N per rank
+    return dict(ranks_per_sec=total_q * reps / dt, queries=total_q, ms_per_sweep=dt / reps * 1e3,
+                mfma_tflops_algorithmic=total_q * reps * flops / dt / 1e12, rank_call_avg_ms=ms / max(1, n),
+                mean_rank=float((1 + c0.float().mean() + 1 + c1.float().mean()).item() / 2))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +188,8 @@ def main():
     k_ms, k_n = _lib.prof_read("train_grads")
     o_ms, o_n = _lib.prof_read("opt")
 
+    ev = eval_leg(torch, dist, model, rank, world)
+
     if rank == 0:
         value = per_step * world * args.steps / dt
         k_avg = k_ms / max(1, k_n) * 1e-3
@@ -149,6 +207,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_step * A_TRAIN, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
                          "opt_kernel_avg_ms": o_ms / max(1, o_n)},
         }
+        res["eval_1vsall"] = ev
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(host_batches, E0, R0)
         print(json.dumps(res), flush=True)

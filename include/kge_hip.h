@@ -116,6 +116,27 @@ int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_o
                   float* gradE, float* gradRel, float grad_scale, float* loss_out, void* workspace,
                   int64_t workspace_bytes, kge_stream_t stream);
 
+/* ---- filtered 1-vs-all ranking: `validate` (utils.py:199-264) = gen_tail_data/gen_head_data (:165-196) +
+ *      model.predict (:211,231) + rankdata(res,'max') (:212,232).  For query i (row i of `triples`; side 0 ranks
+ *      the tail o against (s,p,?), side 1 ranks the head s against (?,p,o)):
+ *          counts[i] (+)= #{c in [cand_offset, cand_offset+cand_rows) : c not filtered, score(i,c) > score(i,target_i)}
+ *      so that real_rank = 1 + counts[i] summed over the shards that cover all entities.  E is the full table
+ *      (query vectors and target scores are built from it); E_cand points at the row of global id cand_offset
+ *      (E_cand = E + cand_offset*d_e for a local full table; a row shard otherwise).  The filter is a COO list
+ *      sorted or not: filt_query[e] = query index, filt_ids[e] = global entity id to exclude (the reference's
+ *      filter_t[(s,p)] / filter_h[(p,o)]); it must not contain the target (the reference raises ValueError).
+ *      accumulate != 0 adds into counts (multi-shard loops); otherwise counts is overwritten.
+ *      DistMult and ComplEx run on the fp32 matrix cores; score comparisons are made on bit-identical fmaf chains. */
+int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries);
+int kge_rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* E_cand, int32_t cand_offset,
+                    int32_t cand_rows, const int32_t* triples, int64_t n_queries, int32_t side, const int32_t* filt_query,
+                    const int32_t* filt_ids, int64_t n_filt, int32_t* counts, int32_t accumulate, float* target_scores_out,
+                    void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* Test hook: out[i*num_entities + c] = the score of (query i, candidate c) exactly as the ranking kernels compare it. */
+int kge_rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples,
+                          int64_t n_queries, int32_t side, float* out, void* workspace, int64_t workspace_bytes,
+                          uint32_t* err_flag, kge_stream_t stream);
+
 /* ---- in-library kernel timing (bench.py's roofline leg): when enabled, every launcher brackets its dominant
  *      kernel with hipEvents recorded on the launch stream.  kge_prof_read synchronises those events, returns the
  *      summed duration (ms) and launch count for one label and clears that label.  Off by default. */

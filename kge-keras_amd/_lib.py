@@ -41,6 +41,9 @@ SIGNATURES = {
     "kge_last_error": (C.c_char_p, []),
     "kge_abi_version": (C.c_int, []),
     "kge_device_props": (C.c_int, [_P]),
+    "kge_rank_workspace_bytes": (_I64, [_MD, _I64]),
+    "kge_rank_counts": (C.c_int, [_MD, _P, _P, _P, _I32, _I32, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _P, _I64, _P, _P]),
+    "kge_rank_chain_scores": (C.c_int, [_MD, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _P]),
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),
     "kge_score": (C.c_int, [_MD, _P, _P, _P, _I64, _P, _P, _P]),

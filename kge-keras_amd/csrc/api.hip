@@ -89,6 +89,12 @@ int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
               int64_t, hipStream_t);
 
+int64_t rank_workspace_bytes(const kge_model_desc*, int64_t);
+int rank_counts(const kge_model_desc*, const float*, const float*, const float*, int, int, const int32_t*, int64_t, int,
+                const int32_t*, const int32_t*, int64_t, int32_t*, int, float*, void*, int64_t, uint32_t*, hipStream_t);
+int rank_chain_scores(const kge_model_desc*, const float*, const float*, const int32_t*, int64_t, int, float*, void*, int64_t,
+                      uint32_t*, hipStream_t);
+
 }  // namespace kge
 
 using namespace kge;
@@ -189,6 +195,37 @@ int kge_train_step(const kge_model_desc* md, const kge_loss_desc* ld, const kge_
   if (int rc = train_grads(md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, scores_out, seed, workspace,
                            workspace_bytes, err_flag, st)) return rc;
   return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, st);
+}
+
+int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries) {
+  if (check_model(md, "kge_rank_workspace_bytes")) return KGE_EINVAL;
+  if (n_queries < 0) return fail(KGE_EINVAL, "negative query count");
+  return rank_workspace_bytes(md, n_queries);
+}
+
+int kge_rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* E_cand, int32_t cand_offset,
+                    int32_t cand_rows, const int32_t* triples, int64_t n_queries, int32_t side, const int32_t* filt_query,
+                    const int32_t* filt_ids, int64_t n_filt, int32_t* counts, int32_t accumulate, float* target_scores_out,
+                    void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_model(md, "kge_rank_counts")) return rc;
+  if (n_queries < 0 || n_filt < 0) return fail(KGE_EINVAL, "kge_rank_counts: negative size");
+  if (n_queries == 0) return KGE_OK;
+  if (side != 0 && side != 1) return fail(KGE_EINVAL, "kge_rank_counts: side must be 0 (tail) or 1 (head)");
+  if (!E || !Rel || !E_cand || !triples || !counts || !workspace || !err_flag || (n_filt && (!filt_query || !filt_ids)))
+    return fail(KGE_EINVAL, "kge_rank_counts: null pointer");
+  if (cand_offset < 0 || cand_rows <= 0 || (int64_t)cand_offset + cand_rows > md->num_entities)
+    return fail(KGE_EINVAL, "kge_rank_counts: candidate range [%d,%d) outside [0,%d)", cand_offset, cand_offset + cand_rows, md->num_entities);
+  return rank_counts(md, E, Rel, E_cand, cand_offset, cand_rows, triples, n_queries, side, filt_query, filt_ids, n_filt, counts,
+                     accumulate, target_scores_out, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n_queries,
+                          int32_t side, float* out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                          kge_stream_t stream) {
+  if (int rc = check_model(md, "kge_rank_chain_scores")) return rc;
+  if (n_queries <= 0 || !E || !Rel || !triples || !out || !workspace || !err_flag) return fail(KGE_EINVAL, "kge_rank_chain_scores: bad arguments");
+  return rank_chain_scores(md, E, Rel, triples, n_queries, side, out, workspace, workspace_bytes, err_flag,
+                           static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

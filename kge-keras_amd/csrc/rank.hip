@@ -1,0 +1,291 @@
+// Filtered 1-vs-all ranking: the evaluation half of the hot path.
+//
+// Replaces (reference repo) KGEkeras/utils.py:199-264 `validate`: per test triple the reference builds the list of
+// all entities minus the target minus the filtered ones (gen_tail_data / gen_head_data, :165-196), scores it with
+// model.predict (:211,231) and takes rankdata(res,'max') (:212,232), i.e.
+//     real_rank = 1 + #{kept candidates c : score_c > score_target}                    (strict; ties optimistic)
+//
+// Here, for DistMult and ComplEx the score of (query q, candidate c) is the dot product of a per-query vector
+// Qv[q] with the candidate's table row (DistMult tail: s*p, head: p*o; ComplEx: the two products derived from
+// models.py:218-222), so the whole sweep is Qv . E^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-for-bit a k-ordered fmaf chain) with the count-greater test fused into the epilogue: the score matrix never
+// exists in memory.  The target score and the scores of the (few) filtered candidates are recomputed by scalar
+// kernels that run the SAME fmaf chain in the SAME k order, so "score_c > score_target" is decided on bit-identical
+// numbers everywhere and a candidate can be un-counted exactly.
+//
+//   rank_build_q_kernel   : Qv[q][0..Kpad) (zero padded)                                    one sub-group per query
+//   rank_target_kernel    : tgt[q] = chain(Qv[q], E[target_q]); counts[q] = 0               one thread per query
+//   rank_sweep_kernel     : counts[q] += #{c in [0,rows) : chain(Qv[q], Ec[c]) > tgt[q]}    MFMA, 128x128 block tiles
+//   rank_filter_kernel    : counts[q] -= [chain(Qv[q], E[c]) > tgt[q]] for filtered (q,c)   one thread per CSR entry
+//
+// k order of the chain (what one 32x32x2 MFMA stream over an LDS tile read with ds_read_b128 produces): inside every
+// aligned block of 8 k-values the order is 0,4,1,5,2,6,3,7 (lane half 0 holds k..k+3, half 1 holds k+4..k+7; MFMA i
+// of the block consumes element i of both halves, half 0 first).
+#include "kge_internal.hpp"
+
+namespace kge {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kTile = 128;  // block tile: 128 queries x 128 candidates, 4 waves as 2x2 of 64x64
+
+__device__ __forceinline__ float chain_dot(const float* __restrict__ q, const float* __restrict__ e, int K, int Kpad) {
+  float acc = 0.f;
+  for (int k0 = 0; k0 < Kpad; k0 += 8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ka = k0 + i, kb = k0 + 4 + i;
+      acc = __fmaf_rn(q[ka], ka < K ? e[ka] : 0.f, acc);
+      acc = __fmaf_rn(q[kb], kb < K ? e[kb] : 0.f, acc);
+    }
+  }
+  return acc;
+}
+
+// side 0 = tail queries (s,p,?) ; side 1 = head queries (?,p,o)
+template <int MODEL>
+__global__ __launch_bounds__(256) void rank_build_q_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
+                                                            const int32_t* __restrict__ triples, int64_t nq, int side, int N,
+                                                            int R, int d_e, int Kpad, float* __restrict__ Qv,
+                                                            uint32_t* __restrict__ err) {
+  constexpr int G = 64;
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (q >= nq) return;
+  const int s = triples[3 * q + 0], p = triples[3 * q + 1], o = triples[3 * q + 2];
+  const int ent = side == 0 ? s : o;
+  const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+  const float* er = E + (int64_t)(ok ? ent : 0) * d_e;
+  const float* rp = Rel + (int64_t)(ok ? p : 0) * d_e;
+  float* out = Qv + q * Kpad;
+  if (!ok && lane == 0) atomicOr(err, 1u);
+  if (MODEL == KGE_DISTMULT) {
+    for (int k = lane; k < Kpad; k += G) out[k] = (ok && k < d_e) ? er[k] * rp[k] : 0.f;
+  } else {  // ComplEx, rows are [real | imag]
+    const int h = d_e >> 1;
+    for (int k = lane; k < Kpad; k += G) {
+      float v = 0.f;
+      if (ok && k < d_e) {
+        const int kk = k < h ? k : k - h;
+        const float xr = er[kk], xi = er[h + kk], pr = rp[kk], pi = rp[h + kk];
+        if (side == 0) v = k < h ? xr * pr - xi * pi : xi * pr + xr * pi;      // coefficients of o_real | o_imag
+        else v = k < h ? pr * xr + pi * xi : pr * xi - pi * xr;                // coefficients of s_real | s_imag
+      }
+      out[k] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rank_target_kernel(const float* __restrict__ Qv, const float* __restrict__ E,
+                                                           const int32_t* __restrict__ triples, int64_t nq, int side, int N,
+                                                           int d_e, int Kpad, float* __restrict__ tgt,
+                                                           int32_t* __restrict__ counts, int zero_counts) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int t = triples[3 * q + (side == 0 ? 2 : 0)];
+  const bool ok = (unsigned)t < (unsigned)N;
+  tgt[q] = ok ? chain_dot(Qv + q * Kpad, E + (int64_t)t * d_e, d_e, Kpad) : __builtin_nanf("");
+  if (zero_counts) counts[q] = 0;
+}
+
+template <int BK, bool VEC4>
+__global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
+                                                          int64_t nq, const float* __restrict__ Ec, int K, int Kpad,
+                                                          int cand_rows, int tiles_per_block, int32_t* __restrict__ counts) {
+  constexpr int LS = BK + 4;         // LDS row stride in floats: (BK+4)/4 odd -> conflict-free ds_read_b128
+  constexpr int C4 = BK / 4;         // float4 per tile row
+  __shared__ __attribute__((aligned(16))) float As[kTile * LS];
+  __shared__ __attribute__((aligned(16))) float Bs[kTile * LS];
+  __shared__ int cnt_s[kTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int64_t q0 = (int64_t)blockIdx.x * kTile;
+  const int nct = (cand_rows + kTile - 1) / kTile;
+  const int ct_begin = blockIdx.y * tiles_per_block;
+  const int ct_end = min(nct, ct_begin + tiles_per_block);
+
+  float tg[2][16];
+  int cnt[2][16];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = q0 + wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      tg[rt][r] = row < nq ? tgt[row] : __builtin_inff();  // nothing is > +inf; NaN targets count nothing either
+      cnt[rt][r] = 0;
+    }
+  if (tid < kTile) cnt_s[tid] = 0;
+
+  for (int ct = ct_begin; ct < ct_end; ++ct) {
+    const int c0 = ct * kTile;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int k0 = 0; k0 < Kpad; k0 += BK) {
+      __syncthreads();  // everyone is done reading the previous chunk
+      for (int idx = tid; idx < kTile * C4; idx += 256) {
+        const int r = idx / C4, c4 = idx - r * C4;
+        const int k = k0 + c4 * 4;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (q0 + r < nq) va = *reinterpret_cast<const float4*>(Qv + (q0 + r) * Kpad + k);  // Qv is zero padded to Kpad
+        const int cr = c0 + r;
+        if (cr < cand_rows) {
+          const float* src = Ec + (int64_t)cr * K + k;
+          if (VEC4) {
+            if (k < K) vb = *reinterpret_cast<const float4*>(src);  // K % 4 == 0
+          } else {
+            if (k + 0 < K) vb.x = src[0];
+            if (k + 1 < K) vb.y = src[1];
+            if (k + 2 < K) vb.z = src[2];
+            if (k + 3 < K) vb.w = src[3];
+          }
+        }
+        *reinterpret_cast<float4*>(As + r * LS + c4 * 4) = va;
+        *reinterpret_cast<float4*>(Bs + r * LS + c4 * 4) = vb;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < BK / 8; ++j) {
+        float4 a[2], b[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          a[x] = *reinterpret_cast<const float4*>(As + (wq * 64 + x * 32 + l31) * LS + 8 * j + 4 * half);
+          b[x] = *reinterpret_cast<const float4*>(Bs + (wc * 64 + x * 32 + l31) * LS + 8 * j + 4 * half);
+        }
+#define KGE_STEP(comp)                                                                                         \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].comp, b[0].comp, acc[0][0], 0, 0, 0);                  \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].comp, b[1].comp, acc[0][1], 0, 0, 0);                  \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1].comp, b[0].comp, acc[1][0], 0, 0, 0);                  \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1].comp, b[1].comp, acc[1][1], 0, 0, 0);
+        KGE_STEP(x) KGE_STEP(y) KGE_STEP(z) KGE_STEP(w)
+#undef KGE_STEP
+      }
+    }
+    // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
+    const bool last = c0 + kTile > cand_rows;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const bool valid = !last || (c0 + wc * 64 + cb * 32 + l31 < cand_rows);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnt[rt][r] += (valid && acc[rt][cb][r] > tg[rt][r]) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
+    }
+  __syncthreads();
+  if (tid < kTile && q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
+}
+
+// One thread per CSR entry (query pair_q[e], filtered global id filt_ids[e]); un-counts it if it was counted.
+__global__ __launch_bounds__(256) void rank_filter_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
+                                                           const float* __restrict__ Ec, int cand_offset, int cand_rows,
+                                                           int K, int Kpad, const int32_t* __restrict__ pair_q,
+                                                           const int32_t* __restrict__ filt_ids, int64_t npairs,
+                                                           int32_t* __restrict__ counts) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npairs) return;
+  const int q = pair_q[e];
+  const int c = filt_ids[e] - cand_offset;
+  if ((unsigned)c >= (unsigned)cand_rows) return;  // another shard owns this candidate
+  const float sc = chain_dot(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, Kpad);
+  if (sc > tgt[q]) atomicSub(&counts[q], 1);
+}
+
+// Debug / test hook: the score matrix entry as the chain computes it.
+__global__ void rank_chain_scores_kernel(const float* __restrict__ Qv, const float* __restrict__ Ec, int K, int Kpad,
+                                          int64_t nq, int cand_rows, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * cand_rows) return;
+  const int64_t q = i / cand_rows;
+  const int c = (int)(i - q * cand_rows);
+  out[i] = chain_dot(Qv + q * Kpad, Ec + (int64_t)c * K, K, Kpad);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int pick_bk(int K) {
+  // least padding among the chunk widths built; (BK+4)/4 must be odd
+  const int cands[2] = {40, 32};
+  int best = 32, waste = 1 << 30;
+  for (int bk : cands) {
+    const int w = (int)align_up(K, bk) - K;
+    if (w < waste) { waste = w; best = bk; }
+  }
+  return best;
+}
+
+int rank_kpad(int K) { return (int)align_up(K, pick_bk(K)); }
+
+int64_t rank_workspace_bytes(const kge_model_desc* md, int64_t nq) {
+  return (int64_t)sizeof(float) * (nq * rank_kpad(md->d_e) + align_up(nq, 64)) + 512;
+}
+
+int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* Ec, int cand_offset, int cand_rows,
+                const int32_t* triples, int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs,
+                int32_t* counts, int accumulate, float* tgt_out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX)
+    return fail(KGE_EUNSUPPORTED, "kge_rank_counts: model %d has no 1-vs-all kernel yet (DistMult and ComplEx are built)", md->model);
+  const int K = md->d_e, BK = pick_bk(K), Kpad = (int)align_up(K, BK);
+  if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_counts: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)rank_workspace_bytes(md, nq));
+  uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  float* Qv = reinterpret_cast<float*>(p);
+  float* tgt = tgt_out ? tgt_out : Qv + nq * Kpad;
+  ProfScope prof(KGE_PROF_RANK, st);
+  {
+    const int grid = (int)cdiv(nq * 64, 256);
+    if (md->model == KGE_DISTMULT)
+      hipLaunchKernelGGL((rank_build_q_kernel<KGE_DISTMULT>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+    else
+      hipLaunchKernelGGL((rank_build_q_kernel<KGE_COMPLEX>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+  }
+  hipLaunchKernelGGL(rank_target_kernel, dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
+  {
+    const int nqt = (int)cdiv(nq, kTile), nct = (int)cdiv(cand_rows, kTile);
+    int splits = (int)cdiv(4 * kCUs, nqt);
+    splits = std::max(1, std::min(splits, nct));
+    const int tpb = (int)cdiv(nct, splits);
+    splits = (int)cdiv(nct, tpb);
+    const bool v4 = (K % 4 == 0) && ((uintptr_t)Ec % 16 == 0);
+    dim3 grid(nqt, splits);
+#define KGE_SWEEP(BKV, V4) hipLaunchKernelGGL((rank_sweep_kernel<BKV, V4>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
+    if (BK == 40) { if (v4) KGE_SWEEP(40, true); else KGE_SWEEP(40, false); }
+    else { if (v4) KGE_SWEEP(32, true); else KGE_SWEEP(32, false); }
+#undef KGE_SWEEP
+  }
+  if (npairs > 0)
+    hipLaunchKernelGGL(rank_filter_kernel, dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+int rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side,
+                      float* out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX) return fail(KGE_EUNSUPPORTED, "kge_rank_chain_scores: model %d", md->model);
+  const int K = md->d_e, Kpad = rank_kpad(K);
+  if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_chain_scores: workspace too small");
+  uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  float* Qv = reinterpret_cast<float*>(p);
+  const int grid = (int)cdiv(nq * 64, 256);
+  if (md->model == KGE_DISTMULT)
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_DISTMULT>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+  else
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_COMPLEX>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+  const int64_t tot = nq * md->num_entities;
+  hipLaunchKernelGGL(rank_chain_scores_kernel, dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, nq, md->num_entities, out);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+}  // namespace kge

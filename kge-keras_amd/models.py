@@ -334,6 +334,62 @@ class EmbeddingModel:
                                  self._err.data_ptr(), _lib.stream_ptr()))
         return self._loss[0].clone()
 
+    # ------------------------------------------------------------------ filtered 1-vs-all ranking (utils.py:165-264)
+    @staticmethod
+    def _filter_coo(test, num_entities, filt, side):
+        """COO (query index, excluded id) of the reference's filter sets; ValueError where list.remove would raise."""
+        qs, ids = [], []
+        for i, (s, p, o) in enumerate(test):
+            target, key = (o, (s, p)) if side == 0 else (s, (p, o))
+            if not 0 <= target < num_entities:
+                raise ValueError("list.remove(x): x not in list")
+            fl = filt.get(key) if hasattr(filt, "get") else filt[key]
+            if not fl:
+                continue
+            for x in fl:
+                if x == target or not 0 <= x < num_entities:
+                    raise ValueError("list.remove(x): x not in list")  # utils.py:168-171 / :184-188
+            qs.extend([i] * len(fl))
+            ids.extend(fl)
+        return np.asarray(qs, dtype=np.int32), np.asarray(ids, dtype=np.int32)
+
+    def rank_counts(self, triples, side, filt_q, filt_ids, num_entities=None, cand_offset=0, cand_rows=None, counts=None):
+        """counts[i] = #{kept candidates c in the range with score(i,c) > score(i,target_i)} on the GPU."""
+        t = as_triples(triples, self.device, self.num_entities, self.num_relations)
+        nq = t.shape[0]
+        num_entities = self.num_entities if num_entities is None else int(num_entities)
+        cand_rows = num_entities - cand_offset if cand_rows is None else cand_rows
+        md = self._model_desc(False)
+        need = check(lib.kge_rank_workspace_bytes(C.byref(md), nq))
+        if getattr(self, "_rank_ws", None) is None or self._rank_ws.numel() < need:
+            self._rank_ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        fq = torch.from_numpy(np.ascontiguousarray(filt_q, dtype=np.int32)).to(self.device)
+        fi = torch.from_numpy(np.ascontiguousarray(filt_ids, dtype=np.int32)).to(self.device)
+        acc = counts is not None
+        if counts is None:
+            counts = torch.empty(nq, dtype=torch.int32, device=self.device)
+        ec_ptr = self.E.data_ptr() + 4 * int(cand_offset) * int(self.e_dim)
+        check(lib.kge_rank_counts(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), ec_ptr, int(cand_offset), int(cand_rows),
+                                  t.data_ptr(), nq, int(side), fq.data_ptr() if fq.numel() else None,
+                                  fi.data_ptr() if fi.numel() else None, fq.numel(), counts.data_ptr(), 1 if acc else 0, None,
+                                  self._rank_ws.data_ptr(), self._rank_ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        return counts
+
+    def rank(self, test_data, num_entities, filter_t, filter_h, chunk=32768):
+        """(tail_ranks, head_ranks) of `validate` (utils.py:199-264): real_rank = 1 + #{kept c: score_c > score_target}."""
+        test = [tuple(int(v) for v in t) for t in test_data]
+        out = []
+        for side, filt in ((0, filter_t), (1, filter_h)):
+            ranks = np.empty(len(test), dtype=np.int64)
+            for a in range(0, len(test), chunk):
+                part = test[a:a + chunk]
+                fq, fi = self._filter_coo(part, num_entities, filt, side)
+                cnt = self.rank_counts(np.asarray(part, dtype=np.int32), side, fq, fi, num_entities)
+                ranks[a:a + chunk] = 1 + cnt.cpu().numpy().astype(np.int64)
+            self._raise_on_flag()
+            out.append(ranks)
+        return out[0], out[1]
+
     # ------------------------------------------------------------------ weights I/O (checkpointing)
     def get_weights(self):
         return self.entity_embedding.get_weights() + self.relational_embedding.get_weights()

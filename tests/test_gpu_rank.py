@@ -1,0 +1,171 @@
+"""GPU parity of the filtered 1-vs-all ranking (utils.py:199-264) through kge_rank_counts."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(model, N, R, d, seed=0, quant=None):
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(seed)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-1, 1, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-1, 1, (R, dr)).astype(np.float32)
+    if quant:
+        E0 = (np.round(E0 * quant) / quant).astype(np.float32)
+        R0 = (np.round(R0 * quant) / quant).astype(np.float32)
+    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0)
+    return mdl, E0, R0, rs
+
+
+def _ids(a):
+    return [tuple(int(x) for x in t) for t in a]
+
+
+def _check_ranks(model, mdl, E0, R0, test, filt, N):
+    fh, ft = O.build_filters(filt)
+    tails, heads = mdl.rank(test, N, ft, fh)
+    gaps = []
+    to, ho = O.ranks_closed_form(model, E0, R0, test, filt, margin_out=gaps)
+    gaps = np.asarray(gaps).reshape(-1, 2)
+    # fp32 rounding of a K-term dot product is <~ 2^-23 * K * max|term|
+    tol = 5e-7 * E0.shape[1] * float(np.abs(E0).max() ** 2 * np.abs(R0).max())
+    for got, ref, gap in ((tails, to, gaps[:, 0]), (heads, ho, gaps[:, 1])):
+        clear = gap > tol  # no candidate within float32 noise of the target: rank must be exact
+        assert clear.mean() > 0.5
+        assert np.array_equal(got[clear], ref[clear])
+        assert np.all(np.abs(got[~clear] - ref[~clear]) <= 2)
+    return tails, heads, to, ho
+
+
+@pytest.mark.parametrize("model", ["DistMult", "ComplEx"])
+@pytest.mark.parametrize("N,d,nq", [(14, 32, 40), (300, 200, 257), (1000, 30, 64), (129, 8, 1)])
+def test_rank_parity_random(model, N, d, nq):
+    mdl, E0, R0, rs = _mk(model, N, 7, d)
+    test = list({(int(rs.randint(N)), int(rs.randint(7)), int(rs.randint(N))) for _ in range(nq)})
+    # filters: random other triples sharing (s,p) or (p,o) with the test triples, never the test triples themselves
+    tes = set(test)
+    filt = set()
+    for (s, p, o) in test:
+        for _ in range(int(rs.randint(0, 6))):
+            c = (s, p, int(rs.randint(N)))
+            if c not in tes:
+                filt.add(c)
+            c = (int(rs.randint(N)), p, o)
+            if c not in tes:
+                filt.add(c)
+    _check_ranks(model, mdl, E0, R0, test, sorted(filt), N)
+
+
+def test_rank_mfma_bit_exact_vs_chain():
+    """The sweep's count must equal the count taken on the chain scores (the numbers the filter kernel and the target
+    use): this is what makes un-counting filtered candidates exact.  Coarse-grid tables give many exact ties."""
+    from kge_keras_amd import _lib
+    for model, quant in (("DistMult", None), ("DistMult", 2), ("ComplEx", 2)):
+        N, d, nq = 517, 40, 200
+        mdl, E0, R0, rs = _mk(model, N, 5, d, seed=3, quant=quant)
+        test = np.stack([rs.randint(0, N, nq), rs.randint(0, 5, nq), rs.randint(0, N, nq)], 1).astype(np.int32)
+        for side in (0, 1):
+            cnt = mdl.rank_counts(test, side, np.zeros(0, np.int32), np.zeros(0, np.int32)).cpu().numpy()
+            t = torch.from_numpy(test).cuda()
+            md = mdl._model_desc(False)
+            out = torch.empty((nq, N), dtype=torch.float32, device="cuda")
+            _lib.check(_lib.lib.kge_rank_chain_scores(C.byref(md), mdl.E.data_ptr(), mdl.Rel.data_ptr(), t.data_ptr(), nq, side,
+                                                      out.data_ptr(), mdl._rank_ws.data_ptr(), mdl._rank_ws.numel(),
+                                                      mdl._err.data_ptr(), _lib.stream_ptr()))
+            sc = out.cpu().numpy()
+            tgt = sc[np.arange(nq), test[:, 2] if side == 0 else test[:, 0]]
+            ref = (sc > tgt[:, None]).sum(1)
+            assert np.array_equal(cnt, ref), (model, quant, side, np.abs(cnt - ref).max())
+            # and the chain scores are the model's scores to fp32 accuracy
+            cols = np.arange(N)
+            q0 = test[0]
+            tri = np.stack([np.full(N, q0[0]) if side == 0 else cols, np.full(N, q0[1]), cols if side == 0 else np.full(N, q0[2])], 1)
+            np.testing.assert_allclose(sc[0], O.call(model, E0, R0, tri), atol=1e-4, rtol=1e-5)
+
+
+def test_rank_ties_are_optimistic():
+    """Quantised tables: exact score ties between target and candidates must NOT count (strict >), as rankdata 'max' gives."""
+    mdl, E0, R0, rs = _mk("DistMult", 64, 3, 8, seed=6, quant=1)  # entries in {-1,0,1}: integer scores, exact in fp32
+    test = list({(int(rs.randint(64)), int(rs.randint(3)), int(rs.randint(64))) for _ in range(50)})
+    tails, heads = mdl.rank(test, 64, {}, {})
+    to, ho = O.ranks_closed_form("DistMult", E0, R0, test, [])
+    assert np.array_equal(tails, to) and np.array_equal(heads, ho)
+    assert (to < 64).all() and len(set(to.tolist())) > 3
+
+
+def test_validate_golden_metrics_on_gpu(golden, datasets):
+    """utils.validate with the GPU ranker reproduces the reference's metric dict for its own DistMult numpy model."""
+    from kge_keras_amd import utils as U
+    from kge_keras_amd.models import DistMult
+    for c in golden("validate")["cases"]:
+        m = c["model"]
+        rs = np.random.RandomState(m["seed"])
+        E = rs.uniform(-1, 1, (m["N"], m["d"]))
+        Rl = rs.uniform(-1, 1, (m["R"], m["d"]))
+        if m["quant"]:
+            E, Rl = np.round(E * m["quant"]) / m["quant"], np.round(Rl * m["quant"]) / m["quant"]
+        mdl = DistMult(e_dim=m["d"], r_dim=m["d"], num_entities=m["N"], num_relations=m["R"], dp=0, init_entities=E, init_relations=Rl)
+        ds = c["dataset"]
+        tes = set(_ids(datasets[ds + "_test"]))
+        filt = [t for t in _ids(datasets[ds + "_train"]) + _ids(datasets[ds + "_valid"]) if t not in tes]
+        met = U.validate(mdl, c["test"], m["N"], 32, filtering_triples=filt)
+        assert list(met.keys()) == list(c["metrics"].keys())
+        if m["quant"]:  # exact arithmetic on the coarse grid: identical ranks, identical metrics
+            for k, v in c["metrics"].items():
+                assert met[k] == pytest.approx(v, abs=1e-12), k
+        else:  # fp32 tables vs the reference's fp64: ranks can move only on float-noise ties
+            for k in ("mr", "tail_mr", "head_mr"):
+                assert met[k] == pytest.approx(c["metrics"][k], rel=2e-3), k
+            for k in ("mrr", "hits@10"):
+                assert met[k] == pytest.approx(c["metrics"][k], abs=2e-2), k
+
+
+def test_rank_error_behaviour():
+    from kge_keras_amd import utils as U
+    mdl, E0, R0, rs = _mk("DistMult", 14, 5, 8)
+    with pytest.raises(ValueError):  # test triple inside its own filter (utils.py:168-171)
+        U.validate(mdl, [(0, 1, 2)], 14, 32, filtering_triples=[(0, 1, 2)])
+    with pytest.raises(TypeError):
+        U.validate(mdl, [(0, 1, 2)], 14, 32)
+
+
+def test_rank_sharded_candidates_sum_to_unsharded():
+    """Row-sharded sweep (SURVEY 8(e) schedule ii on one GPU): counts over candidate shards add up exactly."""
+    mdl, E0, R0, rs = _mk("DistMult", 1000, 4, 64, seed=9)
+    nq = 300
+    test = np.stack([rs.randint(0, 1000, nq), rs.randint(0, 4, nq), rs.randint(0, 1000, nq)], 1).astype(np.int32)
+    fq = np.repeat(np.arange(nq, dtype=np.int32), 3)
+    fi = rs.randint(0, 1000, 3 * nq).astype(np.int32)
+    keep = fi != np.repeat(test[:, 2], 3)
+    fq, fi = fq[keep], fi[keep]
+    full = mdl.rank_counts(test, 0, fq, fi).cpu().numpy()
+    acc = None
+    for a, b in ((0, 125), (125, 500), (500, 1000)):
+        acc = mdl.rank_counts(test, 0, fq, fi, cand_offset=a, cand_rows=b - a, counts=acc)
+    assert np.array_equal(full, acc.cpu().numpy())
+
+
+def test_rank_wn18rr_complex_slice(datasets):
+    """BASELINE config 4 shape: WN18RR (N=40943, R=11), ComplEx d=400 -> K=800, real test triples, real filters."""
+    from kge_keras_amd.models import ComplEx
+    N, R, d = 40943, 11, 400
+    rs = np.random.RandomState(1234)
+    E0, R0 = O.glorot_uniform(N, 2 * d, rs), O.glorot_uniform(R, 2 * d, rs)
+    mdl = ComplEx(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0)
+    test = _ids(datasets["wn18rr_test"][:48])
+    tes = set(_ids(datasets["wn18rr_test"]))
+    filt = [t for t in _ids(datasets["wn18rr_train"]) + _ids(datasets["wn18rr_valid"]) if t not in tes]
+    fh, ft = O.build_filters(filt)
+    tails, heads = mdl.rank(test, N, ft, fh)
+    gaps = []
+    to, ho = O.ranks_closed_form("ComplEx", E0, R0, test, filt, margin_out=gaps)
+    gaps = np.asarray(gaps).reshape(-1, 2)
+    # Glorot tables give scores ~1e-4; a rank may move by the handful of candidates within fp32 noise of the target
+    assert np.all(np.abs(tails - to) <= 3) and np.all(np.abs(heads - ho) <= 3)
+    assert (tails == to).mean() > 0.8 and (heads == ho).mean() > 0.8
