@@ -186,14 +186,24 @@ def main():
     model._raise_on_flag()
     loss = float(model._loss.item())
     k_ms, k_n = _lib.prof_read("train_grads")
+    f_ms, f_n = _lib.prof_read("fwd")
     o_ms, o_n = _lib.prof_read("opt")
 
     ev = eval_leg(torch, dist, model, rank, world)
 
     if rank == 0:
         value = per_step * world * args.steps / dt
-        k_avg = k_ms / max(1, k_n) * 1e-3
-        achieved = per_step * A_TRAIN / k_avg if k_n else 0.0
+        # pull path: two gather kernels (fwd_kernel: A_FWD per triple; pull_kernel: A_BWD per triple); push path: one
+        # fused kernel carrying A_TRAIN.  The roofline object is for the dominant (longest) one.
+        kernels = {}
+        if f_n:
+            kernels["fwd_kernel (gather+score+loss)"] = (f_ms / f_n * 1e-3, per_step * A_FWD)
+            kernels["pull_kernel (per-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, per_step * A_BWD)
+        else:
+            kernels["push_kernel (gather+score+loss+atomic grad)"] = (k_ms / max(1, k_n) * 1e-3, per_step * A_TRAIN)
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        k_avg, k_bytes = kernels[dom]
+        achieved = k_bytes / k_avg if k_avg else 0.0
         res = {
             "metric": "scored triples/sec (train, 100 neg), FB15k-237 d=200", "value": value, "unit": "scored triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -202,9 +212,11 @@ def main():
                        "N": CFG["N"], "R": CFG["R"], "d": CFG["d"], "B": CFG["B"], "ns": CFG["ns"],
                        "parallelism": f"dp{world}" if world > 1 else "single", "sampler": "bit-exact MT19937 batches pre-built on host, resident in HBM",
                        "final_loss": loss},
-            "roofline": {"bound": "hbm", "kernel": "push_kernel (gather+score+loss+grad)", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
-                         "algorithmic_bytes_per_launch": per_step * A_TRAIN, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
+                         "algorithmic_bytes_per_launch": k_bytes, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
+                         "all_kernels": {k: {"avg_ms": v[0] * 1e3, "algorithmic_GBps": v[1] / v[0] / 1e9} for k, v in kernels.items()},
+                         "whole_step_algorithmic_GBps": per_step * A_TRAIN / (dt / args.steps) / 1e9,
                          "opt_kernel_avg_ms": o_ms / max(1, o_n)},
         }
         res["eval_1vsall"] = ev

@@ -137,11 +137,15 @@ int kge_rank_chain_scores(const kge_model_desc* md, const float* E, const float*
                           int64_t n_queries, int32_t side, float* out, void* workspace, int64_t workspace_bytes,
                           uint32_t* err_flag, kge_stream_t stream);
 
+/* Gradient path of kge_train_step / kge_train_grads: 0 (default) = "pull": per-destination-row gather-reduce, no float
+ * atomics; 1 = "push": fused forward + no-return fp32 global atomics.  Same results to fp32 rounding. */
+int kge_set_grad_mode(int mode);
+
 /* ---- in-library kernel timing (bench.py's roofline leg): when enabled, every launcher brackets its dominant
  *      kernel with hipEvents recorded on the launch stream.  kge_prof_read synchronises those events, returns the
  *      summed duration (ms) and launch count for one label and clears that label.  Off by default. */
 typedef enum { KGE_PROF_TRAIN_GRADS = 0, KGE_PROF_OPT = 1, KGE_PROF_SCORE = 2, KGE_PROF_PAIRWISE = 3, KGE_PROF_RANK = 4,
-               KGE_PROF_SAMPLER = 5, KGE_PROF_NLABELS = 6 } kge_prof_label;
+               KGE_PROF_SAMPLER = 5, KGE_PROF_FWD = 6, KGE_PROF_NLABELS = 7 } kge_prof_label;
 int kge_prof_enable(int on);
 int kge_prof_read(int label, double* total_ms, int64_t* launches);
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "kge_rank_workspace_bytes": (_I64, [_MD, _I64]),
     "kge_rank_counts": (C.c_int, [_MD, _P, _P, _P, _I32, _I32, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _P, _I64, _P, _P]),
     "kge_rank_chain_scores": (C.c_int, [_MD, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _P]),
+    "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),
     "kge_score": (C.c_int, [_MD, _P, _P, _P, _I64, _P, _P, _P]),
@@ -65,7 +66,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 
-PROF_LABELS = {"train_grads": 0, "opt": 1, "score": 2, "pairwise": 3, "rank": 4, "sampler": 5}
+PROF_LABELS = {"train_grads": 0, "opt": 1, "score": 2, "pairwise": 3, "rank": 4, "sampler": 5, "fwd": 6}
 
 
 def prof_read(label):

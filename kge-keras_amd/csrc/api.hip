@@ -76,6 +76,23 @@ int score_group_width(int nchunk) {
   return g < 4 ? 4 : (g > 64 ? 64 : g);
 }
 
+int fwd_group_width(int nchunk) {
+  static const int forced = env_int("KGE_FWD_G", 0);
+  if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+  return score_group_width(nchunk);
+}
+
+int pull_chunk() {
+  static const int c = env_int("KGE_PULL_CHUNK", 128);
+  return c < 8 ? 8 : c;
+}
+
+static int g_grad_mode = -1;
+int grad_mode() {
+  if (g_grad_mode < 0) g_grad_mode = env_int("KGE_GRAD_MODE", 0) ? 1 : 0;
+  return g_grad_mode;
+}
+
 int push_group_width(int width) {
   static const int forced = env_int("KGE_PUSH_G", 0);
   if (forced == 16 || forced == 32 || forced == 64) return forced;
@@ -83,7 +100,7 @@ int push_group_width(int width) {
 }
 
 int score_dispatch(const kge_model_desc*, const float*, const float*, const int32_t*, int64_t, float*, uint32_t*, hipStream_t);
-int64_t train_workspace_bytes(int64_t, int64_t);
+int64_t train_workspace_bytes(const kge_model_desc*, int64_t, int64_t);
 int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, const int32_t*, int64_t,
                 const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
@@ -103,6 +120,12 @@ extern "C" {
 
 const char* kge_last_error(void) { return err_buf(); }
 int kge_abi_version(void) { return KGE_ABI_VERSION; }
+
+int kge_set_grad_mode(int mode) {
+  if (mode != 0 && mode != 1) return fail(KGE_EINVAL, "kge_set_grad_mode: 0 = pull (gather-reduce), 1 = push (float atomics)");
+  g_grad_mode = mode;
+  return KGE_OK;
+}
 
 int kge_prof_enable(int on) {
   g_prof.on = on != 0;
@@ -152,7 +175,7 @@ int64_t kge_train_step_workspace_bytes(const kge_model_desc* md, const kge_loss_
   (void)ld;
   if (check_model(md, "kge_train_step_workspace_bytes")) return KGE_EINVAL;
   if (m_pos < 0 || m_neg < 0) return fail(KGE_EINVAL, "negative batch size");
-  return train_workspace_bytes(m_pos, m_neg);
+  return train_workspace_bytes(md, m_pos, m_neg);
 }
 
 static int check_train(const char* who, const kge_model_desc* md, const kge_loss_desc* ld, const void* E, const void* Rel,

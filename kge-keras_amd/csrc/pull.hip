@@ -1,0 +1,597 @@
+// "pull" gradient path of the training batch: no float atomics.
+//
+// Same contract as the push path in train.hip (forward x2, loss, sparse gradients with duplicates summed;
+// reference: tests.py:63-89, KGEkeras/models.py:134-222, KGEkeras/utils.py:288-319), different dataflow:
+//
+//   hist_kernel     one int atomic per (triple, role): how many gradient contributions every table row receives
+//   scan_kernel     exclusive scans -> list offsets, chunking of long lists, partial-slab slots        (1 block)
+//   emap_kernel     (row, chunk) of every extra chunk
+//   fwd_kernel      gather 3 rows, score, dL/dscore in registers (pointwise losses), loss partials    [HBM gather]
+//   fill_kernel     per (triple, role) one 16-byte list entry {other row a, other row b, coefficient} at the
+//                   destination row's cursor
+//   pull_kernel     one wave per (destination row, chunk of <= C entries): re-gathers the two OTHER rows of every
+//                   contribution, forms the gradient term in registers and sums; single-chunk rows add straight
+//                   into the dense gradient table, chunks of long lists (relations, hub entities) write a partial
+//                   row to a slab                                                                      [HBM gather]
+//   pull_finish     sums the slabs of multi-chunk rows in chunk order
+//
+// Every destination row has exactly one writer, so the only non-determinism left is the order of a row's list
+// (cursor atomics).  Bytes moved per scored triple: forward 3 rows + backward 6 rows + 48 B of list entries,
+// against 3 rows + 3 atomic rows on the push path -- but gathers run at the cache/HBM rate (6-10 TB/s) while
+// float atomics are capped near 1.3 TB/s chip-wide (MI355X_MICROARCH.md, Global float atomics).
+#include "kge_internal.hpp"
+#include "pull.hpp"
+
+namespace kge {
+
+constexpr float kEpsP = 1e-6f;  // KGEkeras/utils.py:12
+
+
+
+template <int LOSS>
+__device__ __forceinline__ void pointwise_p(float score, bool is_pos, float margin, float inv, float& g, float& l) {
+  if (LOSS == KGE_POINTWIZE_HINGE) {
+    const float a = is_pos ? margin - score : margin + score;
+    const bool on = a > 0.f;
+    l = on ? a * inv : 0.f;
+    g = on ? (is_pos ? -inv : inv) : 0.f;
+  } else if (LOSS == KGE_POINTWIZE_LOGISTIC) {
+    const float e = expf(is_pos ? -score : score);
+    const float den = kEpsP + 1.f + e;
+    l = logf(den) * inv;
+    g = (is_pos ? -e : e) / den * inv;
+  } else {
+    const float a = is_pos ? margin - score : margin + score;
+    l = a * a * inv;
+    g = (is_pos ? -2.f : 2.f) * a * inv;
+  }
+}
+
+template <int VEC> struct V;
+template <> struct V<4> {
+  using T = float4;
+  static __device__ __forceinline__ T ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct V<1> {
+  using T = float;
+  static __device__ __forceinline__ T ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+  static __device__ __forceinline__ T zero() { return 0.f; }
+};
+
+#define KGE_F4(expr_x, expr_y, expr_z, expr_w) make_float4(expr_x, expr_y, expr_z, expr_w)
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return KGE_F4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return KGE_F4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return KGE_F4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator*(float a, float4 b) { return KGE_F4(a * b.x, a * b.y, a * b.z, a * b.w); }
+__device__ __forceinline__ float hsum(float a) { return a; }
+__device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float vabs(float a) { return fabsf(a); }
+__device__ __forceinline__ float4 vabs(float4 a) { return KGE_F4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w)); }
+__device__ __forceinline__ float sgn1(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float vsgn(float a) { return sgn1(a); }
+__device__ __forceinline__ float4 vsgn(float4 a) { return KGE_F4(sgn1(a.x), sgn1(a.y), sgn1(a.z), sgn1(a.w)); }
+__device__ __forceinline__ float shx(float v, int off) { return __shfl_xor(v, off, 64); }
+__device__ __forceinline__ float4 shx(float4 v, int off) {
+  return KGE_F4(__shfl_xor(v.x, off, 64), __shfl_xor(v.y, off, 64), __shfl_xor(v.z, off, 64), __shfl_xor(v.w, off, 64));
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// LOSS >= 0: pointwise loss fused (coef, loss partials);  LOSS < 0: scores only (pairwise two-phase path).
+template <int MODEL, int NORM, int LOSS, int G, int VEC>
+__global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
+                                                   const int32_t* __restrict__ pos, int64_t m_pos,
+                                                   const int32_t* __restrict__ neg, int64_t m_neg, int N, int R, int d_e,
+                                                   int nchunk, float gamma, float margin, float* __restrict__ coef,
+                                                   float* __restrict__ scores, float* __restrict__ loss_partials,
+                                                   uint32_t* __restrict__ err) {
+  using C = V<VEC>;
+  __shared__ float red[16];
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t group = (int64_t)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
+  const int64_t n = m_pos + m_neg;
+  const int h = d_e >> 1;
+  const float inv_pos = 1.f / (float)m_pos, inv_neg = 1.f / (float)m_neg;
+  float lsum = 0.f;
+  for (int64_t t = group; t < n; t += ngroups) {
+    const bool is_pos = t < m_pos;
+    const int32_t* tr = is_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+    const int s = tr[0], p = tr[1], o = tr[2];
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+    float acc = 0.f;
+    if (ok) {
+      const float* es = E + (int64_t)s * d_e;
+      const float* rp = Rel + (int64_t)p * d_e;
+      const float* eo = E + (int64_t)o * d_e;
+      if (MODEL == KGE_COMPLEX) {
+#pragma unroll 2
+        for (int c = lane; c < nchunk; c += G) {
+          auto sr = C::ld(es + c * VEC), si = C::ld(es + h + c * VEC);
+          auto pr = C::ld(rp + c * VEC), pi = C::ld(rp + h + c * VEC);
+          auto orr = C::ld(eo + c * VEC), oi = C::ld(eo + h + c * VEC);
+          acc += hsum(sr * pr * orr + pr * si * oi + pi * sr * oi - pi * si * orr);
+        }
+      } else {
+#pragma unroll 4
+        for (int c = lane; c < nchunk; c += G) {
+          auto sv = C::ld(es + c * VEC), pv = C::ld(rp + c * VEC), ov = C::ld(eo + c * VEC);
+          if (MODEL == KGE_DISTMULT) acc += hsum(sv * pv * ov);
+          else { auto x = sv + pv - ov; acc += NORM == 1 ? hsum(vabs(x)) : hsum(x * x); }
+        }
+      }
+    }
+    acc = group_sum<G>(acc);
+    if (lane == 0) {
+      float score = acc, dist = acc;
+      if (MODEL == KGE_TRANSE) {
+        if (NORM == 2) dist = sqrtf(acc);
+        score = gamma > 0.f ? gamma - dist : dist;
+      }
+      if (!ok) { score = __builtin_nanf(""); atomicOr(err, 1u); }
+      if (scores) scores[t] = score;
+      if (LOSS >= 0) {
+        float g = 0.f, l = 0.f;
+        if (ok) pointwise_p<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+        lsum += l;
+        if (MODEL == KGE_TRANSE) {
+          g = gamma > 0.f ? -g : g;                            // d score / d dist
+          if (NORM == 2) g = dist > 0.f ? g / dist : 0.f;      // d dist / d x = x / dist (0 at the origin; TF: NaN)
+        }
+        coef[t] = g;
+      }
+    }
+  }
+  if (LOSS >= 0) {
+    const float b = block_sum(lsum, red);
+    if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
+  }
+}
+
+// dL/dscore (pairwise path) -> list coefficient, in place
+template <int MODEL, int NORM>
+__global__ void coef_from_g_kernel(const float* __restrict__ scores, float* __restrict__ g, int64_t n, float gamma) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  float c = g[t];
+  const float sc = scores[t];
+  if (!(sc == sc)) c = 0.f;  // invalid row
+  if (MODEL == KGE_TRANSE) {
+    c = gamma > 0.f ? -c : c;
+    if (NORM == 2) {
+      const float dist = gamma > 0.f ? gamma - sc : sc;
+      c = dist > 0.f ? c / dist : 0.f;
+    }
+  }
+  g[t] = c;
+}
+
+// ------------------------------------------------------------------------------------------------ index build
+// Relation keys are hot (R addresses receive n increments: ~1700 each at FB15k-237 sizes), so they are counted in an LDS
+// histogram per block and flushed with one global atomic per (block, relation); entity keys go straight to L2 atomics.
+// Every atomic returns the contribution's rank inside its destination list, so the later list fill needs no atomics.
+constexpr int kRelLds = 4096;           // relations counted in LDS when R <= kRelLds
+constexpr int kIdxBlockTriples = 1024;  // triples per block of the index-build kernel
+
+__global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
+                                                    const int32_t* __restrict__ neg, int64_t m_neg, int N, int R,
+                                                    int32_t* __restrict__ cnt, int32_t* __restrict__ ranks /* [3][n] */) {
+  __shared__ int lrel[kRelLds];
+  const bool lds = R <= kRelLds;
+  if (lds) for (int i = threadIdx.x; i < R; i += 256) lrel[i] = 0;
+  __syncthreads();
+  const int64_t n = m_pos + m_neg;
+  const int64_t t0 = (int64_t)blockIdx.x * kIdxBlockTriples;
+  constexpr int PER = kIdxBlockTriples / 256;
+  int rs[PER], ro[PER], rp[PER], pp[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int64_t t = t0 + threadIdx.x + i * 256;
+    rs[i] = ro[i] = rp[i] = pp[i] = -1;
+    if (t < n) {
+      const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+      const int s = tr[0], p = tr[1], o = tr[2];
+      if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
+        rs[i] = atomicAdd(&cnt[s], 1);
+        ro[i] = atomicAdd(&cnt[o], 1);
+        pp[i] = p;
+        rp[i] = lds ? atomicAdd(&lrel[p], 1) : atomicAdd(&cnt[N + p], 1);
+      }
+    }
+  }
+  if (lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < R; i += 256) { const int v = lrel[i]; lrel[i] = v ? atomicAdd(&cnt[N + i], v) : 0; }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int64_t t = t0 + threadIdx.x + i * 256;
+    if (t < n) {
+      ranks[t] = rs[i];
+      ranks[n + t] = ro[i];
+      ranks[2 * n + t] = pp[i] < 0 ? -1 : (lds ? lrel[pp[i]] + rp[i] : rp[i]);
+    }
+  }
+}
+
+// Tiled single-block scan: 1024 threads x 4 consecutive keys per tile, wave shuffles inside, carry across tiles.
+struct Tri { int a, b, c; };
+__device__ __forceinline__ Tri tri_add(Tri x, Tri y) { return Tri{x.a + y.a, x.b + y.b, x.c + y.c}; }
+__device__ __forceinline__ Tri tri_shfl_up(Tri x, int d) { return Tri{__shfl_up(x.a, d, 64), __shfl_up(x.b, d, 64), __shfl_up(x.c, d, 64)}; }
+
+__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ cnt, int NK, int C, int32_t* __restrict__ off,
+                                                     int32_t* __restrict__ eoff, int32_t* __restrict__ poff,
+                                                     int32_t* __restrict__ totals) {
+  __shared__ Tri wsum[16];
+  __shared__ Tri carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = Tri{0, 0, 0};
+  __syncthreads();
+  for (int base = 0; base < NK; base += 4096) {
+    const int k0 = base + tid * 4;
+    int n[4];
+    Tri v[4];
+    Tri run{0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      n[j] = k0 + j < NK ? cnt[k0 + j] : 0;
+      const int nch = (n[j] + C - 1) / C;
+      v[j] = run;  // exclusive within the thread
+      run = tri_add(run, Tri{n[j], nch > 1 ? nch - 1 : 0, nch > 1 ? nch : 0});
+    }
+    Tri inc = run;  // inclusive scan of thread totals across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const Tri up = tri_shfl_up(inc, d);
+      if (lane >= d) inc = tri_add(inc, up);
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    Tri wpre{0, 0, 0};
+    for (int w = 0; w < wave; ++w) wpre = tri_add(wpre, wsum[w]);
+    const Tri carry = carry_s;
+    Tri pre = tri_add(tri_add(carry, wpre), Tri{inc.a - run.a, inc.b - run.b, inc.c - run.c});
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < NK) {
+        const Tri x = tri_add(pre, v[j]);
+        off[k0 + j] = x.a; eoff[k0 + j] = x.b; poff[k0 + j] = x.c;
+      }
+    __syncthreads();
+    if (tid == 1023) carry_s = tri_add(tri_add(carry, wpre), inc);
+    __syncthreads();
+  }
+  if (tid == 0) { totals[0] = carry_s.b; totals[1] = carry_s.c; totals[2] = carry_s.a; }
+}
+
+__global__ __launch_bounds__(256) void emap_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ eoff, int NK,
+                                                    int C, int max_extra, int2* __restrict__ emap) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= NK) return;
+  const int nch = (cnt[k] + C - 1) / C;
+  const int base = eoff[k];
+  for (int j = 1; j < nch; ++j)
+    if (base + j - 1 < max_extra) emap[base + j - 1] = make_int2(k, j);
+}
+
+// Atomic-free list fill: position = list start of the destination + the rank handed out by hist_kernel.
+// Entry = {a | kind<<31, b, coefficient bits, t}.
+__global__ __launch_bounds__(256) void fill_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
+                                                    const int32_t* __restrict__ neg, int64_t m_neg, int N,
+                                                    const float* __restrict__ coef, const int32_t* __restrict__ off,
+                                                    const int32_t* __restrict__ ranks, int4* __restrict__ entries) {
+  const int64_t n = m_pos + m_neg;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int r0 = ranks[t];
+  if (r0 < 0) return;  // invalid ids
+  const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+  const int s = tr[0], p = tr[1], o = tr[2];
+  const int cb = __float_as_int(coef[t]);
+  entries[off[s] + r0] = make_int4(p, o, cb, (int)t);                                   // d/ds : needs p, o
+  entries[off[o] + ranks[n + t]] = make_int4(p | (int)0x80000000, s, cb, (int)t);       // d/do : needs p, s
+  entries[off[N + p] + ranks[2 * n + t]] = make_int4(s, o, cb, (int)t);                 // d/dp : needs s, o
+}
+
+// ------------------------------------------------------------------------------------------------ pull
+// One wave per unit.  Lane l of a G-lane sub-group owns chunks l, l+G, ... (NV of them) of the row (of each HALF row for
+// ComplEx); the 64/G sub-groups of the wave take different list entries and meet in a shuffle reduction at the end.
+template <int MODEL, int NORM, int G, int NV, int VEC>
+__global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
+                                                    float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,
+                                                    int nchunk, const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
+                                                    const int32_t* __restrict__ eoff, const int32_t* __restrict__ poff,
+                                                    const int32_t* __restrict__ totals, const int2* __restrict__ emap,
+                                                    const int4* __restrict__ entries, float* __restrict__ slab, int C) {
+  using T = typename V<VEC>::T;
+  using L = V<VEC>;
+  constexpr int NSUB = 64 / G;
+  constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
+  const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+  const int lane = lane64 & (G - 1), sub = lane64 / G;
+  const int unit = blockIdx.x * 4 + wave;
+  int key, chunk;
+  if (unit < NK) { key = unit; chunk = 0; }
+  else {
+    const int x = unit - NK;
+    if (x >= totals[0]) return;
+    const int2 kc = emap[x];
+    key = kc.x; chunk = kc.y;
+  }
+  const int c = cnt[key];
+  if (c == 0) return;
+  const int nch = (c + C - 1) / C;
+  const int start = off[key] + chunk * C;
+  const int len = min(C, c - chunk * C);
+  const bool is_rel = key >= N;
+  const int h = d_e >> 1;
+  const float* self = is_rel ? Rel + (int64_t)(key - N) * d_e : E + (int64_t)key * d_e;
+
+  T acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = L::zero();
+  T me[MODEL == KGE_TRANSE ? NV : 1];
+  if (MODEL == KGE_TRANSE) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const int ch = lane + i * G; me[i] = ch < nchunk ? L::ld(self + ch * VEC) : L::zero(); }
+  }
+
+#pragma unroll 2
+  for (int i = sub; i < len; i += NSUB) {
+    const int4 e = entries[start + i];
+    const float cf = __int_as_float(e.z);
+    if (cf == 0.f) continue;  // inactive hinge rows carry no gradient
+    const int kind1 = is_rel ? 0 : ((unsigned)e.x >> 31);
+    const float* ra = is_rel ? E + (int64_t)e.x * d_e : Rel + (int64_t)(e.x & 0x7fffffff) * d_e;
+    const float* rb = E + (int64_t)e.y * d_e;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int ch = lane + j * G;
+      if (ch < nchunk) {
+        if (MODEL == KGE_DISTMULT) {
+          acc[j] = acc[j] + cf * (L::ld(ra + ch * VEC) * L::ld(rb + ch * VEC));
+        } else if (MODEL == KGE_TRANSE) {
+          // x = s + p - o with the destination row in its own role
+          const T a = L::ld(ra + ch * VEC), b = L::ld(rb + ch * VEC);
+          T x;
+          float sg = cf;
+          if (is_rel) x = a + me[j] - b;              // dest p: a = s, b = o
+          else if (!kind1) x = me[j] + a - b;         // dest s: a = p, b = o
+          else { x = b + a - me[j]; sg = -cf; }        // dest o: a = p, b = s ; d/do = -d/dx
+          acc[j] = acc[j] + sg * (NORM == 1 ? vsgn(x) : x);
+        } else {  // ComplEx: halves [real | imag]
+          const T ar = L::ld(ra + ch * VEC), ai = L::ld(ra + h + ch * VEC);
+          const T br = L::ld(rb + ch * VEC), bi = L::ld(rb + h + ch * VEC);
+          T gr, gi;
+          if (is_rel) { gr = ar * br + ai * bi; gi = ar * bi - ai * br; }            // a = s, b = o
+          else if (!kind1) { gr = ar * br + ai * bi; gi = ar * bi - ai * br; }       // a = p, b = o : pr*or+pi*oi | pr*oi-pi*or
+          else { gr = br * ar - ai * bi; gi = ar * bi + ai * br; }                   // a = p, b = s : sr*pr-pi*si | pr*si+pi*sr
+          acc[j] = acc[j] + cf * gr;
+          acc[NV + j] = acc[NV + j] + cf * gi;
+        }
+      }
+    }
+  }
+  // meet the sub-groups
+#pragma unroll
+  for (int o2 = G; o2 < 64; o2 <<= 1)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = acc[i] + shx(acc[i], o2);
+  if (sub != 0) return;
+  float* dst;
+  bool add;
+  if (nch == 1) { dst = (is_rel ? gR + (int64_t)(key - N) * d_e : gE + (int64_t)key * d_e); add = true; }
+  else { dst = slab + (int64_t)(poff[key] + chunk) * d_e; add = false; }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int ch = lane + j * G;
+    if (ch < nchunk) {
+      if (add) {
+        L::st(dst + ch * VEC, L::ld(dst + ch * VEC) + acc[j]);
+        if (MODEL == KGE_COMPLEX) L::st(dst + h + ch * VEC, L::ld(dst + h + ch * VEC) + acc[NV + j]);
+      } else {
+        L::st(dst + ch * VEC, acc[j]);
+        if (MODEL == KGE_COMPLEX) L::st(dst + h + ch * VEC, acc[NV + j]);
+      }
+    }
+  }
+}
+
+// One wave per key; multi-chunk keys add their slab rows, in chunk order, into the gradient table.
+__global__ __launch_bounds__(256) void pull_finish_kernel(float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,
+                                                           const int32_t* __restrict__ cnt, const int32_t* __restrict__ poff,
+                                                           const float* __restrict__ slab, int C) {
+  const int key = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (key >= NK) return;
+  const int nch = (cnt[key] + C - 1) / C;
+  if (nch <= 1) return;
+  const int lane = threadIdx.x & 63;
+  float* dst = key >= N ? gR + (int64_t)(key - N) * d_e : gE + (int64_t)key * d_e;
+  const float* src = slab + (int64_t)poff[key] * d_e;
+  for (int k = lane; k < d_e; k += 64) {
+    float s = 0.f;
+    int j = 0;
+    for (; j + 8 <= nch; j += 8) {  // eight independent loads in flight, summed in chunk order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(j + u) * d_e + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; j < nch; ++j) s += src[(int64_t)j * d_e + k];
+    dst[k] += s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+int pull_chunk();       // api.hip (env KGE_PULL_CHUNK)
+int fwd_group_width(int nchunk);
+
+static int64_t a256(int64_t x) { return align_up(x, 256); }
+
+int64_t pull_workspace_bytes(const kge_model_desc* md, int64_t n) {
+  const int64_t NK = (int64_t)md->num_entities + md->num_relations;
+  const int C = pull_chunk();
+  const int64_t max_extra = 3 * n / C + 1;
+  return a256(NK * 4) * 4 + 256 + a256(max_extra * 8) + a256(3 * n * 16) + a256(3 * n * 4) + a256(n * 4) + a256(2 * max_extra * md->d_e * 4) + 1024;
+}
+
+static void carve_pull(void* ws, const kge_model_desc* md, int64_t n, PullPlan* p) {
+  const int64_t NK = (int64_t)md->num_entities + md->num_relations;
+  const int C = pull_chunk();
+  const int64_t max_extra = 3 * n / C + 1;
+  char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t bytes) { char* r = q; q += a256(bytes); return r; };
+  p->cnt = (int32_t*)take(NK * 4);
+  p->off = (int32_t*)take(NK * 4);
+  p->eoff = (int32_t*)take(NK * 4);
+  p->poff = (int32_t*)take(NK * 4);
+  p->totals = (int32_t*)take(16);
+  p->emap = (int2*)take(max_extra * 8);
+  p->entries = (int4*)take(3 * n * 16);
+  p->ranks = (int32_t*)take(3 * n * 4);
+  p->coef = (float*)take(n * 4);
+  p->slab = (float*)take(2 * max_extra * md->d_e * 4);
+  p->max_extra = (int)max_extra;
+  p->chunk = C;
+}
+
+bool pull_supported(const kge_model_desc* md) {
+  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX) return false;
+  const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
+  const bool v4 = width % 4 == 0 && md->d_e % 4 == 0;
+  const int nchunk = v4 ? width / 4 : width;
+  return nchunk <= 256;
+}
+
+template <int MODEL, int NORM, int LOSS, int VEC>
+static void launch_fwd(int G, int grid, hipStream_t st, const float* E, const float* Rel, const int32_t* pos, int64_t m_pos,
+                       const int32_t* neg, int64_t m_neg, const kge_model_desc* md, int nchunk, float margin, float* coef,
+                       float* scores, float* partials, uint32_t* err) {
+#define KGE_FWD(GW) hipLaunchKernelGGL((fwd_kernel<MODEL, NORM, LOSS, GW, VEC>), dim3(grid), dim3(256), 0, st, E, Rel, pos, m_pos, neg, m_neg, \
+                                       md->num_entities, md->num_relations, md->d_e, nchunk, md->gamma, margin, coef, scores, partials, err)
+  switch (G) {
+    case 4: KGE_FWD(4); break;
+    case 8: KGE_FWD(8); break;
+    case 16: KGE_FWD(16); break;
+    case 32: KGE_FWD(32); break;
+    default: KGE_FWD(64); break;
+  }
+#undef KGE_FWD
+}
+
+template <int MODEL, int NORM, int VEC>
+static void launch_fwd_loss(int loss, int G, int grid, hipStream_t st, const float* E, const float* Rel, const int32_t* pos,
+                            int64_t m_pos, const int32_t* neg, int64_t m_neg, const kge_model_desc* md, int nchunk, float margin,
+                            float* coef, float* scores, float* partials, uint32_t* err) {
+  switch (loss) {
+    case KGE_POINTWIZE_HINGE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_HINGE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
+    case KGE_POINTWIZE_LOGISTIC: launch_fwd<MODEL, NORM, KGE_POINTWIZE_LOGISTIC, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
+    case KGE_POINTWIZE_SQUARE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_SQUARE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
+    default: launch_fwd<MODEL, NORM, -1, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
+  }
+}
+
+template <int MODEL, int NORM, int VEC>
+static void launch_pull(int nchunk, int grid, hipStream_t st, const float* E, const float* Rel, float* gE, float* gR,
+                        const kge_model_desc* md, const PullPlan& p) {
+  const int N = md->num_entities, NK = N + md->num_relations;
+#define KGE_PULL(GW, NVV) hipLaunchKernelGGL((pull_kernel<MODEL, NORM, GW, NVV, VEC>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, N, NK, md->d_e, \
+                                             nchunk, p.cnt, p.off, p.eoff, p.poff, p.totals, p.emap, p.entries, p.slab, p.chunk)
+  if (nchunk <= 8) KGE_PULL(8, 1);
+  else if (nchunk <= 16) KGE_PULL(16, 1);
+  else if (nchunk <= 32) KGE_PULL(32, 1);
+  else if (nchunk <= 64) KGE_PULL(64, 1);
+  else if (nchunk <= 128) KGE_PULL(64, 2);
+  else KGE_PULL(64, 4);
+#undef KGE_PULL
+}
+
+struct Shape { bool v4; int nchunk; };
+static Shape shape_of(const kge_model_desc* md, const void* a, const void* b, const void* c, const void* d) {
+  const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
+  const bool v4 = width % 4 == 0 && md->d_e % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) % 16 == 0);
+  return Shape{v4, v4 ? width / 4 : width};
+}
+
+int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* pull_ws,
+                 hipStream_t st, PullPlan* plan) {
+  const int64_t n = m_pos + m_neg;
+  carve_pull(pull_ws, md, n, plan);
+  PullPlan& p = *plan;
+  const int N = md->num_entities, NK = N + md->num_relations;
+  const int igrid = (int)cdiv(n, kIdxBlockTriples);
+  ProfScope prof(KGE_PROF_SAMPLER, st);  // index build (ids only)
+  KGE_HIP_TRY(hipMemsetAsync(p.cnt, 0, (size_t)NK * 4, st));
+  hipLaunchKernelGGL(hist_kernel, dim3(igrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, md->num_relations, p.cnt, p.ranks);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals);
+  hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(NK, 256)), dim3(256), 0, st, p.cnt, p.eoff, NK, p.chunk, p.max_extra, p.emap);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+int pull_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
+                 int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p, float* scores, float* loss_partials,
+                 int* n_partials, uint32_t* err, hipStream_t st) {
+  const int64_t n = m_pos + m_neg;
+  const Shape sh = shape_of(md, E, Rel, nullptr, nullptr);
+  const int G = fwd_group_width(sh.nchunk);
+  const int fgrid = (int)std::min<int64_t>(cdiv(n * G, 256), 4096);
+  *n_partials = fgrid;
+  ProfScope prof(KGE_PROF_FWD, st);
+#define KGE_GO(MODEL, NORM)                                                                                                                         \
+  do {                                                                                                                                              \
+    if (sh.v4) launch_fwd_loss<MODEL, NORM, 4>(loss, G, fgrid, st, E, Rel, pos, m_pos, neg, m_neg, md, sh.nchunk, margin, p.coef, scores, loss_partials, err); \
+    else launch_fwd_loss<MODEL, NORM, 1>(loss, G, fgrid, st, E, Rel, pos, m_pos, neg, m_neg, md, sh.nchunk, margin, p.coef, scores, loss_partials, err);       \
+  } while (0)
+  if (md->model == KGE_DISTMULT) KGE_GO(KGE_DISTMULT, 1);
+  else if (md->model == KGE_COMPLEX) KGE_GO(KGE_COMPLEX, 1);
+  else if (md->norm == 1) KGE_GO(KGE_TRANSE, 1);
+  else KGE_GO(KGE_TRANSE, 2);
+#undef KGE_GO
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const int32_t* pos,
+                  int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p, bool g_is_dscore, const float* scores,
+                  hipStream_t st) {
+  const int64_t n = m_pos + m_neg;
+  const int N = md->num_entities, NK = N + md->num_relations;
+  const Shape sh = shape_of(md, E, Rel, gE, gR);
+  const int tgrid = (int)cdiv(n, 256);
+  if (g_is_dscore) {
+    if (md->model == KGE_TRANSE) {
+      if (md->norm == 1) hipLaunchKernelGGL((coef_from_g_kernel<KGE_TRANSE, 1>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma);
+      else hipLaunchKernelGGL((coef_from_g_kernel<KGE_TRANSE, 2>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma);
+    } else {
+      hipLaunchKernelGGL((coef_from_g_kernel<KGE_DISTMULT, 1>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma);
+    }
+  }
+  hipLaunchKernelGGL(fill_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, p.coef, p.off, p.ranks, p.entries);
+  {
+    ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
+    const int units = NK + p.max_extra;
+    const int pgrid = (int)cdiv(units, 4);
+#define KGE_GO(MODEL, NORM)                                                                \
+  do {                                                                                     \
+    if (sh.v4) launch_pull<MODEL, NORM, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, p);   \
+    else launch_pull<MODEL, NORM, 1>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, p);         \
+  } while (0)
+    if (md->model == KGE_DISTMULT) KGE_GO(KGE_DISTMULT, 1);
+    else if (md->model == KGE_COMPLEX) KGE_GO(KGE_COMPLEX, 1);
+    else if (md->norm == 1) KGE_GO(KGE_TRANSE, 1);
+    else KGE_GO(KGE_TRANSE, 2);
+#undef KGE_GO
+  }
+  hipLaunchKernelGGL(pull_finish_kernel, dim3((int)cdiv(NK, 4)), dim3(256), 0, st, gE, gR, N, NK, md->d_e, p.cnt, p.poff, p.slab, p.chunk);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+}  // namespace kge

@@ -1,0 +1,40 @@
+// Shared between pull.hip and train.hip: the per-batch plan of the pull gradient path (all device pointers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/kge_hip.h"
+
+namespace kge {
+
+struct PullPlan {
+  int32_t* cnt;     // [NK]   contributions per key (key = entity id, or N + relation id)
+  int32_t* off;     // [NK]   list start
+  int32_t* ranks;   // [3][n] rank of (triple, role) inside its destination list (-1: invalid ids)
+  int32_t* eoff;    // [NK]   first extra-chunk unit of the key
+  int32_t* poff;    // [NK]   first slab slot of a multi-chunk key
+  int32_t* totals;  // [4]    {extra units, slab slots}
+  int2* emap;       // [max_extra] (key, chunk) of extra units
+  int4* entries;    // [3n]   {a | kind<<31, b, coef bits, t}
+  float* coef;      // [n]
+  float* slab;      // [2*max_extra][d]
+  int max_extra;
+  int chunk;
+};
+
+bool pull_supported(const kge_model_desc* md);
+int64_t pull_workspace_bytes(const kge_model_desc* md, int64_t n);
+// histogram of destination rows + scans + chunk map (depends on the ids only)
+int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* pull_ws,
+                 hipStream_t st, PullPlan* plan);
+// gather + score; loss >= 0: pointwise loss fused (plan->coef, loss_partials[0..*n_partials)); loss < 0: scores only
+int pull_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
+                 int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& plan, float* scores, float* loss_partials,
+                 int* n_partials, uint32_t* err, hipStream_t st);
+// list fill + per-destination gather-reduce into gE/gR (+=).  g_is_dscore: plan.coef holds dL/dscore (pairwise path)
+int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const int32_t* pos,
+                  int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& plan, bool g_is_dscore, const float* scores,
+                  hipStream_t st);
+
+}  // namespace kge

@@ -10,6 +10,7 @@
 // 256 contiguous bytes per wave-instruction (lane l owns elements l, l+G, ...).  Hinge rows with a
 // zero subgradient issue no atomics at all.
 #include "kge_internal.hpp"
+#include "pull.hpp"
 
 namespace kge {
 
@@ -265,25 +266,31 @@ constexpr int kMaxBlocks = 4096;  // partial-sum slots per kernel
 struct Workspace {
   float* loss_partials;  // kMaxBlocks
   float* reg_partials;   // kMaxBlocks
-  float* gbuf;           // m_pos + m_neg (pairwise)
+  float* gbuf;           // m_pos + m_neg (pairwise, push path)
   float* sbuf;           // m_pos + m_neg (pairwise, when scores_out is null)
+  void* pull;            // pull-path plan and lists
 };
 
-int64_t train_workspace_bytes(int64_t m_pos, int64_t m_neg) {
-  return (int64_t)sizeof(float) * (2 * kMaxBlocks + 2 * align_up(m_pos + m_neg, 64)) + 256;
+int grad_mode();  // api.hip: 0 = pull (default), 1 = push (float atomics)
+
+static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 2 * align_up(n, 64); }
+
+int64_t train_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
+  return (int64_t)sizeof(float) * base_floats(m_pos + m_neg) + 512 + (md ? pull_workspace_bytes(md, m_pos + m_neg) : 0);
 }
 
-static int carve(void* ws, int64_t bytes, int64_t m_pos, int64_t m_neg, Workspace* out) {
+static int carve(void* ws, int64_t bytes, const kge_model_desc* md, int64_t m_pos, int64_t m_neg, Workspace* out) {
   if (!ws) return fail(KGE_EINVAL, "workspace is null");
-  if (bytes < train_workspace_bytes(m_pos, m_neg))
+  if (bytes < train_workspace_bytes(md, m_pos, m_neg))
     return fail(KGE_EWORKSPACE, "workspace has %lld bytes, needs %lld", (long long)bytes,
-                (long long)train_workspace_bytes(m_pos, m_neg));
+                (long long)train_workspace_bytes(md, m_pos, m_neg));
   uintptr_t p = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
   float* f = reinterpret_cast<float*>(p);
   out->loss_partials = f;
   out->reg_partials = f + kMaxBlocks;
   out->gbuf = f + 2 * kMaxBlocks;
   out->sbuf = out->gbuf + align_up(m_pos + m_neg, 64);
+  out->pull = f + base_floats(m_pos + m_neg);
   return KGE_OK;
 }
 
@@ -349,10 +356,41 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   (void)seed;
   if (md->dropout != 0.f) return fail(KGE_EUNSUPPORTED, "dropout > 0 is not built yet (models.py:122); pass dp=0");
   Workspace ws;
-  if (int rc = carve(workspace, wbytes, m_pos, m_neg, &ws)) return rc;
+  if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
+  const bool pairwise = ld->loss == KGE_PAIRWIZE_HINGE || ld->loss == KGE_PAIRWIZE_LOGISTIC || ld->loss == KGE_PAIRWIZE_SQUARE;
+  if (pairwise) {
+    // numpy/TF broadcast of false.reshape(-1, ns) against true (m_t,): all-pairs iff ns == 1 or m_t == 1
+    if (ld->negative_samples < 1 || m_neg % ld->negative_samples)
+      return fail(KGE_ESHAPE, "pairwize loss: len(false)=%lld is not divisible by negative_samples=%d", (long long)m_neg, ld->negative_samples);
+    if (!(ld->negative_samples == 1 || m_pos == 1)) {
+      if (ld->negative_samples == m_pos)
+        return fail(KGE_EUNSUPPORTED, "pairwize loss with negative_samples == len(true) (column-aligned broadcast) is not built yet");
+      return fail(KGE_ESHAPE, "pairwize loss: (%lld,%d) does not broadcast against (%lld,)", (long long)(m_neg / ld->negative_samples),
+                  ld->negative_samples, (long long)m_pos);
+    }
+  } else if (ld->loss != KGE_POINTWIZE_HINGE && ld->loss != KGE_POINTWIZE_LOGISTIC && ld->loss != KGE_POINTWIZE_SQUARE) {
+    return fail(KGE_EINVAL, "unknown loss %d", ld->loss);
+  }
+  int nb = 0;
+  if (grad_mode() == 0 && pull_supported(md)) {
+    PullPlan plan;
+    if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull, st, &plan)) return rc;
+    float* sc = scores_out ? scores_out : (pairwise ? ws.sbuf : nullptr);
+    if (int rc = pull_forward(md, pairwise ? -1 : ld->loss, ld->margin, E, Rel, pos, m_pos, neg, m_neg, plan, sc, ws.loss_partials, &nb, err, st)) return rc;
+    if (pairwise) {
+      int rc;
+      if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
+      else if (ld->loss == KGE_PAIRWIZE_LOGISTIC) rc = launch_pairwise<KGE_PAIRWIZE_LOGISTIC>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
+      else rc = launch_pairwise<KGE_PAIRWIZE_SQUARE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
+      if (rc) return rc;
+    }
+    if (int rc = pull_backward(md, E, Rel, gE, gR, pos, m_pos, neg, m_neg, plan, pairwise, sc, st)) return rc;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
+  }
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const int G = push_group_width(width);
-  int nb = 0;
   switch (ld->loss) {
     case KGE_POINTWIZE_HINGE:
       if (int rc = push_by_model<KGE_POINTWIZE_HINGE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb)) return rc;
@@ -366,15 +404,6 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     case KGE_PAIRWIZE_HINGE:
     case KGE_PAIRWIZE_LOGISTIC:
     case KGE_PAIRWIZE_SQUARE: {
-      // numpy/TF broadcast of false.reshape(-1, ns) against true (m_t,): all-pairs iff ns == 1 or m_t == 1
-      if (ld->negative_samples < 1 || m_neg % ld->negative_samples)
-        return fail(KGE_ESHAPE, "pairwize loss: len(false)=%lld is not divisible by negative_samples=%d", (long long)m_neg, ld->negative_samples);
-      if (!(ld->negative_samples == 1 || m_pos == 1)) {
-        if (ld->negative_samples == m_pos)
-          return fail(KGE_EUNSUPPORTED, "pairwize loss with negative_samples == len(true) (column-aligned broadcast) is not built yet");
-        return fail(KGE_ESHAPE, "pairwize loss: (%lld,%d) does not broadcast against (%lld,)", (long long)(m_neg / ld->negative_samples),
-                    ld->negative_samples, (long long)m_pos);
-      }
       float* sc = scores_out ? scores_out : ws.sbuf;
       // phase 1: scores of pos then neg
       if (int rc = score_dispatch(md, E, Rel, pos, m_pos, sc, err, st)) return rc;
@@ -413,7 +442,7 @@ static int launch_opt(bool reg, float* w, float* g, float* m, float* v, int64_t 
 int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gE,
               float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st) {
   Workspace ws;
-  if (int rc = carve(workspace, wbytes, 0, 0, &ws)) return rc;
+  if (int rc = carve(workspace, wbytes, nullptr, 0, 0, &ws)) return rc;
   const int64_t nE = (int64_t)md->num_entities * md->d_e, nR = (int64_t)md->num_relations * md->d_r;
   const bool reg = ld->regularization != 0.f;
   int nb = 0, nb2 = 0;

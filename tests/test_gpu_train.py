@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(params=["pull", "push"], autouse=True)
+def grad_mode(request):
+    """Every training test runs on both gradient paths: per-destination gather-reduce (default) and float atomics."""
+    from kge_keras_amd import _lib
+    _lib.check(_lib.lib.kge_set_grad_mode(0 if request.param == "pull" else 1))
+    yield request.param
+    _lib.lib.kge_set_grad_mode(0)
+
+
 def _mk(model, N, R, d, seed=0, **kw):
     from kge_keras_amd import models as M
     rs = np.random.RandomState(seed)
