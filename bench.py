@@ -79,17 +79,13 @@ def eval_leg(torch, dist, model, rank, world, reps=3):
     keep = (fi != np.repeat(mine[:, 2], 3)) & (fi != np.repeat(mine[:, 0], 3))
     fq, fi = fq[keep], fi[keep]
     tq = torch.from_numpy(mine).cuda()
+    from kge_keras_amd import dist as D
+    lo, hi = D.shard_range(CFG["N"], rank, world)
+    shard_at_rest = model.E[lo:hi].clone()
 
     def sweep():
-        if world > 1:  # all-gather of the row shards into the full table
-            N = CFG["N"]
-            per = (N + world - 1) // world
-            pad = torch.zeros((per * world, CFG["d"]), dtype=torch.float32, device="cuda")
-            shard = model.E[rank * per:min(N, (rank + 1) * per)]
-            mine_pad = torch.zeros((per, CFG["d"]), dtype=torch.float32, device="cuda")
-            mine_pad[:shard.shape[0]] = shard
-            dist.all_gather_into_tensor(pad, mine_pad)
-            model.E.copy_(pad[:N])
+        if world > 1:  # all-gather of the row shards into the full table (kge_keras_amd.dist.allgather_rows)
+            model.E.copy_(D.allgather_rows(shard_at_rest, CFG["N"]))
         c0 = model.rank_counts(tq, 0, fq, fi)
         c1 = model.rank_counts(tq, 1, fq, fi)
         return c0, c1
@@ -140,6 +136,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from kge_keras_amd import _lib
+    from kge_keras_amd import dist as D
     from kge_keras_amd.models import DistMult
     import oracle as O
 
@@ -158,11 +155,8 @@ def main():
         pos, neg = dev[i % n_pool]
         if world == 1:
             model.train_step([pos, neg])
-        else:
-            model.train_grads([pos, neg])
-            dist.all_reduce(model._gE)
-            dist.all_reduce(model._gR)
-            model.apply_grads(1.0 / world)
+        else:  # data-parallel: gradient half, all-reduce of the dense gradient tables over RCCL, optimizer half
+            D.dp_train_step(lambda: model.train_grads([pos, neg]), model.apply_grads, [model._gE, model._gR], model._loss)
 
     def fence():
         if world > 1:

@@ -9,7 +9,7 @@ CPU fallback: importing works anywhere (the library also holds the host-side MT1
 scoring / training / ranking call raises if no MI355X is present.
 """
 from . import _lib  # noqa: F401  (fails loudly if libkge_hip.so is not built)
-from . import models, utils, harness, sampler  # noqa: F401
+from . import models, utils, harness, sampler, dist  # noqa: F401
 
-__all__ = ["models", "utils", "harness", "sampler"]
+__all__ = ["models", "utils", "harness", "sampler", "dist"]
 __version__ = "0.1.0"

@@ -1,0 +1,105 @@
+"""Multi-GPU orchestration of the two halves of the path that shard; one process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+* training  : triples are independent units -> data-parallel replicas.  The one exchange per step is the
+              all-reduce of the dense gradient tables between kge_train_grads and kge_opt_apply; every rank
+              then applies the identical update (tables stay bit-identical across ranks).
+* evaluation: the entity table is row-sharded at rest; for a 1-vs-all sweep the shards are all-gathered into a
+              full table on every GPU (YAGO3-10: 98.5 MB, one collective per evaluation, not per query), the
+              queries are split across ranks and the integer ranks are all-gathered back.
+
+The functions here only move tensors; the compute is injected (the HIP-backed model methods in production, so the
+same orchestration can be exercised on CPU tensors with gloo).  The reference has no counterpart (single process).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world(group=None):
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous row shard [lo, hi) of n rows for `rank`; all shards but the last hold ceil(n/world) rows."""
+    per = (n + world_size - 1) // world_size
+    return min(n, rank * per), min(n, (rank + 1) * per)
+
+
+def allgather_rows(shard, n_rows, group=None):
+    """Row-sharded table -> full (n_rows, d) table on every rank (one all_gather_into_tensor of equal-size padded shards)."""
+    rank, ws = world(group)
+    if ws == 1:
+        return shard[:n_rows]
+    per = (n_rows + ws - 1) // ws
+    d = shard.shape[1]
+    mine = shard
+    if shard.shape[0] != per:
+        mine = torch.zeros((per, d), dtype=shard.dtype, device=shard.device)
+        mine[:shard.shape[0]] = shard
+    full = torch.empty((per * ws, d), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(full, mine.contiguous(), group=group)
+    return full[:n_rows]
+
+
+def split_queries(n_queries, rank, world_size):
+    """Indices of the queries rank `rank` evaluates (strided, so every rank gets the same mix of heads and tails)."""
+    return torch.arange(rank, n_queries, world_size)
+
+
+def gather_ranks(local_ranks, n_queries, group=None):
+    """Inverse of split_queries: int64 ranks of all n_queries on every rank."""
+    rank, ws = world(group)
+    if ws == 1:
+        return local_ranks
+    per = (n_queries + ws - 1) // ws
+    buf = torch.zeros(per, dtype=torch.int64, device=local_ranks.device)
+    buf[:local_ranks.numel()] = local_ranks
+    out = torch.empty(per * ws, dtype=torch.int64, device=local_ranks.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    full = torch.empty(n_queries, dtype=torch.int64, device=local_ranks.device)
+    for r in range(ws):
+        idx = split_queries(n_queries, r, ws)
+        full[idx] = out[r * per:r * per + idx.numel()]
+    return full
+
+
+def allreduce_sum_(tensors, group=None):
+    """In-place sum over ranks of every tensor in the list (dense gradient tables, loss scalars, count vectors)."""
+    _, ws = world(group)
+    if ws > 1:
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return tensors
+
+
+def dp_train_step(grads_fn, apply_fn, grad_tensors, loss_tensor=None, group=None):
+    """One data-parallel step: grads_fn() accumulates this rank's gradients into grad_tensors (and the loss into
+    loss_tensor), the tables are summed over ranks, apply_fn(1/world) applies the mean gradient and re-zeroes.
+    With equal per-rank batch sizes this equals one step on the concatenated batch (reduce_mean over it)."""
+    _, ws = world(group)
+    grads_fn()
+    allreduce_sum_(list(grad_tensors) + ([loss_tensor] if loss_tensor is not None and ws > 1 else []), group)
+    if loss_tensor is not None and ws > 1:
+        loss_tensor /= ws
+    apply_fn(1.0 / ws)
+
+
+def sharded_eval(test, side_fn, n_entities, table_shard=None, set_table=None, group=None):
+    """Filtered 1-vs-all ranks of `test` (list of triples) with the entity table row-sharded across ranks.
+    table_shard/set_table: this rank's rows and a callback installing the gathered full table (skipped when None).
+    side_fn(queries_subset) -> (tail_ranks, head_ranks) int64 tensors for the given subset (the GPU ranker).
+    Returns (tail_ranks, head_ranks) for all of `test` on every rank."""
+    rank, ws = world(group)
+    if table_shard is not None and set_table is not None:
+        set_table(allgather_rows(table_shard, n_entities, group))
+    idx = split_queries(len(test), rank, ws)
+    mine = [test[i] for i in idx.tolist()]
+    if mine:
+        t, h = side_fn(mine)
+    else:
+        t = h = torch.zeros(0, dtype=torch.int64)
+    t = torch.as_tensor(t, dtype=torch.int64)
+    h = torch.as_tensor(h, dtype=torch.int64)
+    return gather_ranks(t, len(test), group), gather_ranks(h.to(t.device), len(test), group)

@@ -1,0 +1,135 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU orchestration in kge_keras_amd.dist.  The compute that the GPU
+kernels do in production is injected from the oracle here, so what is under test is the sharding / collective logic:
+row-shard all-gather, query split + rank gather, data-parallel gradient all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _eval_worker(rank, world):
+    from kge_keras_amd import dist as D
+    rs = np.random.RandomState(0)
+    N, R, d = 103, 5, 8  # N not divisible by world: last shard is short
+    E = rs.uniform(-1, 1, (N, d))
+    Rl = rs.uniform(-1, 1, (R, d))
+    test = [(int(rs.randint(N)), int(rs.randint(R)), int(rs.randint(N))) for _ in range(31)]
+    filt = [(int(rs.randint(N)), int(rs.randint(R)), int(rs.randint(N))) for _ in range(200)]
+    filt = [t for t in filt if t not in set(test)]
+    lo, hi = D.shard_range(N, rank, world)
+    shard = torch.from_numpy(E[lo:hi].copy())
+    box = {}
+
+    def side_fn(queries):
+        t, h = O.ranks_closed_form("DistMult", box["E"].numpy(), Rl, queries, filt)
+        return torch.from_numpy(t), torch.from_numpy(h)
+
+    t, h = D.sharded_eval(test, side_fn, N, shard, lambda full: box.__setitem__("E", full))
+    assert torch.equal(box["E"], torch.from_numpy(E))  # all-gather rebuilt the table exactly
+    return t.numpy(), h.numpy(), (lo, hi)
+
+
+def test_sharded_eval_matches_unsharded():
+    out = _spawn(_eval_worker)
+    rs = np.random.RandomState(0)
+    N, R, d = 103, 5, 8
+    E = rs.uniform(-1, 1, (N, d))
+    Rl = rs.uniform(-1, 1, (R, d))
+    test = [(int(rs.randint(N)), int(rs.randint(R)), int(rs.randint(N))) for _ in range(31)]
+    filt = [(int(rs.randint(N)), int(rs.randint(R)), int(rs.randint(N))) for _ in range(200)]
+    filt = [t for t in filt if t not in set(test)]
+    t, h = O.ranks_closed_form("DistMult", E, Rl, test, filt)
+    for r in range(2):
+        assert np.array_equal(out[r][0], t) and np.array_equal(out[r][1], h)
+    assert out[0][2] == (0, 52) and out[1][2] == (52, 103)
+
+
+def _dp_worker(rank, world):
+    from kge_keras_amd import dist as D
+    rs = np.random.RandomState(1)
+    N, R, d, m = 30, 4, 6, 64
+    E = rs.uniform(-0.5, 0.5, (N, d))
+    Rl = rs.uniform(-0.5, 0.5, (R, d))
+    batches = [(np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1),
+                np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)) for _ in range(2 * world)]
+    opt = O.AdamTF()
+    gE, gR, loss = torch.zeros(N, d, dtype=torch.float64), torch.zeros(R, d, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+    for step in range(2):
+        pos, neg = batches[step * world + rank]
+
+        def grads_fn():
+            L, _, _, a, b = O.dense_grads("DistMult", E, Rl, pos, neg, "pointwize_logistic", 1.0)
+            gE.add_(torch.from_numpy(a))
+            gR.add_(torch.from_numpy(b))
+            loss[0] = L
+
+        def apply_fn(scale):
+            opt.begin_step()
+            opt.apply("E", E, gE.numpy() * scale)
+            opt.apply("R", Rl, gR.numpy() * scale)
+            gE.zero_()
+            gR.zero_()
+
+        D.dp_train_step(grads_fn, apply_fn, [gE, gR], loss)
+    return E, Rl, float(loss[0])
+
+
+def test_data_parallel_step_equals_big_batch():
+    out = _spawn(_dp_worker)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])  # replicas stay identical
+    rs = np.random.RandomState(1)
+    N, R, d, m = 30, 4, 6, 64
+    E = rs.uniform(-0.5, 0.5, (N, d))
+    Rl = rs.uniform(-0.5, 0.5, (R, d))
+    batches = [(np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1),
+                np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)) for _ in range(4)]
+    opt = O.AdamTF()
+    L = None
+    for step in range(2):
+        pos = np.concatenate([batches[2 * step][0], batches[2 * step + 1][0]])
+        neg = np.concatenate([batches[2 * step][1], batches[2 * step + 1][1]])
+        L = O.train_step("DistMult", E, Rl, opt, pos, neg, "pointwize_logistic", 1.0)
+    np.testing.assert_allclose(out[0][0], E, atol=1e-12)
+    np.testing.assert_allclose(out[0][1], Rl, atol=1e-12)
+    assert out[0][2] == pytest.approx(L, rel=1e-12)
+
+
+def test_shard_helpers_single_process():
+    from kge_keras_amd import dist as D
+    assert D.shard_range(123182, 7, 8) == (107786, 123182) and D.shard_range(123182, 0, 8) == (0, 15398)
+    assert D.shard_range(3, 2, 8) == (2, 3) and D.shard_range(3, 5, 8) == (3, 3)  # ragged / empty shards
+    t = torch.arange(12.).reshape(6, 2)
+    assert torch.equal(D.allgather_rows(t, 6), t)
+    assert D.split_queries(7, 1, 3).tolist() == [1, 4]
+    assert torch.equal(D.gather_ranks(torch.tensor([5, 6]), 2), torch.tensor([5, 6]))
