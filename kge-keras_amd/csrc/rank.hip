@@ -61,6 +61,9 @@ __global__ __launch_bounds__(256) void rank_build_q_kernel(const float* __restri
   if (!ok && lane == 0) atomicOr(err, 1u);
   if (MODEL == KGE_DISTMULT) {
     for (int k = lane; k < Kpad; k += G) out[k] = (ok && k < d_e) ? er[k] * rp[k] : 0.f;
+  } else if (MODEL == KGE_TRANSE) {
+    // ||s+p-o||: tail candidates o against q = s+p ; head candidates s against q = o-p  (|q-e| = |e-q|)
+    for (int k = lane; k < Kpad; k += G) out[k] = (ok && k < d_e) ? (side == 0 ? er[k] + rp[k] : er[k] - rp[k]) : 0.f;
   } else {  // ComplEx, rows are [real | imag]
     const int h = d_e >> 1;
     for (int k = lane; k < Kpad; k += G) {
@@ -204,6 +207,135 @@ __global__ __launch_bounds__(256) void rank_filter_kernel(const float* __restric
   if (sc > tgt[q]) atomicSub(&counts[q], 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TransE (models.py:186-190): score = gamma - ||q - e||_n (or +||.|| when gamma <= 0).  No dot product -> no MFMA: a
+// register-tiled VALU sweep (each thread 4 queries x 4 candidates, operands through k-major LDS tiles), 2 VALU ops
+// per (query, candidate, k).  Target and filtered-candidate scores come from dist_chain(), the same operation
+// sequence in the same ascending-k order, so the strict comparisons are made on bit-identical numbers.
+template <int NORM>
+__device__ __forceinline__ float dist_step(float acc, float q, float e) {
+  const float x = q - e;
+  return NORM == 1 ? acc + fabsf(x) : __fmaf_rn(x, x, acc);
+}
+template <int NORM>
+__device__ __forceinline__ float dist_score(float acc, float gamma) {
+  const float d = NORM == 1 ? acc : sqrtf(acc);
+  return gamma > 0.f ? gamma - d : d;
+}
+template <int NORM>
+__device__ __forceinline__ float dist_chain(const float* __restrict__ q, const float* __restrict__ e, int K, float gamma) {
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = dist_step<NORM>(acc, q[k], e[k]);
+  return dist_score<NORM>(acc, gamma);
+}
+
+template <int NORM>
+__global__ __launch_bounds__(256) void rank_dist_target_kernel(const float* __restrict__ Qv, const float* __restrict__ E,
+                                                                const int32_t* __restrict__ triples, int64_t nq, int side, int N,
+                                                                int K, int Kpad, float gamma, float* __restrict__ tgt,
+                                                                int32_t* __restrict__ counts, int zero_counts) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int t = triples[3 * q + (side == 0 ? 2 : 0)];
+  tgt[q] = (unsigned)t < (unsigned)N ? dist_chain<NORM>(Qv + q * Kpad, E + (int64_t)t * K, K, gamma) : __builtin_nanf("");
+  if (zero_counts) counts[q] = 0;
+}
+
+template <int NORM>
+__global__ __launch_bounds__(256) void rank_dist_sweep_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
+                                                               int64_t nq, const float* __restrict__ Ec, int K, int Kpad,
+                                                               int cand_rows, int tiles_per_block, float gamma,
+                                                               int32_t* __restrict__ counts) {
+  constexpr int T = 64, BK = 32;  // 64 queries x 64 candidates per block, 32-deep k chunks
+  __shared__ __attribute__((aligned(16))) float Qs[BK * T];
+  __shared__ __attribute__((aligned(16))) float Es[BK * T];
+  __shared__ int cnt_s[T];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int64_t q0 = (int64_t)blockIdx.x * T;
+  const int nct = (cand_rows + T - 1) / T;
+  const int ct_begin = blockIdx.y * tiles_per_block, ct_end = min(nct, ct_begin + tiles_per_block);
+  float tg[4];
+  int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int64_t row = q0 + ty * 4 + i; tg[i] = row < nq ? tgt[row] : __builtin_inff(); }
+  if (tid < T) cnt_s[tid] = 0;
+  const int srow = tid & 63, skq = tid >> 6;  // staging: lane <-> row, 4 k-quads per pass
+  for (int ct = ct_begin; ct < ct_end; ++ct) {
+    const int c0 = ct * T;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < Kpad; k0 += BK) {
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < BK / 16; ++pass) {
+        const int kl = (pass * 4 + skq) * 4;  // k offset inside the chunk
+        const int k = k0 + kl;
+        float qv[4] = {0.f, 0.f, 0.f, 0.f}, ev[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + srow < nq) {
+          const float* src = Qv + (q0 + srow) * Kpad + k;  // zero padded to Kpad (multiple of 32 here)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) qv[u] = src[u];
+        }
+        if (c0 + srow < cand_rows) {
+          const float* src = Ec + (int64_t)(c0 + srow) * K + k;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (k + u < K) ev[u] = src[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { Qs[(kl + u) * T + srow] = qv[u]; Es[(kl + u) * T + srow] = ev[u]; }
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int kk = 0; kk < BK; ++kk) {
+        const float4 q4 = *reinterpret_cast<const float4*>(Qs + kk * T + ty * 4);
+        const float4 e4 = *reinterpret_cast<const float4*>(Es + kk * T + tx * 4);
+        const float qa[4] = {q4.x, q4.y, q4.z, q4.w}, ea[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = dist_step<NORM>(acc[i][j], qa[i], ea[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool valid = c0 + tx * 4 + j < cand_rows;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cnt[i] += (valid && dist_score<NORM>(acc[i][j], gamma) > tg[i]) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (cnt[i]) atomicAdd(&cnt_s[ty * 4 + i], cnt[i]);
+  __syncthreads();
+  if (tid < T && q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
+}
+
+template <int NORM>
+__global__ __launch_bounds__(256) void rank_dist_filter_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
+                                                                const float* __restrict__ Ec, int cand_offset, int cand_rows,
+                                                                int K, int Kpad, float gamma, const int32_t* __restrict__ pair_q,
+                                                                const int32_t* __restrict__ filt_ids, int64_t npairs,
+                                                                int32_t* __restrict__ counts) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npairs) return;
+  const int q = pair_q[e];
+  const int c = filt_ids[e] - cand_offset;
+  if ((unsigned)c >= (unsigned)cand_rows) return;
+  if (dist_chain<NORM>(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, gamma) > tgt[q]) atomicSub(&counts[q], 1);
+}
+
+template <int NORM>
+__global__ void rank_dist_scores_kernel(const float* __restrict__ Qv, const float* __restrict__ Ec, int K, int Kpad, float gamma,
+                                         int64_t nq, int cand_rows, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * cand_rows) return;
+  const int64_t q = i / cand_rows;
+  out[i] = dist_chain<NORM>(Qv + q * Kpad, Ec + (int64_t)(i - q * cand_rows) * K, K, gamma);
+}
+
 // Debug / test hook: the score matrix entry as the chain computes it.
 __global__ void rank_chain_scores_kernel(const float* __restrict__ Qv, const float* __restrict__ Ec, int K, int Kpad,
                                           int64_t nq, int cand_rows, float* __restrict__ out) {
@@ -227,28 +359,56 @@ static int pick_bk(int K) {
 }
 
 int rank_kpad(int K) { return (int)align_up(K, pick_bk(K)); }
+static int rank_kpad_model(const kge_model_desc* md) { return md->model == KGE_TRANSE ? (int)align_up(md->d_e, 32) : rank_kpad(md->d_e); }
 
 int64_t rank_workspace_bytes(const kge_model_desc* md, int64_t nq) {
-  return (int64_t)sizeof(float) * (nq * rank_kpad(md->d_e) + align_up(nq, 64)) + 512;
+  return (int64_t)sizeof(float) * (nq * rank_kpad_model(md) + align_up(nq, 64)) + 512;
+}
+
+static void launch_build_q(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side,
+                           int Kpad, float* Qv, uint32_t* err, hipStream_t st) {
+  const int grid = (int)cdiv(nq * 64, 256);
+  const int K = md->d_e;
+  if (md->model == KGE_DISTMULT)
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_DISTMULT>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+  else if (md->model == KGE_TRANSE)
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_TRANSE>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+  else
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_COMPLEX>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+}
+
+template <int NORM>
+static void launch_dist(const kge_model_desc* md, const float* E, const float* Ec, int cand_offset, int cand_rows, const int32_t* triples,
+                        int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs, int32_t* counts,
+                        int accumulate, const float* Qv, float* tgt, int Kpad, hipStream_t st) {
+  const int K = md->d_e;
+  hipLaunchKernelGGL((rank_dist_target_kernel<NORM>), dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, md->gamma, tgt, counts, accumulate ? 0 : 1);
+  const int nqt = (int)cdiv(nq, 64), nct = (int)cdiv(cand_rows, 64);
+  int splits = std::max(1, std::min((int)cdiv(8 * kCUs, nqt), nct));
+  const int tpb = (int)cdiv(nct, splits);
+  splits = (int)cdiv(nct, tpb);
+  hipLaunchKernelGGL((rank_dist_sweep_kernel<NORM>), dim3(nqt, splits), dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, md->gamma, counts);
+  if (npairs > 0)
+    hipLaunchKernelGGL((rank_dist_filter_kernel<NORM>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, md->gamma, pair_q, filt_ids, npairs, counts);
 }
 
 int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* Ec, int cand_offset, int cand_rows,
                 const int32_t* triples, int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs,
                 int32_t* counts, int accumulate, float* tgt_out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
-  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX)
-    return fail(KGE_EUNSUPPORTED, "kge_rank_counts: model %d has no 1-vs-all kernel yet (DistMult and ComplEx are built)", md->model);
-  const int K = md->d_e, BK = pick_bk(K), Kpad = (int)align_up(K, BK);
+  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX && md->model != KGE_TRANSE)
+    return fail(KGE_EUNSUPPORTED, "kge_rank_counts: model %d has no 1-vs-all kernel yet (DistMult, ComplEx and TransE are built)", md->model);
+  const int K = md->d_e, BK = pick_bk(K), Kpad = rank_kpad_model(md);
   if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_counts: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)rank_workspace_bytes(md, nq));
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
   float* Qv = reinterpret_cast<float*>(p);
   float* tgt = tgt_out ? tgt_out : Qv + nq * Kpad;
   ProfScope prof(KGE_PROF_RANK, st);
-  {
-    const int grid = (int)cdiv(nq * 64, 256);
-    if (md->model == KGE_DISTMULT)
-      hipLaunchKernelGGL((rank_build_q_kernel<KGE_DISTMULT>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
-    else
-      hipLaunchKernelGGL((rank_build_q_kernel<KGE_COMPLEX>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+  launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
+  if (md->model == KGE_TRANSE) {
+    if (md->norm == 1) launch_dist<1>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
+    else launch_dist<2>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
   }
   hipLaunchKernelGGL(rank_target_kernel, dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
   {
@@ -272,17 +432,19 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
 
 int rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side,
                       float* out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
-  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX) return fail(KGE_EUNSUPPORTED, "kge_rank_chain_scores: model %d", md->model);
-  const int K = md->d_e, Kpad = rank_kpad(K);
+  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX && md->model != KGE_TRANSE) return fail(KGE_EUNSUPPORTED, "kge_rank_chain_scores: model %d", md->model);
+  const int K = md->d_e, Kpad = rank_kpad_model(md);
   if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_chain_scores: workspace too small");
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
   float* Qv = reinterpret_cast<float*>(p);
-  const int grid = (int)cdiv(nq * 64, 256);
-  if (md->model == KGE_DISTMULT)
-    hipLaunchKernelGGL((rank_build_q_kernel<KGE_DISTMULT>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
-  else
-    hipLaunchKernelGGL((rank_build_q_kernel<KGE_COMPLEX>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+  launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
   const int64_t tot = nq * md->num_entities;
+  if (md->model == KGE_TRANSE) {
+    if (md->norm == 1) hipLaunchKernelGGL((rank_dist_scores_kernel<1>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, nq, md->num_entities, out);
+    else hipLaunchKernelGGL((rank_dist_scores_kernel<2>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, nq, md->num_entities, out);
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
+  }
   hipLaunchKernelGGL(rank_chain_scores_kernel, dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, nq, md->num_entities, out);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;

@@ -134,6 +134,7 @@ class EmbeddingModel:
         self.optimizer = None
         self.stop_training = False
         self._gE = None
+        self._gR = None
         self._ws = None
         self._err = torch.zeros(1, dtype=torch.int32, device=dev)
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -207,6 +208,9 @@ class EmbeddingModel:
     # ------------------------------------------------------------------ training (tests.py:63-89,130-134)
     def compile(self, optimizer='adam', loss=None, **kw):
         self.optimizer = optimizer if isinstance(optimizer, _Optimizer) else _Optimizer(optimizer)
+        if self._gE is None:  # dense gradient accumulators (kept all-zero between steps by the optimizer sweep)
+            self._gE = torch.zeros_like(self.E)
+            self._gR = torch.zeros_like(self.Rel)
         return self
 
     def _ensure_train_state(self, m_pos, m_neg):

@@ -10,7 +10,7 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _mk(model, N, R, d, seed=0, quant=None):
+def _mk(model, N, R, d, seed=0, quant=None, **kw):
     from kge_keras_amd import models as M
     rs = np.random.RandomState(seed)
     de, dr = O.table_dims(model, d, d)
@@ -19,7 +19,7 @@ def _mk(model, N, R, d, seed=0, quant=None):
     if quant:
         E0 = (np.round(E0 * quant) / quant).astype(np.float32)
         R0 = (np.round(R0 * quant) / quant).astype(np.float32)
-    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0)
+    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0, **kw)
     return mdl, E0, R0, rs
 
 
@@ -27,14 +27,15 @@ def _ids(a):
     return [tuple(int(x) for x in t) for t in a]
 
 
-def _check_ranks(model, mdl, E0, R0, test, filt, N):
+def _check_ranks(model, mdl, E0, R0, test, filt, N, norm=1, gamma=12):
     fh, ft = O.build_filters(filt)
     tails, heads = mdl.rank(test, N, ft, fh)
     gaps = []
-    to, ho = O.ranks_closed_form(model, E0, R0, test, filt, margin_out=gaps)
+    to, ho = O.ranks_closed_form(model, E0, R0, test, filt, norm, gamma, margin_out=gaps)
     gaps = np.asarray(gaps).reshape(-1, 2)
-    # fp32 rounding of a K-term dot product is <~ 2^-23 * K * max|term|
-    tol = 5e-7 * E0.shape[1] * float(np.abs(E0).max() ** 2 * np.abs(R0).max())
+    # fp32 rounding of a K-term sum is <~ 2^-23 * K * max|term|
+    term = float(np.abs(E0).max() ** 2 * np.abs(R0).max()) if model != "TransE" else float(2 * np.abs(E0).max() + np.abs(R0).max()) ** norm
+    tol = 5e-7 * E0.shape[1] * term + (1e-5 if model == "TransE" else 0.0)
     for got, ref, gap in ((tails, to, gaps[:, 0]), (heads, ho, gaps[:, 1])):
         clear = gap > tol  # no candidate within float32 noise of the target: rank must be exact
         assert clear.mean() > 0.5
@@ -43,10 +44,11 @@ def _check_ranks(model, mdl, E0, R0, test, filt, N):
     return tails, heads, to, ho
 
 
-@pytest.mark.parametrize("model", ["DistMult", "ComplEx"])
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("ComplEx", {}), ("TransE", dict(norm=1, gamma=12)),
+                                      ("TransE", dict(norm=2, gamma=12)), ("TransE", dict(norm=2, gamma=0))])
 @pytest.mark.parametrize("N,d,nq", [(14, 32, 40), (300, 200, 257), (1000, 30, 64), (129, 8, 1)])
-def test_rank_parity_random(model, N, d, nq):
-    mdl, E0, R0, rs = _mk(model, N, 7, d)
+def test_rank_parity_random(model, kw, N, d, nq):
+    mdl, E0, R0, rs = _mk(model, N, 7, d, **kw)
     test = list({(int(rs.randint(N)), int(rs.randint(7)), int(rs.randint(N))) for _ in range(nq)})
     # filters: random other triples sharing (s,p) or (p,o) with the test triples, never the test triples themselves
     tes = set(test)
@@ -59,16 +61,17 @@ def test_rank_parity_random(model, N, d, nq):
             c = (int(rs.randint(N)), p, o)
             if c not in tes:
                 filt.add(c)
-    _check_ranks(model, mdl, E0, R0, test, sorted(filt), N)
+    _check_ranks(model, mdl, E0, R0, test, sorted(filt), N, kw.get("norm", 1), kw.get("gamma", 12))
 
 
 def test_rank_mfma_bit_exact_vs_chain():
     """The sweep's count must equal the count taken on the chain scores (the numbers the filter kernel and the target
     use): this is what makes un-counting filtered candidates exact.  Coarse-grid tables give many exact ties."""
     from kge_keras_amd import _lib
-    for model, quant in (("DistMult", None), ("DistMult", 2), ("ComplEx", 2)):
+    for model, quant, kw in (("DistMult", None, {}), ("DistMult", 2, {}), ("ComplEx", 2, {}), ("TransE", None, dict(norm=1, gamma=12)),
+                             ("TransE", 2, dict(norm=1, gamma=12)), ("TransE", 2, dict(norm=2, gamma=12)), ("TransE", None, dict(norm=2, gamma=0))):
         N, d, nq = 517, 40, 200
-        mdl, E0, R0, rs = _mk(model, N, 5, d, seed=3, quant=quant)
+        mdl, E0, R0, rs = _mk(model, N, 5, d, seed=3, quant=quant, **kw)
         test = np.stack([rs.randint(0, N, nq), rs.randint(0, 5, nq), rs.randint(0, N, nq)], 1).astype(np.int32)
         for side in (0, 1):
             cnt = mdl.rank_counts(test, side, np.zeros(0, np.int32), np.zeros(0, np.int32)).cpu().numpy()
@@ -86,7 +89,7 @@ def test_rank_mfma_bit_exact_vs_chain():
             cols = np.arange(N)
             q0 = test[0]
             tri = np.stack([np.full(N, q0[0]) if side == 0 else cols, np.full(N, q0[1]), cols if side == 0 else np.full(N, q0[2])], 1)
-            np.testing.assert_allclose(sc[0], O.call(model, E0, R0, tri), atol=1e-4, rtol=1e-5)
+            np.testing.assert_allclose(sc[0], O.call(model, E0, R0, tri, kw.get("norm", 1), kw.get("gamma", 12)), atol=1e-4, rtol=1e-5)
 
 
 def test_rank_ties_are_optimistic():
