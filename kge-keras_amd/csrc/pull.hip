@@ -21,6 +21,7 @@
 // float atomics are capped near 1.3 TB/s chip-wide (MI355X_MICROARCH.md, Global float atomics).
 #include "kge_internal.hpp"
 #include "pull.hpp"
+#include "dropout.hpp"
 
 namespace kge {
 
@@ -61,6 +62,10 @@ template <> struct V<1> {
   static __device__ __forceinline__ T zero() { return 0.f; }
 };
 
+template <int VEC> struct DM;
+template <> struct DM<4> { static __device__ __forceinline__ float4 mul(DropKey k, int c, uint32_t thr, float sc) { return drop_mul4(k, (uint32_t)c, thr, sc); } };
+template <> struct DM<1> { static __device__ __forceinline__ float mul(DropKey k, int c, uint32_t thr, float sc) { return drop_mul(k, (uint32_t)c, thr, sc); } };
+
 #define KGE_F4(expr_x, expr_y, expr_z, expr_w) make_float4(expr_x, expr_y, expr_z, expr_w)
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return KGE_F4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return KGE_F4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -80,14 +85,15 @@ __device__ __forceinline__ float4 shx(float4 v, int off) {
 
 // ------------------------------------------------------------------------------------------------ forward
 // LOSS >= 0: pointwise loss fused (coef, loss partials);  LOSS < 0: scores only (pairwise two-phase path).
-template <int MODEL, int NORM, int LOSS, int G, int VEC>
+template <int MODEL, int NORM, int LOSS, int G, int VEC, bool DROP>
 __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                    const int32_t* __restrict__ pos, int64_t m_pos,
                                                    const int32_t* __restrict__ neg, int64_t m_neg, int N, int R, int d_e,
                                                    int nchunk, float gamma, float margin, float* __restrict__ coef,
                                                    float* __restrict__ scores, float* __restrict__ loss_partials,
-                                                   uint32_t* __restrict__ err) {
+                                                   uint32_t* __restrict__ err, uint64_t seed, uint32_t thr, float dscale) {
   using C = V<VEC>;
+  using D = DM<VEC>;
   __shared__ float red[16];
   const int lane = threadIdx.x & (G - 1);
   const int64_t group = (int64_t)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
@@ -106,18 +112,27 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, c
       const float* es = E + (int64_t)s * d_e;
       const float* rp = Rel + (int64_t)p * d_e;
       const float* eo = E + (int64_t)o * d_e;
+      DropKey ks{0, 0}, kp{0, 0}, ko{0, 0};
+      if (DROP) { ks = drop_key(seed, t, 0); kp = drop_key(seed, t, 1); ko = drop_key(seed, t, 2); }
+      const int hc = h / VEC;  // chunk index of the imaginary half
       if (MODEL == KGE_COMPLEX) {
 #pragma unroll 2
         for (int c = lane; c < nchunk; c += G) {
           auto sr = C::ld(es + c * VEC), si = C::ld(es + h + c * VEC);
           auto pr = C::ld(rp + c * VEC), pi = C::ld(rp + h + c * VEC);
           auto orr = C::ld(eo + c * VEC), oi = C::ld(eo + h + c * VEC);
+          if (DROP) {
+            sr = sr * D::mul(ks, c, thr, dscale); si = si * D::mul(ks, hc + c, thr, dscale);
+            pr = pr * D::mul(kp, c, thr, dscale); pi = pi * D::mul(kp, hc + c, thr, dscale);
+            orr = orr * D::mul(ko, c, thr, dscale); oi = oi * D::mul(ko, hc + c, thr, dscale);
+          }
           acc += hsum(sr * pr * orr + pr * si * oi + pi * sr * oi - pi * si * orr);
         }
       } else {
 #pragma unroll 4
         for (int c = lane; c < nchunk; c += G) {
           auto sv = C::ld(es + c * VEC), pv = C::ld(rp + c * VEC), ov = C::ld(eo + c * VEC);
+          if (DROP) { sv = sv * D::mul(ks, c, thr, dscale); pv = pv * D::mul(kp, c, thr, dscale); ov = ov * D::mul(ko, c, thr, dscale); }
           if (MODEL == KGE_DISTMULT) acc += hsum(sv * pv * ov);
           else { auto x = sv + pv - ov; acc += NORM == 1 ? hsum(vabs(x)) : hsum(x * x); }
         }
@@ -299,15 +314,18 @@ __global__ __launch_bounds__(256) void fill_kernel(const int32_t* __restrict__ p
 // ------------------------------------------------------------------------------------------------ pull
 // One wave per unit.  Lane l of a G-lane sub-group owns chunks l, l+G, ... (NV of them) of the row (of each HALF row for
 // ComplEx); the 64/G sub-groups of the wave take different list entries and meet in a shuffle reduction at the end.
-template <int MODEL, int NORM, int G, int NV, int VEC>
+template <int MODEL, int NORM, int G, int NV, int VEC, bool DROP>
 __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                     float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,
                                                     int nchunk, const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
                                                     const int32_t* __restrict__ eoff, const int32_t* __restrict__ poff,
                                                     const int32_t* __restrict__ totals, const int2* __restrict__ emap,
-                                                    const int4* __restrict__ entries, float* __restrict__ slab, int C) {
+                                                    const int4* __restrict__ entries, float* __restrict__ slab, int C,
+                                                    uint64_t seed, uint32_t thr, float dscale) {
   using T = typename V<VEC>::T;
   using L = V<VEC>;
+  using D = DM<VEC>;
+  const int hc = (d_e >> 1) / VEC;
   constexpr int NSUB = 64 / G;
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
@@ -347,28 +365,45 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
     const int kind1 = is_rel ? 0 : ((unsigned)e.x >> 31);
     const float* ra = is_rel ? E + (int64_t)e.x * d_e : Rel + (int64_t)(e.x & 0x7fffffff) * d_e;
     const float* rb = E + (int64_t)e.y * d_e;
+    // dropout: roles of (destination, a, b) in the triple e.w
+    DropKey kd{0, 0}, ka{0, 0}, kb{0, 0};
+    if (DROP) {
+      const int rd = is_rel ? 1 : (kind1 ? 2 : 0), rra = is_rel ? 0 : 1, rrb = is_rel ? 2 : (kind1 ? 0 : 2);
+      kd = drop_key(seed, e.w, rd); ka = drop_key(seed, e.w, rra); kb = drop_key(seed, e.w, rrb);
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int ch = lane + j * G;
       if (ch < nchunk) {
         if (MODEL == KGE_DISTMULT) {
-          acc[j] = acc[j] + cf * (L::ld(ra + ch * VEC) * L::ld(rb + ch * VEC));
+          T a = L::ld(ra + ch * VEC), b = L::ld(rb + ch * VEC);
+          if (DROP) a = a * D::mul(ka, ch, thr, dscale) * D::mul(kb, ch, thr, dscale) * D::mul(kd, ch, thr, dscale);
+          acc[j] = acc[j] + cf * (a * b);
         } else if (MODEL == KGE_TRANSE) {
           // x = s + p - o with the destination row in its own role
-          const T a = L::ld(ra + ch * VEC), b = L::ld(rb + ch * VEC);
+          T a = L::ld(ra + ch * VEC), b = L::ld(rb + ch * VEC), m = me[j];
+          T md1;
+          if (DROP) { md1 = D::mul(kd, ch, thr, dscale); a = a * D::mul(ka, ch, thr, dscale); b = b * D::mul(kb, ch, thr, dscale); m = m * md1; }
           T x;
           float sg = cf;
-          if (is_rel) x = a + me[j] - b;              // dest p: a = s, b = o
-          else if (!kind1) x = me[j] + a - b;         // dest s: a = p, b = o
-          else { x = b + a - me[j]; sg = -cf; }        // dest o: a = p, b = s ; d/do = -d/dx
-          acc[j] = acc[j] + sg * (NORM == 1 ? vsgn(x) : x);
+          if (is_rel) x = a + m - b;              // dest p: a = s, b = o
+          else if (!kind1) x = m + a - b;         // dest s: a = p, b = o
+          else { x = b + a - m; sg = -cf; }        // dest o: a = p, b = s ; d/do = -d/dx
+          T term = sg * (NORM == 1 ? vsgn(x) : x);
+          if (DROP) term = term * md1;
+          acc[j] = acc[j] + term;
         } else {  // ComplEx: halves [real | imag]
-          const T ar = L::ld(ra + ch * VEC), ai = L::ld(ra + h + ch * VEC);
-          const T br = L::ld(rb + ch * VEC), bi = L::ld(rb + h + ch * VEC);
+          T ar = L::ld(ra + ch * VEC), ai = L::ld(ra + h + ch * VEC);
+          T br = L::ld(rb + ch * VEC), bi = L::ld(rb + h + ch * VEC);
+          if (DROP) {
+            ar = ar * D::mul(ka, ch, thr, dscale); ai = ai * D::mul(ka, hc + ch, thr, dscale);
+            br = br * D::mul(kb, ch, thr, dscale); bi = bi * D::mul(kb, hc + ch, thr, dscale);
+          }
           T gr, gi;
           if (is_rel) { gr = ar * br + ai * bi; gi = ar * bi - ai * br; }            // a = s, b = o
           else if (!kind1) { gr = ar * br + ai * bi; gi = ar * bi - ai * br; }       // a = p, b = o : pr*or+pi*oi | pr*oi-pi*or
           else { gr = br * ar - ai * bi; gi = ar * bi + ai * br; }                   // a = p, b = s : sr*pr-pi*si | pr*si+pi*sr
+          if (DROP) { gr = gr * D::mul(kd, ch, thr, dscale); gi = gi * D::mul(kd, hc + ch, thr, dscale); }
           acc[j] = acc[j] + cf * gr;
           acc[NV + j] = acc[NV + j] + cf * gi;
         }
@@ -472,37 +507,46 @@ bool pull_supported(const kge_model_desc* md) {
 template <int MODEL, int NORM, int LOSS, int VEC>
 static void launch_fwd(int G, int grid, hipStream_t st, const float* E, const float* Rel, const int32_t* pos, int64_t m_pos,
                        const int32_t* neg, int64_t m_neg, const kge_model_desc* md, int nchunk, float margin, float* coef,
-                       float* scores, float* partials, uint32_t* err) {
-#define KGE_FWD(GW) hipLaunchKernelGGL((fwd_kernel<MODEL, NORM, LOSS, GW, VEC>), dim3(grid), dim3(256), 0, st, E, Rel, pos, m_pos, neg, m_neg, \
-                                       md->num_entities, md->num_relations, md->d_e, nchunk, md->gamma, margin, coef, scores, partials, err)
+                       float* scores, float* partials, uint32_t* err, uint64_t seed) {
+  const bool drop = md->dropout > 0.f;
+  const uint32_t thr = drop_thr(md->dropout);
+  const float dscale = 1.f / (1.f - md->dropout);
+#define KGE_FWD(GW, DR) hipLaunchKernelGGL((fwd_kernel<MODEL, NORM, LOSS, GW, VEC, DR>), dim3(grid), dim3(256), 0, st, E, Rel, pos, m_pos, neg, m_neg, \
+                                           md->num_entities, md->num_relations, md->d_e, nchunk, md->gamma, margin, coef, scores, partials, err, seed, thr, dscale)
+#define KGE_FWD2(GW) do { if (drop) KGE_FWD(GW, true); else KGE_FWD(GW, false); } while (0)
   switch (G) {
-    case 4: KGE_FWD(4); break;
-    case 8: KGE_FWD(8); break;
-    case 16: KGE_FWD(16); break;
-    case 32: KGE_FWD(32); break;
-    default: KGE_FWD(64); break;
+    case 4: KGE_FWD2(4); break;
+    case 8: KGE_FWD2(8); break;
+    case 16: KGE_FWD2(16); break;
+    case 32: KGE_FWD2(32); break;
+    default: KGE_FWD2(64); break;
   }
+#undef KGE_FWD2
 #undef KGE_FWD
 }
 
 template <int MODEL, int NORM, int VEC>
 static void launch_fwd_loss(int loss, int G, int grid, hipStream_t st, const float* E, const float* Rel, const int32_t* pos,
                             int64_t m_pos, const int32_t* neg, int64_t m_neg, const kge_model_desc* md, int nchunk, float margin,
-                            float* coef, float* scores, float* partials, uint32_t* err) {
+                            float* coef, float* scores, float* partials, uint32_t* err, uint64_t seed) {
   switch (loss) {
-    case KGE_POINTWIZE_HINGE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_HINGE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
-    case KGE_POINTWIZE_LOGISTIC: launch_fwd<MODEL, NORM, KGE_POINTWIZE_LOGISTIC, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
-    case KGE_POINTWIZE_SQUARE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_SQUARE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
-    default: launch_fwd<MODEL, NORM, -1, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err); break;
+    case KGE_POINTWIZE_HINGE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_HINGE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
+    case KGE_POINTWIZE_LOGISTIC: launch_fwd<MODEL, NORM, KGE_POINTWIZE_LOGISTIC, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
+    case KGE_POINTWIZE_SQUARE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_SQUARE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
+    default: launch_fwd<MODEL, NORM, -1, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
   }
 }
 
 template <int MODEL, int NORM, int VEC>
 static void launch_pull(int nchunk, int grid, hipStream_t st, const float* E, const float* Rel, float* gE, float* gR,
-                        const kge_model_desc* md, const PullPlan& p) {
+                        const kge_model_desc* md, const PullPlan& p, uint64_t seed) {
   const int N = md->num_entities, NK = N + md->num_relations;
-#define KGE_PULL(GW, NVV) hipLaunchKernelGGL((pull_kernel<MODEL, NORM, GW, NVV, VEC>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, N, NK, md->d_e, \
-                                             nchunk, p.cnt, p.off, p.eoff, p.poff, p.totals, p.emap, p.entries, p.slab, p.chunk)
+  const bool drop = md->dropout > 0.f;
+  const uint32_t thr = drop_thr(md->dropout);
+  const float dscale = 1.f / (1.f - md->dropout);
+#define KGE_PULL1(GW, NVV, DR) hipLaunchKernelGGL((pull_kernel<MODEL, NORM, GW, NVV, VEC, DR>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, N, NK, md->d_e, \
+                                                  nchunk, p.cnt, p.off, p.eoff, p.poff, p.totals, p.emap, p.entries, p.slab, p.chunk, seed, thr, dscale)
+#define KGE_PULL(GW, NVV) do { if (drop) KGE_PULL1(GW, NVV, true); else KGE_PULL1(GW, NVV, false); } while (0)
   if (nchunk <= 8) KGE_PULL(8, 1);
   else if (nchunk <= 16) KGE_PULL(16, 1);
   else if (nchunk <= 32) KGE_PULL(32, 1);
@@ -510,6 +554,7 @@ static void launch_pull(int nchunk, int grid, hipStream_t st, const float* E, co
   else if (nchunk <= 128) KGE_PULL(64, 2);
   else KGE_PULL(64, 4);
 #undef KGE_PULL
+#undef KGE_PULL1
 }
 
 struct Shape { bool v4; int nchunk; };
@@ -537,7 +582,7 @@ int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, co
 
 int pull_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
                  int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p, float* scores, float* loss_partials,
-                 int* n_partials, uint32_t* err, hipStream_t st) {
+                 int* n_partials, uint32_t* err, uint64_t seed, hipStream_t st) {
   const int64_t n = m_pos + m_neg;
   const Shape sh = shape_of(md, E, Rel, nullptr, nullptr);
   const int G = fwd_group_width(sh.nchunk);
@@ -546,8 +591,8 @@ int pull_forward(const kge_model_desc* md, int loss, float margin, const float* 
   ProfScope prof(KGE_PROF_FWD, st);
 #define KGE_GO(MODEL, NORM)                                                                                                                         \
   do {                                                                                                                                              \
-    if (sh.v4) launch_fwd_loss<MODEL, NORM, 4>(loss, G, fgrid, st, E, Rel, pos, m_pos, neg, m_neg, md, sh.nchunk, margin, p.coef, scores, loss_partials, err); \
-    else launch_fwd_loss<MODEL, NORM, 1>(loss, G, fgrid, st, E, Rel, pos, m_pos, neg, m_neg, md, sh.nchunk, margin, p.coef, scores, loss_partials, err);       \
+    if (sh.v4) launch_fwd_loss<MODEL, NORM, 4>(loss, G, fgrid, st, E, Rel, pos, m_pos, neg, m_neg, md, sh.nchunk, margin, p.coef, scores, loss_partials, err, seed); \
+    else launch_fwd_loss<MODEL, NORM, 1>(loss, G, fgrid, st, E, Rel, pos, m_pos, neg, m_neg, md, sh.nchunk, margin, p.coef, scores, loss_partials, err, seed);       \
   } while (0)
   if (md->model == KGE_DISTMULT) KGE_GO(KGE_DISTMULT, 1);
   else if (md->model == KGE_COMPLEX) KGE_GO(KGE_COMPLEX, 1);
@@ -560,7 +605,7 @@ int pull_forward(const kge_model_desc* md, int loss, float margin, const float* 
 
 int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const int32_t* pos,
                   int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p, bool g_is_dscore, const float* scores,
-                  hipStream_t st) {
+                  uint64_t seed, hipStream_t st) {
   const int64_t n = m_pos + m_neg;
   const int N = md->num_entities, NK = N + md->num_relations;
   const Shape sh = shape_of(md, E, Rel, gE, gR);
@@ -580,8 +625,8 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
     const int pgrid = (int)cdiv(units, 4);
 #define KGE_GO(MODEL, NORM)                                                                \
   do {                                                                                     \
-    if (sh.v4) launch_pull<MODEL, NORM, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, p);   \
-    else launch_pull<MODEL, NORM, 1>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, p);         \
+    if (sh.v4) launch_pull<MODEL, NORM, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, p, seed);   \
+    else launch_pull<MODEL, NORM, 1>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, p, seed);         \
   } while (0)
     if (md->model == KGE_DISTMULT) KGE_GO(KGE_DISTMULT, 1);
     else if (md->model == KGE_COMPLEX) KGE_GO(KGE_COMPLEX, 1);

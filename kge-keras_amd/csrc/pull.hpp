@@ -31,10 +31,10 @@ int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, co
 // gather + score; loss >= 0: pointwise loss fused (plan->coef, loss_partials[0..*n_partials)); loss < 0: scores only
 int pull_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
                  int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& plan, float* scores, float* loss_partials,
-                 int* n_partials, uint32_t* err, hipStream_t st);
+                 int* n_partials, uint32_t* err, uint64_t seed, hipStream_t st);
 // list fill + per-destination gather-reduce into gE/gR (+=).  g_is_dscore: plan.coef holds dL/dscore (pairwise path)
 int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const int32_t* pos,
                   int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& plan, bool g_is_dscore, const float* scores,
-                  hipStream_t st);
+                  uint64_t seed, hipStream_t st);
 
 }  // namespace kge

@@ -11,6 +11,7 @@
 // zero subgradient issue no atomics at all.
 #include "kge_internal.hpp"
 #include "pull.hpp"
+#include "dropout.hpp"
 
 namespace kge {
 
@@ -38,14 +39,14 @@ __device__ __forceinline__ void pointwise(float score, bool is_pos, float margin
 }
 
 // LOSS < 0: dL/dscore comes from gbuf (two-phase pairwise path) and no loss term is produced here.
-template <int MODEL, int NORM, int LOSS, int G>
+template <int MODEL, int NORM, int LOSS, int G, bool DROP>
 __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                     float* __restrict__ gE, float* __restrict__ gR,
                                                     const int32_t* __restrict__ pos, int64_t m_pos,
                                                     const int32_t* __restrict__ neg, int64_t m_neg, int N, int R, int d_e,
                                                     int d_r, float gamma, float margin, const float* __restrict__ gbuf,
                                                     float* __restrict__ scores, float* __restrict__ loss_partials,
-                                                    uint32_t* __restrict__ err) {
+                                                    uint32_t* __restrict__ err, uint64_t seed, uint32_t thr, float dscale) {
   __shared__ float red[16];
   const int lane = threadIdx.x & (G - 1);
   const int64_t group = (int64_t)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
@@ -63,14 +64,21 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
     const float* es = E + (int64_t)(ok ? s : 0) * d_e;
     const float* rp = Rel + (int64_t)(ok ? p : 0) * d_r;
     const float* eo = E + (int64_t)(ok ? o : 0) * d_e;
+    // inverted-dropout multipliers of element e of the s / p / o row of this batch row (1 when DROP is off)
+    DropKey ks{0, 0}, kp{0, 0}, ko{0, 0};
+    if (DROP) { ks = drop_key(seed, t, 0); kp = drop_key(seed, t, 1); ko = drop_key(seed, t, 2); }
+    auto ms = [&](int e) { return DROP ? drop_mul(ks, e, thr, dscale) : 1.f; };
+    auto mp = [&](int e) { return DROP ? drop_mul(kp, e, thr, dscale) : 1.f; };
+    auto mo = [&](int e) { return DROP ? drop_mul(ko, e, thr, dscale) : 1.f; };
     // ---- pass 1: score
     float acc = 0.f;
     for (int k = lane; k < width; k += G) {
       if (MODEL == KGE_COMPLEX) {
-        const float sr = es[k], si = es[h + k], pr = rp[k], pi = rp[h + k], orr = eo[k], oi = eo[h + k];
+        const float sr = es[k] * ms(k), si = es[h + k] * ms(h + k), pr = rp[k] * mp(k), pi = rp[h + k] * mp(h + k),
+                    orr = eo[k] * mo(k), oi = eo[h + k] * mo(h + k);
         acc += sr * pr * orr + pr * si * oi + pi * sr * oi - pi * si * orr;
       } else {
-        const float sv = es[k], pv = rp[k], ov = eo[k];
+        const float sv = es[k] * ms(k), pv = rp[k] * mp(k), ov = eo[k] * mo(k);
         if (MODEL == KGE_DISTMULT) acc += sv * pv * ov;
         else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : x * x; }
       }
@@ -100,28 +108,31 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
       const float sgn = gamma > 0.f ? -g : g;
       const float rn = (NORM == 2) ? (dist > 0.f ? sgn / dist : 0.f) : sgn;
       for (int k = lane; k < width; k += G) {
-        const float x = es[k] + rp[k] - eo[k];
+        const float a = ms(k), b = mp(k), c = mo(k);
+        const float x = es[k] * a + rp[k] * b - eo[k] * c;
         const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f)) : rn * x;
-        atomicAdd(gs + k, dx);
-        atomicAdd(gp + k, dx);
-        atomicAdd(go + k, -dx);
+        atomicAdd(gs + k, dx * a);
+        atomicAdd(gp + k, dx * b);
+        atomicAdd(go + k, -dx * c);
       }
     } else if (MODEL == KGE_DISTMULT) {
       for (int k = lane; k < width; k += G) {
-        const float sv = es[k], pv = rp[k], ov = eo[k];
-        atomicAdd(gs + k, g * pv * ov);
-        atomicAdd(gp + k, g * sv * ov);
-        atomicAdd(go + k, g * sv * pv);
+        const float a = ms(k), b = mp(k), c = mo(k);
+        const float sv = es[k] * a, pv = rp[k] * b, ov = eo[k] * c;
+        atomicAdd(gs + k, g * pv * ov * a);
+        atomicAdd(gp + k, g * sv * ov * b);
+        atomicAdd(go + k, g * sv * pv * c);
       }
     } else {  // ComplEx
       for (int k = lane; k < width; k += G) {
-        const float sr = es[k], si = es[h + k], pr = rp[k], pi = rp[h + k], orr = eo[k], oi = eo[h + k];
-        atomicAdd(gs + k, g * (pr * orr + pi * oi));
-        atomicAdd(gs + h + k, g * (pr * oi - pi * orr));
-        atomicAdd(gp + k, g * (sr * orr + si * oi));
-        atomicAdd(gp + h + k, g * (sr * oi - si * orr));
-        atomicAdd(go + k, g * (sr * pr - pi * si));
-        atomicAdd(go + h + k, g * (pr * si + pi * sr));
+        const float asr = ms(k), asi = ms(h + k), apr = mp(k), api = mp(h + k), aor = mo(k), aoi = mo(h + k);
+        const float sr = es[k] * asr, si = es[h + k] * asi, pr = rp[k] * apr, pi = rp[h + k] * api, orr = eo[k] * aor, oi = eo[h + k] * aoi;
+        atomicAdd(gs + k, g * (pr * orr + pi * oi) * asr);
+        atomicAdd(gs + h + k, g * (pr * oi - pi * orr) * asi);
+        atomicAdd(gp + k, g * (sr * orr + si * oi) * apr);
+        atomicAdd(gp + h + k, g * (sr * oi - si * orr) * api);
+        atomicAdd(go + k, g * (sr * pr - pi * si) * aor);
+        atomicAdd(go + h + k, g * (pr * si + pi * sr) * aoi);
       }
     }
   }
@@ -301,19 +312,21 @@ int push_group_width(int width);  // tuning.cpp
 template <int MODEL, int NORM, int LOSS>
 static int launch_push(int G, const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE,
                        float* gR, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const float* gbuf,
-                       float* scores, float* partials, uint32_t* err, hipStream_t st, int* nblocks) {
+                       float* scores, float* partials, uint32_t* err, hipStream_t st, int* nblocks, uint64_t seed = 0) {
   const int64_t n = m_pos + m_neg;
   const int64_t want = cdiv(n * G, 256);
   const int grid = (int)(want < kMaxBlocks ? want : kMaxBlocks);
   *nblocks = grid;
   ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
-#define KGE_PUSH(GW)                                                                                                \
-  hipLaunchKernelGGL((push_kernel<MODEL, NORM, LOSS, GW>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, pos, m_pos, \
-                     neg, m_neg, md->num_entities, md->num_relations, md->d_e, md->d_r, md->gamma, ld->margin, gbuf,  \
-                     scores, partials, err)
-  if (G == 16) KGE_PUSH(16);
-  else if (G == 32) KGE_PUSH(32);
-  else KGE_PUSH(64);
+  const bool drop = md->dropout > 0.f;
+  const uint32_t thr = drop_thr(md->dropout);
+  const float dscale = 1.f / (1.f - md->dropout);
+#define KGE_PUSH(GW, DR)                                                                                                \
+  hipLaunchKernelGGL((push_kernel<MODEL, NORM, LOSS, GW, DR>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, pos, m_pos, \
+                     neg, m_neg, md->num_entities, md->num_relations, md->d_e, md->d_r, md->gamma, ld->margin, gbuf,      \
+                     scores, partials, err, seed, thr, dscale)
+  if (drop) { if (G == 16) KGE_PUSH(16, true); else if (G == 32) KGE_PUSH(32, true); else KGE_PUSH(64, true); }
+  else { if (G == 16) KGE_PUSH(16, false); else if (G == 32) KGE_PUSH(32, false); else KGE_PUSH(64, false); }
 #undef KGE_PUSH
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
@@ -322,16 +335,16 @@ static int launch_push(int G, const kge_model_desc* md, const kge_loss_desc* ld,
 template <int LOSS>
 static int push_by_model(int G, const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE,
                          float* gR, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const float* gbuf,
-                         float* scores, float* partials, uint32_t* err, hipStream_t st, int* nb) {
+                         float* scores, float* partials, uint32_t* err, hipStream_t st, int* nb, uint64_t seed = 0) {
   switch (md->model) {
     case KGE_DISTMULT:
-      return launch_push<KGE_DISTMULT, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
+      return launch_push<KGE_DISTMULT, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
     case KGE_TRANSE:
       if (md->norm == 1)
-        return launch_push<KGE_TRANSE, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
-      return launch_push<KGE_TRANSE, 2, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
+        return launch_push<KGE_TRANSE, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
+      return launch_push<KGE_TRANSE, 2, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
     case KGE_COMPLEX:
-      return launch_push<KGE_COMPLEX, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb);
+      return launch_push<KGE_COMPLEX, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
     default:
       return fail(KGE_EUNSUPPORTED, "kge_train_step: model %d has no HIP training kernel yet", md->model);
   }
@@ -353,8 +366,6 @@ static int launch_pairwise(const float* ts, int64_t m_t, const float* fs, int64_
 int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
                 const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out,
                 uint64_t seed, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
-  (void)seed;
-  if (md->dropout != 0.f) return fail(KGE_EUNSUPPORTED, "dropout > 0 is not built yet (models.py:122); pass dp=0");
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   const bool pairwise = ld->loss == KGE_PAIRWIZE_HINGE || ld->loss == KGE_PAIRWIZE_LOGISTIC || ld->loss == KGE_PAIRWIZE_SQUARE;
@@ -376,7 +387,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     PullPlan plan;
     if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull, st, &plan)) return rc;
     float* sc = scores_out ? scores_out : (pairwise ? ws.sbuf : nullptr);
-    if (int rc = pull_forward(md, pairwise ? -1 : ld->loss, ld->margin, E, Rel, pos, m_pos, neg, m_neg, plan, sc, ws.loss_partials, &nb, err, st)) return rc;
+    if (int rc = pull_forward(md, pairwise ? -1 : ld->loss, ld->margin, E, Rel, pos, m_pos, neg, m_neg, plan, sc, ws.loss_partials, &nb, err, seed, st)) return rc;
     if (pairwise) {
       int rc;
       if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
@@ -384,22 +395,24 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
       else rc = launch_pairwise<KGE_PAIRWIZE_SQUARE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
       if (rc) return rc;
     }
-    if (int rc = pull_backward(md, E, Rel, gE, gR, pos, m_pos, neg, m_neg, plan, pairwise, sc, st)) return rc;
+    if (int rc = pull_backward(md, E, Rel, gE, gR, pos, m_pos, neg, m_neg, plan, pairwise, sc, seed, st)) return rc;
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
+  if (pairwise && md->dropout > 0.f)
+    return fail(KGE_EUNSUPPORTED, "pairwize loss with dropout needs the pull gradient path (kge_set_grad_mode(0))");
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const int G = push_group_width(width);
   switch (ld->loss) {
     case KGE_POINTWIZE_HINGE:
-      if (int rc = push_by_model<KGE_POINTWIZE_HINGE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb)) return rc;
+      if (int rc = push_by_model<KGE_POINTWIZE_HINGE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb, seed)) return rc;
       break;
     case KGE_POINTWIZE_LOGISTIC:
-      if (int rc = push_by_model<KGE_POINTWIZE_LOGISTIC>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb)) return rc;
+      if (int rc = push_by_model<KGE_POINTWIZE_LOGISTIC>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb, seed)) return rc;
       break;
     case KGE_POINTWIZE_SQUARE:
-      if (int rc = push_by_model<KGE_POINTWIZE_SQUARE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb)) return rc;
+      if (int rc = push_by_model<KGE_POINTWIZE_SQUARE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb, seed)) return rc;
       break;
     case KGE_PAIRWIZE_HINGE:
     case KGE_PAIRWIZE_LOGISTIC:
@@ -416,7 +429,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
       if (rc) return rc;
       // phase 3: gradient rows
       int nb2 = 0;
-      if ((rc = push_by_model<-1>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, ws.gbuf, nullptr, nullptr, err, st, &nb2))) return rc;
+      if ((rc = push_by_model<-1>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, ws.gbuf, nullptr, nullptr, err, st, &nb2, seed))) return rc;
       break;
     }
     default:

@@ -254,6 +254,39 @@ def make_optimizer(name, **kw):
 
 
 # ----------------------------------------------------------------------------------------------
+# dropout on the gathered rows (models.py:122,144-148).  [TF] inverted dropout: kept entries scaled by 1/(1-rate).
+# TensorFlow's mask stream is not reproducible; the checker regenerates the product's counter-based masks
+# (kge-keras_amd/csrc/dropout.hpp: splitmix64 key of (seed, batch row, role) + a 32-bit mix per element pair).
+# ----------------------------------------------------------------------------------------------
+def dropout_multipliers(seed, n_rows, role, width, rate, row_offset=0):
+    """(n_rows, width) array of 0 / 1/(1-rate) for batch rows row_offset..row_offset+n_rows-1 in role 0/1/2 (s/p/o)."""
+    M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        t = np.arange(row_offset, row_offset + n_rows, dtype=np.uint64)
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (np.uint64(3) * t + np.uint64(role + 1))) & M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M64
+        z = z ^ (z >> np.uint64(31))
+        lo = (z & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None]
+        hi = (z >> np.uint64(32)).astype(np.uint32)[:, None]
+        nw = (width + 1) // 2
+        w = np.arange(nw, dtype=np.uint32)[None, :]
+        x = (w * np.uint32(0x9E3779B1)) ^ lo
+        x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x85EBCA6B)
+        x = x ^ (x >> np.uint32(13)); x = x * np.uint32(0xC2B2AE35)
+        x = x ^ (x >> np.uint32(16)); x = x + hi
+        x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x2C1B3C6D)
+        x = x ^ (x >> np.uint32(12))
+    bits = np.empty((n_rows, 2 * nw), dtype=np.uint32)
+    bits[:, 0::2] = x & np.uint32(0xFFFF)
+    bits[:, 1::2] = x >> np.uint32(16)
+    thr = int(np.float32(rate) * np.float32(65536.0) + np.float32(0.5))
+    thr = max(0, min(65535, thr))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+    return np.where(bits[:, :width] >= thr, scale, np.float32(0.0)).astype(np.float64)
+
+
+# ----------------------------------------------------------------------------------------------
 # one training batch: the default Keras train_step over add_loss (tests.py:63-89, SURVEY 3.2)
 # ----------------------------------------------------------------------------------------------
 def _scatter_add(G, idx, rows):
@@ -267,23 +300,31 @@ def _scatter_add(G, idx, rows):
     G += S @ rows
 
 
-def dense_grads(model, E, Rel, pos, neg, loss, margin=1, negative_samples=1, norm=1, gamma=12, regularization=0.0):
+def dense_grads(model, E, Rel, pos, neg, loss, margin=1, negative_samples=1, norm=1, gamma=12, regularization=0.0,
+                dropout=0.0, seed=0):
     """Forward on pos and neg with the SAME tables (tests.py:77-78), loss (tests.py:80-81), and the dense
     equivalents of the IndexedSlices gradients (duplicates summed) [TF].  Returns (loss, scores_pos,
     scores_neg, gE, gRel).  `regularization` adds w*sum|E|^3 over the whole entity table (models.py:10-11,78-92)."""
     dt = E.dtype
     pos = np.asarray(pos).reshape(-1, 3).astype(np.int64)
     neg = np.asarray(neg).reshape(-1, 3).astype(np.int64)
-    rows = []
-    for t in (pos, neg):
-        rows.append((E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]]))
+    rows, masks = [], []
+    for t, off in ((pos, 0), (neg, len(pos))):
+        s_, p_, o_ = E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]]
+        if dropout:  # batch row index = position in [pos ; neg]
+            ms = [dropout_multipliers(seed, len(t), r, E.shape[1], dropout, off).astype(dt) for r in range(3)]
+            s_, p_, o_ = s_ * ms[0], p_ * ms[1], o_ * ms[2]
+            masks.append(ms)
+        rows.append((s_, p_, o_))
     sp = score_rows(model, *rows[0], norm, gamma).astype(dt)
     sn = score_rows(model, *rows[1], norm, gamma).astype(dt)
     L, gt, gf = loss_value_and_grads(loss, sp, sn, margin, negative_samples)
     gE = np.zeros_like(E)
     gR = np.zeros_like(Rel)
-    for t, (s, p, o), g in ((pos, rows[0], gt), (neg, rows[1], gf)):
+    for i, (t, (s, p, o), g) in enumerate(((pos, rows[0], gt), (neg, rows[1], gf))):
         ds, dp, do = score_row_grads(model, s, p, o, g.astype(dt), norm, gamma)
+        if dropout:
+            ds, dp, do = ds * masks[i][0], dp * masks[i][1], do * masks[i][2]
         _scatter_add(gE, t[:, 0], ds.astype(dt))
         _scatter_add(gR, t[:, 1], dp.astype(dt))
         _scatter_add(gE, t[:, 2], do.astype(dt))
@@ -295,9 +336,10 @@ def dense_grads(model, E, Rel, pos, neg, loss, margin=1, negative_samples=1, nor
 
 
 def train_step(model, E, Rel, opt, pos, neg, loss="pointwize_hinge", margin=1, negative_samples=1,
-               norm=1, gamma=12, regularization=0.0):
+               norm=1, gamma=12, regularization=0.0, dropout=0.0, seed=0):
     """In-place update of E and Rel; returns the batch loss (what Keras logs as `loss`)."""
-    L, _, _, gE, gR = dense_grads(model, E, Rel, pos, neg, loss, margin, negative_samples, norm, gamma, regularization)
+    L, _, _, gE, gR = dense_grads(model, E, Rel, pos, neg, loss, margin, negative_samples, norm, gamma, regularization,
+                                  dropout, seed)
     opt.begin_step()
     opt.apply("E", E, gE)
     opt.apply("R", Rel, gR)

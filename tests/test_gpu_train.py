@@ -230,3 +230,46 @@ def test_full_size_fb15k237_step(model, kw):
     perm = np.random.RandomState(5).permutation(len(pos))
     mdl2.train_step([pos[perm], neg[perm[::-1]]])
     np.testing.assert_allclose(mdl2.E.cpu().numpy(), mdl.E.cpu().numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize("model,kw", CASES)
+@pytest.mark.parametrize("loss", ["pointwize_logistic", "pairwize_hinge"])
+def test_dropout_training_parity(model, kw, loss, grad_mode):
+    """Dropout(dp) on the three gathered rows (models.py:122,144-148): masks are regenerated by the oracle from the
+    same (seed, row, role, element) hash, so the whole step is checked, forward and backward."""
+    if loss.startswith("pairwize") and grad_mode == "push":
+        pytest.skip("pairwise + dropout is built on the pull path only")
+    N, R, d, m = 40, 6, 32, 300
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(11)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.3, init_entities=E0, init_relations=R0,
+                            loss_function=loss, margin=0.5, seed=5, **kw)
+    mdl.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.AdamTF()
+    for step in range(2):
+        pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
+        L = float(mdl.train_step([pos, neg])["loss"].item())
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12),
+                          dropout=0.3, seed=mdl._seed)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    # predict is dropout-free (keras Dropout is the identity outside fit)
+    t = _triples(rs, 50, N, R)
+    np.testing.assert_allclose(mdl.predict(t), O.call(model, Eo, Ro, t, kw.get("norm", 1), kw.get("gamma", 12)), atol=2 * TOL)
+
+
+def test_dropout_default_rate_trains(datasets):
+    """The reference's default dp=0.2 (models.py:22) through fit()."""
+    from kge_keras_amd.harness import DataGenerator, build_model
+    np.random.seed(2)
+    random.seed(2)
+    mdl = build_model(dict(num_entities=14, num_relations=55, dim=32, embedding_model="DistMult",
+                           loss_function="pointwize_logistic", margin=1, seed=4))
+    assert mdl.dp == 0.2
+    h = mdl.fit(DataGenerator(datasets["nations_train"], ns=10, batch_size=32), epochs=3, verbose=0)
+    assert h.history["loss"][-1] < h.history["loss"][0]

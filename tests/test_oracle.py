@@ -254,3 +254,17 @@ def test_glorot_limits():
     rs = np.random.RandomState(0)
     E = O.glorot_uniform(14541, 200, rs)
     assert abs(np.abs(E).max() - np.sqrt(6 / (14541 + 200))) < 1e-4 and E.dtype == np.float32
+
+
+def test_dropout_multipliers_statistics_and_determinism():
+    m = O.dropout_multipliers(7, 400, 1, 200, 0.2)
+    assert m.shape == (400, 200)
+    assert set(np.unique(m).tolist()) == {0.0, float(np.float32(1) / (np.float32(1) - np.float32(0.2)))}
+    assert abs((m > 0).mean() - 0.8) < 0.01  # keep probability
+    assert abs(m.mean() - 1.0) < 0.02        # inverted dropout is unbiased
+    assert np.array_equal(m, O.dropout_multipliers(7, 400, 1, 200, 0.2))
+    assert not np.array_equal(m, O.dropout_multipliers(8, 400, 1, 200, 0.2))
+    assert not np.array_equal(m, O.dropout_multipliers(7, 400, 2, 200, 0.2))
+    # row_offset addresses the same batch rows
+    assert np.array_equal(m[100:], O.dropout_multipliers(7, 300, 1, 200, 0.2, row_offset=100))
+    assert (O.dropout_multipliers(1, 10, 0, 31, 0.0) == 1.0).all()
