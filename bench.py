@@ -33,6 +33,21 @@ A_TRAIN = A_FWD + A_BWD                          # 4816 B per scored triple at d
 HBM_PEAK = 8.0e12                                # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the named kernel family from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    produced by tools_pmc.sh; FETCH_SIZE x2 + WRITE_SIZE, see that file's _source).  None when no pass exists."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return None
+    fam = kernel_label.split()[0]
+    best = None
+    for name, v in d.get("kernels", {}).items():
+        if v.get("family") == fam and (best is None or v["hbm_bytes_per_launch"] > best):
+            best = v["hbm_bytes_per_launch"]
+    return best
+
+
 def make_batches(n_batches, rank):
     from kge_keras_amd.sampler import NumpyStream, PythonStream, build_batch
     rs = np.random.RandomState(1234 + 7919 * rank)
@@ -212,7 +227,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single", "sampler": "bit-exact MT19937 batches pre-built on host, resident in HBM",
                        "final_loss": loss},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": k_bytes, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
                          "all_kernels": {k: {"avg_ms": v[0] * 1e3, "algorithmic_GBps": v[1] / v[0] / 1e9} for k, v in kernels.items()},
                          "whole_step_algorithmic_GBps": per_step * A_TRAIN / (dt / args.steps) / 1e9,
