@@ -164,6 +164,15 @@ int kge_mt_raw(void* state_host, uint32_t* out_host, int64_t n);              /*
 int kge_build_batch_host(void* np_state_host, void* py_state_host, const int32_t* batch_host, int64_t B, int64_t ns,
                          int64_t num_e, int32_t* pos_out_host, int32_t* neg_out_host);
 
+/* The same batch builder on the GPU: states are the same 2504-byte blobs resident in device memory, batch (B,3) int32 on
+ * the device, pos_out / neg_out (B*ns,3) int32 on the device.  Bit-identical to kge_build_batch_host, including the
+ * generator states left behind.  err_flag bit 1 is set if the rejection-sampling margin of the raw buffer ever ran
+ * short (never observed; the states are then left at the end of the buffer). */
+int64_t kge_sampler_workspace_bytes(int64_t B, int64_t ns, int64_t num_e);
+int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t* batch_dev, int64_t B, int64_t ns,
+                           int64_t num_e, int32_t* pos_out_dev, int32_t* neg_out_dev, void* workspace, int64_t workspace_bytes,
+                           uint32_t* err_flag, kge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
     "kge_mt_shuffle": (C.c_int, [_P, _P, _I64]),
     "kge_mt_choices": (C.c_int, [_P, _I64, _P, _I64]),
     "kge_mt_raw": (C.c_int, [_P, _P, _I64]),
+    "kge_sampler_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "kge_build_batch_device": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _P, _P]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

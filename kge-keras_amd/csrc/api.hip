@@ -112,6 +112,9 @@ int rank_counts(const kge_model_desc*, const float*, const float*, const float*,
 int rank_chain_scores(const kge_model_desc*, const float*, const float*, const int32_t*, int64_t, int, float*, void*, int64_t,
                       uint32_t*, hipStream_t);
 
+int64_t sampler_workspace_bytes(int64_t, int64_t, int64_t);
+int build_batch_device(void*, void*, const int32_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, void*, int64_t, uint32_t*, hipStream_t);
+
 }  // namespace kge
 
 using namespace kge;
@@ -249,6 +252,21 @@ int kge_rank_chain_scores(const kge_model_desc* md, const float* E, const float*
   if (n_queries <= 0 || !E || !Rel || !triples || !out || !workspace || !err_flag) return fail(KGE_EINVAL, "kge_rank_chain_scores: bad arguments");
   return rank_chain_scores(md, E, Rel, triples, n_queries, side, out, workspace, workspace_bytes, err_flag,
                            static_cast<hipStream_t>(stream));
+}
+
+int64_t kge_sampler_workspace_bytes(int64_t B, int64_t ns, int64_t num_e) {
+  if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_sampler_workspace_bytes: bad sizes");
+  return sampler_workspace_bytes(B, ns, num_e);
+}
+
+int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t* batch_dev, int64_t B, int64_t ns, int64_t num_e,
+                           int32_t* pos_out_dev, int32_t* neg_out_dev, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                           kge_stream_t stream) {
+  if (!np_state_dev || !py_state_dev || !batch_dev || !pos_out_dev || !neg_out_dev || !workspace || !err_flag)
+    return fail(KGE_EINVAL, "kge_build_batch_device: null pointer");
+  if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_build_batch_device: bad sizes");
+  return build_batch_device(np_state_dev, py_state_dev, batch_dev, B, ns, num_e, pos_out_dev, neg_out_dev, workspace, workspace_bytes,
+                            err_flag, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,283 @@
+// Device-side, bit-exact batch builder: the draws of generate_negative + oversample_data (KGEkeras/utils.py:114-147,
+// driven as in tests.py:55-61) produced on the GPU, so that a training batch never leaves HBM.
+//
+// Both of the reference's generators are MT19937.  Its state transition is sequential over 624-word blocks, but inside
+// one block word i depends on words i, i+1 and i+397 (mod 624), so 227 words can be produced at a time: one workgroup
+// regenerates a block in three barrier-separated phases (0..226 | 227..453 | 454..623).  Everything after that is
+// embarrassingly parallel:
+//
+//   mt_generate_kernel   2 workgroups (NumPy stream, Python stream): K blocks of raw state words each  -> U_np, U_py
+//   np_count_kernel      temper + mask + accept (NumPy's masked rejection, utils.py:118-119) -> per-tile accept counts
+//   np_scan_kernel       exclusive scan of the tile counts (one workgroup)
+//   np_scatter_kernel    the first m accepted draws -> fs, the next m -> fo; position of the 2m-th -> words consumed
+//   py_assemble_kernel   choices: idx = floor(((a>>5)*2^26 + (b>>6)) / 2^53 * n) from word pairs (utils.py:136),
+//                        then pos_out[i] = batch[idxA[i]], neg_out[i] = (fs[j], batch[j/ns].p, fo[j]), j = idxB[i]
+//   mt_advance_kernel    new generator states (the block the consumption stopped in + position inside it)
+//
+// The NumPy stream consumes a data-dependent number of words; the raw buffer is sized with a margin of tens of
+// standard deviations and err_flag bit 1 is raised if it ever ran short (the host then falls back to a larger margin).
+#include "kge_internal.hpp"
+
+namespace kge {
+
+struct MTDev {
+  uint32_t mt[624];
+  int32_t pos;
+  int32_t pad;
+};
+static_assert(sizeof(MTDev) == KGE_MT_STATE_BYTES, "state blob size");
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) {
+  const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+  return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// blockIdx.x == 0: NumPy stream (K0 blocks), 1: Python stream (K1 blocks).  U holds RAW state words (untempered), so
+// any block of U is itself a valid generator state.
+__global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
+                                                           uint32_t* __restrict__ U_np, int K0, uint32_t* __restrict__ U_py, int K1) {
+  __shared__ uint32_t buf[2][624];
+  const MTDev* st = blockIdx.x == 0 ? st_np : st_py;
+  uint32_t* U = blockIdx.x == 0 ? U_np : U_py;
+  const int K = blockIdx.x == 0 ? K0 : K1;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 624; i += 256) buf[0][i] = st->mt[i];
+  __syncthreads();
+  int cur = 0;
+  for (int b = 0; b < K; ++b) {
+    const uint32_t* o = buf[cur];
+    uint32_t* n = buf[cur ^ 1];
+    if (tid < 227) n[tid] = o[tid + 397] ^ mt_twist(o[tid], o[tid + 1]);
+    __syncthreads();
+    if (tid < 227) { const int i = 227 + tid; n[i] = n[i - 227] ^ mt_twist(o[i], o[i + 1]); }
+    __syncthreads();
+    if (tid < 169) { const int i = 454 + tid; n[i] = n[i - 227] ^ mt_twist(o[i], o[i + 1]); }
+    else if (tid == 169) n[623] = n[396] ^ mt_twist(o[623], n[0]);
+    __syncthreads();
+    uint32_t* dst = U + (int64_t)b * 624;
+    for (int i = tid; i < 624; i += 256) dst[i] = n[i];
+    cur ^= 1;
+  }
+}
+
+// word `i` of the stream that starts at the generator's current position: tail of the state, then U
+__device__ __forceinline__ uint32_t stream_word(const MTDev* st, const uint32_t* U, int p0, int64_t i) {
+  const int tail = 624 - p0;
+  return mt_temper(i < tail ? st->mt[p0 + i] : U[i - tail]);
+}
+
+constexpr int kTileW = 1024;  // stream words per tile (256 threads x 4)
+
+__global__ __launch_bounds__(256) void np_count_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
+                                                        uint32_t rng, uint32_t mask, int32_t* __restrict__ tile_cnt) {
+  __shared__ int red[4];
+  const int p0 = st->pos;
+  const int64_t L = (624 - p0) + L_u;
+  const int64_t base = (int64_t)blockIdx.x * kTileW + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < L) c += ((stream_word(st, U, p0, base + j) & mask) <= rng) ? 1 : 0;
+  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of up to 1024*per tile counts, one workgroup
+__global__ __launch_bounds__(1024) void np_scan_kernel(int32_t* __restrict__ tile_cnt, int ntiles, int32_t* __restrict__ total) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (ntiles + 1023) / 1024;
+  const int k0 = tid * per, k1 = min(ntiles, k0 + per);
+  int s = 0;
+  for (int k = k0; k < k1; ++k) s += tile_cnt[k];
+  int inc = s;
+  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int pre = inc - s;
+  for (int w = 0; w < wave; ++w) pre += wsum[w];
+  for (int k = k0; k < k1; ++k) { const int v = tile_cnt[k]; tile_cnt[k] = pre; pre += v; }
+  if (tid == 1023) *total = pre;
+}
+
+__global__ __launch_bounds__(256) void np_scatter_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
+                                                          uint32_t rng, uint32_t mask, const int32_t* __restrict__ tile_off,
+                                                          int64_t m, int32_t* __restrict__ fs, int32_t* __restrict__ fo,
+                                                          int64_t* __restrict__ consumed) {
+  __shared__ int wsum[4];
+  const int p0 = st->pos;
+  const int64_t L = (624 - p0) + L_u;
+  const int64_t base = (int64_t)blockIdx.x * kTileW + threadIdx.x * 4;
+  uint32_t v[4];
+  int a[4], c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = base + j < L ? (stream_word(st, U, p0, base + j) & mask) : 0xFFFFFFFFu;
+    a[j] = (base + j < L && v[j] <= rng) ? 1 : 0;
+    c += a[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = c;
+  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int64_t r = (int64_t)tile_off[blockIdx.x] + inc - c;
+  for (int w = 0; w < wave; ++w) r += wsum[w];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!a[j]) continue;
+    if (r < m) fs[r] = (int32_t)v[j];
+    else if (r < 2 * m) fo[r - m] = (int32_t)v[j];
+    if (r == 2 * m - 1) *consumed = base + j + 1;
+    ++r;
+  }
+}
+
+// CPython random.random() from two consecutive outputs; choices index = floor(random() * n)
+__device__ __forceinline__ int64_t py_choice(const MTDev* st, const uint32_t* U, int p0, int64_t i, double n) {
+  const uint32_t a = stream_word(st, U, p0, 2 * i) >> 5, b = stream_word(st, U, p0, 2 * i + 1) >> 6;
+  const double r = ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+  return (int64_t)floor(r * n);
+}
+
+__global__ __launch_bounds__(256) void py_assemble_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U,
+                                                           const int32_t* __restrict__ batch, int64_t B, int64_t ns,
+                                                           const int32_t* __restrict__ fs, const int32_t* __restrict__ fo,
+                                                           int32_t* __restrict__ pos_out, int32_t* __restrict__ neg_out) {
+  const int64_t m = B * ns;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * m) return;
+  const int p0 = st->pos;
+  if (i < m) {  // choices over the positives (len B) come first in the stream
+    const int64_t a = py_choice(st, U, p0, i, (double)B);
+    pos_out[3 * i + 0] = batch[3 * a + 0];
+    pos_out[3 * i + 1] = batch[3 * a + 1];
+    pos_out[3 * i + 2] = batch[3 * a + 2];
+  } else {      // then over the negatives (len m); row j of generate_negative carries the relation of positive j // ns
+    const int64_t j = py_choice(st, U, p0, i, (double)m);
+    const int64_t o = i - m;
+    neg_out[3 * o + 0] = fs[j];
+    neg_out[3 * o + 1] = batch[3 * (j / ns) + 1];
+    neg_out[3 * o + 2] = fo[j];
+  }
+}
+
+// New state after consuming `c` words: the block of U the consumption stopped in (NumPy/CPython keep pos = 624 at a
+// block end and regenerate lazily, which is the representation kept here).
+__global__ __launch_bounds__(256) void mt_advance_kernel(MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
+                                                          const int64_t* __restrict__ consumed_ptr, int64_t consumed_fixed,
+                                                          int64_t need, uint32_t* __restrict__ err) {
+  __shared__ int64_t c_s;
+  if (threadIdx.x == 0) c_s = consumed_ptr ? *consumed_ptr : consumed_fixed;
+  __syncthreads();
+  int64_t c = c_s;
+  const int p0 = st->pos;
+  if (consumed_ptr && c < 0) {  // fewer than `need` accepted draws in the buffer
+    if (threadIdx.x == 0) atomicOr(err, 2u);
+    c = (624 - p0) + L_u;
+  }
+  (void)need;
+  const int64_t a = p0 + c;  // absolute position counted from the start of the current state block
+  if (a <= 624) {
+    __syncthreads();
+    if (threadIdx.x == 0) st->pos = (int32_t)a;
+    return;
+  }
+  const int64_t idx = a - 624;             // words consumed out of U (idx >= 1)
+  const int64_t blk = (idx - 1) / 624;     // block holding the last consumed word
+  const int newpos = (int)(idx - blk * 624);
+  const uint32_t* src = U + blk * 624;
+  uint32_t tmp[3];
+  for (int i = threadIdx.x, k = 0; i < 624; i += 256, ++k) tmp[k] = src[i];
+  __syncthreads();
+  for (int i = threadIdx.x, k = 0; i < 624; i += 256, ++k) st->mt[i] = tmp[k];
+  if (threadIdx.x == 0) st->pos = newpos;
+}
+
+__global__ void set_i64_kernel(int64_t* p, int64_t v) { *p = v; }
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct SamplerPlan {
+  int64_t K_np, K_py, ntiles;
+  uint32_t* U_np;
+  uint32_t* U_py;
+  int32_t* tile_cnt;
+  int32_t* total;
+  int64_t* consumed;
+  int32_t* fs;
+  int32_t* fo;
+  int64_t bytes;
+};
+
+static uint64_t smear64(uint64_t v) {
+  v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v |= v >> 32;
+  return v;
+}
+
+static SamplerPlan plan_sampler(int64_t B, int64_t ns, int64_t num_e, void* ws) {
+  SamplerPlan p;
+  const int64_t m = B * ns;
+  const uint64_t rng = (uint64_t)(num_e - 1), mask = smear64(rng);
+  const double pacc = rng ? (double)(rng + 1) / (double)(mask + 1) : 1.0;
+  const int64_t raw_np = rng ? (int64_t)(2.0 * m / pacc * 1.03) + 8192 : 0;
+  p.K_np = rng ? cdiv(raw_np, 624) + 1 : 0;
+  p.K_py = cdiv(4 * m, 624) + 1;
+  p.ntiles = cdiv(624 + p.K_np * 624, kTileW);
+  char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t bytes) { char* r = q; q += align_up(bytes, 256); return r; };
+  p.U_np = (uint32_t*)take(std::max<int64_t>(1, p.K_np) * 624 * 4);
+  p.U_py = (uint32_t*)take(p.K_py * 624 * 4);
+  p.tile_cnt = (int32_t*)take(p.ntiles * 4);
+  p.total = (int32_t*)take(256);
+  p.consumed = (int64_t*)take(256);
+  p.fs = (int32_t*)take(m * 4);
+  p.fo = (int32_t*)take(m * 4);
+  p.bytes = (q - reinterpret_cast<char*>(ws)) + 256;
+  return p;
+}
+
+int64_t sampler_workspace_bytes(int64_t B, int64_t ns, int64_t num_e) { return plan_sampler(B, ns, num_e, nullptr).bytes + 512; }
+
+int build_batch_device(void* np_state, void* py_state, const int32_t* batch, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out,
+                       int32_t* neg_out, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  if (wbytes < sampler_workspace_bytes(B, ns, num_e))
+    return fail(KGE_EWORKSPACE, "kge_build_batch_device: workspace has %lld bytes, needs %lld", (long long)wbytes,
+                (long long)sampler_workspace_bytes(B, ns, num_e));
+  const SamplerPlan p = plan_sampler(B, ns, num_e, ws);
+  const int64_t m = B * ns;
+  MTDev* nps = static_cast<MTDev*>(np_state);
+  MTDev* pys = static_cast<MTDev*>(py_state);
+  const uint32_t rng = (uint32_t)(num_e - 1), mask = (uint32_t)smear64(rng);
+  ProfScope prof(KGE_PROF_SAMPLER, st);
+  hipLaunchKernelGGL(mt_generate_kernel, dim3(2), dim3(256), 0, st, nps, pys, p.U_np, (int)p.K_np, p.U_py, (int)p.K_py);
+  if (rng) {
+    const int64_t L_u = p.K_np * 624;
+    hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, p.consumed, (int64_t)-1);
+    hipLaunchKernelGGL(np_count_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt);
+    hipLaunchKernelGGL(np_scan_kernel, dim3(1), dim3(1024), 0, st, p.tile_cnt, (int)p.ntiles, p.total);
+    hipLaunchKernelGGL(np_scatter_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt, m, p.fs, p.fo, p.consumed);
+  } else {  // a range of one: numpy draws nothing
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fs, m, 0);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fo, m, 0);
+  }
+  hipLaunchKernelGGL(py_assemble_kernel, dim3((int)cdiv(2 * m, 256)), dim3(256), 0, st, pys, p.U_py, batch, B, ns, p.fs, p.fo, pos_out, neg_out);
+  if (rng) hipLaunchKernelGGL(mt_advance_kernel, dim3(1), dim3(256), 0, st, nps, p.U_np, p.K_np * 624, p.consumed, (int64_t)0, 2 * m, err);
+  hipLaunchKernelGGL(mt_advance_kernel, dim3(1), dim3(256), 0, st, pys, p.U_py, p.K_py * 624, (const int64_t*)nullptr, 4 * m, 4 * m, err);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+}  // namespace kge

@@ -111,3 +111,48 @@ def build_batch(np_stream, py_stream, batch, ns, num_e):
     check(lib.kge_build_batch_host(np_stream.ptr, py_stream.ptr, b.ctypes.data, b.shape[0], int(ns), int(num_e),
                                    pos.ctypes.data, neg.ctypes.data))
     return pos, neg
+
+
+class DeviceSampler:
+    """The two generator states resident in HBM; build_batch() is kge_build_batch_device: the same draws as the host
+    builder (and as the reference), produced by HIP kernels, with pos/neg left on the device."""
+
+    def __init__(self, np_stream, py_stream, device=None):
+        import torch
+        from . import _lib
+        _lib.require_gpu()
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.np_state = torch.from_numpy(np_stream._buf.view(np.uint8).copy()).to(self.device)
+        self.py_state = torch.from_numpy(py_stream._buf.view(np.uint8).copy()).to(self.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._ws = None
+
+    def to_streams(self):
+        """Copy the device states back into host twins (e.g. for the epoch shuffle, which is sequential by nature)."""
+        nps, pys = NumpyStream(), PythonStream()
+        nps._buf[:] = self.np_state.cpu().numpy().view(np.uint32)
+        pys._buf[:] = self.py_state.cpu().numpy().view(np.uint32)
+        return nps, pys
+
+    def load_streams(self, np_stream=None, py_stream=None):
+        import torch
+        if np_stream is not None:
+            self.np_state.copy_(torch.from_numpy(np_stream._buf.view(np.uint8).copy()))
+        if py_stream is not None:
+            self.py_state.copy_(torch.from_numpy(py_stream._buf.view(np.uint8).copy()))
+
+    def build_batch(self, batch, ns, num_e, pos_out=None, neg_out=None):
+        import torch
+        from . import _lib
+        B = batch.shape[0]
+        m = B * int(ns)
+        need = check(lib.kge_sampler_workspace_bytes(B, int(ns), int(num_e)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        if pos_out is None:
+            pos_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
+            neg_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
+        check(lib.kge_build_batch_device(self.np_state.data_ptr(), self.py_state.data_ptr(), batch.data_ptr(), B, int(ns), int(num_e),
+                                         pos_out.data_ptr(), neg_out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                         self.err.data_ptr(), _lib.stream_ptr()))
+        return pos_out, neg_out
