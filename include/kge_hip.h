@@ -145,7 +145,7 @@ int kge_set_grad_mode(int mode);
  *      kernel with hipEvents recorded on the launch stream.  kge_prof_read synchronises those events, returns the
  *      summed duration (ms) and launch count for one label and clears that label.  Off by default. */
 typedef enum { KGE_PROF_TRAIN_GRADS = 0, KGE_PROF_OPT = 1, KGE_PROF_SCORE = 2, KGE_PROF_PAIRWISE = 3, KGE_PROF_RANK = 4,
-               KGE_PROF_SAMPLER = 5, KGE_PROF_FWD = 6, KGE_PROF_NLABELS = 7 } kge_prof_label;
+               KGE_PROF_SAMPLER = 5, KGE_PROF_FWD = 6, KGE_PROF_INDEX = 7, KGE_PROF_NLABELS = 8 } kge_prof_label;
 int kge_prof_enable(int on);
 int kge_prof_read(int label, double* total_ms, int64_t* launches);
 

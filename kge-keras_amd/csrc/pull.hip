@@ -571,7 +571,7 @@ int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, co
   PullPlan& p = *plan;
   const int N = md->num_entities, NK = N + md->num_relations;
   const int igrid = (int)cdiv(n, kIdxBlockTriples);
-  ProfScope prof(KGE_PROF_SAMPLER, st);  // index build (ids only)
+  ProfScope prof(KGE_PROF_INDEX, st);  // index build (ids only)
   KGE_HIP_TRY(hipMemsetAsync(p.cnt, 0, (size_t)NK * 4, st));
   hipLaunchKernelGGL(hist_kernel, dim3(igrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, md->num_relations, p.cnt, p.ranks);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals);

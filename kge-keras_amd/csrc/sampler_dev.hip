@@ -41,6 +41,9 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 
 // blockIdx.x == 0: NumPy stream (K0 blocks), 1: Python stream (K1 blocks).  U holds RAW state words (untempered), so
 // any block of U is itself a valid generator state.
+// One workgroup of 256 threads per stream.  The barrier is a raw s_barrier behind an LDS-only wait: __syncthreads()
+// would also drain the global stores of the previous block (vmcnt(0)) on the critical path.
+#define KGE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
                                                            uint32_t* __restrict__ U_np, int K0, uint32_t* __restrict__ U_py, int K1) {
   __shared__ uint32_t buf[2][624];
@@ -48,24 +51,42 @@ __global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restric
   uint32_t* U = blockIdx.x == 0 ? U_np : U_py;
   const int K = blockIdx.x == 0 ? K0 : K1;
   const int tid = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);  // a latency chain of 2 workgroups beside chip-filling gather kernels: win the issue arbitration
   for (int i = tid; i < 624; i += 256) buf[0][i] = st->mt[i];
   __syncthreads();
+  // Thread tid owns words tid, 227+tid and 454+tid of a block.  The phase-2 / phase-3 inputs new[i-227] are then the
+  // thread's OWN phase-1 / phase-2 results, so a whole block is computed from one round of LDS reads of the previous
+  // block: one barrier per block instead of three.  (new[623] needs new[0]: thread 169 recomputes it.)
   int cur = 0;
   for (int b = 0; b < K; ++b) {
     const uint32_t* o = buf[cur];
     uint32_t* n = buf[cur ^ 1];
-    if (tid < 227) n[tid] = o[tid + 397] ^ mt_twist(o[tid], o[tid + 1]);
-    __syncthreads();
-    if (tid < 227) { const int i = 227 + tid; n[i] = n[i - 227] ^ mt_twist(o[i], o[i + 1]); }
-    __syncthreads();
-    if (tid < 169) { const int i = 454 + tid; n[i] = n[i - 227] ^ mt_twist(o[i], o[i + 1]); }
-    else if (tid == 169) n[623] = n[396] ^ mt_twist(o[623], n[0]);
-    __syncthreads();
     uint32_t* dst = U + (int64_t)b * 624;
-    for (int i = tid; i < 624; i += 256) dst[i] = n[i];
+    if (tid < 227) {
+      const uint32_t a0 = o[tid], a1 = o[tid + 1], a397 = o[tid + 397];
+      const uint32_t b0 = o[227 + tid], b1 = o[228 + tid];
+      const uint32_t v0 = a397 ^ mt_twist(a0, a1);
+      const uint32_t v1 = v0 ^ mt_twist(b0, b1);
+      n[tid] = v0;
+      n[227 + tid] = v1;
+      dst[tid] = v0;
+      dst[227 + tid] = v1;
+      if (tid < 169) {
+        const uint32_t v2 = v1 ^ mt_twist(o[454 + tid], o[455 + tid]);
+        n[454 + tid] = v2;
+        dst[454 + tid] = v2;
+      } else if (tid == 169) {
+        const uint32_t n0 = o[397] ^ mt_twist(o[0], o[1]);
+        const uint32_t v2 = v1 ^ mt_twist(o[623], n0);  // v1 of thread 169 is new[396]
+        n[623] = v2;
+        dst[623] = v2;
+      }
+    }
+    KGE_LDS_BARRIER();
     cur ^= 1;
   }
 }
+#undef KGE_LDS_BARRIER
 
 // word `i` of the stream that starts at the generator's current position: tail of the state, then U
 __device__ __forceinline__ uint32_t stream_word(const MTDev* st, const uint32_t* U, int p0, int64_t i) {

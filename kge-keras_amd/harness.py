@@ -45,6 +45,52 @@ class DataGenerator:
             st.release_global()
 
 
+class DeviceDataGenerator:
+    """Same batches as DataGenerator, built on the GPU: the training triples and the epoch permutation live in HBM, every
+    batch is produced by kge_build_batch_device (bit-exact MT19937 on the device) and never touches the host.  The two
+    generator states are adopted from NumPy's / Python's global generators at construction and handed back by
+    `release_global()`; the epoch shuffle (sequential Fisher-Yates, tests.py:50-53) runs on the host twin of the
+    NumPy state."""
+
+    def __init__(self, kg, ns=10, batch_size=32, shuffle=True, device=None):
+        import torch
+        from .sampler import DeviceSampler
+        self.batch_size = min(batch_size, len(kg))
+        kg = np.ascontiguousarray(np.asarray(kg, dtype=np.int32).reshape(-1, 3))
+        self.n = len(kg)
+        self.ns = ns
+        self.num_e = len(set(kg[:, 0].tolist()) | set(kg[:, 2].tolist()))  # tests.py:34
+        self.shuffle = shuffle
+        self.sampler = DeviceSampler(NumpyStream().adopt_global(), PythonStream().adopt_global(), device)
+        self.device = self.sampler.device
+        self.kg = torch.from_numpy(kg).to(self.device)
+        self.on_epoch_end()
+
+    def __len__(self):
+        return self.n // self.batch_size
+
+    def on_epoch_end(self):
+        import torch
+        index = np.arange(self.n, dtype=np.int64)
+        if self.shuffle:
+            nps, _ = self.sampler.to_streams()
+            nps.shuffle(index)
+            self.sampler.load_streams(np_stream=nps)
+        self.index = torch.from_numpy(index).to(self.device)
+
+    def __getitem__(self, i):
+        sl = self.index[i * self.batch_size:(i + 1) * self.batch_size]
+        batch = self.kg.index_select(0, sl).contiguous()
+        pos, neg = self.sampler.build_batch(batch, self.ns, self.num_e)
+        return [pos, neg], None
+
+    def release_global(self):
+        """Write the generator states back into np.random / random (where the reference's generator would stand)."""
+        nps, pys = self.sampler.to_streams()
+        nps.release_global()
+        pys.release_global()
+
+
 def build_model(hp):
     """tests.py:63-89: instantiate the embedding model from the hp dict (all keys passed as kwargs), attach the
     looked-up loss with `margin or 1` and negative_samples=1, compile with Adam."""
