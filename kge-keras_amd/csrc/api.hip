@@ -82,6 +82,11 @@ int fwd_group_width(int nchunk) {
   return score_group_width(nchunk);
 }
 
+int rank_blocks_target() {
+  static const int t = env_int("KGE_RANK_BLOCKS", 16 * kCUs);
+  return t < 1 ? 1 : t;
+}
+
 int pull_chunk() {
   static const int c = env_int("KGE_PULL_CHUNK", 128);
   return c < 8 ? 8 : c;
@@ -91,6 +96,20 @@ static int g_grad_mode = -1;
 int grad_mode() {
   if (g_grad_mode < 0) g_grad_mode = env_int("KGE_GRAD_MODE", 0) ? 1 : 0;
   return g_grad_mode;
+}
+
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
+SideStream* side_stream() {
+  static SideStream ss;
+  static int state = 0;  // 0 = not tried, 1 = ready, -1 = disabled / failed
+  if (state == 0) {
+    state = -1;
+    if (!env_int("KGE_NO_SIDE_STREAM", 0) && hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
+      state = 1;
+  }
+  return state == 1 ? &ss : nullptr;
 }
 
 int push_group_width(int width) {

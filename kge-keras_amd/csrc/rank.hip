@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
   __shared__ __attribute__((aligned(16))) float As[kTile * LS];
   __shared__ __attribute__((aligned(16))) float Bs[kTile * LS];
   __shared__ int cnt_s[kTile];
+  __shared__ float tg_s[kTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
   const int64_t q0 = (int64_t)blockIdx.x * kTile;
@@ -107,77 +108,106 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
   const int ct_begin = blockIdx.y * tiles_per_block;
   const int ct_end = min(nct, ct_begin + tiles_per_block);
 
-  float tg[2][16];
-  int cnt[2][16];
+  // Register budget (2 waves per SIMD need <= 256): the per-row targets live in LDS (broadcast reads in the epilogue)
+  // and the 32 per-lane counters are packed four to a register (a lane adds at most 2 per candidate tile, and
+  // tiles_per_block <= 60, so a byte never overflows).
+  uint32_t cntp[2][4];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = q0 + wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      tg[rt][r] = row < nq ? tgt[row] : __builtin_inff();  // nothing is > +inf; NaN targets count nothing either
-      cnt[rt][r] = 0;
-    }
-  if (tid < kTile) cnt_s[tid] = 0;
+    for (int w = 0; w < 4; ++w) cntp[rt][w] = 0u;
+  if (tid < kTile) {
+    cnt_s[tid] = 0;
+    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : __builtin_inff();  // nothing is > +inf; NaN targets count nothing either
+  }
 
-  for (int ct = ct_begin; ct < ct_end; ++ct) {
-    const int c0 = ct * kTile;
-    f32x16 acc[2][2];
+  // Software pipeline over the flattened (candidate tile, k chunk) sequence: the global loads of step it+1 are issued
+  // into registers before the MFMAs of step it and written to LDS after them, so L2 latency hides under matrix work.
+  constexpr int PF = (kTile * C4 + 255) / 256;  // float4 per thread per operand per chunk
+  const int nchunk = Kpad / BK;
+  const int nsteps = (ct_end - ct_begin) * nchunk;
+  float4 pa[PF], pb[PF];
+  auto prefetch = [&](int it) {
+    const int c0 = (ct_begin + it / nchunk) * kTile, k0 = (it % nchunk) * BK;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    for (int k0 = 0; k0 < Kpad; k0 += BK) {
-      __syncthreads();  // everyone is done reading the previous chunk
-      for (int idx = tid; idx < kTile * C4; idx += 256) {
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + u * 256;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[u] = pa[u];
+      if (idx < kTile * C4) {
         const int r = idx / C4, c4 = idx - r * C4;
         const int k = k0 + c4 * 4;
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-        if (q0 + r < nq) va = *reinterpret_cast<const float4*>(Qv + (q0 + r) * Kpad + k);  // Qv is zero padded to Kpad
+        if (q0 + r < nq) pa[u] = *reinterpret_cast<const float4*>(Qv + (q0 + r) * Kpad + k);  // Qv is zero padded to Kpad
         const int cr = c0 + r;
         if (cr < cand_rows) {
           const float* src = Ec + (int64_t)cr * K + k;
           if (VEC4) {
-            if (k < K) vb = *reinterpret_cast<const float4*>(src);  // K % 4 == 0
+            if (k < K) pb[u] = *reinterpret_cast<const float4*>(src);  // K % 4 == 0
           } else {
-            if (k + 0 < K) vb.x = src[0];
-            if (k + 1 < K) vb.y = src[1];
-            if (k + 2 < K) vb.z = src[2];
-            if (k + 3 < K) vb.w = src[3];
+            if (k + 0 < K) pb[u].x = src[0];
+            if (k + 1 < K) pb[u].y = src[1];
+            if (k + 2 < K) pb[u].z = src[2];
+            if (k + 3 < K) pb[u].w = src[3];
           }
         }
-        *reinterpret_cast<float4*>(As + r * LS + c4 * 4) = va;
-        *reinterpret_cast<float4*>(Bs + r * LS + c4 * 4) = vb;
       }
-      __syncthreads();
+    }
+  };
+  f32x16 acc[2][2];
+  if (nsteps > 0) prefetch(0);
+  for (int it = 0; it < nsteps; ++it) {
+    const int kc = it % nchunk;
+    if (kc == 0) {
 #pragma unroll
-      for (int j = 0; j < BK / 8; ++j) {
-        float4 a[2], b[2];
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          a[x] = *reinterpret_cast<const float4*>(As + (wq * 64 + x * 32 + l31) * LS + 8 * j + 4 * half);
-          b[x] = *reinterpret_cast<const float4*>(Bs + (wc * 64 + x * 32 + l31) * LS + 8 * j + 4 * half);
-        }
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
+    __syncthreads();  // everyone is done reading the previous chunk
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < kTile * C4) {
+        const int r = idx / C4, c4 = idx - r * C4;
+        *reinterpret_cast<float4*>(As + r * LS + c4 * 4) = pa[u];
+        *reinterpret_cast<float4*>(Bs + r * LS + c4 * 4) = pb[u];
+      }
+    }
+    __syncthreads();
+    if (it + 1 < nsteps) prefetch(it + 1);
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        a[x] = *reinterpret_cast<const float4*>(As + (wq * 64 + x * 32 + l31) * LS + 8 * j + 4 * half);
+        b[x] = *reinterpret_cast<const float4*>(Bs + (wc * 64 + x * 32 + l31) * LS + 8 * j + 4 * half);
+      }
 #define KGE_STEP(comp)                                                                                         \
   acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].comp, b[0].comp, acc[0][0], 0, 0, 0);                  \
   acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].comp, b[1].comp, acc[0][1], 0, 0, 0);                  \
   acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1].comp, b[0].comp, acc[1][0], 0, 0, 0);                  \
   acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1].comp, b[1].comp, acc[1][1], 0, 0, 0);
-        KGE_STEP(x) KGE_STEP(y) KGE_STEP(z) KGE_STEP(w)
+      KGE_STEP(x) KGE_STEP(y) KGE_STEP(z) KGE_STEP(w)
 #undef KGE_STEP
-      }
     }
-    // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
-    const bool last = c0 + kTile > cand_rows;
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const bool valid = !last || (c0 + wc * 64 + cb * 32 + l31 < cand_rows);
+    if (kc == nchunk - 1) {
+      // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
+      const int c0 = (ct_begin + it / nchunk) * kTile;
+      const bool last = c0 + kTile > cand_rows;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cnt[rt][r] += (valid && acc[rt][cb][r] > tg[rt][r]) ? 1 : 0;
+        for (int r = 0; r < 16; ++r) {
+          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const bool valid = !last || (c0 + wc * 64 + cb * 32 + l31 < cand_rows);
+            cntp[rt][r >> 2] += (valid && acc[rt][cb][r] > tgv) ? (1u << (8 * (r & 3))) : 0u;
+          }
+        }
     }
   }
   __syncthreads();
@@ -186,7 +216,8 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
+      const int c = (int)((cntp[rt][r >> 2] >> (8 * (r & 3))) & 0xFFu);
+      if (c) atomicAdd(&cnt_s[row], c);
     }
   __syncthreads();
   if (tid < kTile && q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
@@ -347,6 +378,8 @@ __global__ void rank_chain_scores_kernel(const float* __restrict__ Qv, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+int rank_blocks_target();  // api.hip (env KGE_RANK_BLOCKS)
+
 static int pick_bk(int K) {
   // least padding among the chunk widths built; (BK+4)/4 must be odd
   const int cands[2] = {40, 32};
@@ -384,7 +417,7 @@ static void launch_dist(const kge_model_desc* md, const float* E, const float* E
   const int K = md->d_e;
   hipLaunchKernelGGL((rank_dist_target_kernel<NORM>), dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, md->gamma, tgt, counts, accumulate ? 0 : 1);
   const int nqt = (int)cdiv(nq, 64), nct = (int)cdiv(cand_rows, 64);
-  int splits = std::max(1, std::min((int)cdiv(8 * kCUs, nqt), nct));
+  int splits = std::max(1, std::min((int)cdiv(rank_blocks_target(), nqt), nct));
   const int tpb = (int)cdiv(nct, splits);
   splits = (int)cdiv(nct, tpb);
   hipLaunchKernelGGL((rank_dist_sweep_kernel<NORM>), dim3(nqt, splits), dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, md->gamma, counts);
@@ -413,9 +446,9 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
   hipLaunchKernelGGL(rank_target_kernel, dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
   {
     const int nqt = (int)cdiv(nq, kTile), nct = (int)cdiv(cand_rows, kTile);
-    int splits = (int)cdiv(4 * kCUs, nqt);
+    int splits = (int)cdiv(rank_blocks_target(), nqt);  // >= ~16 blocks per CU so the last, partially filled round is short
     splits = std::max(1, std::min(splits, nct));
-    const int tpb = (int)cdiv(nct, splits);
+    const int tpb = std::min(60, (int)cdiv(nct, splits));  // packed 8-bit epilogue counters: <= 60 tiles per block
     splits = (int)cdiv(nct, tpb);
     const bool v4 = (K % 4 == 0) && ((uintptr_t)Ec % 16 == 0);
     dim3 grid(nqt, splits);

@@ -283,6 +283,8 @@ struct Workspace {
 };
 
 int grad_mode();  // api.hip: 0 = pull (default), 1 = push (float atomics)
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
+SideStream* side_stream();  // api.hip: lazily created helper stream (nullptr when disabled by KGE_NO_SIDE_STREAM=1)
 
 static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 2 * align_up(n, 64); }
 
@@ -384,10 +386,21 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   }
   int nb = 0;
   if (grad_mode() == 0 && pull_supported(md)) {
+    // The index build depends on the ids only and the forward gather does not need it: fork it onto the library's side
+    // stream and join before the list fill (event fork/join, capturable into a hipGraph).
     PullPlan plan;
-    if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull, st, &plan)) return rc;
+    SideStream* ss = side_stream();
+    if (ss) {
+      KGE_HIP_TRY(hipEventRecord(ss->fork, st));
+      KGE_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
+      if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull, ss->stream, &plan)) return rc;
+      KGE_HIP_TRY(hipEventRecord(ss->join, ss->stream));
+    } else {
+      if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull, st, &plan)) return rc;
+    }
     float* sc = scores_out ? scores_out : (pairwise ? ws.sbuf : nullptr);
     if (int rc = pull_forward(md, pairwise ? -1 : ld->loss, ld->margin, E, Rel, pos, m_pos, neg, m_neg, plan, sc, ws.loss_partials, &nb, err, seed, st)) return rc;
+    if (ss) KGE_HIP_TRY(hipStreamWaitEvent(st, ss->join, 0));
     if (pairwise) {
       int rc;
       if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
