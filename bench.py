@@ -35,7 +35,7 @@ HBM_PEAK = 8.0e12                                # MI355X_MICROARCH.md: 8 TB/s s
 
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the named kernel family from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    produced by tools_pmc.sh; FETCH_SIZE x2 + WRITE_SIZE, see that file's _source).  None when no pass exists."""
+    produced by tools/pmc.sh; FETCH_SIZE x2 + WRITE_SIZE, see that file's _source).  None when no pass exists."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:

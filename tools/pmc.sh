@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools_pmc.sh <tag>
+# usage (GPU box, repo root): bash tools/pmc.sh <tag>
 # Two separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950: MI355X_MICROARCH.md, PMC slots),
 # each with --kernel-trace only.  Output: gpurun_out/pmc_<tag>_{fetch,write}/ + a per-kernel summary JSON.
 tag=$1

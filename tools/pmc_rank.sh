@@ -3,7 +3,7 @@
 tag=$1
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $root/gpurun_out/pmcr_${tag} -- python3 $root/tools_rank_bench.py > $root/gpurun_out/pmcr_${tag}.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $root/gpurun_out/pmcr_${tag} -- python3 $root/tools/rank_bench.py > $root/gpurun_out/pmcr_${tag}.log 2>&1
 cd $root
 python3 - <<EOF
 import csv, glob, collections

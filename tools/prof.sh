@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_prof.sh <tag>   -> gpurun_out/prof_<tag>/ + summary print
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag>   -> gpurun_out/prof_<tag>/ + summary print
 tag=$1; shift
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
