@@ -497,6 +497,7 @@ static void carve_pull(void* ws, const kge_model_desc* md, int64_t n, PullPlan* 
 }
 
 bool pull_supported(const kge_model_desc* md) {
+  if (md->model == KGE_HOLE) return md->d_e <= 1024;
   if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX) return false;
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const bool v4 = width % 4 == 0 && md->d_e % 4 == 0;
@@ -584,6 +585,8 @@ int pull_forward(const kge_model_desc* md, int loss, float margin, const float* 
                  int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p, float* scores, float* loss_partials,
                  int* n_partials, uint32_t* err, uint64_t seed, hipStream_t st) {
   const int64_t n = m_pos + m_neg;
+  if (md->model == KGE_HOLE)
+    return hole_forward(md, loss, margin, E, Rel, pos, m_pos, neg, m_neg, p.coef, scores, loss_partials, n_partials, err, seed, true, st);
   const Shape sh = shape_of(md, E, Rel, nullptr, nullptr);
   const int G = fwd_group_width(sh.nchunk);
   const int fgrid = (int)std::min<int64_t>(cdiv(n * G, 256), 4096);
@@ -619,7 +622,9 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
     }
   }
   hipLaunchKernelGGL(fill_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, p.coef, p.off, p.ranks, p.entries);
-  {
+  if (md->model == KGE_HOLE) {
+    if (int rc = hole_backward(md, E, Rel, gE, gR, p, seed, st)) return rc;
+  } else {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
     const int units = NK + p.max_extra;
     const int pgrid = (int)cdiv(units, 4);

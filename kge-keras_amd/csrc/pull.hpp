@@ -37,4 +37,13 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
                   int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& plan, bool g_is_dscore, const float* scores,
                   uint64_t seed, hipStream_t st);
 
+// HolE (hole.hip)
+int hole_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
+                 int64_t m_pos, const int32_t* neg, int64_t m_neg, float* coef, float* scores, float* loss_partials,
+                 int* n_partials, uint32_t* err, uint64_t seed, bool training, hipStream_t st);
+int hole_backward(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const PullPlan& plan,
+                  uint64_t seed, hipStream_t st);
+int hole_build_q(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side, int Kpad,
+                 float* Qv, uint32_t* err, hipStream_t st);
+
 }  // namespace kge

@@ -22,6 +22,7 @@
 // aligned block of 8 k-values the order is 0,4,1,5,2,6,3,7 (lane half 0 holds k..k+3, half 1 holds k+4..k+7; MFMA i
 // of the block consumes element i of both halves, half 0 first).
 #include "kge_internal.hpp"
+#include "pull.hpp"
 
 namespace kge {
 
@@ -400,6 +401,7 @@ int64_t rank_workspace_bytes(const kge_model_desc* md, int64_t nq) {
 
 static void launch_build_q(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side,
                            int Kpad, float* Qv, uint32_t* err, hipStream_t st) {
+  if (md->model == KGE_HOLE) { (void)hole_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st); return; }
   const int grid = (int)cdiv(nq * 64, 256);
   const int K = md->d_e;
   if (md->model == KGE_DISTMULT)
@@ -428,8 +430,7 @@ static void launch_dist(const kge_model_desc* md, const float* E, const float* E
 int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* Ec, int cand_offset, int cand_rows,
                 const int32_t* triples, int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs,
                 int32_t* counts, int accumulate, float* tgt_out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
-  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX && md->model != KGE_TRANSE)
-    return fail(KGE_EUNSUPPORTED, "kge_rank_counts: model %d has no 1-vs-all kernel yet (DistMult, ComplEx and TransE are built)", md->model);
+  if (md->model == KGE_HOLE && md->d_e > 1024) return fail(KGE_EUNSUPPORTED, "kge_rank_counts: HolE rows wider than 1024 floats are not built");
   const int K = md->d_e, BK = pick_bk(K), Kpad = rank_kpad_model(md);
   if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_counts: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)rank_workspace_bytes(md, nq));
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
@@ -465,7 +466,7 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
 
 int rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side,
                       float* out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
-  if (md->model != KGE_DISTMULT && md->model != KGE_COMPLEX && md->model != KGE_TRANSE) return fail(KGE_EUNSUPPORTED, "kge_rank_chain_scores: model %d", md->model);
+  if (md->model == KGE_HOLE && md->d_e > 1024) return fail(KGE_EUNSUPPORTED, "kge_rank_chain_scores: HolE rows wider than 1024 floats are not built");
   const int K = md->d_e, Kpad = rank_kpad_model(md);
   if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_chain_scores: workspace too small");
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;

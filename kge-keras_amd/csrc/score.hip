@@ -10,6 +10,7 @@
 // reduction.  No LDS, no re-read: algorithmic bytes = 4*(2*d_e + d_r) + 12 + 4 per triple, and the
 // kernel is bound by how many row bytes the chip keeps in flight (HBM / Infinity Cache / L2).
 #include "kge_internal.hpp"
+#include "pull.hpp"
 
 namespace kge {
 
@@ -140,6 +141,8 @@ int score_dispatch(const kge_model_desc* md, const float* E, const float* Rel, c
       if (md->norm == 1) { KGE_GO(KGE_TRANSE, 1); }
       KGE_GO(KGE_TRANSE, 2);
     case KGE_COMPLEX: KGE_GO(KGE_COMPLEX, 1);
+    case KGE_HOLE:
+      return hole_forward(md, -1, 0.f, E, Rel, triples, n, nullptr, 0, nullptr, out, nullptr, nullptr, err, 0, false, st);
     default: return fail(KGE_EUNSUPPORTED, "kge_score: model %d has no HIP scoring kernel yet", md->model);
   }
 #undef KGE_GO

@@ -385,7 +385,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     return fail(KGE_EINVAL, "unknown loss %d", ld->loss);
   }
   int nb = 0;
-  if (grad_mode() == 0 && pull_supported(md)) {
+  if ((grad_mode() == 0 || md->model == KGE_HOLE) && pull_supported(md)) {
     // The index build depends on the ids only and the forward gather does not need it: fork it onto the library's side
     // stream and join before the list fill (event fork/join, capturable into a hipGraph).
     PullPlan plan;

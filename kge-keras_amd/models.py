@@ -448,7 +448,8 @@ class ComplEx(EmbeddingModel):
 
 
 class HolE(EmbeddingModel):
-    """models.py:224-237 (surface; the circular-correlation kernel is a SURVEY 8(f) 'next' row)."""
+    """models.py:224-237: score = sum_k p_k * ccorr(s, o)_k, computed directly (O(d^2) per triple) in LDS-tiled VALU kernels;
+    1-vs-all ranking reuses the MFMA sweep with query vectors conv(p, s) / ccorr(p, o) (csrc/hole.hip)."""
     MODEL = "HolE"
 
     def __init__(self, name='HolE', **kwargs):

@@ -35,6 +35,8 @@ def _check_ranks(model, mdl, E0, R0, test, filt, N, norm=1, gamma=12):
     gaps = np.asarray(gaps).reshape(-1, 2)
     # fp32 rounding of a K-term sum is <~ 2^-23 * K * max|term|
     term = float(np.abs(E0).max() ** 2 * np.abs(R0).max()) if model != "TransE" else float(2 * np.abs(E0).max() + np.abs(R0).max()) ** norm
+    if model == "HolE":
+        term *= E0.shape[1]  # d^2 terms per score
     tol = 5e-7 * E0.shape[1] * term + (1e-5 if model == "TransE" else 0.0)
     for got, ref, gap in ((tails, to, gaps[:, 0]), (heads, ho, gaps[:, 1])):
         clear = gap > tol  # no candidate within float32 noise of the target: rank must be exact
@@ -44,7 +46,7 @@ def _check_ranks(model, mdl, E0, R0, test, filt, N, norm=1, gamma=12):
     return tails, heads, to, ho
 
 
-@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("ComplEx", {}), ("TransE", dict(norm=1, gamma=12)),
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("ComplEx", {}), ("HolE", {}), ("TransE", dict(norm=1, gamma=12)),
                                       ("TransE", dict(norm=2, gamma=12)), ("TransE", dict(norm=2, gamma=0))])
 @pytest.mark.parametrize("N,d,nq", [(14, 32, 40), (300, 200, 257), (1000, 30, 64), (129, 8, 1)])
 def test_rank_parity_random(model, kw, N, d, nq):
@@ -68,7 +70,8 @@ def test_rank_mfma_bit_exact_vs_chain():
     """The sweep's count must equal the count taken on the chain scores (the numbers the filter kernel and the target
     use): this is what makes un-counting filtered candidates exact.  Coarse-grid tables give many exact ties."""
     from kge_keras_amd import _lib
-    for model, quant, kw in (("DistMult", None, {}), ("DistMult", 2, {}), ("ComplEx", 2, {}), ("TransE", None, dict(norm=1, gamma=12)),
+    for model, quant, kw in (("DistMult", None, {}), ("DistMult", 2, {}), ("ComplEx", 2, {}), ("HolE", None, {}), ("HolE", 2, {}),
+                             ("TransE", None, dict(norm=1, gamma=12)),
                              ("TransE", 2, dict(norm=1, gamma=12)), ("TransE", 2, dict(norm=2, gamma=12)), ("TransE", None, dict(norm=2, gamma=0))):
         N, d, nq = 517, 40, 200
         mdl, E0, R0, rs = _mk(model, N, 5, d, seed=3, quant=quant, **kw)

@@ -38,7 +38,7 @@ def _triples(rs, n, N, R):
 
 
 CASES = [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)),
-         ("TransE", dict(norm=2, gamma=0)), ("ComplEx", {})]
+         ("TransE", dict(norm=2, gamma=0)), ("ComplEx", {}), ("HolE", {})]
 
 
 @pytest.mark.parametrize("model,kw", CASES)
