@@ -164,6 +164,13 @@ int kge_mt_raw(void* state_host, uint32_t* out_host, int64_t n);              /*
 int kge_build_batch_host(void* np_state_host, void* py_state_host, const int32_t* batch_host, int64_t B, int64_t ns,
                          int64_t num_e, int32_t* pos_out_host, int32_t* neg_out_host);
 
+/* ---- filter index of `validate` (utils.py:201-205 + the candidate removal of :165-196) on the host: from the test
+ *      triples of one side and the (n_filt,3) filtering triples, the COO list (query index, excluded entity id) that
+ *      kge_rank_counts consumes.  Two-pass: with out_q == NULL only *n_out is written.  KGE_EINVAL where the reference
+ *      raises ValueError (evaluated triple inside its own filter; ids outside range(num_entities)). */
+int kge_filter_coo_host(const int32_t* test_host, int64_t n_queries, int32_t side, const int32_t* filt_host, int64_t n_filt,
+                        int64_t num_entities, int32_t* out_q_host, int32_t* out_id_host, int64_t* n_out);
+
 /* The same batch builder on the GPU: states are the same 2504-byte blobs resident in device memory, batch (B,3) int32 on
  * the device, pos_out / neg_out (B*ns,3) int32 on the device.  Bit-identical to kge_build_batch_host, including the
  * generator states left behind.  err_flag bit 1 is set if the rejection-sampling margin of the raw buffer ever ran

@@ -58,6 +58,7 @@ SIGNATURES = {
     "kge_mt_shuffle": (C.c_int, [_P, _P, _I64]),
     "kge_mt_choices": (C.c_int, [_P, _I64, _P, _I64]),
     "kge_mt_raw": (C.c_int, [_P, _P, _I64]),
+    "kge_filter_coo_host": (C.c_int, [_P, _I64, _I32, _P, _I64, _I64, _P, _P, _P]),
     "kge_sampler_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "kge_build_batch_device": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _P, _P]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),

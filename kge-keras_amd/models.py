@@ -394,6 +394,22 @@ class EmbeddingModel:
             out.append(ranks)
         return out[0], out[1]
 
+    def rank_triples(self, test, num_entities, filt, chunk=65536):
+        """Same as rank(), from raw (n,3) arrays: the filter index is built by the C++ front-end (utils.filter_coo)."""
+        from .utils import filter_coo
+        test = np.ascontiguousarray(np.asarray(test, dtype=np.int32).reshape(-1, 3))
+        out = []
+        for side in (0, 1):
+            ranks = np.empty(len(test), dtype=np.int64)
+            for a in range(0, len(test), chunk):
+                part = test[a:a + chunk]
+                fq, fi = filter_coo(part, side, filt, num_entities)
+                cnt = self.rank_counts(part, side, fq, fi, num_entities)
+                ranks[a:a + chunk] = 1 + cnt.cpu().numpy().astype(np.int64)
+            self._raise_on_flag()
+            out.append(ranks)
+        return out[0], out[1]
+
     # ------------------------------------------------------------------ weights I/O (checkpointing)
     def get_weights(self):
         return self.entity_embedding.get_weights() + self.relational_embedding.get_weights()

@@ -150,11 +150,34 @@ def metrics_from_ranks(tail_ranks, head_ranks):
             'mr': (tmr + hmr) / 2, 'mrr': (tmrr + hmrr) / 2}
 
 
+def filter_coo(test, side, filtering_triples, num_entities):
+    """COO (query index, excluded id) of the reference's filter_t[(s,p)] / filter_h[(p,o)] sets for every test triple
+    (side 0 = tails, 1 = heads), built by the C++ front-end (sort + binary search).  ValueError where the reference's
+    list.remove would raise."""
+    import ctypes as C
+    test = np.ascontiguousarray(np.asarray(test, dtype=np.int32).reshape(-1, 3))
+    filt = np.ascontiguousarray(np.asarray(filtering_triples, dtype=np.int32).reshape(-1, 3))
+    n = C.c_int64(0)
+    _lib.check(_lib.lib.kge_filter_coo_host(test.ctypes.data, len(test), side, filt.ctypes.data, len(filt), int(num_entities), None, None, C.byref(n)))
+    q = np.empty(n.value, dtype=np.int32)
+    ids = np.empty(n.value, dtype=np.int32)
+    _lib.check(_lib.lib.kge_filter_coo_host(test.ctypes.data, len(test), side, filt.ctypes.data, len(filt), int(num_entities),
+                                           q.ctypes.data, ids.ctypes.data, C.byref(n)))
+    return q, ids
+
+
 def validate(model, test_data, num_entities, bs, filtering_triples=None):
     """utils.py:199-264.  `bs` is unused, as in the reference; `filtering_triples=None` raises TypeError, as there.
 
     For the models of this package the 1-vs-all sweep runs on the GPU (`model.rank`); any other object with a
     `.predict` is driven exactly like the reference drives it (candidate list per query, target in row 0)."""
+    if hasattr(model, "rank_triples"):  # GPU ranker + C++ filter index: no per-query Python work
+        if filtering_triples is None:
+            raise TypeError("'NoneType' object is not iterable")  # the reference iterates over it (utils.py:203)
+        filt = np.asarray([tuple(int(v) for v in t) for t in filtering_triples] if not isinstance(filtering_triples, np.ndarray)
+                          else filtering_triples, dtype=np.int32).reshape(-1, 3)
+        tail_ranks, head_ranks = model.rank_triples(np.asarray(test_data, dtype=np.int32).reshape(-1, 3), num_entities, filt)
+        return metrics_from_ranks(tail_ranks, head_ranks)
     filter_h = defaultdict(set)
     filter_t = defaultdict(set)
     for s, p, o in filtering_triples:  # TypeError on None, like the reference

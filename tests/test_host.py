@@ -252,3 +252,34 @@ def test_no_product_import_of_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_filter_coo_frontend_matches_reference_sets(golden, datasets):
+    """C++ filter index == the reference's filter_t / filter_h dict-of-sets, for every query of nations and a WN18RR slice."""
+    from collections import defaultdict
+    for ds, n_ent in (("nations", 14), ("wn18rr", 40943)):
+        tes = set(_ids(datasets[ds + "_test"]))
+        filt = [t for t in _ids(datasets[ds + "_train"]) + _ids(datasets[ds + "_valid"]) if t not in tes]
+        filt = filt + filt[:50]  # duplicates must collapse (sets)
+        test = _ids(datasets[ds + "_test"])[:300]
+        fh, ft = defaultdict(set), defaultdict(set)
+        for s, p, o in filt:
+            fh[(p, o)].add(s)
+            ft[(s, p)].add(o)
+        for side in (0, 1):
+            q, ids = U.filter_coo(test, side, filt, n_ent)
+            got = defaultdict(set)
+            for a, b in zip(q.tolist(), ids.tolist()):
+                assert b not in got[a]
+                got[a].add(b)
+            for i, (s, p, o) in enumerate(test):
+                want = ft.get((s, p), set()) if side == 0 else fh.get((p, o), set())
+                assert got.get(i, set()) == want, (ds, side, i)
+    with pytest.raises(ValueError):
+        U.filter_coo([(0, 1, 2)], 0, [(0, 1, 2)], 14)      # evaluated triple inside the filter
+    with pytest.raises(ValueError):
+        U.filter_coo([(0, 1, 2)], 0, [(0, 1, 99)], 14)     # filtered id outside range(num_entities)
+    with pytest.raises(ValueError):
+        U.filter_coo([(0, 1, 14)], 0, [], 14)              # target outside range(num_entities)
+    q, ids = U.filter_coo(np.zeros((0, 3), np.int32), 1, [(0, 1, 2)], 14)
+    assert len(q) == 0
