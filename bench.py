@@ -250,7 +250,12 @@ def main():
         # pull path: two gather kernels (fwd_kernel: A_FWD per triple; pull_kernel: A_BWD per triple); push path: one
         # fused kernel carrying A_TRAIN.  The roofline object is for the dominant (longest) one.
         kernels = {}
-        if f_n:
+        variant = 1 if os.environ.get("KGE_PULL_VARIANT", "2") == "1" else 2
+        if f_n and variant == 2:
+            # relation-grouped forward carries the relation-gradient row too; the pull is left with the two entity rows
+            kernels["fwd_rel_kernel (gather+score+loss+relation gradient)"] = (f_ms / f_n * 1e-3, per_step * (A_FWD + 4 * CFG["d"]))
+            kernels["pull_kernel (per-entity-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, per_step * 8 * CFG["d"])
+        elif f_n:
             kernels["fwd_kernel (gather+score+loss)"] = (f_ms / f_n * 1e-3, per_step * A_FWD)
             kernels["pull_kernel (per-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, per_step * A_BWD)
         else:

@@ -92,6 +92,11 @@ int pull_chunk() {
   return c < 8 ? 8 : c;
 }
 
+int pull_variant() {
+  static const int v = env_int("KGE_PULL_VARIANT", 2);
+  return v == 1 ? 1 : 2;
+}
+
 static int g_grad_mode = -1;
 int grad_mode() {
   if (g_grad_mode < 0) g_grad_mode = env_int("KGE_GRAD_MODE", 0) ? 1 : 0;

@@ -540,8 +540,8 @@ static void launch_fwd_loss(int loss, int G, int grid, hipStream_t st, const flo
 
 template <int MODEL, int NORM, int VEC>
 static void launch_pull(int nchunk, int grid, hipStream_t st, const float* E, const float* Rel, float* gE, float* gR,
-                        const kge_model_desc* md, const PullPlan& p, uint64_t seed) {
-  const int N = md->num_entities, NK = N + md->num_relations;
+                        const kge_model_desc* md, const PullPlan& p, uint64_t seed, int nk_override = -1) {
+  const int N = md->num_entities, NK = nk_override >= 0 ? nk_override : N + md->num_relations;
   const bool drop = md->dropout > 0.f;
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
@@ -640,6 +640,29 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
 #undef KGE_GO
   }
   hipLaunchKernelGGL(pull_finish_kernel, dim3((int)cdiv(NK, 4)), dim3(256), 0, st, gE, gR, N, NK, md->d_e, p.cnt, p.poff, p.slab, p.chunk);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// ---- entry points for pull2.hip: the same scan / pull / finish kernels over the N entity keys only
+void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st) {
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals);
+  hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(N, 256)), dim3(256), 0, st, e.cnt, e.eoff, N, e.chunk, e.max_extra, e.emap);
+}
+
+int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const PullPlan& e, uint64_t seed,
+                      hipStream_t st) {
+  const int N = md->num_entities;
+  const Shape sh = shape_of(md, E, Rel, gE, gR);
+  {
+    ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
+    const int pgrid = (int)cdiv(N + e.max_extra, 4);
+    if (md->model == KGE_DISTMULT) launch_pull<KGE_DISTMULT, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
+    else if (md->model == KGE_COMPLEX) launch_pull<KGE_COMPLEX, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
+    else if (md->norm == 1) launch_pull<KGE_TRANSE, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
+    else launch_pull<KGE_TRANSE, 2, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
+  }
+  hipLaunchKernelGGL(pull_finish_kernel, dim3((int)cdiv(N, 4)), dim3(256), 0, st, gE, gR, N, N, md->d_e, e.cnt, e.poff, e.slab, e.chunk);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

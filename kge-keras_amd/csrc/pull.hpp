@@ -37,6 +37,14 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
                   int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& plan, bool g_is_dscore, const float* scores,
                   uint64_t seed, hipStream_t st);
 
+// variant 2 (pull2.hip): relation-grouped forward with the relation gradient fused in; pointwise losses only
+bool pull2_supported(const kge_model_desc* md, const kge_loss_desc* ld);
+int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n);
+int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
+                      const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* scores, float* loss_partials,
+                      int* n_partials, void* ws, uint32_t* err, uint64_t seed, hipStream_t st, hipStream_t side, hipEvent_t fork,
+                      hipEvent_t join);
+
 // HolE (hole.hip)
 int hole_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
                  int64_t m_pos, const int32_t* neg, int64_t m_neg, float* coef, float* scores, float* loss_partials,

@@ -284,12 +284,14 @@ struct Workspace {
 
 int grad_mode();  // api.hip: 0 = pull (default), 1 = push (float atomics)
 struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
+int pull_variant();          // api.hip: 2 (default) = relation-grouped forward (pull2.hip), 1 = generic lists (pull.hip)
 SideStream* side_stream();  // api.hip: lazily created helper stream (nullptr when disabled by KGE_NO_SIDE_STREAM=1)
 
 static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 2 * align_up(n, 64); }
 
 int64_t train_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
-  return (int64_t)sizeof(float) * base_floats(m_pos + m_neg) + 512 + (md ? pull_workspace_bytes(md, m_pos + m_neg) : 0);
+  return (int64_t)sizeof(float) * base_floats(m_pos + m_neg) + 512 +
+         (md ? std::max(pull_workspace_bytes(md, m_pos + m_neg), pull2_workspace_bytes(md, m_pos + m_neg)) : 0);
 }
 
 static int carve(void* ws, int64_t bytes, const kge_model_desc* md, int64_t m_pos, int64_t m_neg, Workspace* out) {
@@ -385,6 +387,14 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     return fail(KGE_EINVAL, "unknown loss %d", ld->loss);
   }
   int nb = 0;
+  if (grad_mode() == 0 && pull_variant() == 2 && pull2_supported(md, ld)) {
+    SideStream* ss = side_stream();
+    if (int rc = train_grads_pull2(md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, scores_out, ws.loss_partials, &nb, ws.pull, err, seed, st,
+                                   ss ? ss->stream : nullptr, ss ? ss->fork : nullptr, ss ? ss->join : nullptr)) return rc;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
+  }
   if ((grad_mode() == 0 || md->model == KGE_HOLE) && pull_supported(md)) {
     // The index build depends on the ids only and the forward gather does not need it: fork it onto the library's side
     // stream and join before the list fill (event fork/join, capturable into a hipGraph).
