@@ -97,7 +97,9 @@ int kge_score(const kge_model_desc* md, const float* E, const float* Rel, const 
  *      oversample_data (utils.py:123-147).  gradE/gradRel are dense fp32 accumulators of the tables' shapes
  *      that must be all-zero on entry and are all-zero again on return.  *loss_out receives the batch loss
  *      (what Keras logs).  scores_out (optional, may be NULL) receives the m_pos+m_neg forward scores.
- *      seed feeds the dropout mask generator when md->dropout > 0.  */
+ *      seed feeds the dropout mask generator when md->dropout > 0.
+ *      The workspace must be ZERO-FILLED ONCE when it is allocated (hipMemset); the library then leaves its counters
+ *      clean at the end of every step (no per-step memset launches).  */
 int64_t kge_train_step_workspace_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg);
 int kge_train_step(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel,
                    float* gradE, float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,

@@ -436,14 +436,17 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
 }
 
 // One wave per key; multi-chunk keys add their slab rows, in chunk order, into the gradient table.
+// Also leaves cnt all-zero for the next step: the workspace is self-cleaning (it is zeroed once, at allocation).
 __global__ __launch_bounds__(256) void pull_finish_kernel(float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,
-                                                           const int32_t* __restrict__ cnt, const int32_t* __restrict__ poff,
+                                                           int32_t* __restrict__ cnt, const int32_t* __restrict__ poff,
                                                            const float* __restrict__ slab, int C) {
   const int key = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (key >= NK) return;
-  const int nch = (cnt[key] + C - 1) / C;
-  if (nch <= 1) return;
   const int lane = threadIdx.x & 63;
+  const int c = cnt[key];
+  if (lane == 0 && c) cnt[key] = 0;
+  const int nch = (c + C - 1) / C;
+  if (nch <= 1) return;
   float* dst = key >= N ? gR + (int64_t)(key - N) * d_e : gE + (int64_t)key * d_e;
   const float* src = slab + (int64_t)poff[key] * d_e;
   for (int k = lane; k < d_e; k += 64) {
@@ -469,20 +472,24 @@ int fwd_group_width(int nchunk);
 
 static int64_t a256(int64_t x) { return align_up(x, 256); }
 
+// The per-key counters live in a header at a FIXED place of the caller's workspace (independent of the batch size and
+// shared by both pull variants): they are the only state that must be zero on entry, and every step leaves them zero.
+int64_t pull_header_bytes(const kge_model_desc* md) { return a256((int64_t)md->num_entities * 4) + a256((int64_t)md->num_relations * 4) + 256; }
+
 int64_t pull_workspace_bytes(const kge_model_desc* md, int64_t n) {
   const int64_t NK = (int64_t)md->num_entities + md->num_relations;
   const int C = pull_chunk();
   const int64_t max_extra = 3 * n / C + 1;
-  return a256(NK * 4) * 4 + 256 + a256(max_extra * 8) + a256(3 * n * 16) + a256(3 * n * 4) + a256(n * 4) + a256(2 * max_extra * md->d_e * 4) + 1024;
+  return a256(NK * 4) * 3 + 256 + a256(max_extra * 8) + a256(3 * n * 16) + a256(3 * n * 4) + a256(n * 4) + a256(2 * max_extra * md->d_e * 4) + 1024;
 }
 
-static void carve_pull(void* ws, const kge_model_desc* md, int64_t n, PullPlan* p) {
+static void carve_pull(void* hdr, void* ws, const kge_model_desc* md, int64_t n, PullPlan* p) {
   const int64_t NK = (int64_t)md->num_entities + md->num_relations;
   const int C = pull_chunk();
   const int64_t max_extra = 3 * n / C + 1;
   char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   auto take = [&](int64_t bytes) { char* r = q; q += a256(bytes); return r; };
-  p->cnt = (int32_t*)take(NK * 4);
+  p->cnt = reinterpret_cast<int32_t*>(((uintptr_t)hdr + 255) & ~(uintptr_t)255);  // entity counters, then relation counters
   p->off = (int32_t*)take(NK * 4);
   p->eoff = (int32_t*)take(NK * 4);
   p->poff = (int32_t*)take(NK * 4);
@@ -565,15 +572,14 @@ static Shape shape_of(const kge_model_desc* md, const void* a, const void* b, co
   return Shape{v4, v4 ? width / 4 : width};
 }
 
-int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* pull_ws,
-                 hipStream_t st, PullPlan* plan) {
+int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* pull_hdr,
+                 void* pull_ws, hipStream_t st, PullPlan* plan) {
   const int64_t n = m_pos + m_neg;
-  carve_pull(pull_ws, md, n, plan);
+  carve_pull(pull_hdr, pull_ws, md, n, plan);
   PullPlan& p = *plan;
   const int N = md->num_entities, NK = N + md->num_relations;
   const int igrid = (int)cdiv(n, kIdxBlockTriples);
   ProfScope prof(KGE_PROF_INDEX, st);  // index build (ids only)
-  KGE_HIP_TRY(hipMemsetAsync(p.cnt, 0, (size_t)NK * 4, st));
   hipLaunchKernelGGL(hist_kernel, dim3(igrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, md->num_relations, p.cnt, p.ranks);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals);
   hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(NK, 256)), dim3(256), 0, st, p.cnt, p.eoff, NK, p.chunk, p.max_extra, p.emap);

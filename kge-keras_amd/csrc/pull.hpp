@@ -26,8 +26,9 @@ struct PullPlan {
 bool pull_supported(const kge_model_desc* md);
 int64_t pull_workspace_bytes(const kge_model_desc* md, int64_t n);
 // histogram of destination rows + scans + chunk map (depends on the ids only)
-int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* pull_ws,
-                 hipStream_t st, PullPlan* plan);
+int64_t pull_header_bytes(const kge_model_desc* md);  // zero-on-entry counters at a fixed place of the workspace
+int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* pull_hdr,
+                 void* pull_ws, hipStream_t st, PullPlan* plan);
 // gather + score; loss >= 0: pointwise loss fused (plan->coef, loss_partials[0..*n_partials)); loss < 0: scores only
 int pull_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
                  int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& plan, float* scores, float* loss_partials,
@@ -42,8 +43,8 @@ bool pull2_supported(const kge_model_desc* md, const kge_loss_desc* ld);
 int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n);
 int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
                       const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* scores, float* loss_partials,
-                      int* n_partials, void* ws, uint32_t* err, uint64_t seed, hipStream_t st, hipStream_t side, hipEvent_t fork,
-                      hipEvent_t join);
+                      int* n_partials, float* loss_out, void* hdr, void* ws, uint32_t* err, uint64_t seed, hipStream_t st, hipStream_t side,
+                      hipEvent_t fork, hipEvent_t join);
 
 // HolE (hole.hip)
 int hole_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,

@@ -68,33 +68,32 @@ __global__ __launch_bounds__(256) void rel_hist_kernel(const int32_t* __restrict
   }
 }
 
-// One workgroup: exclusive scans over R <= 4096 relations (list offsets, unit offsets) and the unit map.
-__global__ __launch_bounds__(1024) void rel_plan_kernel(const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
-                                                         int32_t* __restrict__ ruoff, int32_t* __restrict__ rtotal,
-                                                         int2* __restrict__ rumap, int max_units) {
-  __shared__ int sa[1024], sb[1024];
-  const int tid = threadIdx.x;
-  const int per = (R + 1023) / 1024;
+// One workgroup of 256 threads: exclusive scans over R <= 4096 relations (list offsets, unit offsets) and the unit map.
+__global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
+                                                        int32_t* __restrict__ ruoff, int32_t* __restrict__ rtotal,
+                                                        int2* __restrict__ rumap, int max_units) {
+  __shared__ int wa[4], wb[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (R + 255) / 256;  // <= 16
   const int k0 = tid * per, k1 = min(R, k0 + per);
   int a = 0, b = 0;
   for (int k = k0; k < k1; ++k) { const int c = rcnt[k]; a += c; b += (c + kRelChunk - 1) / kRelChunk; }
-  sa[tid] = a; sb[tid] = b;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    int xa = 0, xb = 0;
-    if (tid >= d) { xa = sa[tid - d]; xb = sb[tid - d]; }
-    __syncthreads();
-    sa[tid] += xa; sb[tid] += xb;
-    __syncthreads();
+  int ia = a, ib = b;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+    if (lane >= d) { ia += ua; ib += ub; }
   }
-  int ra = sa[tid] - a, rb = sb[tid] - b;
+  if (lane == 63) { wa[wave] = ia; wb[wave] = ib; }
+  __syncthreads();
+  int ra = ia - a, rb = ib - b;
+  for (int w = 0; w < wave; ++w) { ra += wa[w]; rb += wb[w]; }
   for (int k = k0; k < k1; ++k) {
     const int c = rcnt[k], nch = (c + kRelChunk - 1) / kRelChunk;
     roff[k] = ra; ruoff[k] = rb;
     for (int j = 0; j < nch; ++j) if (rb + j < max_units) rumap[rb + j] = make_int2(k, j);
     ra += c; rb += nch;
   }
-  if (tid == 1023) rtotal[0] = sb[1023];
+  if (tid == 255) rtotal[0] = rb;
 }
 
 __global__ __launch_bounds__(256) void rel_fill_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
@@ -309,13 +308,27 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
 }
 
 // gR[p] += sum of the relation's slab rows, in chunk order (one wave per relation, 8 independent loads in flight)
-__global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR, int R, int d_e, const int32_t* __restrict__ rcnt,
-                                                          const int32_t* __restrict__ ruoff, const float* __restrict__ rslab) {
+// Also: leaves rcnt all-zero for the next step (the workspace is self-cleaning; it is zeroed once at allocation), and the
+// extra last block reduces the forward's loss partials (fixed order) into *loss_out.
+__global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR, int R, int d_e, int32_t* __restrict__ rcnt,
+                                                          const int32_t* __restrict__ ruoff, const float* __restrict__ rslab,
+                                                          const float* __restrict__ loss_partials, int n_partials,
+                                                          float* __restrict__ loss_out) {
+  __shared__ float red[16];
+  if (blockIdx.x == gridDim.x - 1) {  // loss = sum of block partials
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_partials; i += 256) s += loss_partials[i];
+    const float b = block_sum(s, red);
+    if (threadIdx.x == 0) loss_out[0] = b;
+    return;
+  }
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= R) return;
-  const int nch = (rcnt[p] + kRelChunk - 1) / kRelChunk;
-  if (nch == 0) return;
   const int lane = threadIdx.x & 63;
+  const int c = rcnt[p];
+  if (lane == 0) rcnt[p] = 0;
+  const int nch = (c + kRelChunk - 1) / kRelChunk;
+  if (nch == 0) return;
   const float* src = rslab + (int64_t)ruoff[p] * d_e;
   float* dst = gR + (int64_t)p * d_e;
   for (int k = lane; k < d_e; k += 64) {
@@ -354,14 +367,16 @@ int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n) {
          b256(N * 4) * 4 + 256 + b256(max_extra * 8) + b256(2 * n * 16) + b256(2 * n * 4) + b256(n * 4) + b256(2 * max_extra * md->d_e * 4) + 2048;
 }
 
-static void carve2(void* ws, const kge_model_desc* md, int64_t n, Plan2* p) {
+static void carve2(void* hdr, void* ws, const kge_model_desc* md, int64_t n, Plan2* p) {
   const int64_t R = md->num_relations, N = md->num_entities;
   const int64_t max_units = n / kRelChunk + R + 1;
   const int C = pull_chunk();
   const int64_t max_extra = 2 * n / C + 1;
   char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   auto take = [&](int64_t bytes) { char* r = q; q += b256(bytes); return r; };
-  p->rcnt = (int32_t*)take(R * 4);
+  char* hq = reinterpret_cast<char*>(((uintptr_t)hdr + 255) & ~(uintptr_t)255);
+  p->ent.cnt = (int32_t*)hq;                 // header (fixed place, zero on entry, left zero): entity counters ...
+  p->rcnt = (int32_t*)(hq + b256(N * 4));    // ... then relation counters
   p->roff = (int32_t*)take(R * 4);
   p->ruoff = (int32_t*)take(R * 4);
   p->rtotal = (int32_t*)take(16);
@@ -370,7 +385,6 @@ static void carve2(void* ws, const kge_model_desc* md, int64_t n, Plan2* p) {
   p->rentries = (int4*)take(n * 16);
   p->rslab = (float*)take(max_units * md->d_e * 4);
   p->max_units = (int)max_units;
-  p->ent.cnt = (int32_t*)take(N * 4);
   p->ent.off = (int32_t*)take(N * 4);
   p->ent.eoff = (int32_t*)take(N * 4);
   p->ent.poff = (int32_t*)take(N * 4);
@@ -419,11 +433,11 @@ static void launch_fwd_rel_loss(int loss, int nv, bool drop, int grid, hipStream
 // `side` may be null (then everything runs on `st`).
 int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
                       const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* scores, float* loss_partials,
-                      int* n_partials, void* ws, uint32_t* err, uint64_t seed, hipStream_t st, hipStream_t side, hipEvent_t fork,
-                      hipEvent_t join) {
+                      int* n_partials, float* loss_out, void* hdr, void* ws, uint32_t* err, uint64_t seed, hipStream_t st, hipStream_t side,
+                      hipEvent_t fork, hipEvent_t join) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
-  carve2(ws, md, n, &p);
+  carve2(hdr, ws, md, n, &p);
   const int N = md->num_entities, R = md->num_relations;
   const int tgrid = (int)cdiv(n, 256);
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
@@ -434,15 +448,13 @@ int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const f
   if (side) { KGE_HIP_TRY(hipEventRecord(fork, st)); KGE_HIP_TRY(hipStreamWaitEvent(side, fork, 0)); }
   {
     ProfScope prof(KGE_PROF_INDEX, es);
-    KGE_HIP_TRY(hipMemsetAsync(p.ent.cnt, 0, (size_t)N * 4, es));
     hipLaunchKernelGGL(ent_hist_kernel, dim3(tgrid), dim3(256), 0, es, pos, m_pos, neg, m_neg, N, R, p.ent.cnt, p.erank);
     pull2_entity_plan(p.ent, N, es);
   }
   if (side) KGE_HIP_TRY(hipEventRecord(join, side));
   // ---- relation index + forward on the main stream
-  KGE_HIP_TRY(hipMemsetAsync(p.rcnt, 0, (size_t)R * 4, st));
   hipLaunchKernelGGL(rel_hist_kernel, dim3((int)cdiv(n, kRelBlockTriples)), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, R, p.rcnt, p.rrank);
-  hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(1024), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
+  hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
   hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, p.roff, p.rrank, p.rentries, p.ent.coef, scores, err);
   const int fgrid = (int)cdiv(p.max_units, 4);
   *n_partials = fgrid;
@@ -457,7 +469,8 @@ int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const f
   if (side) KGE_HIP_TRY(hipStreamWaitEvent(st, join, 0));
   hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, p.ent.coef, p.ent.off, p.erank, p.ent.entries);
   if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st)) return rc;
-  hipLaunchKernelGGL(rel_finish_kernel, dim3((int)cdiv(R, 4)), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab);
+  hipLaunchKernelGGL(rel_finish_kernel, dim3((int)cdiv(R, 4) + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
+                     *n_partials, loss_out);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

@@ -279,6 +279,7 @@ struct Workspace {
   float* reg_partials;   // kMaxBlocks
   float* gbuf;           // m_pos + m_neg (pairwise, push path)
   float* sbuf;           // m_pos + m_neg (pairwise, when scores_out is null)
+  void* pull_hdr;        // pull-path counters: fixed place, zero on entry, left zero by every step
   void* pull;            // pull-path plan and lists
 };
 
@@ -291,7 +292,7 @@ static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 2 * align_up(n, 
 
 int64_t train_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
   return (int64_t)sizeof(float) * base_floats(m_pos + m_neg) + 512 +
-         (md ? std::max(pull_workspace_bytes(md, m_pos + m_neg), pull2_workspace_bytes(md, m_pos + m_neg)) : 0);
+         (md ? pull_header_bytes(md) + std::max(pull_workspace_bytes(md, m_pos + m_neg), pull2_workspace_bytes(md, m_pos + m_neg)) : 0);
 }
 
 static int carve(void* ws, int64_t bytes, const kge_model_desc* md, int64_t m_pos, int64_t m_neg, Workspace* out) {
@@ -300,6 +301,8 @@ static int carve(void* ws, int64_t bytes, const kge_model_desc* md, int64_t m_po
     return fail(KGE_EWORKSPACE, "workspace has %lld bytes, needs %lld", (long long)bytes,
                 (long long)train_workspace_bytes(md, m_pos, m_neg));
   uintptr_t p = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
+  out->pull_hdr = reinterpret_cast<void*>(p);
+  if (md) p += (uintptr_t)align_up(pull_header_bytes(md), 256);
   float* f = reinterpret_cast<float*>(p);
   out->loss_partials = f;
   out->reg_partials = f + kMaxBlocks;
@@ -389,11 +392,8 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   int nb = 0;
   if (grad_mode() == 0 && pull_variant() == 2 && pull2_supported(md, ld)) {
     SideStream* ss = side_stream();
-    if (int rc = train_grads_pull2(md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, scores_out, ws.loss_partials, &nb, ws.pull, err, seed, st,
-                                   ss ? ss->stream : nullptr, ss ? ss->fork : nullptr, ss ? ss->join : nullptr)) return rc;
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
-    KGE_HIP_TRY(hipGetLastError());
-    return KGE_OK;
+    return train_grads_pull2(md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, scores_out, ws.loss_partials, &nb, loss_out, ws.pull_hdr, ws.pull, err, seed,
+                             st, ss ? ss->stream : nullptr, ss ? ss->fork : nullptr, ss ? ss->join : nullptr);
   }
   if ((grad_mode() == 0 || md->model == KGE_HOLE) && pull_supported(md)) {
     // The index build depends on the ids only and the forward gather does not need it: fork it onto the library's side
@@ -403,10 +403,10 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     if (ss) {
       KGE_HIP_TRY(hipEventRecord(ss->fork, st));
       KGE_HIP_TRY(hipStreamWaitEvent(ss->stream, ss->fork, 0));
-      if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull, ss->stream, &plan)) return rc;
+      if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull_hdr, ws.pull, ss->stream, &plan)) return rc;
       KGE_HIP_TRY(hipEventRecord(ss->join, ss->stream));
     } else {
-      if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull, st, &plan)) return rc;
+      if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, ws.pull_hdr, ws.pull, st, &plan)) return rc;
     }
     float* sc = scores_out ? scores_out : (pairwise ? ws.sbuf : nullptr);
     if (int rc = pull_forward(md, pairwise ? -1 : ld->loss, ld->margin, E, Rel, pos, m_pos, neg, m_neg, plan, sc, ws.loss_partials, &nb, err, seed, st)) return rc;
@@ -478,7 +478,7 @@ static int launch_opt(bool reg, float* w, float* g, float* m, float* v, int64_t 
 int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gE,
               float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st) {
   Workspace ws;
-  if (int rc = carve(workspace, wbytes, nullptr, 0, 0, &ws)) return rc;
+  if (int rc = carve(workspace, wbytes, md, 0, 0, &ws)) return rc;
   const int64_t nE = (int64_t)md->num_entities * md->d_e, nR = (int64_t)md->num_relations * md->d_r;
   const bool reg = ld->regularization != 0.f;
   int nb = 0, nb2 = 0;

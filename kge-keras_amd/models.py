@@ -224,7 +224,7 @@ class EmbeddingModel:
         md, ld = self._model_desc(True), self._loss_desc()
         need = check(lib.kge_train_step_workspace_bytes(C.byref(md), C.byref(ld), m_pos, m_neg))
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            self._ws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)  # zero-filled once (kge_hip.h)
         return md, ld
 
     def _opt_desc(self):
