@@ -15,3 +15,4 @@ Pinning status (see DESIGN.md "Oracle"):
     by torch-CPU autograd.
 """
 from .kge_oracle import *  # noqa: F401,F403
+from . import c_port  # noqa: F401  (C restatement, built on first use by oracle/Makefile)

@@ -273,3 +273,22 @@ def test_dropout_default_rate_trains(datasets):
     assert mdl.dp == 0.2
     h = mdl.fit(DataGenerator(datasets["nations_train"], ns=10, batch_size=32), epochs=3, verbose=0)
     assert h.history["loss"][-1] < h.history["loss"][0]
+
+
+def test_changing_batch_size_and_loss_on_one_model():
+    """The workspace counters sit at a fixed header and are left clean by every step: batch sizes and the gradient-path
+    variant (pointwise -> relation-grouped forward, pairwise -> generic lists) may change between steps of one model."""
+    N, R, d = 60, 9, 32
+    mdl, E0, R0, rs = _mk("DistMult", N, R, d, loss_function="pointwize_hinge", margin=0.5)
+    mdl.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.AdamTF()
+    for m, loss in ((300, "pointwize_hinge"), (64, "pairwize_hinge"), (1000, "pointwize_logistic"), (7, "pointwize_hinge"),
+                    (513, "pairwize_logistic"), (300, "pointwize_square_loss")):
+        mdl.loss_function = loss
+        pos, neg = _triples(rs, m, N, R), _triples(rs, m + 3, N, R)  # len(pos) != len(neg) is legal for the reference's losses
+        L = float(mdl.train_step([pos, neg])["loss"].item())
+        Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, loss, 0.5, 1)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (m, loss)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)

@@ -268,3 +268,27 @@ def test_dropout_multipliers_statistics_and_determinism():
     # row_offset addresses the same batch rows
     assert np.array_equal(m[100:], O.dropout_multipliers(7, 300, 1, 200, 0.2, row_offset=100))
     assert (O.dropout_multipliers(1, 10, 0, 31, 0.0) == 1.0).all()
+
+
+@pytest.mark.parametrize("model,norm,gamma", [("DistMult", 1, 12), ("TransE", 1, 12), ("TransE", 2, 12), ("TransE", 2, 0), ("ComplEx", 1, 12)])
+@pytest.mark.parametrize("loss", ["pointwize_hinge", "pointwize_logistic"])
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_c_port_matches_numpy_oracle(model, norm, gamma, loss, opt):
+    """oracle/kge_oracle_c.c (the cpu_baseline port) against the NumPy restatement, three steps."""
+    from oracle import c_port
+    rs = np.random.RandomState(4)
+    N, R, d, m = 50, 6, 16, 500
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    ct = c_port.CTrainer(model, E0, R0, opt, loss, 0.7, norm, gamma)
+    Eo, Ro, oo = E0.astype(np.float64), R0.astype(np.float64), O.make_optimizer(opt)
+    for _ in range(3):
+        pos = np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)
+        neg = np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)
+        Lc = ct.step(pos, neg)
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.7, 1, norm, gamma)
+        assert Lc == pytest.approx(Lo, abs=1e-4, rel=1e-5)
+        np.testing.assert_allclose(ct.E, Eo, atol=1e-4)
+        np.testing.assert_allclose(ct.Rel, Ro, atol=1e-4)
+    assert c_port.threads() >= 1
