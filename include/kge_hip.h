@@ -177,10 +177,20 @@ int kge_filter_coo_host(const int32_t* test_host, int64_t n_queries, int32_t sid
  * the device, pos_out / neg_out (B*ns,3) int32 on the device.  Bit-identical to kge_build_batch_host, including the
  * generator states left behind.  err_flag bit 1 is set if the rejection-sampling margin of the raw buffer ever ran
  * short (never observed; the states are then left at the end of the buffer). */
+/* plan (optional): MT19937's word stream is sequential, but the state J words ahead is a GF(2)-linear function of the
+ * current one.  kge_sampler_plan_host computes, for this batch shape, the jump polynomials x^J mod phi of the starts of
+ * 8 segments per stream (host, ~0.1-1 s once, cached); uploaded and passed as plan_dev, the generator then runs as 8
+ * workgroups per stream after one short sequential pre-pass.  plan_dev == NULL: fully sequential generation.  Same bits. */
 int64_t kge_sampler_workspace_bytes(int64_t B, int64_t ns, int64_t num_e);
+int64_t kge_sampler_plan_bytes(void);
+int kge_sampler_plan_host(int64_t B, int64_t ns, int64_t num_e, void* plan_host);
 int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t* batch_dev, int64_t B, int64_t ns,
-                           int64_t num_e, int32_t* pos_out_dev, int32_t* neg_out_dev, void* workspace, int64_t workspace_bytes,
-                           uint32_t* err_flag, kge_stream_t stream);
+                           int64_t num_e, int32_t* pos_out_dev, int32_t* neg_out_dev, const void* plan_dev, void* workspace,
+                           int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* GF(2) jump-ahead primitives (host): out[312] uint64 = coefficients of x^J mod phi; kge_mt_jump_host replaces the 624
+ * state words by raw words [J, J+624) of the stream (bits 0..30 of word 0 are not state and not guaranteed). */
+int kge_mt_jump_poly(int64_t J, uint64_t* out_host);
+int kge_mt_jump_host(void* state_host, int64_t J);
 
 #ifdef __cplusplus
 }

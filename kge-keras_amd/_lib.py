@@ -60,7 +60,11 @@ SIGNATURES = {
     "kge_mt_raw": (C.c_int, [_P, _P, _I64]),
     "kge_filter_coo_host": (C.c_int, [_P, _I64, _I32, _P, _I64, _I64, _P, _P, _P]),
     "kge_sampler_workspace_bytes": (_I64, [_I64, _I64, _I64]),
-    "kge_build_batch_device": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _P, _P]),
+    "kge_sampler_plan_bytes": (_I64, []),
+    "kge_sampler_plan_host": (C.c_int, [_I64, _I64, _I64, _P]),
+    "kge_build_batch_device": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P]),
+    "kge_mt_jump_poly": (C.c_int, [_I64, _P]),
+    "kge_mt_jump_host": (C.c_int, [_P, _I64]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

@@ -137,7 +137,10 @@ int rank_chain_scores(const kge_model_desc*, const float*, const float*, const i
                       uint32_t*, hipStream_t);
 
 int64_t sampler_workspace_bytes(int64_t, int64_t, int64_t);
-int build_batch_device(void*, void*, const int32_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, void*, int64_t, uint32_t*, hipStream_t);
+int build_batch_device(void*, void*, const int32_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, const void*, void*, int64_t, uint32_t*,
+                       hipStream_t);
+int sampler_plan_host(int64_t, int64_t, int64_t, uint64_t*);
+int64_t sampler_plan_bytes();
 
 }  // namespace kge
 
@@ -283,14 +286,21 @@ int64_t kge_sampler_workspace_bytes(int64_t B, int64_t ns, int64_t num_e) {
   return sampler_workspace_bytes(B, ns, num_e);
 }
 
+int64_t kge_sampler_plan_bytes(void) { return sampler_plan_bytes(); }
+
+int kge_sampler_plan_host(int64_t B, int64_t ns, int64_t num_e, void* plan_host) {
+  if (!plan_host || B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_sampler_plan_host: bad arguments");
+  return sampler_plan_host(B, ns, num_e, static_cast<uint64_t*>(plan_host));
+}
+
 int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t* batch_dev, int64_t B, int64_t ns, int64_t num_e,
-                           int32_t* pos_out_dev, int32_t* neg_out_dev, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
-                           kge_stream_t stream) {
+                           int32_t* pos_out_dev, int32_t* neg_out_dev, const void* plan_dev, void* workspace, int64_t workspace_bytes,
+                           uint32_t* err_flag, kge_stream_t stream) {
   if (!np_state_dev || !py_state_dev || !batch_dev || !pos_out_dev || !neg_out_dev || !workspace || !err_flag)
     return fail(KGE_EINVAL, "kge_build_batch_device: null pointer");
   if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_build_batch_device: bad sizes");
-  return build_batch_device(np_state_dev, py_state_dev, batch_dev, B, ns, num_e, pos_out_dev, neg_out_dev, workspace, workspace_bytes,
-                            err_flag, static_cast<hipStream_t>(stream));
+  return build_batch_device(np_state_dev, py_state_dev, batch_dev, B, ns, num_e, pos_out_dev, neg_out_dev, plan_dev, workspace,
+                            workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

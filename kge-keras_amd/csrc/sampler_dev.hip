@@ -16,6 +16,8 @@
 //
 // The NumPy stream consumes a data-dependent number of words; the raw buffer is sized with a margin of tens of
 // standard deviations and err_flag bit 1 is raised if it ever ran short (the host then falls back to a larger margin).
+#include <cstring>
+
 #include "kge_internal.hpp"
 
 namespace kge {
@@ -41,24 +43,17 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 
 // blockIdx.x == 0: NumPy stream (K0 blocks), 1: Python stream (K1 blocks).  U holds RAW state words (untempered), so
 // any block of U is itself a valid generator state.
-// One workgroup of 256 threads per stream.  The barrier is a raw s_barrier behind an LDS-only wait: __syncthreads()
-// would also drain the global stores of the previous block (vmcnt(0)) on the critical path.
+// The barrier is a raw s_barrier behind an LDS-only wait: __syncthreads() would also drain the global stores of the
+// previous block (vmcnt(0)) on the critical path.
 #define KGE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-__global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
-                                                           uint32_t* __restrict__ U_np, int K0, uint32_t* __restrict__ U_py, int K1) {
-  __shared__ uint32_t buf[2][624];
-  const MTDev* st = blockIdx.x == 0 ? st_np : st_py;
-  uint32_t* U = blockIdx.x == 0 ? U_np : U_py;
-  const int K = blockIdx.x == 0 ? K0 : K1;
+// Regenerates blocks [b_begin, b_end) of U from the state block held in buf[0] (256 threads, all must call).
+// Thread tid owns words tid, 227+tid and 454+tid of a block.  The phase-2 / phase-3 inputs new[i-227] are then the
+// thread's OWN phase-1 / phase-2 results, so a whole block is computed from one round of LDS reads of the previous
+// block: one barrier per block instead of three.  (new[623] needs new[0]: thread 169 recomputes it.)
+__device__ __forceinline__ void mt_regen_blocks(uint32_t (*buf)[624], uint32_t* __restrict__ U, int b_begin, int b_end) {
   const int tid = threadIdx.x;
-  __builtin_amdgcn_s_setprio(3);  // a latency chain of 2 workgroups beside chip-filling gather kernels: win the issue arbitration
-  for (int i = tid; i < 624; i += 256) buf[0][i] = st->mt[i];
-  __syncthreads();
-  // Thread tid owns words tid, 227+tid and 454+tid of a block.  The phase-2 / phase-3 inputs new[i-227] are then the
-  // thread's OWN phase-1 / phase-2 results, so a whole block is computed from one round of LDS reads of the previous
-  // block: one barrier per block instead of three.  (new[623] needs new[0]: thread 169 recomputes it.)
   int cur = 0;
-  for (int b = 0; b < K; ++b) {
+  for (int b = b_begin; b < b_end; ++b) {
     const uint32_t* o = buf[cur];
     uint32_t* n = buf[cur ^ 1];
     uint32_t* dst = U + (int64_t)b * 624;
@@ -85,6 +80,84 @@ __global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restric
     KGE_LDS_BARRIER();
     cur ^= 1;
   }
+}
+
+// blockIdx.x == 0: NumPy stream (K0 blocks), 1: Python stream (K1 blocks), generated sequentially from the state.
+constexpr int kSeg = 8;
+__global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
+                                                           uint32_t* __restrict__ U_np, int K0, uint32_t* __restrict__ U_py, int K1,
+                                                           uint32_t* __restrict__ Jst_zero) {
+  __shared__ uint32_t buf[2][624];
+  const MTDev* st = blockIdx.x == 0 ? st_np : st_py;
+  __builtin_amdgcn_s_setprio(3);  // a latency chain of a few workgroups beside chip-filling gather kernels: win the issue arbitration
+  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = st->mt[i];
+  if (Jst_zero) for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * kSeg * 624; i += 512) Jst_zero[i] = 0u;  // accumulated into by mt_jump_kernel
+  __syncthreads();
+  mt_regen_blocks(buf, blockIdx.x == 0 ? U_np : U_py, 0, blockIdx.x == 0 ? K0 : K1);
+}
+
+// ---- segmented generation: GF(2) jump-ahead (mtjump.cpp) gives the state at the start of every segment as a XOR of
+// windows of the first 33 blocks of the raw stream, so kSeg workgroups per stream regenerate in parallel.
+constexpr int kJumpBlocks = 33;   // 624 * 33 >= 19937 + 623 raw words after the state block
+constexpr int kPolyWords = 312;   // uint64 words of one jump polynomial
+
+// Jst[z][s][j] ^= XOR_{k in this block's slice : g_{z,s}[k]} W_z[k + j]  (W = state block followed by U; Jst pre-zeroed).
+// grid (10 j-tiles x kJumpSplit k-slices, kSeg-1, 2).  Loads are unconditional (select on the coefficient bit) so that
+// many are in flight; a block's footprint (its k slice + 64 words) stays L1-resident.
+constexpr int kJumpSplit = 16;
+__global__ __launch_bounds__(256) void mt_jump_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
+                                                       const uint32_t* __restrict__ U_np, const uint32_t* __restrict__ U_py,
+                                                       const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jst, int seg_np,
+                                                       int seg_py) {
+  __shared__ uint32_t part[4][64];
+  const int z = blockIdx.z, s = blockIdx.y + 1;
+  if ((z == 0 ? seg_np : seg_py) == 0) return;  // this stream is generated sequentially
+  const MTDev* st = z == 0 ? st_np : st_py;
+  const uint32_t* U = z == 0 ? U_np : U_py;
+  const uint64_t* poly = polys + ((int64_t)z * (kSeg - 1) + (s - 1)) * kPolyWords;
+  const int tile = blockIdx.x % 10, slice = blockIdx.x / 10;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = tile * 64 + lane;
+  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;  // polynomial words per slice (20)
+  uint32_t acc = 0;
+  for (int wi = wave; wi < WPS; wi += 4) {
+    const int w = slice * WPS + wi;
+    if (w >= kPolyWords) break;
+    const uint64_t gw = poly[w];  // wave-uniform
+    const int base = w * 64 + j;
+#pragma unroll 16
+    for (int bit = 0; bit < 64; ++bit) {
+      const int idx = base + bit;
+      const uint32_t v = idx < 624 ? st->mt[idx] : U[idx - 624];
+      acc ^= ((gw >> bit) & 1ull) ? v : 0u;
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && j < 624) {
+    const uint32_t v = part[0][lane] ^ part[1][lane] ^ part[2][lane] ^ part[3][lane];
+    if (v) atomicXor(&Jst[((int64_t)z * kSeg + s) * 624 + j], v);
+  }
+}
+
+// grid (kSeg, 2): segment s of stream z regenerates blocks [s*segb, (s+1)*segb) (segment 0 starts after the 33 blocks
+// the sequential pre-pass already produced).
+__global__ __launch_bounds__(256) void mt_generate_seg_kernel(uint32_t* __restrict__ U_np, int K_np, int segb_np,
+                                                               uint32_t* __restrict__ U_py, int K_py, int segb_py,
+                                                               const uint32_t* __restrict__ Jst) {
+  __shared__ uint32_t buf[2][624];
+  const int z = blockIdx.y, s = blockIdx.x;
+  uint32_t* U = z == 0 ? U_np : U_py;
+  const int K = z == 0 ? K_np : K_py, segb = z == 0 ? segb_np : segb_py;
+  if (segb == 0) return;
+  int b0 = s * segb, b1 = min(K, (s + 1) * segb);
+  if (s == 0) b0 = kJumpBlocks;
+  if (b0 >= b1) return;
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t* src = s == 0 ? U + (int64_t)(kJumpBlocks - 1) * 624 : Jst + ((int64_t)z * kSeg + s) * 624;
+  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = src[i];
+  __syncthreads();
+  mt_regen_blocks(buf, U, b0, b1);
 }
 #undef KGE_LDS_BARRIER
 
@@ -240,6 +313,8 @@ struct SamplerPlan {
   int64_t* consumed;
   int32_t* fs;
   int32_t* fo;
+  uint32_t* Jst;      // [2][kSeg][624] jumped segment-start states
+  int segb_np, segb_py;  // blocks per segment (0 = the stream is generated sequentially)
   int64_t bytes;
 };
 
@@ -266,14 +341,33 @@ static SamplerPlan plan_sampler(int64_t B, int64_t ns, int64_t num_e, void* ws) 
   p.consumed = (int64_t*)take(256);
   p.fs = (int32_t*)take(m * 4);
   p.fo = (int32_t*)take(m * 4);
+  p.Jst = (uint32_t*)take(2 * kSeg * 624 * 4);
+  auto segb = [](int64_t K) { const int64_t sb = cdiv(K, kSeg); return (int)(sb > kJumpBlocks ? sb : 0); };
+  p.segb_np = segb(p.K_np);
+  p.segb_py = segb(p.K_py);
   p.bytes = (q - reinterpret_cast<char*>(ws)) + 256;
   return p;
 }
 
 int64_t sampler_workspace_bytes(int64_t B, int64_t ns, int64_t num_e) { return plan_sampler(B, ns, num_e, nullptr).bytes + 512; }
 
+// Fills polys_host[2][kSeg-1][312] (uint64) with the jump polynomials of the segment starts for this batch shape.
+int sampler_plan_host(int64_t B, int64_t ns, int64_t num_e, uint64_t* polys_host) {
+  const SamplerPlan p = plan_sampler(B, ns, num_e, nullptr);
+  for (int z = 0; z < 2; ++z) {
+    const int segb = z == 0 ? p.segb_np : p.segb_py;
+    for (int s = 1; s < kSeg; ++s) {
+      uint64_t* out = polys_host + ((int64_t)z * (kSeg - 1) + (s - 1)) * kPolyWords;
+      if (segb == 0) { std::memset(out, 0, kPolyWords * 8); continue; }
+      if (int rc = kge_mt_jump_poly((int64_t)624 * s * segb, out)) return rc;
+    }
+  }
+  return KGE_OK;
+}
+int64_t sampler_plan_bytes() { return (int64_t)2 * (kSeg - 1) * kPolyWords * 8; }
+
 int build_batch_device(void* np_state, void* py_state, const int32_t* batch, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out,
-                       int32_t* neg_out, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+                       int32_t* neg_out, const void* plan_dev, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
   if (wbytes < sampler_workspace_bytes(B, ns, num_e))
     return fail(KGE_EWORKSPACE, "kge_build_batch_device: workspace has %lld bytes, needs %lld", (long long)wbytes,
                 (long long)sampler_workspace_bytes(B, ns, num_e));
@@ -283,7 +377,14 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, int
   MTDev* pys = static_cast<MTDev*>(py_state);
   const uint32_t rng = (uint32_t)(num_e - 1), mask = (uint32_t)smear64(rng);
   ProfScope prof(KGE_PROF_SAMPLER, st);
-  hipLaunchKernelGGL(mt_generate_kernel, dim3(2), dim3(256), 0, st, nps, pys, p.U_np, (int)p.K_np, p.U_py, (int)p.K_py);
+  const int sb_np = plan_dev ? p.segb_np : 0, sb_py = plan_dev ? p.segb_py : 0;
+  hipLaunchKernelGGL(mt_generate_kernel, dim3(2), dim3(256), 0, st, nps, pys, p.U_np, sb_np ? kJumpBlocks : (int)p.K_np, p.U_py,
+                     sb_py ? kJumpBlocks : (int)p.K_py, (sb_np || sb_py) ? p.Jst : nullptr);
+  if (sb_np || sb_py) {
+    hipLaunchKernelGGL(mt_jump_kernel, dim3(10 * kJumpSplit, kSeg - 1, 2), dim3(256), 0, st, nps, pys, p.U_np, p.U_py, static_cast<const uint64_t*>(plan_dev),
+                       p.Jst, sb_np, sb_py);
+    hipLaunchKernelGGL(mt_generate_seg_kernel, dim3(kSeg, 2), dim3(256), 0, st, p.U_np, (int)p.K_np, sb_np, p.U_py, (int)p.K_py, sb_py, p.Jst);
+  }
   if (rng) {
     const int64_t L_u = p.K_np * 624;
     hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, p.consumed, (int64_t)-1);

@@ -126,6 +126,8 @@ class DeviceSampler:
         self.py_state = torch.from_numpy(py_stream._buf.view(np.uint8).copy()).to(self.device)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._ws = None
+        self._plans = {}  # (B, ns, num_e) -> device tensor of jump polynomials (segmented generation)
+        self.segmented = True
 
     def to_streams(self):
         """Copy the device states back into host twins (e.g. for the epoch shuffle, which is sequential by nature)."""
@@ -152,7 +154,15 @@ class DeviceSampler:
         if pos_out is None:
             pos_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
             neg_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
+        plan_ptr = None
+        if self.segmented:
+            key = (B, int(ns), int(num_e))
+            if key not in self._plans:  # GF(2) jump polynomials of the segment starts (host, once per batch shape)
+                buf = np.empty(int(lib.kge_sampler_plan_bytes()) // 8, dtype=np.uint64)
+                check(lib.kge_sampler_plan_host(B, int(ns), int(num_e), buf.ctypes.data))
+                self._plans[key] = torch.from_numpy(buf.view(np.int64)).to(self.device)
+            plan_ptr = self._plans[key].data_ptr()
         check(lib.kge_build_batch_device(self.np_state.data_ptr(), self.py_state.data_ptr(), batch.data_ptr(), B, int(ns), int(num_e),
-                                         pos_out.data_ptr(), neg_out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                         pos_out.data_ptr(), neg_out.data_ptr(), plan_ptr, self._ws.data_ptr(), self._ws.numel(),
                                          self.err.data_ptr(), _lib.stream_ptr()))
         return pos_out, neg_out

@@ -283,3 +283,24 @@ def test_filter_coo_frontend_matches_reference_sets(golden, datasets):
         U.filter_coo([(0, 1, 14)], 0, [], 14)              # target outside range(num_entities)
     q, ids = U.filter_coo(np.zeros((0, 3), np.int32), 1, [(0, 1, 2)], 14)
     assert len(q) == 0
+
+
+def test_mt19937_jump_ahead_polynomial():
+    """GF(2) jump-ahead (csrc/mtjump.cpp): the state advanced by J words through x^J mod phi continues the stream exactly
+    where stepping the generator J words does."""
+    for seed, J in ((1, 1), (5, 624), (7, 1000), (11, 20592), (2024, 624 * 165), (99, 819200)):
+        a = NumpyStream(seed)
+        a.raw(624)                      # make the state block a regenerated one (every word in the recurrence regime)
+        b = NumpyStream()
+        b._buf[:] = a._buf
+        _lib.check(_lib.lib.kge_mt_jump_host(b._buf.ctypes.data, J))
+        b._buf[624] = 624               # jumped block = raw words [J, J+624): continue with the block after it
+        got = b.raw(700)
+        ref = NumpyStream()
+        ref._buf[:] = a._buf
+        ref._buf[624] = 0               # pos 0: the state block's own words are words 0..623 of the stream
+        ref.raw(J + 624)
+        assert got.tolist() == ref.raw(700).tolist(), (seed, J)
+    poly = np.zeros(312, dtype=np.uint64)
+    _lib.check(_lib.lib.kge_mt_jump_poly(5, poly.ctypes.data))
+    assert int(poly[0]) == 32 and not poly[1:].any()   # x^5 mod phi = x^5
