@@ -232,20 +232,21 @@ __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ p
   }
 }
 
-// Tiled single-block scan: 1024 threads x 4 consecutive keys per tile, wave shuffles inside, carry across tiles.
+// Tiled single-workgroup scan: 256 threads x 4 consecutive keys per tile, wave shuffles inside, carry across tiles
+// (a small workgroup is admitted quickly beside the chip-filling gather kernels).
 struct Tri { int a, b, c; };
 __device__ __forceinline__ Tri tri_add(Tri x, Tri y) { return Tri{x.a + y.a, x.b + y.b, x.c + y.c}; }
 __device__ __forceinline__ Tri tri_shfl_up(Tri x, int d) { return Tri{__shfl_up(x.a, d, 64), __shfl_up(x.b, d, 64), __shfl_up(x.c, d, 64)}; }
 
-__global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ cnt, int NK, int C, int32_t* __restrict__ off,
+__global__ __launch_bounds__(256) void scan_kernel(const int32_t* __restrict__ cnt, int NK, int C, int32_t* __restrict__ off,
                                                      int32_t* __restrict__ eoff, int32_t* __restrict__ poff,
                                                      int32_t* __restrict__ totals) {
-  __shared__ Tri wsum[16];
+  __shared__ Tri wsum[4];
   __shared__ Tri carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = Tri{0, 0, 0};
   __syncthreads();
-  for (int base = 0; base < NK; base += 4096) {
+  for (int base = 0; base < NK; base += 1024) {
     const int k0 = base + tid * 4;
     int n[4];
     Tri v[4];
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int32_t* __restrict__ 
         off[k0 + j] = x.a; eoff[k0 + j] = x.b; poff[k0 + j] = x.c;
       }
     __syncthreads();
-    if (tid == 1023) carry_s = tri_add(tri_add(carry, wpre), inc);
+    if (tid == 255) carry_s = tri_add(tri_add(carry, wpre), inc);
     __syncthreads();
   }
   if (tid == 0) { totals[0] = carry_s.b; totals[1] = carry_s.c; totals[2] = carry_s.a; }
@@ -581,7 +582,7 @@ int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, co
   const int igrid = (int)cdiv(n, kIdxBlockTriples);
   ProfScope prof(KGE_PROF_INDEX, st);  // index build (ids only)
   hipLaunchKernelGGL(hist_kernel, dim3(igrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, md->num_relations, p.cnt, p.ranks);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals);
   hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(NK, 256)), dim3(256), 0, st, p.cnt, p.eoff, NK, p.chunk, p.max_extra, p.emap);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
@@ -652,7 +653,7 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
 
 // ---- entry points for pull2.hip: the same scan / pull / finish kernels over the N entity keys only
 void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st) {
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals);
   hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(N, 256)), dim3(256), 0, st, e.cnt, e.eoff, N, e.chunk, e.max_extra, e.emap);
 }
 

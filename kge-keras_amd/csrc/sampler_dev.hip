@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const MTDev* __restrict__ 
                                                        const uint32_t* __restrict__ U_np, const uint32_t* __restrict__ U_py,
                                                        const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jst, int seg_np,
                                                        int seg_py) {
+  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;  // polynomial words per slice (20)
+  constexpr int WIN = WPS * 64 + 64;                               // raw words this block touches
+  __shared__ uint32_t win[WIN];
   __shared__ uint32_t part[4][64];
   const int z = blockIdx.z, s = blockIdx.y + 1;
   if ((z == 0 ? seg_np : seg_py) == 0) return;  // this stream is generated sequentially
@@ -118,19 +121,20 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const MTDev* __restrict__ 
   const int tile = blockIdx.x % 10, slice = blockIdx.x / 10;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = tile * 64 + lane;
-  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;  // polynomial words per slice (20)
+  const int lo = slice * WPS * 64 + tile * 64;  // first raw word of the window
+  for (int i = threadIdx.x; i < WIN; i += 256) {
+    const int idx = lo + i;
+    win[i] = idx < 624 ? st->mt[idx] : (idx < 624 * (kJumpBlocks + 1) ? U[idx - 624] : 0u);
+  }
+  __syncthreads();
   uint32_t acc = 0;
   for (int wi = wave; wi < WPS; wi += 4) {
     const int w = slice * WPS + wi;
     if (w >= kPolyWords) break;
     const uint64_t gw = poly[w];  // wave-uniform
-    const int base = w * 64 + j;
+    const uint32_t* src = win + wi * 64 + lane;  // conflict-free: consecutive lanes, consecutive words
 #pragma unroll 16
-    for (int bit = 0; bit < 64; ++bit) {
-      const int idx = base + bit;
-      const uint32_t v = idx < 624 ? st->mt[idx] : U[idx - 624];
-      acc ^= ((gw >> bit) & 1ull) ? v : 0u;
-    }
+    for (int bit = 0; bit < 64; ++bit) acc ^= ((gw >> bit) & 1ull) ? src[bit] : 0u;
   }
   part[wave][lane] = acc;
   __syncthreads();
@@ -186,10 +190,10 @@ __global__ __launch_bounds__(256) void np_count_kernel(const MTDev* __restrict__
 }
 
 // exclusive scan of up to 1024*per tile counts, one workgroup
-__global__ __launch_bounds__(1024) void np_scan_kernel(int32_t* __restrict__ tile_cnt, int ntiles, int32_t* __restrict__ total) {
-  __shared__ int wsum[16];
+__global__ __launch_bounds__(256) void np_scan_kernel(int32_t* __restrict__ tile_cnt, int ntiles, int32_t* __restrict__ total) {
+  __shared__ int wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (ntiles + 1023) / 1024;
+  const int per = (ntiles + 255) / 256;
   const int k0 = tid * per, k1 = min(ntiles, k0 + per);
   int s = 0;
   for (int k = k0; k < k1; ++k) s += tile_cnt[k];
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(1024) void np_scan_kernel(int32_t* __restrict__ til
   int pre = inc - s;
   for (int w = 0; w < wave; ++w) pre += wsum[w];
   for (int k = k0; k < k1; ++k) { const int v = tile_cnt[k]; tile_cnt[k] = pre; pre += v; }
-  if (tid == 1023) *total = pre;
+  if (tid == 255) *total = pre;
 }
 
 __global__ __launch_bounds__(256) void np_scatter_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
@@ -389,7 +393,7 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, int
     const int64_t L_u = p.K_np * 624;
     hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, p.consumed, (int64_t)-1);
     hipLaunchKernelGGL(np_count_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt);
-    hipLaunchKernelGGL(np_scan_kernel, dim3(1), dim3(1024), 0, st, p.tile_cnt, (int)p.ntiles, p.total);
+    hipLaunchKernelGGL(np_scan_kernel, dim3(1), dim3(256), 0, st, p.tile_cnt, (int)p.ntiles, p.total);
     hipLaunchKernelGGL(np_scatter_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt, m, p.fs, p.fo, p.consumed);
   } else {  // a range of one: numpy draws nothing
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fs, m, 0);
