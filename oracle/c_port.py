@@ -25,6 +25,9 @@ def lib():
         _lib.kge_oracle_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_int64]
         _lib.kge_oracle_threads.restype = C.c_int
+        _lib.kge_oracle_set_threads.argtypes = [C.c_int]
+        # a 1-GPU box gets a 16-core CPU share; wider teams only add private-table reduction work
+        _lib.kge_oracle_set_threads(min(16, os.cpu_count() or 1, int(os.environ.get("KGE_ORACLE_THREADS", "16"))))
     return _lib
 
 

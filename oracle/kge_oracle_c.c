@@ -129,6 +129,15 @@ void kge_oracle_apply(int kind, float* w, float* g, float* m, float* v, int64_t 
   }
 }
 
+/* cap the OpenMP team (per-thread private gradient tables make very wide teams counter-productive) */
+void kge_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int kge_oracle_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
