@@ -139,6 +139,14 @@ int kge_rank_chain_scores(const kge_model_desc* md, const float* E, const float*
                           int64_t n_queries, int32_t side, float* out, void* workspace, int64_t workspace_bytes,
                           uint32_t* err_flag, kge_stream_t stream);
 
+/* ---- the reference's loss functions as callables on two score vectors (utils.py:288-319, reduce_mean=True):
+ *      *loss_out = loss(true, false, margin, negative_samples); d_true / d_false (optional, may be NULL) receive the
+ *      derivatives.  Workspace: kge_train_step_workspace_bytes(NULL-free md of any shape, ld, m_true, m_false) suffices;
+ *      kge_loss_workspace_bytes gives the exact need. */
+int64_t kge_loss_workspace_bytes(int64_t m_true, int64_t m_false);
+int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,
+                   float* loss_out, float* d_true, float* d_false, void* workspace, int64_t workspace_bytes, kge_stream_t stream);
+
 /* Gradient path of kge_train_step / kge_train_grads: 0 (default) = "pull": per-destination-row gather-reduce, no float
  * atomics; 1 = "push": fused forward + no-return fp32 global atomics.  Same results to fp32 rounding. */
 int kge_set_grad_mode(int mode);

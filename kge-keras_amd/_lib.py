@@ -44,6 +44,8 @@ SIGNATURES = {
     "kge_rank_workspace_bytes": (_I64, [_MD, _I64]),
     "kge_rank_counts": (C.c_int, [_MD, _P, _P, _P, _I32, _I32, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _P, _I64, _P, _P]),
     "kge_rank_chain_scores": (C.c_int, [_MD, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _P]),
+    "kge_loss_workspace_bytes": (_I64, [_I64, _I64]),
+    "kge_loss_value": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),

@@ -130,6 +130,7 @@ int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
               int64_t, hipStream_t);
 
+int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
 int64_t rank_workspace_bytes(const kge_model_desc*, int64_t);
 int rank_counts(const kge_model_desc*, const float*, const float*, const float*, int, int, const int32_t*, int64_t, int,
                 const int32_t*, const int32_t*, int64_t, int32_t*, int, float*, void*, int64_t, uint32_t*, hipStream_t);
@@ -301,6 +302,19 @@ int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t
   if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_build_batch_device: bad sizes");
   return build_batch_device(np_state_dev, py_state_dev, batch_dev, B, ns, num_e, pos_out_dev, neg_out_dev, plan_dev, workspace,
                             workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int64_t kge_loss_workspace_bytes(int64_t m_true, int64_t m_false) {
+  if (m_true < 0 || m_false < 0) return fail(KGE_EINVAL, "negative size");
+  return train_workspace_bytes(nullptr, m_true, m_false);
+}
+
+int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,
+                   float* loss_out, float* d_true, float* d_false, void* workspace, int64_t workspace_bytes, kge_stream_t stream) {
+  if (!ld || !true_scores || !false_scores || !loss_out || !workspace) return fail(KGE_EINVAL, "kge_loss_value: null pointer");
+  if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_value: empty score vector (reduce_mean of nothing)");
+  return loss_value(ld, true_scores, m_true, false_scores, m_false, loss_out, d_true, d_false, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -370,6 +370,57 @@ static int launch_pairwise(const float* ts, int64_t m_t, const float* fs, int64_
   return KGE_OK;
 }
 
+// ---- the reference's loss functions as callables on two score vectors (utils.py:288-319): value and, optionally,
+// d loss / d true and d loss / d false
+template <int LOSS>
+__global__ __launch_bounds__(256) void pointwise_loss_kernel(const float* __restrict__ ts, int64_t m_t, const float* __restrict__ fs,
+                                                              int64_t m_f, float margin, float* __restrict__ g_t,
+                                                              float* __restrict__ g_f, float* __restrict__ partials) {
+  __shared__ float red[16];
+  const float inv_t = 1.f / (float)m_t, inv_f = 1.f / (float)m_f;
+  float lsum = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m_t + m_f; i += (int64_t)gridDim.x * 256) {
+    const bool is_pos = i < m_t;
+    float g, l;
+    pointwise<LOSS>(is_pos ? ts[i] : fs[i - m_t], is_pos, margin, is_pos ? inv_t : inv_f, g, l);
+    lsum += l;
+    if (is_pos) { if (g_t) g_t[i] = g; } else if (g_f) g_f[i - m_t] = g;
+  }
+  const float b = block_sum(lsum, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = b;
+}
+
+int loss_value(const kge_loss_desc* ld, const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* loss_out, float* g_t,
+               float* g_f, void* workspace, int64_t wbytes, hipStream_t st) {
+  Workspace ws;
+  if (int rc = carve(workspace, wbytes, nullptr, m_t, m_f, &ws)) return rc;
+  int nb = 0;
+  const bool pairwise = ld->loss == KGE_PAIRWIZE_HINGE || ld->loss == KGE_PAIRWIZE_LOGISTIC || ld->loss == KGE_PAIRWIZE_SQUARE;
+  if (pairwise) {
+    if (ld->negative_samples < 1 || m_f % ld->negative_samples)
+      return fail(KGE_ESHAPE, "pairwize loss: len(false)=%lld is not divisible by negative_samples=%d", (long long)m_f, ld->negative_samples);
+    if (!(ld->negative_samples == 1 || m_t == 1))
+      return fail(ld->negative_samples == m_t ? KGE_EUNSUPPORTED : KGE_ESHAPE, "pairwize loss: (%lld,%d) against (%lld,) is not the all-pairs broadcast",
+                  (long long)(m_f / ld->negative_samples), ld->negative_samples, (long long)m_t);
+    float* gt = g_t ? g_t : ws.gbuf;
+    float* gf = g_f ? g_f : ws.gbuf + m_t;
+    int rc;
+    if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(ts, m_t, fs, m_f, ld->margin, gt, gf, ws.loss_partials, st, &nb);
+    else if (ld->loss == KGE_PAIRWIZE_LOGISTIC) rc = launch_pairwise<KGE_PAIRWIZE_LOGISTIC>(ts, m_t, fs, m_f, ld->margin, gt, gf, ws.loss_partials, st, &nb);
+    else rc = launch_pairwise<KGE_PAIRWIZE_SQUARE>(ts, m_t, fs, m_f, ld->margin, gt, gf, ws.loss_partials, st, &nb);
+    if (rc) return rc;
+  } else {
+    nb = (int)std::min<int64_t>(cdiv(m_t + m_f, 256), kMaxBlocks);
+    if (ld->loss == KGE_POINTWIZE_HINGE) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_HINGE>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
+    else if (ld->loss == KGE_POINTWIZE_LOGISTIC) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_LOGISTIC>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
+    else if (ld->loss == KGE_POINTWIZE_SQUARE) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_SQUARE>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
+    else return fail(KGE_EINVAL, "unknown loss %d", ld->loss);
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
 int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
                 const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out,
                 uint64_t seed, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {

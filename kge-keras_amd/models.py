@@ -83,8 +83,26 @@ class _Optimizer:
         self.slots = None  # (mE, vE, mRel, vRel)
 
 
-def loss_value(name, true, false, margin=1, negative_samples=1):
-    raise NotImplementedError("stand-alone loss evaluation on score vectors is provided through EmbeddingModel.train_step")
+def loss_value(name, true, false, margin=1, negative_samples=1, return_grads=False):
+    """loss_function_lookup(name)(true, false, margin, negative_samples) of the reference (utils.py:288-319) on the GPU:
+    a 0-d device tensor (and, with return_grads, d loss/d true and d loss/d false)."""
+    if name not in LOSS_IDS:
+        if name == "pointwize_cross_entropy":
+            raise NotImplementedError("pointwize_cross_entropy (utils.py:297-298) is not on the built path")
+        raise KeyError(name)
+    dev = _device()
+    t = torch.as_tensor(true, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    f = torch.as_tensor(false, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    need = check(lib.kge_loss_workspace_bytes(t.numel(), f.numel()))
+    ws = torch.zeros(int(need), dtype=torch.uint8, device=dev)
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    gt = torch.empty_like(t) if return_grads else None
+    gf = torch.empty_like(f) if return_grads else None
+    ld = LossDesc(LOSS_IDS[name], int(negative_samples), float(margin), 0.0)
+    check(lib.kge_loss_value(C.byref(ld), t.data_ptr(), t.numel(), f.data_ptr(), f.numel(), out.data_ptr(),
+                             gt.data_ptr() if return_grads else None, gf.data_ptr() if return_grads else None,
+                             ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    return (out[0], gt, gf) if return_grads else out[0]
 
 
 class EmbeddingModel:

@@ -292,3 +292,23 @@ def test_changing_batch_size_and_loss_on_one_model():
         assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (m, loss)
         np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
         np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+
+
+@pytest.mark.parametrize("name", LOSSES)
+def test_loss_functions_callable(name):
+    """loss_function_lookup(name)(true, false, margin, negative_samples) as the reference exposes it (utils.py:288-330)."""
+    from kge_keras_amd.utils import loss_function_lookup
+    from kge_keras_amd.models import loss_value
+    rs = np.random.RandomState(2)
+    t, f = rs.uniform(-2, 2, 700), rs.uniform(-2, 2, 300)
+    L = float(loss_function_lookup(name)(t, f, 0.7, 1).item())
+    Lo, gto, gfo = O.loss_value_and_grads(name, t, f, 0.7, 1)
+    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+    _, gt, gf = loss_value(name, t, f, 0.7, 1, return_grads=True)
+    np.testing.assert_allclose(gt.cpu().numpy(), gto, atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(gf.cpu().numpy(), gfo, atol=1e-6, rtol=1e-4)
+    if name.startswith("pairwize"):
+        with pytest.raises(ValueError):  # (100,3) does not broadcast against (700,)
+            loss_function_lookup(name)(t, f, 0.7, 3)
+    with pytest.raises(KeyError):
+        loss_function_lookup("nope")
