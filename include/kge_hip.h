@@ -39,7 +39,7 @@ typedef enum {
 } kge_status;
 
 /* KGEkeras.models.* classes on the path (models.py:164-237). */
-typedef enum { KGE_DISTMULT = 0, KGE_TRANSE = 1, KGE_COMPLEX = 2, KGE_HOLE = 3 } kge_model;
+typedef enum { KGE_DISTMULT = 0, KGE_TRANSE = 1, KGE_COMPLEX = 2, KGE_HOLE = 3, KGE_CONVE = 4 } kge_model;
 
 /* KGEkeras.utils.loss_function_lookup names (utils.py:321-330). */
 typedef enum {
@@ -62,6 +62,8 @@ typedef struct {
   int32_t norm;          /* TransE: 1 or 2 (models.py:178,188) */
   float gamma;           /* TransE (models.py:179,187-190): score = gamma - dist if gamma > 0 else +dist */
   float dropout;         /* Dropout(dp) on the three gathered rows, training only (models.py:122,144-148) */
+  int32_t conv_filters;  /* ConvE: Conv2D filters (models.py:242; 8 is built) */
+  float hidden_dropout;  /* ConvE: Dropout(hidden_dp) after each batch norm (models.py:241,257,262) */
 } kge_model_desc;
 
 /* loss_function(true, false, margin, negative_samples) as called at tests.py:80-81. */
@@ -138,6 +140,35 @@ int kge_rank_counts(const kge_model_desc* md, const float* E, const float* Rel, 
 int kge_rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples,
                           int64_t n_queries, int32_t side, float* out, void* workspace, int64_t workspace_bytes,
                           uint32_t* err_flag, kge_stream_t stream);
+
+/* ---- ConvE (models.py:239-275): the conv / batch-norm / dense parameters live in one flat fp32 vector
+ *      theta = [K(3,3,C) | bc(C) | g1(C) | b1(C) | Wd(F,d) | bd(d) | g2(d) | b2(d)]  (F = (2w-2)(h-2)C, (w,h) = largest factor pair of d)
+ *      and the non-trainable moving statistics in stats = [mean1(C) | var1(C) | mean2(d) | var2(d)].
+ *      kge_conve_score / kge_conve_hidden run in inference mode (moving statistics, no dropout): scores, or the hidden
+ *      vectors x(s,p) (n,d) with score = <x, E[o]> (what the 1-vs-all sweep consumes).  kge_conve_train_grads is the
+ *      gradient half of a Keras train step (batch statistics per call of the wrapper: pos and neg separately; moving
+ *      statistics updated; gradients accumulated into gradE / gradRel / gtheta, all zero on entry); the optimizer half is
+ *      kge_opt_apply for the tables plus kge_opt_apply_vector for theta.  The dense layer is rocBLAS sgemm. */
+int kge_conve_sizes(const kge_model_desc* md, int64_t* n_theta, int64_t* n_stats);
+int64_t kge_conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg);
+int64_t kge_conve_infer_workspace_bytes(const kge_model_desc* md, int64_t n);
+int kge_conve_score(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* stats, const int32_t* triples,
+                    int64_t n, float* out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+int kge_conve_hidden(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* stats, const int32_t* triples,
+                     int64_t n, float* hidden_out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+int kge_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta,
+                          float* stats, float* gradE, float* gradRel, float* gtheta, const int32_t* pos, int64_t m_pos,
+                          const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
+                          int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* Keras optimizer update of one flat fp32 vector (w -= ..., g re-zeroed); od->mE / od->vE are its Adam slots. */
+int kge_opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float grad_scale, kge_stream_t stream);
+/* Filtered rank counts for any model whose score is a dot product <q_i, c_j>: Q is (n_queries, K), Cand holds rows
+ * cand_offset .. cand_offset+cand_rows of the K-wide candidate matrix, target_ids[i] is the global candidate id of query i's
+ * target (must lie in the range), filters as in kge_rank_counts.  Same MFMA sweep, same bit-exact comparisons. */
+int64_t kge_rank_sweep_q_workspace_bytes(int64_t n_queries, int32_t K);
+int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* Cand, int32_t cand_offset, int32_t cand_rows,
+                     const int32_t* target_ids, const int32_t* filt_query, const int32_t* filt_ids, int64_t n_filt, int32_t* counts,
+                     int32_t accumulate, void* workspace, int64_t workspace_bytes, kge_stream_t stream);
 
 /* ---- the reference's loss functions as callables on two score vectors (utils.py:288-319, reduce_mean=True):
  *      *loss_out = loss(true, false, margin, negative_samples); d_true / d_false (optional, may be NULL) receive the

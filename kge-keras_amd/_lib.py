@@ -12,7 +12,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 KGE_OK, KGE_EINVAL, KGE_ESHAPE, KGE_EHIP, KGE_EWORKSPACE, KGE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3}
+MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4}
 LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, "pairwize_logistic": 3,
             "pointwize_square_loss": 4, "pairwize_square_loss": 5}
 OPT_IDS = {"sgd": 0, "adam": 1}
@@ -21,7 +21,8 @@ MT_STATE_BYTES = 2504
 
 class ModelDesc(C.Structure):
     _fields_ = [("model", C.c_int32), ("num_entities", C.c_int32), ("num_relations", C.c_int32), ("d_e", C.c_int32),
-                ("d_r", C.c_int32), ("norm", C.c_int32), ("gamma", C.c_float), ("dropout", C.c_float)]
+                ("d_r", C.c_int32), ("norm", C.c_int32), ("gamma", C.c_float), ("dropout", C.c_float),
+                ("conv_filters", C.c_int32), ("hidden_dropout", C.c_float)]
 
 
 class LossDesc(C.Structure):
@@ -44,6 +45,15 @@ SIGNATURES = {
     "kge_rank_workspace_bytes": (_I64, [_MD, _I64]),
     "kge_rank_counts": (C.c_int, [_MD, _P, _P, _P, _I32, _I32, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _P, _I64, _P, _P]),
     "kge_rank_chain_scores": (C.c_int, [_MD, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _P]),
+    "kge_conve_sizes": (C.c_int, [_MD, _P, _P]),
+    "kge_conve_workspace_bytes": (_I64, [_MD, _I64, _I64]),
+    "kge_conve_infer_workspace_bytes": (_I64, [_MD, _I64]),
+    "kge_conve_score": (C.c_int, [_MD, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P]),
+    "kge_conve_hidden": (C.c_int, [_MD, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P]),
+    "kge_conve_train_grads": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
+    "kge_opt_apply_vector": (C.c_int, [_OD, _P, _P, _I64, _F, _P]),
+    "kge_rank_sweep_q_workspace_bytes": (_I64, [_I64, _I32]),
+    "kge_rank_sweep_q": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _I32, _P, _I64, _P]),
     "kge_loss_workspace_bytes": (_I64, [_I64, _I64]),
     "kge_loss_value": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),

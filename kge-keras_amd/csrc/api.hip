@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) {
 
 int check_model(const kge_model_desc* md, const char* who) {
   if (!md) return fail(KGE_EINVAL, "%s: model descriptor is null", who);
-  if (md->model < KGE_DISTMULT || md->model > KGE_HOLE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
+  if (md->model < KGE_DISTMULT || md->model > KGE_CONVE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
   if (md->num_entities <= 0 || md->num_relations <= 0 || md->d_e <= 0 || md->d_r <= 0)
     return fail(KGE_EINVAL, "%s: non-positive table shape (%d,%d) (%d,%d)", who, md->num_entities, md->d_e, md->num_relations, md->d_r);
   // s*p*o, s+p-o and the ComplEx products broadcast row-against-row: TensorFlow rejects unequal widths
@@ -132,6 +132,17 @@ int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, 
 
 int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
 int64_t rank_workspace_bytes(const kge_model_desc*, int64_t);
+int conve_sizes(const kge_model_desc*, int64_t*, int64_t*);
+int64_t conve_workspace_bytes(const kge_model_desc*, int64_t, int64_t);
+int64_t conve_infer_workspace_bytes(const kge_model_desc*, int64_t);
+int conve_infer(const kge_model_desc*, const float*, const float*, const float*, float*, const int32_t*, int64_t, float*, int, void*, int64_t,
+                uint32_t*, hipStream_t);
+int conve_train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, const float*, float*, float*, float*, float*,
+                      const int32_t*, int64_t, const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
+int opt_apply_vector(const kge_opt_desc*, float*, float*, int64_t, float, hipStream_t);
+int64_t rank_sweep_q_workspace_bytes(int64_t, int);
+int rank_sweep_q(const float*, int64_t, int, const float*, int, int, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, int,
+                 void*, int64_t, hipStream_t);
 int rank_counts(const kge_model_desc*, const float*, const float*, const float*, int, int, const int32_t*, int64_t, int,
                 const int32_t*, const int32_t*, int64_t, int32_t*, int, float*, void*, int64_t, uint32_t*, hipStream_t);
 int rank_chain_scores(const kge_model_desc*, const float*, const float*, const int32_t*, int64_t, int, float*, void*, int64_t,
@@ -315,6 +326,79 @@ int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_
   if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_value: empty score vector (reduce_mean of nothing)");
   return loss_value(ld, true_scores, m_true, false_scores, m_false, loss_out, d_true, d_false, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+static int check_conve(const kge_model_desc* md, const char* who) {
+  if (int rc = check_model(md, who)) return rc;
+  if (md->model != KGE_CONVE) return fail(KGE_EINVAL, "%s: model %d is not ConvE", who, md->model);
+  if (!(md->hidden_dropout >= 0.f && md->hidden_dropout < 1.f)) return fail(KGE_EINVAL, "%s: hidden dropout rate %f outside [0,1)", who, md->hidden_dropout);
+  return KGE_OK;
+}
+
+int kge_conve_sizes(const kge_model_desc* md, int64_t* n_theta, int64_t* n_stats) {
+  if (int rc = check_conve(md, "kge_conve_sizes")) return rc;
+  if (!n_theta || !n_stats) return fail(KGE_EINVAL, "kge_conve_sizes: null output");
+  return conve_sizes(md, n_theta, n_stats);
+}
+
+int64_t kge_conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
+  if (check_conve(md, "kge_conve_workspace_bytes")) return KGE_EINVAL;
+  if (m_pos < 0 || m_neg < 0) return fail(KGE_EINVAL, "negative batch size");
+  return conve_workspace_bytes(md, m_pos, m_neg);
+}
+
+int64_t kge_conve_infer_workspace_bytes(const kge_model_desc* md, int64_t n) {
+  if (check_conve(md, "kge_conve_infer_workspace_bytes")) return KGE_EINVAL;
+  if (n < 0) return fail(KGE_EINVAL, "negative size");
+  return conve_infer_workspace_bytes(md, n);
+}
+
+int kge_conve_score(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* stats, const int32_t* triples,
+                    int64_t n, float* out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_conve(md, "kge_conve_score")) return rc;
+  if (n == 0) return KGE_OK;
+  if (n < 0 || !E || !Rel || !theta || !stats || !triples || !out || !workspace || !err_flag) return fail(KGE_EINVAL, "kge_conve_score: bad arguments");
+  return conve_infer(md, E, Rel, theta, stats, triples, n, out, 0, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_conve_hidden(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* stats, const int32_t* triples,
+                     int64_t n, float* hidden_out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_conve(md, "kge_conve_hidden")) return rc;
+  if (n == 0) return KGE_OK;
+  if (n < 0 || !E || !Rel || !theta || !stats || !triples || !hidden_out || !workspace || !err_flag) return fail(KGE_EINVAL, "kge_conve_hidden: bad arguments");
+  return conve_infer(md, E, Rel, theta, stats, triples, n, hidden_out, 1, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta,
+                          float* stats, float* gradE, float* gradRel, float* gtheta, const int32_t* pos, int64_t m_pos,
+                          const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
+                          int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_conve(md, "kge_conve_train_grads")) return rc;
+  if (int rc = check_train("kge_conve_train_grads", md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, err_flag)) return rc;
+  if (!theta || !stats || !gtheta || !workspace) return fail(KGE_EINVAL, "kge_conve_train_grads: null pointer");
+  return conve_train_grads(md, ld, E, Rel, theta, stats, gradE, gradRel, gtheta, pos, m_pos, neg, m_neg, loss_out, scores_out, seed, workspace,
+                           workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float grad_scale, kge_stream_t stream) {
+  if (!od || !w || !g || n < 0) return fail(KGE_EINVAL, "kge_opt_apply_vector: bad arguments");
+  return opt_apply_vector(od, w, g, n, grad_scale, static_cast<hipStream_t>(stream));
+}
+
+int64_t kge_rank_sweep_q_workspace_bytes(int64_t n_queries, int32_t K) {
+  if (n_queries < 0 || K <= 0) return fail(KGE_EINVAL, "kge_rank_sweep_q_workspace_bytes: bad sizes");
+  return rank_sweep_q_workspace_bytes(n_queries, K);
+}
+
+int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* Cand, int32_t cand_offset, int32_t cand_rows,
+                     const int32_t* target_ids, const int32_t* filt_query, const int32_t* filt_ids, int64_t n_filt, int32_t* counts,
+                     int32_t accumulate, void* workspace, int64_t workspace_bytes, kge_stream_t stream) {
+  if (n_queries == 0) return KGE_OK;
+  if (n_queries < 0 || K <= 0 || !Q || !Cand || !target_ids || !counts || !workspace || cand_rows <= 0 || cand_offset < 0 || n_filt < 0 ||
+      (n_filt && (!filt_query || !filt_ids)))
+    return fail(KGE_EINVAL, "kge_rank_sweep_q: bad arguments");
+  return rank_sweep_q(Q, n_queries, K, Cand, cand_offset, cand_rows, target_ids, filt_query, filt_ids, n_filt, counts, accumulate, workspace,
+                      workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

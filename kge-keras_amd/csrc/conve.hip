@@ -1,0 +1,697 @@
+// ConvE (KGEkeras/models.py:239-275):  x = Drop(ReLU(BN2(Dense(Flatten(Drop(ReLU(BN1(Conv3x3x8([s ; p] as a 2w x h image)))))))),
+// score = <x, o>.  Unlike the other models this is a small CNN whose layers are shared by all triples: its conv / batch-norm /
+// dense parameters live in one flat fp32 vector `theta` (so the optimizer is the same dense sweep as for the tables),
+// batch statistics are reductions over the whole call, and the dense layer is a plain GEMM (rocBLAS sgemm, fp32).
+// Everything around the GEMMs is hand-written HIP; the per-triple rows dS, dP, dO that come out of the backward pass are
+// summed into the embedding tables' gradients by the same per-destination lists as the other models (pull.hip).
+//
+// theta = [K(3,3,C) | bc(C) | g1(C) | b1(C) | Wd(F,d) | bd(d) | g2(d) | b2(d)],   stats = [mm1(C) | mv1(C) | mm2(d) | mv2(d)]
+// [TF semantics restated in oracle/kge_oracle.py conve_*]: BN eps 1e-3, momentum 0.99, the 4-D BN's moving variance takes
+// Bessel's correction (fused kernel), Flatten order (H, W, C); the two calls of the wrapper (pos, neg) are separate BN batches.
+// The biases bc and bd feed straight into a batch norm, so their gradients are identically zero; they are left untouched.
+#include <rocblas/rocblas.h>
+
+#include "dropout.hpp"
+#include "kge_internal.hpp"
+#include "pull.hpp"
+
+namespace kge {
+
+constexpr float kBnEps = 1e-3f, kBnMom = 0.99f;
+
+struct CvShape { int d, w, h, H, W, Ho, Wo, C, F; };
+static CvShape cv_shape(int d, int C) {
+  int w = 1;
+  for (int i = 1; i * i <= d; ++i) if (d % i == 0) w = i;  // largest i <= sqrt(d) dividing d (models.py:250-251)
+  CvShape s;
+  s.d = d; s.w = w; s.h = d / w; s.H = 2 * w; s.W = s.h; s.Ho = s.H - 2; s.Wo = s.W - 2; s.C = C; s.F = s.Ho * s.Wo * C;
+  return s;
+}
+struct CvOff { int64_t K, bc, g1, b1, Wd, bd, g2, b2, total; };
+static CvOff cv_off(const CvShape& s) {
+  CvOff o;
+  o.K = 0; o.bc = 9 * s.C; o.g1 = o.bc + s.C; o.b1 = o.g1 + s.C; o.Wd = o.b1 + s.C; o.bd = o.Wd + (int64_t)s.F * s.d;
+  o.g2 = o.bd + s.d; o.b2 = o.g2 + s.d; o.total = o.b2 + s.d;
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------ forward kernels
+// One wave per triple: the 2w x h image of (s ; p) is staged in LDS, every lane computes the C channels of positions
+// lane, lane+64, ...  Y[i][(pos)*C + c].  TRAIN: per-block partial sums of y and y^2 per channel.
+template <bool TRAIN, bool DROP, int C>
+__global__ __launch_bounds__(256) void cv_conv_fwd(const float* __restrict__ E, const float* __restrict__ Rel,
+                                                    const int32_t* __restrict__ tri, int64_t m, int N, int R, CvShape sh,
+                                                    const float* __restrict__ theta, float* __restrict__ Y,
+                                                    float* __restrict__ psum, uint32_t* __restrict__ err, uint64_t seed,
+                                                    int64_t row_offset, uint32_t thr, float dscale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4][2 * C];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* img = lds + wave * (sh.H * sh.W);
+  float kk[9][C], bcv[C];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int c = 0; c < C; ++c) kk[a][c] = theta[a * C + c];
+#pragma unroll
+  for (int c = 0; c < C; ++c) bcv[c] = theta[9 * C + c];
+  float s1[C], s2[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
+    const int s = tri[3 * i], p = tri[3 * i + 1], o = tri[3 * i + 2];
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+    if (!ok && lane == 0) atomicOr(err, 1u);
+    const float* es = E + (int64_t)(ok ? s : 0) * sh.d;
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * sh.d;
+    DropKey ks{0, 0}, kp{0, 0};
+    if (DROP) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
+    for (int k = lane; k < sh.d; k += 64) {
+      float a = es[k], b = rp[k];
+      if (DROP) { a *= drop_mul(ks, k, thr, dscale); b *= drop_mul(kp, k, thr, dscale); }
+      img[k] = ok ? a : 0.f;             // rows 0..w-1   = s reshaped (w, h)
+      img[sh.d + k] = ok ? b : 0.f;      // rows w..2w-1  = p reshaped (w, h)
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* yrow = Y + i * (int64_t)sh.F;
+    for (int pos = lane; pos < sh.Ho * sh.Wo; pos += 64) {
+      const int r = pos / sh.Wo, q = pos - r * sh.Wo;
+      float acc[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] = bcv[c];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const float xv = img[(r + a) * sh.W + q + b];
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[c] = fmaf(xv, kk[a * 3 + b][c], acc[c]);
+        }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        yrow[pos * C + c] = acc[c];
+        if (TRAIN) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (TRAIN) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) { s1[c] = group_sum<64>(s1[c]); s2[c] = group_sum<64>(s2[c]); }
+    if (lane == 0)
+#pragma unroll
+      for (int c = 0; c < C; ++c) { red[wave][c] = s1[c]; red[wave][C + c] = s2[c]; }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) psum[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+// partials[nb][2*nch] (sum, sum of squares) over `count` values per channel -> callstat[0..nch) = mean, [nch..2nch) = 1/sqrt(var+eps);
+// TRAIN: moving statistics updated (bessel: the fused 4-D batch norm).  One workgroup, double accumulation, fixed order.
+__global__ __launch_bounds__(256) void cv_bn_finalize(const float* __restrict__ partials, int nb, int nch, double count, int bessel,
+                                                       float* __restrict__ callstat, float* __restrict__ mov_mean,
+                                                       float* __restrict__ mov_var, int use_moving) {
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    float mean, var;
+    if (use_moving) { mean = mov_mean[c]; var = mov_var[c]; }
+    else {
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < nb; ++i) { a += partials[(int64_t)i * 2 * nch + c]; b += partials[(int64_t)i * 2 * nch + nch + c]; }
+      const double mu = a / count;
+      double v = b / count - mu * mu;
+      if (v < 0.0) v = 0.0;
+      mean = (float)mu; var = (float)v;
+      mov_mean[c] = mov_mean[c] * kBnMom + mean * (1.f - kBnMom);
+      const float vu = bessel ? (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0))) : var;
+      mov_var[c] = mov_var[c] * kBnMom + vu * (1.f - kBnMom);
+    }
+    callstat[c] = mean;
+    callstat[nch + c] = 1.f / sqrtf(var + kBnEps);
+  }
+}
+
+// A = Drop(ReLU(g1 * (Y - mu) * inv + b1)), elementwise over m*F (channel = index % C).
+template <bool DROP, int C>
+__global__ __launch_bounds__(256) void cv_bn1_apply(const float* __restrict__ Y, float* __restrict__ A, int64_t m, int F,
+                                                     const float* __restrict__ theta_g1, const float* __restrict__ theta_b1,
+                                                     const float* __restrict__ stat, uint64_t seed, int64_t row_offset, uint32_t thr,
+                                                     float dscale) {
+  const int64_t total4 = m * (int64_t)F / 4;  // F % 4 == 0 because C % 4 == 0
+  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+    const float4 y = reinterpret_cast<const float4*>(Y)[i4];
+    const int64_t idx = i4 * 4;
+    const int c0 = (int)(idx % C);
+    float v[4] = {y.x, y.y, y.z, y.w};
+    const int64_t row = idx / F;
+    const int e0 = (int)(idx - row * F);
+    DropKey k{0, 0};
+    if (DROP) k = drop_key(seed, row_offset + row, 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j;
+      float a = fmaf(theta_g1[c] * stat[C + c], v[j] - stat[c], theta_b1[c]);
+      a = a > 0.f ? a : 0.f;
+      if (DROP) a *= drop_mul(k, (uint32_t)(e0 + j), thr, dscale);
+      v[j] = a;
+    }
+    reinterpret_cast<float4*>(A)[i4] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// Z += bd (per column) and, TRAIN, per-block partial column sums of z and z^2.  Block = 256 threads over columns, 64 rows.
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void cv_z_stats(float* __restrict__ Z, int64_t m, int d, const float* __restrict__ bd,
+                                                   float* __restrict__ psum) {
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    const float b = bd[k];
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t r = r0; r < min(m, r0 + 64); ++r) {
+      const float z = Z[r * d + k] + b;
+      Z[r * d + k] = z;
+      s1 += z; s2 = fmaf(z, z, s2);
+    }
+    if (TRAIN) { psum[(int64_t)blockIdx.x * 2 * d + k] = s1; psum[(int64_t)blockIdx.x * 2 * d + d + k] = s2; }
+  }
+}
+
+// x = Drop(ReLU(g2 * (Z - mu2) * inv2 + b2));  X[i] = x;  score_i = <x, o'>.  One wave per triple.
+template <bool DROP>
+__global__ __launch_bounds__(256) void cv_head_out(const float* __restrict__ E, const int32_t* __restrict__ tri, int64_t m, int N,
+                                                    int d, const float* __restrict__ Z, const float* __restrict__ g2,
+                                                    const float* __restrict__ b2, const float* __restrict__ stat,
+                                                    float* __restrict__ X, float* __restrict__ scores, uint64_t seed,
+                                                    int64_t row_offset, uint32_t thr_e, float dscale_e, uint32_t thr_h, float dscale_h,
+                                                    int want_score) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
+    const int o = tri[3 * i + 2];
+    const bool ok = (unsigned)tri[3 * i] < (unsigned)N && (unsigned)o < (unsigned)N;
+    const float* eo = E + (int64_t)(ok ? o : 0) * d;
+    DropKey ko{0, 0}, kh{0, 0};
+    if (DROP) { ko = drop_key(seed, row_offset + i, 2); kh = drop_key(seed, row_offset + i, 4); }
+    float part = 0.f;
+    for (int k = lane; k < d; k += 64) {
+      float x = fmaf(g2[k] * stat[d + k], Z[i * d + k] - stat[k], b2[k]);
+      x = x > 0.f ? x : 0.f;
+      if (DROP) x *= drop_mul(kh, k, thr_h, dscale_h);
+      X[i * d + k] = x;
+      if (want_score) {
+        float ov = eo[k];
+        if (DROP) ov *= drop_mul(ko, k, thr_e, dscale_e);
+        part = fmaf(x, ov, part);
+      }
+    }
+    if (want_score) {
+      part = group_sum<64>(part);
+      if (lane == 0) scores[i] = ok ? part : __builtin_nanf("");
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward kernels
+// dO[t] = mask_o * g * x ; dy2 = g * o' * (x > 0 ? hscale : 0) written over X ; per-block partial column sums of dy2 and dy2*xhat2.
+template <bool DROP>
+__global__ __launch_bounds__(256) void cv_head_bwd(const float* __restrict__ E, const int32_t* __restrict__ tri, int64_t m, int N,
+                                                    int d, const float* __restrict__ Z, const float* __restrict__ stat,
+                                                    const float* __restrict__ g, float* __restrict__ X, float* __restrict__ dO,
+                                                    float* __restrict__ psum, uint64_t seed, int64_t row_offset, uint32_t thr_e,
+                                                    float dscale_e, float dscale_h) {
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    const float mu = stat[k], inv = stat[d + k];
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = r0; i < min(m, r0 + 64); ++i) {
+      const int o = tri[3 * i + 2];
+      const bool ok = (unsigned)tri[3 * i] < (unsigned)N && (unsigned)o < (unsigned)N;
+      const float gi = ok ? g[i] : 0.f;
+      float ov = E[(int64_t)(ok ? o : 0) * d + k], mo = 1.f;
+      if (DROP) { mo = drop_mul(drop_key(seed, row_offset + i, 2), k, thr_e, dscale_e); ov *= mo; }
+      const float x = X[i * d + k];
+      dO[i * d + k] = gi * x * mo;
+      const float dy = x > 0.f ? gi * ov * (DROP ? dscale_h : 1.f) : 0.f;
+      X[i * d + k] = dy;
+      const float xh = (Z[i * d + k] - mu) * inv;
+      s1 += dy; s2 = fmaf(dy, xh, s2);
+    }
+    psum[(int64_t)blockIdx.x * 2 * d + k] = s1;
+    psum[(int64_t)blockIdx.x * 2 * d + d + k] = s2;
+  }
+}
+
+// partials[nb][2*nch] -> bst[0..nch) = mean(gamma*dy), bst[nch..2nch) = mean(gamma*dy*xhat); dgamma += sum(dy*xhat), dbeta += sum(dy)
+__global__ __launch_bounds__(256) void cv_bn_bwd_finalize(const float* __restrict__ partials, int nb, int nch, double count,
+                                                           const float* __restrict__ gamma, float* __restrict__ bst,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < nb; ++i) { a += partials[(int64_t)i * 2 * nch + c]; b += partials[(int64_t)i * 2 * nch + nch + c]; }
+    dbeta[c] += (float)a;
+    dgamma[c] += (float)b;
+    bst[c] = (float)(a / count) * gamma[c];
+    bst[nch + c] = (float)(b / count) * gamma[c];
+  }
+}
+
+// dZ = inv2 * (g2*dy2 - mean(g2 dy2) - xhat2 * mean(g2 dy2 xhat2)) written over Z (dy2 is in X)
+__global__ __launch_bounds__(256) void cv_bn2_bwd_apply(float* __restrict__ Z, const float* __restrict__ X, int64_t m, int d,
+                                                         const float* __restrict__ g2, const float* __restrict__ stat,
+                                                         const float* __restrict__ bst) {
+  const int64_t total = m * (int64_t)d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % d);
+    const float inv = stat[d + k];
+    const float xh = (Z[i] - stat[k]) * inv;
+    Z[i] = inv * (g2[k] * X[i] - bst[k] - xh * bst[d + k]);
+  }
+}
+
+// dy1 = dA * (A > 0 ? hscale : 0) written over dA; per-block partial channel sums of dy1 and dy1*xhat1.  Each block: a
+// slab of 4096 float4; thread's channel group is fixed because 256*4 % C == 0.
+template <int C>
+__global__ __launch_bounds__(256) void cv_bn1_bwd_stats(float* __restrict__ dA, const float* __restrict__ A, const float* __restrict__ Y,
+                                                         int64_t total4, const float* __restrict__ stat, float hscale,
+                                                         float* __restrict__ psum) {
+  __shared__ float red[256][8];
+  const int64_t b0 = (int64_t)blockIdx.x * 4096;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int c0 = (int)((threadIdx.x * 4) % C);
+  for (int64_t i4 = b0 + threadIdx.x; i4 < min(total4, b0 + 4096); i4 += 256) {
+    float4 da = reinterpret_cast<float4*>(dA)[i4];
+    const float4 a = reinterpret_cast<const float4*>(A)[i4];
+    const float4 y = reinterpret_cast<const float4*>(Y)[i4];
+    float dv[4] = {da.x, da.y, da.z, da.w};
+    const float av[4] = {a.x, a.y, a.z, a.w}, yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j;
+      const float dy = av[j] > 0.f ? dv[j] * hscale : 0.f;
+      dv[j] = dy;
+      s1[j] += dy;
+      s2[j] = fmaf(dy, (yv[j] - stat[c]) * stat[C + c], s2[j]);
+    }
+    reinterpret_cast<float4*>(dA)[i4] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][4 + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) {  // channel c (or C + c): sum over the threads whose float4 covers it
+    const int c = threadIdx.x % C, which = threadIdx.x / C;
+    float acc = 0.f;
+    for (int t = (c / 4); t < 256; t += C / 4) acc += red[t][which * 4 + (c & 3)];
+    psum[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = acc;
+  }
+}
+
+// One wave per triple: dY = inv1 * (g1*dy1 - mean - xhat1*mean2) on the fly (dy1 in dA); dK partial sums; dX -> dS, dP rows.
+template <bool DROP, int C>
+__global__ __launch_bounds__(256) void cv_conv_bwd(const float* __restrict__ E, const float* __restrict__ Rel,
+                                                    const int32_t* __restrict__ tri, int64_t m, int N, int R, CvShape sh,
+                                                    const float* __restrict__ theta, const float* __restrict__ stat,
+                                                    const float* __restrict__ bst, const float* __restrict__ dA,
+                                                    const float* __restrict__ Y, float* __restrict__ dS, float* __restrict__ dP,
+                                                    float* __restrict__ pk, uint64_t seed, int64_t row_offset, uint32_t thr,
+                                                    float dscale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4][9 * C];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int npos = sh.Ho * sh.Wo;
+  float* img = lds + wave * (sh.H * sh.W + npos * C);
+  float* dy = img + sh.H * sh.W;  // [npos][C]
+  float dk[9][C];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int c = 0; c < C; ++c) dk[a][c] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
+    const int s = tri[3 * i], p = tri[3 * i + 1], o = tri[3 * i + 2];
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+    const float* es = E + (int64_t)(ok ? s : 0) * sh.d;
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * sh.d;
+    DropKey ks{0, 0}, kp{0, 0};
+    if (DROP) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
+    for (int k = lane; k < sh.d; k += 64) {
+      float a = es[k], b = rp[k];
+      if (DROP) { a *= drop_mul(ks, k, thr, dscale); b *= drop_mul(kp, k, thr, dscale); }
+      img[k] = ok ? a : 0.f;
+      img[sh.d + k] = ok ? b : 0.f;
+    }
+    const float* da = dA + i * (int64_t)sh.F;
+    const float* yr = Y + i * (int64_t)sh.F;
+    for (int e = lane; e < sh.F; e += 64) {
+      const int c = e % C;
+      const float inv = stat[C + c];
+      const float xh = (yr[e] - stat[c]) * inv;
+      dy[e] = ok ? inv * (theta[10 * C + c] * da[e] - bst[c] - xh * bst[C + c]) : 0.f;  // theta[10C..11C) = g1
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dK[a][b][c] += sum_pos X[r+a][q+b] * dY[pos][c]
+    for (int pos = lane; pos < npos; pos += 64) {
+      const int r = pos / sh.Wo, q = pos - r * sh.Wo;
+      float dv[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) dv[c] = dy[pos * C + c];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const float xv = img[(r + a) * sh.W + q + b];
+#pragma unroll
+          for (int c = 0; c < C; ++c) dk[a * 3 + b][c] = fmaf(xv, dv[c], dk[a * 3 + b][c]);
+        }
+    }
+    // dX[u][v] = sum_{a,b,c} dY[u-a][v-b][c] * K[a][b][c]  (positions inside the valid output only)
+    for (int k = lane; k < 2 * sh.d; k += 64) {
+      const int u = k / sh.W, v = k - u * sh.W;
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int r = u - a;
+        if (r < 0 || r >= sh.Ho) continue;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const int q = v - b;
+          if (q < 0 || q >= sh.Wo) continue;
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc = fmaf(dy[(r * sh.Wo + q) * C + c], theta[(a * 3 + b) * C + c], acc);
+        }
+      }
+      if (k < sh.d) {
+        if (DROP) acc *= drop_mul(ks, k, thr, dscale);
+        dS[i * sh.d + k] = acc;
+      } else {
+        const int kk2 = k - sh.d;
+        if (DROP) acc *= drop_mul(kp, kk2, thr, dscale);
+        dP[i * sh.d + kk2] = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int c = 0; c < C; ++c) dk[a][c] = group_sum<64>(dk[a][c]);
+  if (lane == 0)
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int c = 0; c < C; ++c) red[wave][a * C + c] = dk[a][c];
+  __syncthreads();
+  if (threadIdx.x < 9 * C) pk[(int64_t)blockIdx.x * 9 * C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void cv_sum_partials(const float* __restrict__ partials, int nb, int n, float* __restrict__ out) {
+  for (int c = threadIdx.x; c < n; c += 256) {
+    double a = 0.0;
+    for (int i = 0; i < nb; ++i) a += partials[(int64_t)i * n + c];
+    out[c] += (float)a;
+  }
+}
+
+// gradient of the embedding tables: sum of the per-triple rows over the destination lists (entries of pull.hip's fill_kernel:
+// .w = t, entity keys carry the role in bit 31 of .x).  One wave per (destination row, chunk).
+__global__ __launch_bounds__(256) void cv_rowsum_kernel(float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d,
+                                                         const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
+                                                         const int32_t* __restrict__ eoff, const int32_t* __restrict__ poff,
+                                                         const int32_t* __restrict__ totals, const int2* __restrict__ emap,
+                                                         const int4* __restrict__ entries, float* __restrict__ slab, int Cc,
+                                                         const float* __restrict__ dS, const float* __restrict__ dP,
+                                                         const float* __restrict__ dO) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + wave;
+  int key, chunk;
+  if (unit < NK) { key = unit; chunk = 0; }
+  else {
+    const int x = unit - NK;
+    if (x >= totals[0]) return;
+    const int2 kc = emap[x];
+    key = kc.x; chunk = kc.y;
+  }
+  const int c = cnt[key];
+  if (c == 0) return;
+  const int nch = (c + Cc - 1) / Cc;
+  const int start = off[key] + chunk * Cc, len = min(Cc, c - chunk * Cc);
+  const bool is_rel = key >= N;
+  float* dst = nch == 1 ? (is_rel ? gR + (int64_t)(key - N) * d : gE + (int64_t)key * d) : slab + (int64_t)(poff[key] + chunk) * d;
+  for (int k = lane; k < d; k += 64) {
+    float acc = 0.f;
+    for (int i = 0; i < len; ++i) {
+      const int4 e = entries[start + i];
+      const float* src = is_rel ? dP : (((unsigned)e.x >> 31) ? dO : dS);
+      acc += src[(int64_t)e.w * d + k];
+    }
+    dst[k] = nch == 1 ? dst[k] + acc : acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static rocblas_handle blas_handle() {
+  static rocblas_handle h = nullptr;
+  static int state = 0;
+  if (state == 0) state = rocblas_create_handle(&h) == rocblas_status_success ? 1 : -1;
+  return state == 1 ? h : nullptr;
+}
+
+#define KGE_BLAS_TRY(expr)                                                                  \
+  do {                                                                                      \
+    rocblas_status s__ = (expr);                                                            \
+    if (s__ != rocblas_status_success) return fail(KGE_EHIP, "%s: rocblas status %d", #expr, (int)s__); \
+  } while (0)
+
+struct CvBuf {  // per call
+  float *Y, *A, *Z, *X, *stat1, *stat2;
+};
+struct CvWs {
+  CvBuf call[2];
+  float *dA, *dS, *dP, *dO, *psum, *bst, *g, *sc;
+  void* pull_hdr;
+  void* pull_body;
+  int64_t psum_floats;
+};
+
+static int64_t c256(int64_t x) { return align_up(x, 256); }
+int pull_chunk();
+int64_t train_workspace_bytes(const kge_model_desc*, int64_t, int64_t);
+int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
+int pull2_fill_entries(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p,
+                       hipStream_t st);
+int pull_finish_launch(const kge_model_desc* md, float* gE, float* gR, const PullPlan& p, hipStream_t st);
+
+static int64_t cv_psum_floats(const CvShape& s, int64_t m) {
+  const int64_t nb_conv = std::min<int64_t>(cdiv(m, 4), 2048);
+  const int64_t nb_rows = cdiv(m, 64);
+  const int64_t nb_bn1 = cdiv(m * s.F / 4, 4096);
+  return std::max<int64_t>({nb_conv * 9 * s.C, nb_rows * 2 * s.d, nb_bn1 * 2 * s.C, nb_conv * 2 * s.C}) + 64;
+}
+
+int64_t conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
+  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const int64_t n = m_pos + m_neg, mm = std::max(m_pos, m_neg);
+  int64_t b = 0;
+  for (int64_t m : {m_pos, m_neg}) b += 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4);
+  b += c256(mm * s.F * 4) + 3 * c256(n * s.d * 4) + c256(cv_psum_floats(s, mm) * 4) + c256(2 * (s.d + s.C) * 4) + 2 * c256(n * 4);
+  b += pull_header_bytes(md) + pull_workspace_bytes(md, n) + c256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096;
+  return b;
+}
+
+static void cv_carve(void* ws, const kge_model_desc* md, int64_t m_pos, int64_t m_neg, CvWs* w, void** loss_ws, int64_t* loss_ws_bytes) {
+  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const int64_t n = m_pos + m_neg, mm = std::max(m_pos, m_neg);
+  char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t bytes) { char* r = q; q += c256(bytes); return r; };
+  w->pull_hdr = take(pull_header_bytes(md));  // fixed place: zero on entry, left zero
+  const int64_t ms[2] = {m_pos, m_neg};
+  for (int c = 0; c < 2; ++c) {
+    w->call[c].Y = (float*)take(ms[c] * s.F * 4);
+    w->call[c].A = (float*)take(ms[c] * s.F * 4);
+    w->call[c].Z = (float*)take(ms[c] * s.d * 4);
+    w->call[c].X = (float*)take(ms[c] * s.d * 4);
+    w->call[c].stat1 = (float*)take(2 * s.C * 4);
+    w->call[c].stat2 = (float*)take(2 * s.d * 4);
+  }
+  w->dA = (float*)take(mm * s.F * 4);
+  w->dS = (float*)take(n * s.d * 4);
+  w->dP = (float*)take(n * s.d * 4);
+  w->dO = (float*)take(n * s.d * 4);
+  w->psum_floats = cv_psum_floats(s, mm);
+  w->psum = (float*)take(w->psum_floats * 4);
+  w->bst = (float*)take(2 * (s.d + s.C) * 4);
+  w->g = (float*)take(n * 4);
+  w->sc = (float*)take(n * 4);
+  w->pull_body = take(pull_workspace_bytes(md, n));
+  *loss_ws_bytes = train_workspace_bytes(nullptr, m_pos, m_neg);
+  *loss_ws = take(*loss_ws_bytes);
+}
+
+int conve_sizes(const kge_model_desc* md, int64_t* n_theta, int64_t* n_stats) {
+  if (md->conv_filters != 8) return fail(KGE_EUNSUPPORTED, "ConvE: conv_filters = %d (8, the reference default, is built)", md->conv_filters);
+  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  if (s.w < 2 && s.h < 2) return fail(KGE_ESHAPE, "ConvE: e_dim %d has no factor pair with w > 1 or h > 1 (models.py:252)", md->d_e);
+  if (s.Ho < 1 || s.Wo < 1) return fail(KGE_ESHAPE, "ConvE: image %dx%d is smaller than the 3x3 kernel", s.H, s.W);
+  if (s.d > 1024) return fail(KGE_EUNSUPPORTED, "ConvE: e_dim above 1024 is not built");
+  *n_theta = cv_off(s).total;
+  *n_stats = 2 * s.C + 2 * s.d;
+  return KGE_OK;
+}
+
+// forward of one call (rows of `tri`).  training: batch statistics + dropout; else moving statistics.
+static int cv_forward(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* stats, const int32_t* tri,
+                      int64_t m, int64_t row_offset, bool training, const CvBuf& b, float* psum, float* scores, int want_score,
+                      uint32_t* err, uint64_t seed, hipStream_t st) {
+  constexpr int C = 8;
+  const CvShape s = cv_shape(md->d_e, C);
+  const CvOff o = cv_off(s);
+  const bool drop_e = training && md->dropout > 0.f, drop_h = training && md->hidden_dropout > 0.f;
+  const uint32_t thr_e = drop_thr(md->dropout), thr_h = drop_thr(md->hidden_dropout);
+  const float ds_e = 1.f / (1.f - md->dropout), ds_h = 1.f / (1.f - md->hidden_dropout);
+  const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
+  const size_t smem = (size_t)4 * s.H * s.W * sizeof(float);
+#define KGE_CONV(TR, DR) hipLaunchKernelGGL((cv_conv_fwd<TR, DR, C>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, \
+                                            md->num_relations, s, theta, b.Y, psum, err, seed, row_offset, thr_e, ds_e)
+  if (training) { if (drop_e) KGE_CONV(true, true); else KGE_CONV(true, false); }
+  else KGE_CONV(false, false);
+#undef KGE_CONV
+  hipLaunchKernelGGL(cv_bn_finalize, dim3(1), dim3(256), 0, st, psum, nb_conv, C, (double)m * s.Ho * s.Wo, 1, b.stat1, stats, stats + C, training ? 0 : 1);
+  const int nb_el = (int)std::min<int64_t>(cdiv(m * s.F / 4, 256), 8192);
+  if (drop_h) hipLaunchKernelGGL((cv_bn1_apply<true, C>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+  else hipLaunchKernelGGL((cv_bn1_apply<false, C>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+  rocblas_handle h = blas_handle();
+  if (!h) return fail(KGE_EHIP, "ConvE: rocblas handle could not be created");
+  KGE_BLAS_TRY(rocblas_set_stream(h, st));
+  const float one = 1.f, zero = 0.f;
+  // row-major Z(m,d) = A(m,F) * Wd(F,d)  ==  column-major Z'(d,m) = Wd'(d,F) * A'(F,m)
+  KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, s.d, (rocblas_int)m, s.F, &one, theta + o.Wd, s.d, b.A, s.F, &zero, b.Z, s.d));
+  const int nb_rows = (int)cdiv(m, 64);
+  if (training) hipLaunchKernelGGL((cv_z_stats<true>), dim3(nb_rows), dim3(256), 0, st, b.Z, m, s.d, theta + o.bd, psum);
+  else hipLaunchKernelGGL((cv_z_stats<false>), dim3(nb_rows), dim3(256), 0, st, b.Z, m, s.d, theta + o.bd, psum);
+  hipLaunchKernelGGL(cv_bn_finalize, dim3(1), dim3(256), 0, st, psum, nb_rows, s.d, (double)m, 0, b.stat2, stats + 2 * C, stats + 2 * C + s.d, training ? 0 : 1);
+  const int nb_w = (int)std::min<int64_t>(cdiv(m, 4), 4096);
+  if (drop_e || drop_h)
+    hipLaunchKernelGGL((cv_head_out<true>), dim3(nb_w), dim3(256), 0, st, E, tri, m, md->num_entities, s.d, b.Z, theta + o.g2, theta + o.b2, b.stat2, b.X,
+                       scores, seed, row_offset, drop_e ? thr_e : 0u, drop_e ? ds_e : 1.f, drop_h ? thr_h : 0u, drop_h ? ds_h : 1.f, want_score);
+  else
+    hipLaunchKernelGGL((cv_head_out<false>), dim3(nb_w), dim3(256), 0, st, E, tri, m, md->num_entities, s.d, b.Z, theta + o.g2, theta + o.b2, b.stat2, b.X,
+                       scores, seed, row_offset, 0u, 1.f, 0u, 1.f, want_score);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+static int cv_backward(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* gtheta, const int32_t* tri,
+                       int64_t m, int64_t row_offset, const CvBuf& b, const CvWs& w, const float* g, uint64_t seed, hipStream_t st) {
+  constexpr int C = 8;
+  const CvShape s = cv_shape(md->d_e, C);
+  const CvOff o = cv_off(s);
+  const bool drop_e = md->dropout > 0.f, drop_h = md->hidden_dropout > 0.f;
+  const uint32_t thr_e = drop_thr(md->dropout);
+  const float ds_e = 1.f / (1.f - md->dropout), ds_h = drop_h ? 1.f / (1.f - md->hidden_dropout) : 1.f;
+  float* dS = w.dS + row_offset * s.d;
+  float* dP = w.dP + row_offset * s.d;
+  float* dO = w.dO + row_offset * s.d;
+  float* bst2 = w.bst;
+  float* bst1 = w.bst + 2 * s.d;
+  const int nb_rows = (int)cdiv(m, 64);
+  if (drop_e || drop_h)
+    hipLaunchKernelGGL((cv_head_bwd<true>), dim3(nb_rows), dim3(256), 0, st, E, tri, m, md->num_entities, s.d, b.Z, b.stat2, g, b.X, dO, w.psum, seed,
+                       row_offset, drop_e ? thr_e : 0u, drop_e ? ds_e : 1.f, ds_h);
+  else
+    hipLaunchKernelGGL((cv_head_bwd<false>), dim3(nb_rows), dim3(256), 0, st, E, tri, m, md->num_entities, s.d, b.Z, b.stat2, g, b.X, dO, w.psum, seed,
+                       row_offset, 0u, 1.f, 1.f);
+  hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(1), dim3(256), 0, st, w.psum, nb_rows, s.d, (double)m, theta + o.g2, bst2, gtheta + o.g2, gtheta + o.b2);
+  const int nb_el2 = (int)std::min<int64_t>(cdiv(m * s.d, 256), 8192);
+  hipLaunchKernelGGL(cv_bn2_bwd_apply, dim3(nb_el2), dim3(256), 0, st, b.Z, b.X, m, s.d, theta + o.g2, b.stat2, bst2);
+  rocblas_handle h = blas_handle();
+  if (!h) return fail(KGE_EHIP, "ConvE: rocblas handle could not be created");
+  KGE_BLAS_TRY(rocblas_set_stream(h, st));
+  const float one = 1.f, zero = 0.f;
+  // dA(m,F) = dZ(m,d) * Wd^T     ==  dA'(F,m) = Wd'(d,F)^T * dZ'(d,m)
+  KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, s.F, (rocblas_int)m, s.d, &one, theta + o.Wd, s.d, b.Z, s.d, &zero, w.dA, s.F));
+  // dWd(F,d) += A^T(F,m) * dZ(m,d)  ==  dWd'(d,F) += dZ'(d,m) * A'(F,m)^T
+  KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, s.d, s.F, (rocblas_int)m, &one, b.Z, s.d, b.A, s.F, &one, gtheta + o.Wd, s.d));
+  const int64_t total4 = m * (int64_t)s.F / 4;
+  const int nb_bn1 = (int)cdiv(total4, 4096);
+  hipLaunchKernelGGL((cv_bn1_bwd_stats<C>), dim3(nb_bn1), dim3(256), 0, st, w.dA, b.A, b.Y, total4, b.stat1, ds_h, w.psum);
+  hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(1), dim3(256), 0, st, w.psum, nb_bn1, C, (double)m * s.Ho * s.Wo, theta + o.g1, bst1, gtheta + o.g1, gtheta + o.b1);
+  const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
+  const size_t smem = (size_t)4 * (s.H * s.W + s.Ho * s.Wo * C) * sizeof(float);
+  if (drop_e)
+    hipLaunchKernelGGL((cv_conv_bwd<true, C>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
+                       bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
+  else
+    hipLaunchKernelGGL((cv_conv_bwd<false, C>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
+                       bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
+  hipLaunchKernelGGL(cv_sum_partials, dim3(1), dim3(256), 0, st, w.psum, nb_conv, 9 * C, gtheta + o.K);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// scores (want_hidden == 0) or the hidden vectors x(s,p) (want_hidden != 0; out is (n, d)) in inference mode
+int conve_infer(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* stats, const int32_t* tri, int64_t n,
+                float* out, int want_hidden, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  int64_t nt, ns;
+  if (int rc = conve_sizes(md, &nt, &ns)) return rc;
+  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const int64_t CH = 32768;  // rows per pass: bounds the activation buffers
+  const int64_t m = std::min(n, CH);
+  const int64_t need = 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 1024;
+  if (wbytes < need) return fail(KGE_EWORKSPACE, "ConvE inference: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)need);
+  char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t bytes) { char* r = q; q += c256(bytes); return r; };
+  CvBuf b;
+  b.Y = (float*)take(m * s.F * 4); b.A = (float*)take(m * s.F * 4); b.Z = (float*)take(m * s.d * 4);
+  float* Xtmp = (float*)take(m * s.d * 4);
+  b.stat1 = (float*)take(2 * s.C * 4); b.stat2 = (float*)take(2 * s.d * 4);
+  float* psum = (float*)take(cv_psum_floats(s, m) * 4);
+  ProfScope prof(KGE_PROF_SCORE, st);
+  for (int64_t a = 0; a < n; a += CH) {
+    const int64_t mm = std::min(CH, n - a);
+    b.X = want_hidden ? out + a * s.d : Xtmp;
+    if (int rc = cv_forward(md, E, Rel, theta, stats, tri + 3 * a, mm, 0, false, b, psum, want_hidden ? nullptr : out + a, want_hidden ? 0 : 1, err, 0, st)) return rc;
+  }
+  return KGE_OK;
+}
+
+int64_t conve_infer_workspace_bytes(const kge_model_desc* md, int64_t n) {
+  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const int64_t m = std::min<int64_t>(n, 32768);
+  return 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 2048;
+}
+
+int conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta, float* stats,
+                      float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                      float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  int64_t nt, ns;
+  if (int rc = conve_sizes(md, &nt, &ns)) return rc;
+  if (wbytes < conve_workspace_bytes(md, m_pos, m_neg))
+    return fail(KGE_EWORKSPACE, "ConvE: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)conve_workspace_bytes(md, m_pos, m_neg));
+  CvWs w;
+  void* loss_ws;
+  int64_t loss_ws_bytes;
+  cv_carve(ws, md, m_pos, m_neg, &w, &loss_ws, &loss_ws_bytes);
+  const int64_t n = m_pos + m_neg;
+  float* sc = scores_out ? scores_out : w.sc;
+  // destination lists (ids only)
+  PullPlan plan;
+  if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, w.pull_hdr, w.pull_body, st, &plan)) return rc;
+  {
+    ProfScope prof(KGE_PROF_FWD, st);
+    if (int rc = cv_forward(md, E, Rel, theta, stats, pos, m_pos, 0, true, w.call[0], w.psum, sc, 1, err, seed, st)) return rc;
+    if (int rc = cv_forward(md, E, Rel, theta, stats, neg, m_neg, m_pos, true, w.call[1], w.psum, sc + m_pos, 1, err, seed, st)) return rc;
+  }
+  if (int rc = loss_value(ld, sc, m_pos, sc + m_pos, m_neg, loss_out, w.g, w.g + m_pos, loss_ws, loss_ws_bytes, st)) return rc;
+  {
+    ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
+    if (int rc = cv_backward(md, E, Rel, theta, gtheta, pos, m_pos, 0, w.call[0], w, w.g, seed, st)) return rc;
+    if (int rc = cv_backward(md, E, Rel, theta, gtheta, neg, m_neg, m_pos, w.call[1], w, w.g + m_pos, seed, st)) return rc;
+    if (int rc = pull2_fill_entries(md, pos, m_pos, neg, m_neg, plan, st)) return rc;
+    const int N = md->num_entities, NK = N + md->num_relations;
+    hipLaunchKernelGGL(cv_rowsum_kernel, dim3((int)cdiv(NK + plan.max_extra, 4)), dim3(256), 0, st, gE, gR, N, NK, md->d_e, plan.cnt, plan.off, plan.eoff,
+                       plan.poff, plan.totals, plan.emap, plan.entries, plan.slab, plan.chunk, w.dS, w.dP, w.dO);
+    if (int rc = pull_finish_launch(md, gE, gR, plan, st)) return rc;
+  }
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+}  // namespace kge

@@ -651,6 +651,22 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
   return KGE_OK;
 }
 
+// ---- entry points for conve.hip: list entries without coefficients (.w = t, role in bit 31 of .x) and the closing pass
+int pull2_fill_entries(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p,
+                       hipStream_t st) {
+  const int64_t n = m_pos + m_neg;
+  KGE_HIP_TRY(hipMemsetAsync(p.coef, 0, (size_t)n * 4, st));
+  hipLaunchKernelGGL(fill_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, pos, m_pos, neg, m_neg, md->num_entities, p.coef, p.off, p.ranks, p.entries);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+int pull_finish_launch(const kge_model_desc* md, float* gE, float* gR, const PullPlan& p, hipStream_t st) {
+  const int N = md->num_entities, NK = N + md->num_relations;
+  hipLaunchKernelGGL(pull_finish_kernel, dim3((int)cdiv(NK, 4)), dim3(256), 0, st, gE, gR, N, NK, md->d_e, p.cnt, p.poff, p.slab, p.chunk);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
 // ---- entry points for pull2.hip: the same scan / pull / finish kernels over the N entity keys only
 void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st) {
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals);

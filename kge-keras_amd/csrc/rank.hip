@@ -464,6 +464,57 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
   return KGE_OK;
 }
 
+// ---- generic entry: queries given as vectors (ConvE's hidden vectors; head queries against a per-relation candidate matrix)
+__global__ void rank_pad_q_kernel(const float* __restrict__ Q, int64_t nq, int K, int Kpad, float* __restrict__ Qv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * Kpad) return;
+  const int64_t q = i / Kpad;
+  const int k = (int)(i - q * Kpad);
+  Qv[i] = k < K ? Q[q * K + k] : 0.f;
+}
+__global__ __launch_bounds__(256) void rank_target_ids_kernel(const float* __restrict__ Qv, const float* __restrict__ Cand, int cand_offset,
+                                                               int cand_rows, const int32_t* __restrict__ target_ids, int64_t nq, int K,
+                                                               int Kpad, float* __restrict__ tgt, int32_t* __restrict__ counts, int zero_counts) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int t = target_ids[q] - cand_offset;
+  tgt[q] = (unsigned)t < (unsigned)cand_rows ? chain_dot(Qv + q * Kpad, Cand + (int64_t)t * K, K, Kpad) : __builtin_nanf("");
+  if (zero_counts) counts[q] = 0;
+}
+
+int64_t rank_sweep_q_workspace_bytes(int64_t nq, int K) { return (int64_t)sizeof(float) * (nq * rank_kpad(K) + align_up(nq, 64)) + 512; }
+
+int rank_sweep_q(const float* Q, int64_t nq, int K, const float* Ec, int cand_offset, int cand_rows, const int32_t* target_ids,
+                 const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs, int32_t* counts, int accumulate, void* workspace,
+                 int64_t wbytes, hipStream_t st) {
+  if (wbytes < rank_sweep_q_workspace_bytes(nq, K)) return fail(KGE_EWORKSPACE, "kge_rank_sweep_q: workspace too small");
+  const int BK = pick_bk(K), Kpad = (int)align_up(K, BK);
+  uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  float* Qv = reinterpret_cast<float*>(p);
+  float* tgt = Qv + nq * Kpad;
+  ProfScope prof(KGE_PROF_RANK, st);
+  hipLaunchKernelGGL(rank_pad_q_kernel, dim3((int)cdiv(nq * Kpad, 256)), dim3(256), 0, st, Q, nq, K, Kpad, Qv);
+  hipLaunchKernelGGL(rank_target_ids_kernel, dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, Ec, cand_offset, cand_rows, target_ids, nq, K, Kpad, tgt,
+                     counts, accumulate ? 0 : 1);
+  {
+    const int nqt = (int)cdiv(nq, kTile), nct = (int)cdiv(cand_rows, kTile);
+    int splits = (int)cdiv(rank_blocks_target(), nqt);
+    splits = std::max(1, std::min(splits, nct));
+    const int tpb = std::min(60, (int)cdiv(nct, splits));
+    splits = (int)cdiv(nct, tpb);
+    const bool v4 = (K % 4 == 0) && ((uintptr_t)Ec % 16 == 0);
+    dim3 grid(nqt, splits);
+#define KGE_SWEEP(BKV, V4) hipLaunchKernelGGL((rank_sweep_kernel<BKV, V4>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
+    if (BK == 40) { if (v4) KGE_SWEEP(40, true); else KGE_SWEEP(40, false); }
+    else { if (v4) KGE_SWEEP(32, true); else KGE_SWEEP(32, false); }
+#undef KGE_SWEEP
+  }
+  if (npairs > 0)
+    hipLaunchKernelGGL(rank_filter_kernel, dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
 int rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side,
                       float* out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
   if (md->model == KGE_HOLE && md->d_e > 1024) return fail(KGE_EUNSUPPORTED, "kge_rank_chain_scores: HolE rows wider than 1024 floats are not built");

@@ -526,6 +526,19 @@ static int launch_opt(bool reg, float* w, float* g, float* m, float* v, int64_t 
   return KGE_OK;
 }
 
+int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float gscale, hipStream_t st) {
+  int nb = 0;
+  if (od->kind == KGE_OPT_ADAM_TF) {
+    if (!od->mE || !od->vE) return fail(KGE_EINVAL, "adam: moment buffers (mE, vE) are null");
+    if (od->step < 1) return fail(KGE_EINVAL, "adam: step must be >= 1");
+    const double t = (double)od->step;
+    const float lr_t = (float)((double)od->lr * std::sqrt(1.0 - std::pow((double)od->beta2, t)) / (1.0 - std::pow((double)od->beta1, t)));
+    return launch_opt<KGE_OPT_ADAM_TF>(false, w, g, od->mE, od->vE, n, lr_t, od, gscale, 0.f, nullptr, st, &nb);
+  }
+  if (od->kind == KGE_OPT_SGD) return launch_opt<KGE_OPT_SGD>(false, w, g, nullptr, nullptr, n, od->lr, od, gscale, 0.f, nullptr, st, &nb);
+  return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
+}
+
 int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gE,
               float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st) {
   Workspace ws;

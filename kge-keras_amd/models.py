@@ -162,7 +162,8 @@ class EmbeddingModel:
     # ------------------------------------------------------------------ descriptors
     def _model_desc(self, training=False):
         return ModelDesc(MODEL_IDS[self.MODEL], self.num_entities, self.num_relations, int(self.e_dim), int(self.r_dim),
-                         int(getattr(self, "norm", 1)), float(getattr(self, "gamma", 0.0)), float(self.dp) if training else 0.0)
+                         int(getattr(self, "norm", 1)), float(getattr(self, "gamma", 0.0)), float(self.dp) if training else 0.0,
+                         int(getattr(self, "conv_filters", 0)), float(getattr(self, "hidden_dp", 0.0)) if training else 0.0)
 
     def _loss_desc(self):
         if self.loss_function not in LOSS_IDS:
@@ -491,15 +492,198 @@ class HolE(EmbeddingModel):
 
 
 class ConvE(EmbeddingModel):
-    """models.py:239-275 (surface only; conv/BN/Dense kernels are a SURVEY 8(f) 'next' row)."""
+    """models.py:239-275: x = Drop(ReLU(BN(Dense(Flatten(Drop(ReLU(BN(Conv2D(8,3x3)([s ; p] as a 2w x h image)))))))), score = <x, o>.
+    The layer parameters live in one flat vector `theta` (+ the batch norms' moving statistics `bn_stats`), see csrc/conve.hip."""
     MODEL = "ConvE"
 
     def __init__(self, name='ConvE', hidden_dp=0.2, conv_filters=8, conv_size_w=3, conv_size_h=3, **kwargs):
         super().__init__(name=name, **kwargs)
+        if (conv_size_w, conv_size_h) != (3, 3) or conv_filters != 8:
+            raise NotImplementedError("ConvE is built for the reference's defaults (8 filters of 3x3)")
         self.dim = kwargs['e_dim']
         factors = [(int(i), int(self.dim / i)) for i in range(1, int(self.dim ** 0.5) + 1) if self.dim % i == 0]
         self.w, self.h = factors.pop(-1)
         assert self.w > 1 or self.h > 1  # models.py:252
+        self.hidden_dp = float(hidden_dp)
+        self.conv_filters = int(conv_filters)
+        md = self._model_desc(False)
+        nt, ns = C.c_int64(0), C.c_int64(0)
+        check(lib.kge_conve_sizes(C.byref(md), C.byref(nt), C.byref(ns)))
+        Cc, d = self.conv_filters, int(self.dim)
+        Ho, Wo = 2 * self.w - 2, self.h - 2
+        F = Ho * Wo * Cc
+        self._F = F
+        seed = kwargs.get("seed", None)
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(int(seed) + 1)
+        theta = torch.zeros(nt.value, dtype=torch.float32, device=self.device)
+        # Keras defaults: Glorot-uniform kernels, zero biases, gamma 1, beta 0, moving mean 0 / variance 1
+        limk = float(np.sqrt(6.0 / (9 + 9 * Cc)))
+        limd = float(np.sqrt(6.0 / (F + d)))
+        theta[:9 * Cc].uniform_(-limk, limk, generator=gen)
+        theta[10 * Cc:11 * Cc] = 1.0
+        off_wd = 12 * Cc
+        theta[off_wd:off_wd + F * d].uniform_(-limd, limd, generator=gen)
+        theta[off_wd + F * d + d:off_wd + F * d + 2 * d] = 1.0
+        self.theta = theta
+        st = torch.zeros(ns.value, dtype=torch.float32, device=self.device)
+        st[Cc:2 * Cc] = 1.0
+        st[2 * Cc + d:] = 1.0
+        self.bn_stats = st
+        self._gtheta = torch.zeros_like(theta)
+        self._tslots = None
+        self._cws = None
+        self._iws = None
 
-    def _model_desc(self, training=False):
-        raise NotImplementedError("ConvE scoring (models.py:265-275) has no HIP kernel yet")
+    # theta <-> named parameters (K, bc, g1, b1, Wd, bd, g2, b2) and stats <-> (mm1, mv1, mm2, mv2)
+    def _layout(self):
+        Cc, d, F = self.conv_filters, int(self.dim), self._F
+        sizes = [("K", 9 * Cc), ("bc", Cc), ("g1", Cc), ("b1", Cc), ("Wd", F * d), ("bd", d), ("g2", d), ("b2", d)]
+        out, o = {}, 0
+        for k, n in sizes:
+            out[k] = (o, n)
+            o += n
+        return out
+
+    def get_head_params(self):
+        lay = self._layout()
+        Cc, d, F = self.conv_filters, int(self.dim), self._F
+        th = self.theta.cpu().numpy()
+        st = self.bn_stats.cpu().numpy()
+        P = {k: th[o:o + n].copy() for k, (o, n) in lay.items()}
+        P["K"] = P["K"].reshape(3, 3, Cc)
+        P["Wd"] = P["Wd"].reshape(F, d)
+        P.update(mm1=st[:Cc].copy(), mv1=st[Cc:2 * Cc].copy(), mm2=st[2 * Cc:2 * Cc + d].copy(), mv2=st[2 * Cc + d:].copy())
+        return P
+
+    def set_head_params(self, P):
+        lay = self._layout()
+        th = self.theta.cpu().numpy()
+        for k, (o, n) in lay.items():
+            if k in P:
+                th[o:o + n] = np.asarray(P[k], dtype=np.float32).reshape(-1)
+        self.theta.copy_(torch.from_numpy(th))
+        if "mm1" in P:
+            st = np.concatenate([np.asarray(P[k], dtype=np.float32).reshape(-1) for k in ("mm1", "mv1", "mm2", "mv2")])
+            self.bn_stats.copy_(torch.from_numpy(st))
+
+    def _infer_ws(self, n):
+        md = self._model_desc(False)
+        need = check(lib.kge_conve_infer_workspace_bytes(C.byref(md), n))
+        if self._iws is None or self._iws.numel() < need:
+            self._iws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return md
+
+    def call(self, inputs, training=False):
+        t = as_triples(inputs, self.device, self.num_entities, self.num_relations)
+        n = t.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        md = self._infer_ws(n)
+        check(lib.kge_conve_score(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(),
+                                  t.data_ptr(), n, out.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(),
+                                  _lib.stream_ptr()))
+        return out
+
+    __call__ = call
+
+    def func(self, s, p, o, training=False):
+        raise NotImplementedError("ConvE.func on pre-gathered rows: use call()/predict() on id triples")
+
+    def hidden(self, triples):
+        """x(s, p) of every row in inference mode, (n, dim) on the device; score(s, p, o) = <x, E[o]>."""
+        t = as_triples(triples, self.device, self.num_entities, self.num_relations)
+        n = t.shape[0]
+        out = torch.empty((n, int(self.dim)), dtype=torch.float32, device=self.device)
+        md = self._infer_ws(n)
+        check(lib.kge_conve_hidden(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(),
+                                   t.data_ptr(), n, out.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(),
+                                   _lib.stream_ptr()))
+        return out
+
+    def train_step(self, data, scores_out=None):
+        if isinstance(data, tuple) and len(data) == 2 and (data[1] is None or isinstance(data[0], (list, tuple))):
+            data = data[0]
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        if self.optimizer is None:
+            raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+        o = self.optimizer
+        if o.kind == "adam" and o.slots is None:
+            o.slots = tuple(torch.zeros_like(x) for x in (self.E, self.E, self.Rel, self.Rel))
+        if o.kind == "adam" and self._tslots is None:
+            self._tslots = (torch.zeros_like(self.theta), torch.zeros_like(self.theta))
+        md, ld = self._model_desc(True), self._loss_desc()
+        need = check(lib.kge_conve_workspace_bytes(C.byref(md), pos.shape[0], neg.shape[0]))
+        if self._cws is None or self._cws.numel() < need:
+            self._cws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+        o.iterations += 1
+        self._seed += 1
+        check(lib.kge_conve_train_grads(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(),
+                                        self.bn_stats.data_ptr(), self._gE.data_ptr(), self._gR.data_ptr(), self._gtheta.data_ptr(),
+                                        pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0], self._loss.data_ptr(),
+                                        scores_out.data_ptr() if scores_out is not None else None, self._seed, self._cws.data_ptr(),
+                                        self._cws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        od = self._opt_desc()
+        if self._ws is None:
+            need2 = check(lib.kge_train_step_workspace_bytes(C.byref(md), C.byref(ld), 0, 0))
+            self._ws = torch.zeros(int(need2), dtype=torch.uint8, device=self.device)
+        check(lib.kge_opt_apply(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                self._gR.data_ptr(), 1.0, self._loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()))
+        ts = [x.data_ptr() for x in self._tslots] if self._tslots else [None, None]
+        odv = OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, o.iterations, ts[0], ts[1], None, None)
+        check(lib.kge_opt_apply_vector(C.byref(odv), self.theta.data_ptr(), self._gtheta.data_ptr(), self.theta.numel(), 1.0, _lib.stream_ptr()))
+        return {"loss": self._loss[0]}
+
+    def batch_loss(self, data):
+        raise NotImplementedError("ConvE: evaluation-only loss is not built (use predict / validate)")
+
+    def rank_triples(self, test, num_entities, filt, chunk=8192):
+        """Filtered ranks (utils.py:199-264).  Tails: queries x(s,p) against the entity table.  Heads: x depends on the
+        candidate subject, so per relation the hidden vectors of ALL (s', p) are built once and swept against E[o]."""
+        from .utils import filter_coo
+        test = np.ascontiguousarray(np.asarray(test, dtype=np.int32).reshape(-1, 3))
+        N, d = int(num_entities), int(self.dim)
+        tails = np.empty(len(test), dtype=np.int64)
+        heads = np.empty(len(test), dtype=np.int64)
+
+        def sweep(Q, cand, targets, fq, fi):
+            nq = Q.shape[0]
+            need = check(lib.kge_rank_sweep_q_workspace_bytes(nq, d))
+            ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            cnt = torch.empty(nq, dtype=torch.int32, device=self.device)
+            tg = torch.from_numpy(np.ascontiguousarray(targets, dtype=np.int32)).to(self.device)
+            fqd = torch.from_numpy(fq).to(self.device)
+            fid = torch.from_numpy(fi).to(self.device)
+            check(lib.kge_rank_sweep_q(Q.data_ptr(), nq, d, cand.data_ptr(), 0, N, tg.data_ptr(), fqd.data_ptr() if len(fq) else None,
+                                       fid.data_ptr() if len(fi) else None, len(fq), cnt.data_ptr(), 0, ws.data_ptr(), ws.numel(),
+                                       _lib.stream_ptr()))
+            return 1 + cnt.cpu().numpy().astype(np.int64)
+
+        Ecand = self.E[:N].contiguous()
+        for a in range(0, len(test), chunk):
+            part = test[a:a + chunk]
+            fq, fi = filter_coo(part, 0, filt, N)
+            tails[a:a + chunk] = sweep(self.hidden(part), Ecand, part[:, 2], fq, fi)
+        ent = np.arange(N, dtype=np.int32)
+        for p in np.unique(test[:, 1]):
+            idx = np.nonzero(test[:, 1] == p)[0]
+            allsp = np.stack([ent, np.full(N, p, dtype=np.int32), np.zeros(N, dtype=np.int32)], 1)
+            Xp = self.hidden(allsp)  # (N, d): candidate matrix of this relation
+            for a in range(0, len(idx), chunk):
+                sel = idx[a:a + chunk]
+                part = test[sel]
+                fq, fi = filter_coo(part, 1, filt, N)
+                Q = self.E.index_select(0, torch.from_numpy(part[:, 2].astype(np.int64)).to(self.device)).contiguous()
+                heads[sel] = sweep(Q, Xp, part[:, 0], fq, fi)
+        self._raise_on_flag()
+        return tails, heads
+
+    def rank(self, test_data, num_entities, filter_t, filter_h, chunk=8192):
+        filt = [(s, p, o) for (s, p), os_ in filter_t.items() for o in os_]
+        return self.rank_triples(np.asarray([tuple(int(v) for v in t) for t in test_data], dtype=np.int32), num_entities,
+                                 np.asarray(filt, dtype=np.int32).reshape(-1, 3))
+
+    def get_weights(self):
+        return super().get_weights() + [self.theta.cpu().numpy(), self.bn_stats.cpu().numpy()]

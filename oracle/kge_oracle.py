@@ -495,3 +495,150 @@ def sorted_id_maps(*splits):
     ents = sorted({x for sp in splits for (s, _, o) in sp for x in (s, o)})
     rels = sorted({p for sp in splits for (_, p, _) in sp})
     return {e: i for i, e in enumerate(ents)}, {r: i for i, r in enumerate(rels)}
+
+
+# ----------------------------------------------------------------------------------------------
+# ConvE (models.py:239-275).  [TF] throughout: Conv2D 'valid' cross-correlation + bias, BatchNormalization
+# (momentum 0.99, epsilon 1e-3, training mode = batch statistics; the 4-D one is Keras' fused kernel whose MOVING variance
+# takes Bessel's correction, the 2-D one is not fused and does not), ReLU, Dropout, Flatten in (H, W, C) order, Dense.
+# The two calls of the wrapper (tests.py:77-78) are separate invocations: batch statistics are per call.
+# ----------------------------------------------------------------------------------------------
+def conve_shape(dim, filters=8):
+    """models.py:250-251: (w, h) = the largest factor pair i <= sqrt(dim); image (2w, h); conv output (2w-2, h-2, filters)."""
+    fac = [(int(i), int(dim / i)) for i in range(1, int(dim ** 0.5) + 1) if dim % i == 0]
+    w, h = fac[-1]
+    assert w > 1 or h > 1  # models.py:252
+    Ho, Wo = 2 * w - 2, h - 2
+    return w, h, Ho, Wo, Ho * Wo * filters
+
+
+def conve_init(dim, rs, filters=8, dtype=np.float32):
+    """Trainable parameters with the Keras default initialisers (Glorot uniform kernels, zero biases, BN gamma 1 / beta 0)
+    and the non-trainable moving statistics (mean 0, variance 1)."""
+    w, h, Ho, Wo, F = conve_shape(dim, filters)
+    lim_k = np.sqrt(6.0 / (9 * 1 + 9 * filters))  # fan_in = 3*3*1, fan_out = 3*3*filters
+    lim_d = np.sqrt(6.0 / (F + dim))
+    return dict(K=rs.uniform(-lim_k, lim_k, (3, 3, filters)).astype(dtype), bc=np.zeros(filters, dtype), g1=np.ones(filters, dtype),
+                b1=np.zeros(filters, dtype), Wd=rs.uniform(-lim_d, lim_d, (F, dim)).astype(dtype), bd=np.zeros(dim, dtype),
+                g2=np.ones(dim, dtype), b2=np.zeros(dim, dtype),
+                mm1=np.zeros(filters, dtype), mv1=np.ones(filters, dtype), mm2=np.zeros(dim, dtype), mv2=np.ones(dim, dtype))
+
+
+CONVE_TRAINABLE = ("K", "bc", "g1", "b1", "Wd", "bd", "g2", "b2")
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99
+
+
+def conve_forward(P, s, p, o, training=False, hidden_dp=0.0, seed=0, row_offset=0, cache=None, update_moving=True):
+    """x = ConvE.func's hidden vector (m, dim) and score = sum(x * o, -1) (models.py:265-275)."""
+    m, dim = s.shape
+    C = P["K"].shape[2]
+    w, h, Ho, Wo, F = conve_shape(dim, C)
+    X = np.concatenate([s.reshape(m, w, h), p.reshape(m, w, h)], axis=1)  # (m, 2w, h): tf.concat axis=1
+    Y = np.zeros((m, Ho, Wo, C), dtype=s.dtype)
+    for a in range(3):
+        for b in range(3):
+            Y += X[:, a:a + Ho, b:b + Wo, None] * P["K"][a, b][None, None, None, :]
+    Y += P["bc"]
+    if training:
+        mu1 = Y.mean(axis=(0, 1, 2))
+        var1 = Y.var(axis=(0, 1, 2))
+        if update_moving:
+            n1 = m * Ho * Wo
+            P["mm1"][...] = P["mm1"] * BN_MOMENTUM + mu1 * (1 - BN_MOMENTUM)
+            P["mv1"][...] = P["mv1"] * BN_MOMENTUM + var1 * (n1 / max(n1 - 1, 1)) * (1 - BN_MOMENTUM)  # fused BN: Bessel
+    else:
+        mu1, var1 = P["mm1"], P["mv1"]
+    inv1 = 1.0 / np.sqrt(var1 + BN_EPS)
+    xh1 = (Y - mu1) * inv1
+    A = np.maximum(xh1 * P["g1"] + P["b1"], 0).reshape(m, F)
+    d1 = np.ones_like(A)
+    if training and hidden_dp:
+        d1 = dropout_multipliers(seed, m, 3, F, hidden_dp, row_offset).astype(A.dtype)
+        A = A * d1
+    Z = A @ P["Wd"] + P["bd"]
+    if training:
+        mu2, var2 = Z.mean(0), Z.var(0)
+        if update_moving:
+            P["mm2"][...] = P["mm2"] * BN_MOMENTUM + mu2 * (1 - BN_MOMENTUM)
+            P["mv2"][...] = P["mv2"] * BN_MOMENTUM + var2 * (1 - BN_MOMENTUM)
+    else:
+        mu2, var2 = P["mm2"], P["mv2"]
+    inv2 = 1.0 / np.sqrt(var2 + BN_EPS)
+    xh2 = (Z - mu2) * inv2
+    x = np.maximum(xh2 * P["g2"] + P["b2"], 0)
+    d2 = np.ones_like(x)
+    if training and hidden_dp:
+        d2 = dropout_multipliers(seed, m, 4, dim, hidden_dp, row_offset).astype(x.dtype)
+        x = x * d2
+    if cache is not None:
+        cache.update(X=X, xh1=xh1, inv1=inv1, A=A, d1=d1, xh2=xh2, inv2=inv2, x=x, d2=d2, shape=(w, h, Ho, Wo, F, C))
+    return x, np.sum(x * o, axis=-1)
+
+
+def conve_backward(P, cache, o, g):
+    """Gradients of sum_i g_i * score_i (training mode): returns (ds, dp, do, dict of parameter gradients)."""
+    w, h, Ho, Wo, F, C = cache["shape"]
+    m = o.shape[0]
+    x, A = cache["x"], cache["A"]
+    do = g[:, None] * x
+    dx = g[:, None] * o
+    relu2 = (cache["xh2"] * P["g2"] + P["b2"]) > 0
+    dy2 = dx * cache["d2"] * relu2
+    dg2 = np.sum(dy2 * cache["xh2"], 0)
+    db2 = np.sum(dy2, 0)
+    dxh2 = dy2 * P["g2"]
+    dZ = cache["inv2"] * (dxh2 - dxh2.mean(0) - cache["xh2"] * (dxh2 * cache["xh2"]).mean(0))
+    dWd = A.T @ dZ
+    dbd = dZ.sum(0)
+    dA = dZ @ P["Wd"].T
+    relu1 = ((cache["xh1"] * P["g1"] + P["b1"]) > 0).reshape(m, F)
+    dy1 = (dA * cache["d1"] * relu1).reshape(m, Ho, Wo, C)
+    dg1 = np.sum(dy1 * cache["xh1"], axis=(0, 1, 2))
+    db1 = np.sum(dy1, axis=(0, 1, 2))
+    dxh1 = dy1 * P["g1"]
+    dY = cache["inv1"] * (dxh1 - dxh1.mean(axis=(0, 1, 2)) - cache["xh1"] * (dxh1 * cache["xh1"]).mean(axis=(0, 1, 2)))
+    dbc = dY.sum(axis=(0, 1, 2))
+    X = cache["X"]
+    dK = np.zeros_like(P["K"])
+    dX = np.zeros_like(X)
+    for a in range(3):
+        for b in range(3):
+            dK[a, b] = np.einsum("mij,mijc->c", X[:, a:a + Ho, b:b + Wo], dY)
+            dX[:, a:a + Ho, b:b + Wo] += dY @ P["K"][a, b]
+    ds = dX[:, :w, :].reshape(m, w * h)
+    dp = dX[:, w:, :].reshape(m, w * h)
+    return ds, dp, do, dict(K=dK, bc=dbc, g1=dg1, b1=db1, Wd=dWd, bd=dbd, g2=dg2, b2=db2)
+
+
+def conve_train_step(P, E, Rel, opt, pos, neg, loss="pointwize_hinge", margin=1, negative_samples=1, dropout=0.0, hidden_dp=0.0, seed=0):
+    """One Keras train step of the two-input wrapper with a ConvE embedding model: the head runs once on pos and once on
+    neg (separate batch statistics), both update the moving statistics; every trainable variable gets an Adam/SGD update."""
+    dt = E.dtype
+    pos = np.asarray(pos).reshape(-1, 3).astype(np.int64)
+    neg = np.asarray(neg).reshape(-1, 3).astype(np.int64)
+    caches, rows, masks, scores = [], [], [], []
+    for t, off in ((pos, 0), (neg, len(pos))):
+        s_, p_, o_ = E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]]
+        ms = [np.ones_like(s_)] * 3
+        if dropout:
+            ms = [dropout_multipliers(seed, len(t), r, E.shape[1], dropout, off).astype(dt) for r in range(3)]
+            s_, p_, o_ = s_ * ms[0], p_ * ms[1], o_ * ms[2]
+        c = {}
+        _, sc = conve_forward(P, s_, p_, o_, True, hidden_dp, seed, off, c)
+        caches.append(c); rows.append((s_, p_, o_)); masks.append(ms); scores.append(sc.astype(dt))
+    L, gt, gf = loss_value_and_grads(loss, scores[0], scores[1], margin, negative_samples)
+    gE, gR = np.zeros_like(E), np.zeros_like(Rel)
+    gP = {k: np.zeros_like(P[k]) for k in CONVE_TRAINABLE}
+    for t, c, (s_, p_, o_), ms, g in ((pos, caches[0], rows[0], masks[0], gt), (neg, caches[1], rows[1], masks[1], gf)):
+        ds, dp, do, gp = conve_backward(P, c, o_, g.astype(dt))
+        _scatter_add(gE, t[:, 0], (ds * ms[0]).astype(dt))
+        _scatter_add(gR, t[:, 1], (dp * ms[1]).astype(dt))
+        _scatter_add(gE, t[:, 2], (do * ms[2]).astype(dt))
+        for k in CONVE_TRAINABLE:
+            gP[k] += gp[k]
+    opt.begin_step()
+    opt.apply("E", E, gE)
+    opt.apply("R", Rel, gR)
+    for k in CONVE_TRAINABLE:
+        opt.apply("conve_" + k, P[k], gP[k])
+    return L, scores[0], scores[1]

@@ -36,23 +36,23 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_abi_struct_layouts():
-    assert ctypes.sizeof(_lib.ModelDesc) == 32
+    assert ctypes.sizeof(_lib.ModelDesc) == 40
     assert ctypes.sizeof(_lib.LossDesc) == 16
     assert ctypes.sizeof(_lib.OptDesc) == 64
     assert _lib.OptDesc.step.offset == 24 and _lib.OptDesc.mE.offset == 32
 
 
 def test_argument_errors_without_gpu():
-    md = _lib.ModelDesc(0, 10, 3, 8, 4, 1, 0.0, 0.0)  # e_dim != r_dim
+    md = _lib.ModelDesc(0, 10, 3, 8, 4, 1, 0.0, 0.0, 0, 0.0)  # e_dim != r_dim
     rc = _lib.lib.kge_score(ctypes.byref(md), 1, 1, 1, 4, 1, 1, None)
     assert rc == _lib.KGE_ESHAPE and b"broadcast" in _lib.lib.kge_last_error()
     with pytest.raises(ValueError):
         _lib.check(rc)
-    md = _lib.ModelDesc(9, 10, 3, 8, 8, 1, 0.0, 0.0)
+    md = _lib.ModelDesc(9, 10, 3, 8, 8, 1, 0.0, 0.0, 0, 0.0)
     assert _lib.lib.kge_score(ctypes.byref(md), 1, 1, 1, 4, 1, 1, None) == _lib.KGE_EINVAL
-    md = _lib.ModelDesc(2, 10, 3, 7, 7, 1, 0.0, 0.0)  # ComplEx odd width
+    md = _lib.ModelDesc(2, 10, 3, 7, 7, 1, 0.0, 0.0, 0, 0.0)  # ComplEx odd width
     assert _lib.lib.kge_score(ctypes.byref(md), 1, 1, 1, 4, 1, 1, None) == _lib.KGE_ESHAPE
-    md = _lib.ModelDesc(0, 10, 3, 8, 8, 1, 0.0, 0.0)
+    md = _lib.ModelDesc(0, 10, 3, 8, 8, 1, 0.0, 0.0, 0, 0.0)
     assert _lib.lib.kge_score(ctypes.byref(md), 1, 1, 1, 0, 1, 1, None) == 0  # empty input is a no-op
     assert _lib.lib.kge_score(ctypes.byref(md), None, 1, 1, 4, 1, 1, None) == _lib.KGE_EINVAL
 
