@@ -106,25 +106,42 @@ __global__ __launch_bounds__(256) void cv_conv_fwd(const float* __restrict__ E, 
   }
 }
 
+// Block-wide double sums of two strided columns of the partials matrix: one workgroup per channel, fixed tree order.
+__device__ __forceinline__ void cv_col_sums(const float* __restrict__ partials, int nb, int stride, int c1, int c2, double& a, double& b) {
+  __shared__ double sa[256], sb[256];
+  double x = 0.0, y = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) { x += partials[(int64_t)i * stride + c1]; y += partials[(int64_t)i * stride + c2]; }
+  sa[threadIdx.x] = x; sb[threadIdx.x] = y;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sa[threadIdx.x] += sa[threadIdx.x + o]; sb[threadIdx.x] += sb[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  a = sa[0]; b = sb[0];
+}
+
 // partials[nb][2*nch] (sum, sum of squares) over `count` values per channel -> callstat[0..nch) = mean, [nch..2nch) = 1/sqrt(var+eps);
-// TRAIN: moving statistics updated (bessel: the fused 4-D batch norm).  One workgroup, double accumulation, fixed order.
+// training: moving statistics updated (bessel: the fused 4-D batch norm).  grid = nch workgroups.
 __global__ __launch_bounds__(256) void cv_bn_finalize(const float* __restrict__ partials, int nb, int nch, double count, int bessel,
                                                        float* __restrict__ callstat, float* __restrict__ mov_mean,
                                                        float* __restrict__ mov_var, int use_moving) {
-  for (int c = threadIdx.x; c < nch; c += 256) {
-    float mean, var;
-    if (use_moving) { mean = mov_mean[c]; var = mov_var[c]; }
-    else {
-      double a = 0.0, b = 0.0;
-      for (int i = 0; i < nb; ++i) { a += partials[(int64_t)i * 2 * nch + c]; b += partials[(int64_t)i * 2 * nch + nch + c]; }
-      const double mu = a / count;
-      double v = b / count - mu * mu;
-      if (v < 0.0) v = 0.0;
-      mean = (float)mu; var = (float)v;
+  const int c = blockIdx.x;
+  float mean, var;
+  if (use_moving) { mean = mov_mean[c]; var = mov_var[c]; }
+  else {
+    double a, b;
+    cv_col_sums(partials, nb, 2 * nch, c, nch + c, a, b);
+    const double mu = a / count;
+    double v = b / count - mu * mu;
+    if (v < 0.0) v = 0.0;
+    mean = (float)mu; var = (float)v;
+    if (threadIdx.x == 0) {
       mov_mean[c] = mov_mean[c] * kBnMom + mean * (1.f - kBnMom);
       const float vu = bessel ? (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0))) : var;
       mov_var[c] = mov_var[c] * kBnMom + vu * (1.f - kBnMom);
     }
+  }
+  if (threadIdx.x == 0) {
     callstat[c] = mean;
     callstat[nch + c] = 1.f / sqrtf(var + kBnEps);
   }
@@ -239,13 +256,15 @@ __global__ __launch_bounds__(256) void cv_head_bwd(const float* __restrict__ E, 
   }
 }
 
-// partials[nb][2*nch] -> bst[0..nch) = mean(gamma*dy), bst[nch..2nch) = mean(gamma*dy*xhat); dgamma += sum(dy*xhat), dbeta += sum(dy)
+// partials[nb][2*nch] -> bst[0..nch) = mean(gamma*dy), bst[nch..2nch) = mean(gamma*dy*xhat); dgamma += sum(dy*xhat), dbeta += sum(dy).
+// grid = nch workgroups.
 __global__ __launch_bounds__(256) void cv_bn_bwd_finalize(const float* __restrict__ partials, int nb, int nch, double count,
                                                            const float* __restrict__ gamma, float* __restrict__ bst,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  for (int c = threadIdx.x; c < nch; c += 256) {
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < nb; ++i) { a += partials[(int64_t)i * 2 * nch + c]; b += partials[(int64_t)i * 2 * nch + nch + c]; }
+  const int c = blockIdx.x;
+  double a, b;
+  cv_col_sums(partials, nb, 2 * nch, c, nch + c, a, b);
+  if (threadIdx.x == 0) {
     dbeta[c] += (float)a;
     dgamma[c] += (float)b;
     bst[c] = (float)(a / count) * gamma[c];
@@ -401,11 +420,10 @@ __global__ __launch_bounds__(256) void cv_conv_bwd(const float* __restrict__ E, 
 }
 
 __global__ __launch_bounds__(256) void cv_sum_partials(const float* __restrict__ partials, int nb, int n, float* __restrict__ out) {
-  for (int c = threadIdx.x; c < n; c += 256) {
-    double a = 0.0;
-    for (int i = 0; i < nb; ++i) a += partials[(int64_t)i * n + c];
-    out[c] += (float)a;
-  }
+  const int c = blockIdx.x;  // grid = n workgroups
+  double a, b;
+  cv_col_sums(partials, nb, n, c, c, a, b);
+  if (threadIdx.x == 0) out[c] += (float)a;
 }
 
 // gradient of the embedding tables: sum of the per-triple rows over the destination lists (entries of pull.hip's fill_kernel:
@@ -553,7 +571,7 @@ static int cv_forward(const kge_model_desc* md, const float* E, const float* Rel
   if (training) { if (drop_e) KGE_CONV(true, true); else KGE_CONV(true, false); }
   else KGE_CONV(false, false);
 #undef KGE_CONV
-  hipLaunchKernelGGL(cv_bn_finalize, dim3(1), dim3(256), 0, st, psum, nb_conv, C, (double)m * s.Ho * s.Wo, 1, b.stat1, stats, stats + C, training ? 0 : 1);
+  hipLaunchKernelGGL(cv_bn_finalize, dim3(C), dim3(256), 0, st, psum, nb_conv, C, (double)m * s.Ho * s.Wo, 1, b.stat1, stats, stats + C, training ? 0 : 1);
   const int nb_el = (int)std::min<int64_t>(cdiv(m * s.F / 4, 256), 8192);
   if (drop_h) hipLaunchKernelGGL((cv_bn1_apply<true, C>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
   else hipLaunchKernelGGL((cv_bn1_apply<false, C>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
@@ -566,7 +584,7 @@ static int cv_forward(const kge_model_desc* md, const float* E, const float* Rel
   const int nb_rows = (int)cdiv(m, 64);
   if (training) hipLaunchKernelGGL((cv_z_stats<true>), dim3(nb_rows), dim3(256), 0, st, b.Z, m, s.d, theta + o.bd, psum);
   else hipLaunchKernelGGL((cv_z_stats<false>), dim3(nb_rows), dim3(256), 0, st, b.Z, m, s.d, theta + o.bd, psum);
-  hipLaunchKernelGGL(cv_bn_finalize, dim3(1), dim3(256), 0, st, psum, nb_rows, s.d, (double)m, 0, b.stat2, stats + 2 * C, stats + 2 * C + s.d, training ? 0 : 1);
+  hipLaunchKernelGGL(cv_bn_finalize, dim3(s.d), dim3(256), 0, st, psum, nb_rows, s.d, (double)m, 0, b.stat2, stats + 2 * C, stats + 2 * C + s.d, training ? 0 : 1);
   const int nb_w = (int)std::min<int64_t>(cdiv(m, 4), 4096);
   if (drop_e || drop_h)
     hipLaunchKernelGGL((cv_head_out<true>), dim3(nb_w), dim3(256), 0, st, E, tri, m, md->num_entities, s.d, b.Z, theta + o.g2, theta + o.b2, b.stat2, b.X,
@@ -598,7 +616,7 @@ static int cv_backward(const kge_model_desc* md, const float* E, const float* Re
   else
     hipLaunchKernelGGL((cv_head_bwd<false>), dim3(nb_rows), dim3(256), 0, st, E, tri, m, md->num_entities, s.d, b.Z, b.stat2, g, b.X, dO, w.psum, seed,
                        row_offset, 0u, 1.f, 1.f);
-  hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(1), dim3(256), 0, st, w.psum, nb_rows, s.d, (double)m, theta + o.g2, bst2, gtheta + o.g2, gtheta + o.b2);
+  hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(s.d), dim3(256), 0, st, w.psum, nb_rows, s.d, (double)m, theta + o.g2, bst2, gtheta + o.g2, gtheta + o.b2);
   const int nb_el2 = (int)std::min<int64_t>(cdiv(m * s.d, 256), 8192);
   hipLaunchKernelGGL(cv_bn2_bwd_apply, dim3(nb_el2), dim3(256), 0, st, b.Z, b.X, m, s.d, theta + o.g2, b.stat2, bst2);
   rocblas_handle h = blas_handle();
@@ -612,7 +630,7 @@ static int cv_backward(const kge_model_desc* md, const float* E, const float* Re
   const int64_t total4 = m * (int64_t)s.F / 4;
   const int nb_bn1 = (int)cdiv(total4, 4096);
   hipLaunchKernelGGL((cv_bn1_bwd_stats<C>), dim3(nb_bn1), dim3(256), 0, st, w.dA, b.A, b.Y, total4, b.stat1, ds_h, w.psum);
-  hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(1), dim3(256), 0, st, w.psum, nb_bn1, C, (double)m * s.Ho * s.Wo, theta + o.g1, bst1, gtheta + o.g1, gtheta + o.b1);
+  hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(C), dim3(256), 0, st, w.psum, nb_bn1, C, (double)m * s.Ho * s.Wo, theta + o.g1, bst1, gtheta + o.g1, gtheta + o.b1);
   const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
   const size_t smem = (size_t)4 * (s.H * s.W + s.Ho * s.Wo * C) * sizeof(float);
   if (drop_e)
@@ -621,7 +639,7 @@ static int cv_backward(const kge_model_desc* md, const float* E, const float* Re
   else
     hipLaunchKernelGGL((cv_conv_bwd<false, C>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
                        bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
-  hipLaunchKernelGGL(cv_sum_partials, dim3(1), dim3(256), 0, st, w.psum, nb_conv, 9 * C, gtheta + o.K);
+  hipLaunchKernelGGL(cv_sum_partials, dim3(9 * C), dim3(256), 0, st, w.psum, nb_conv, 9 * C, gtheta + o.K);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
@@ -669,7 +687,6 @@ int conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const f
   void* loss_ws;
   int64_t loss_ws_bytes;
   cv_carve(ws, md, m_pos, m_neg, &w, &loss_ws, &loss_ws_bytes);
-  const int64_t n = m_pos + m_neg;
   float* sc = scores_out ? scores_out : w.sc;
   // destination lists (ids only)
   PullPlan plan;

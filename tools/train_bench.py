@@ -11,7 +11,7 @@ from kge_keras_amd import models as M  # noqa: E402
 
 model, loss, d, B, ns = (sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else ("HolE", "pointwize_hinge", 200, 2048, 100)
 N, R = 14541, 237
-kw = dict(norm=2, gamma=12) if model == "TransE" else {}
+kw = dict(norm=2, gamma=12) if model == "TransE" else ({"hidden_dp": float(os.environ.get("HDP", "0"))} if model == "ConvE" else {})
 dp = float(os.environ.get("DP", "0"))
 mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=dp, seed=1, loss_function=loss, **kw)
 mdl.compile("adam")
