@@ -160,6 +160,20 @@ int kge_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, con
                           float* stats, float* gradE, float* gradRel, float* gtheta, const int32_t* pos, int64_t m_pos,
                           const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
                           int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* ---- LiteralE-style input path (models.py:114-120,152-158; tests.py:113,125-126): s_hat = act(Dense([dp(E[s]) ; dp(Lit[s])])),
+ *      o_hat likewise with the same Dense, score = func(s_hat, dp(Rel[p]), o_hat).  Lit is the frozen (lit_rows, L) literal table,
+ *      theta_l = [W (d_e + L, d_e) row-major | b (d_e)], act = 0 linear, 1 relu, 2 sigmoid, 3 tanh, 4 softplus, 5 softsign, 6 elu,
+ *      7 selu, 8 exponential.  kge_lit_transform builds the transformed entity table (rows, d_e) in inference mode: predict and
+ *      the 1-vs-all ranking then run the ordinary kernels on it.  kge_lit_train_grads is the gradient half of a train step
+ *      (gradients into gradE / gradRel / gtheta_l, zero on entry); DistMult, TransE and ComplEx are built. */
+int64_t kge_lit_workspace_bytes(const kge_model_desc* md, int32_t L, int64_t m_pos, int64_t m_neg);
+int64_t kge_lit_transform_workspace_bytes(const kge_model_desc* md, int32_t L, int32_t rows);
+int kge_lit_transform(const kge_model_desc* md, int32_t act, const float* E, const float* Lit, int32_t L, int32_t lit_rows, const float* theta_l,
+                      int32_t rows, float* out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+int kge_lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32_t act, const float* E, const float* Rel, const float* Lit,
+                        int32_t L, int32_t lit_rows, const float* theta_l, float* gradE, float* gradRel, float* gtheta_l, const int32_t* pos,
+                        int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
+                        int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
 /* Keras optimizer update of one flat fp32 vector (w -= ..., g re-zeroed); od->mE / od->vE are its Adam slots. */
 int kge_opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float grad_scale, kge_stream_t stream);
 /* Filtered rank counts for any model whose score is a dot product <q_i, c_j>: Q is (n_queries, K), Cand holds rows

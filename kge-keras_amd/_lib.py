@@ -16,6 +16,7 @@ MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4}
 LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, "pairwize_logistic": 3,
             "pointwize_square_loss": 4, "pairwize_square_loss": 5}
 OPT_IDS = {"sgd": 0, "adam": 1}
+ACT_IDS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "softsign": 5, "elu": 6, "selu": 7, "exponential": 8}
 MT_STATE_BYTES = 2504
 
 
@@ -51,6 +52,10 @@ SIGNATURES = {
     "kge_conve_score": (C.c_int, [_MD, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P]),
     "kge_conve_hidden": (C.c_int, [_MD, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P]),
     "kge_conve_train_grads": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
+    "kge_lit_workspace_bytes": (_I64, [_MD, _I32, _I64, _I64]),
+    "kge_lit_transform_workspace_bytes": (_I64, [_MD, _I32, _I32]),
+    "kge_lit_transform": (C.c_int, [_MD, _I32, _P, _P, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P]),
+    "kge_lit_train_grads": (C.c_int, [_MD, _LD, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
     "kge_opt_apply_vector": (C.c_int, [_OD, _P, _P, _I64, _F, _P]),
     "kge_rank_sweep_q_workspace_bytes": (_I64, [_I64, _I32]),
     "kge_rank_sweep_q": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _I32, _P, _I64, _P]),

@@ -140,6 +140,11 @@ int conve_infer(const kge_model_desc*, const float*, const float*, const float*,
 int conve_train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, const float*, float*, float*, float*, float*,
                       const int32_t*, int64_t, const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
 int opt_apply_vector(const kge_opt_desc*, float*, float*, int64_t, float, hipStream_t);
+int64_t lit_workspace_bytes(const kge_model_desc*, int, int64_t, int64_t);
+int64_t lit_transform_workspace_bytes(const kge_model_desc*, int, int);
+int lit_transform(const kge_model_desc*, int, const float*, const float*, int, int, const float*, int, float*, void*, int64_t, uint32_t*, hipStream_t);
+int lit_train_grads(const kge_model_desc*, const kge_loss_desc*, int, const float*, const float*, const float*, int, int, const float*, float*, float*,
+                    float*, const int32_t*, int64_t, const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
 int64_t rank_sweep_q_workspace_bytes(int64_t, int);
 int rank_sweep_q(const float*, int64_t, int, const float*, int, int, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, int,
                  void*, int64_t, hipStream_t);
@@ -399,6 +404,36 @@ int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* 
     return fail(KGE_EINVAL, "kge_rank_sweep_q: bad arguments");
   return rank_sweep_q(Q, n_queries, K, Cand, cand_offset, cand_rows, target_ids, filt_query, filt_ids, n_filt, counts, accumulate, workspace,
                       workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int64_t kge_lit_workspace_bytes(const kge_model_desc* md, int32_t L, int64_t m_pos, int64_t m_neg) {
+  if (check_model(md, "kge_lit_workspace_bytes")) return KGE_EINVAL;
+  if (L <= 0 || m_pos < 0 || m_neg < 0) return fail(KGE_EINVAL, "kge_lit_workspace_bytes: bad sizes");
+  return lit_workspace_bytes(md, L, m_pos, m_neg);
+}
+
+int64_t kge_lit_transform_workspace_bytes(const kge_model_desc* md, int32_t L, int32_t rows) {
+  if (check_model(md, "kge_lit_transform_workspace_bytes")) return KGE_EINVAL;
+  if (L <= 0 || rows < 0) return fail(KGE_EINVAL, "kge_lit_transform_workspace_bytes: bad sizes");
+  return lit_transform_workspace_bytes(md, L, rows);
+}
+
+int kge_lit_transform(const kge_model_desc* md, int32_t act, const float* E, const float* Lit, int32_t L, int32_t lit_rows, const float* theta_l,
+                      int32_t rows, float* out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_model(md, "kge_lit_transform")) return rc;
+  if (rows == 0) return KGE_OK;
+  if (rows < 0 || rows > md->num_entities || !E || !Lit || !theta_l || !out || !workspace || !err_flag) return fail(KGE_EINVAL, "kge_lit_transform: bad arguments");
+  return lit_transform(md, act, E, Lit, L, lit_rows, theta_l, rows, out, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32_t act, const float* E, const float* Rel, const float* Lit,
+                        int32_t L, int32_t lit_rows, const float* theta_l, float* gradE, float* gradRel, float* gtheta_l, const int32_t* pos,
+                        int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
+                        int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_train("kge_lit_train_grads", md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, err_flag)) return rc;
+  if (!Lit || !theta_l || !gtheta_l || !workspace) return fail(KGE_EINVAL, "kge_lit_train_grads: null pointer");
+  return lit_train_grads(md, ld, act, E, Rel, Lit, L, lit_rows, theta_l, gradE, gradRel, gtheta_l, pos, m_pos, neg, m_neg, loss_out, scores_out, seed,
+                         workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -472,6 +472,8 @@ static rocblas_handle blas_handle() {
   return state == 1 ? h : nullptr;
 }
 
+rocblas_handle blas_handle_shared() { return blas_handle(); }
+
 #define KGE_BLAS_TRY(expr)                                                                  \
   do {                                                                                      \
     rocblas_status s__ = (expr);                                                            \
@@ -667,6 +669,16 @@ int conve_infer(const kge_model_desc* md, const float* E, const float* Rel, cons
     b.X = want_hidden ? out + a * s.d : Xtmp;
     if (int rc = cv_forward(md, E, Rel, theta, stats, tri + 3 * a, mm, 0, false, b, psum, want_hidden ? nullptr : out + a, want_hidden ? 0 : 1, err, 0, st)) return rc;
   }
+  return KGE_OK;
+}
+
+// list-sum of per-triple rows into the table gradients (also used by literal.hip)
+int cv_rowsum_launch(const kge_model_desc* md, float* gE, float* gR, const PullPlan& plan, const float* dS, const float* dP, const float* dO,
+                     hipStream_t st) {
+  const int N = md->num_entities, NK = N + md->num_relations;
+  hipLaunchKernelGGL(cv_rowsum_kernel, dim3((int)cdiv(NK + plan.max_extra, 4)), dim3(256), 0, st, gE, gR, N, NK, md->d_e, plan.cnt, plan.off, plan.eoff,
+                     plan.poff, plan.totals, plan.emap, plan.entries, plan.slab, plan.chunk, dS, dP, dO);
+  KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
 

@@ -1,0 +1,331 @@
+// LiteralE-style input path (KGEkeras/models.py:114-120,152-158; used by the reference's own script, tests.py:113,125-126):
+//     s_hat = act(Dense([dp(E[s]) ; dp(Lit[s])])),   o_hat likewise with the SAME Dense,   score = func(s_hat, dp(Rel[p]), o_hat).
+// The Dense layer is shared by all rows, so it is one GEMM over the stacked (2n, d+L) input (rocBLAS sgemm, fp32); the gather,
+// activation, per-triple score / row gradients and the compaction around it are HIP kernels; the per-triple entity rows
+// that come out of the backward GEMM are summed into the table gradient by the destination lists of pull.hip.
+// theta_l = [W (d+L, d) row-major | b (d)].  Dropout multipliers: roles 0/1/2 = s/p/o rows, 5/6 = literal rows of s/o.
+#include <rocblas/rocblas.h>
+
+#include "dropout.hpp"
+#include "kge_internal.hpp"
+#include "pull.hpp"
+
+namespace kge {
+
+rocblas_handle blas_handle_shared();  // conve.hip
+int cv_rowsum_launch(const kge_model_desc* md, float* gE, float* gR, const PullPlan& plan, const float* dS, const float* dP, const float* dO,
+                     hipStream_t st);  // conve.hip
+int pull2_fill_entries(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p,
+                       hipStream_t st);
+int pull_finish_launch(const kge_model_desc* md, float* gE, float* gR, const PullPlan& p, hipStream_t st);
+int64_t train_workspace_bytes(const kge_model_desc*, int64_t, int64_t);
+int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
+
+__device__ __forceinline__ void act_eval(int act, float z, float& h, float& dh) {
+  switch (act) {
+    case 1: h = z > 0.f ? z : 0.f; dh = z > 0.f ? 1.f : 0.f; break;                                     // relu
+    case 2: h = 1.f / (1.f + expf(-z)); dh = h * (1.f - h); break;                                      // sigmoid
+    case 3: h = tanhf(z); dh = 1.f - h * h; break;                                                      // tanh
+    case 4: h = z > 20.f ? z : log1pf(expf(z)); dh = 1.f / (1.f + expf(-z)); break;                     // softplus
+    case 5: { const float a = 1.f + fabsf(z); h = z / a; dh = 1.f / (a * a); break; }                   // softsign
+    case 6: { const float e = expf(fminf(z, 0.f)); h = z > 0.f ? z : e - 1.f; dh = z > 0.f ? 1.f : e; break; }  // elu
+    case 7: { const float e = expf(fminf(z, 0.f)); const float A = 1.6732632423543772f, S = 1.0507009873554805f;
+              h = S * (z > 0.f ? z : A * (e - 1.f)); dh = S * (z > 0.f ? 1.f : A * e); break; }          // selu
+    case 8: h = expf(z); dh = h; break;                                                                 // exponential
+    default: h = z; dh = 1.f; break;                                                                    // linear
+  }
+}
+
+// A[t] = [E[s]*m | Lit[s]*m], A[n+t] = [E[o]*m | Lit[o]*m]; ids == nullptr: identity rows (table transform), single role.
+template <bool DROP>
+__global__ __launch_bounds__(256) void lit_gather(const float* __restrict__ E, const float* __restrict__ Lit, const int32_t* __restrict__ pos,
+                                                   int64_t m_pos, const int32_t* __restrict__ neg, int64_t m_neg, int N, int NL, int d, int L,
+                                                   float* __restrict__ A, uint32_t* __restrict__ err, uint64_t seed, uint32_t thr, float dscale) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = m_pos + m_neg;
+  const int K1 = d + L;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n; t += (int64_t)gridDim.x * 4) {
+    int s, o;
+    if (pos) {
+      const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+      s = tr[0]; o = tr[2];
+    } else { s = (int)t; o = (int)t; }
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)o < (unsigned)N && (unsigned)s < (unsigned)NL && (unsigned)o < (unsigned)NL;
+    if (!ok && lane == 0) atomicOr(err, 1u);
+    const int roles = pos ? 2 : 1;
+    for (int r = 0; r < roles; ++r) {
+      const int id = ok ? (r == 0 ? s : o) : 0;
+      float* dst = A + (r == 0 ? t : n + t) * K1;
+      DropKey ke{0, 0}, kl{0, 0};
+      if (DROP) { ke = drop_key(seed, t, r == 0 ? 0 : 2); kl = drop_key(seed, t, r == 0 ? 5 : 6); }
+      for (int k = lane; k < K1; k += 64) {
+        float v = k < d ? E[(int64_t)id * d + k] : Lit[(int64_t)id * L + (k - d)];
+        if (DROP) v *= k < d ? drop_mul(ke, k, thr, dscale) : drop_mul(kl, k - d, thr, dscale);
+        dst[k] = ok ? v : 0.f;
+      }
+    }
+  }
+}
+
+// Zb = Z + b ; H = act(Zb)
+__global__ __launch_bounds__(256) void lit_act_fwd(float* __restrict__ Z, float* __restrict__ H, int64_t rows, int d, const float* __restrict__ b,
+                                                    int act) {
+  const int64_t total = rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float z = Z[i] + b[i % d];
+    float h, dh;
+    act_eval(act, z, h, dh);
+    Z[i] = z;
+    H[i] = h;
+  }
+}
+
+// per triple: s_hat = H[t], o_hat = H[n+t], p' = Rel[p]*mask.  MODE 0: score.  MODE 1: row gradients dH[t], dH[n+t], dP[t] (masked).
+template <int MODEL, int NORM, int MODE, bool DROP>
+__global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, const int32_t* __restrict__ pos, int64_t m_pos,
+                                                 const int32_t* __restrict__ neg, int64_t m_neg, int R, int d, float gamma,
+                                                 const float* __restrict__ H, const float* __restrict__ g, float* __restrict__ scores,
+                                                 float* __restrict__ dH, float* __restrict__ dP, uint64_t seed, uint32_t thr, float dscale) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = m_pos + m_neg;
+  const int h = d >> 1;
+  const int width = MODEL == KGE_COMPLEX ? h : d;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n; t += (int64_t)gridDim.x * 4) {
+    const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+    const int p = tr[1];
+    const bool ok = (unsigned)p < (unsigned)R;
+    const float* hs = H + t * d;
+    const float* ho = H + (n + t) * d;
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * d;
+    DropKey kp{0, 0};
+    if (DROP) kp = drop_key(seed, t, 1);
+    auto mp = [&](int e) { return DROP ? drop_mul(kp, e, thr, dscale) : 1.f; };
+    float acc = 0.f;
+    for (int k = lane; k < width; k += 64) {
+      if (MODEL == KGE_COMPLEX) {
+        const float sr = hs[k], si = hs[h + k], pr = rp[k] * mp(k), pi = rp[h + k] * mp(h + k), orr = ho[k], oi = ho[h + k];
+        acc += sr * pr * orr + pr * si * oi + pi * sr * oi - pi * si * orr;
+      } else {
+        const float sv = hs[k], pv = rp[k] * mp(k), ov = ho[k];
+        if (MODEL == KGE_DISTMULT) acc += sv * pv * ov;
+        else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : x * x; }
+      }
+    }
+    acc = group_sum<64>(acc);
+    float dist = acc, score = acc;
+    if (MODEL == KGE_TRANSE) {
+      if (NORM == 2) dist = sqrtf(acc);
+      score = gamma > 0.f ? gamma - dist : dist;
+    }
+    if (MODE == 0) {
+      if (lane == 0) scores[t] = ok ? score : __builtin_nanf("");
+      continue;
+    }
+    float gi = ok ? g[t] : 0.f;
+    if (!(gi == gi)) gi = 0.f;
+    float* ds = dH + t * d;
+    float* dob = dH + (n + t) * d;
+    float* dp = dP + t * d;
+    if (MODEL == KGE_TRANSE) {
+      const float sgn = gamma > 0.f ? -gi : gi;
+      const float rn = NORM == 2 ? (dist > 0.f ? sgn / dist : 0.f) : sgn;
+      for (int k = lane; k < width; k += 64) {
+        const float b = mp(k);
+        const float x = hs[k] + rp[k] * b - ho[k];
+        const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f)) : rn * x;
+        ds[k] = dx; dob[k] = -dx; dp[k] = dx * b;
+      }
+    } else if (MODEL == KGE_DISTMULT) {
+      for (int k = lane; k < width; k += 64) {
+        const float b = mp(k);
+        const float sv = hs[k], pv = rp[k] * b, ov = ho[k];
+        ds[k] = gi * pv * ov; dob[k] = gi * sv * pv; dp[k] = gi * sv * ov * b;
+      }
+    } else {
+      for (int k = lane; k < width; k += 64) {
+        const float br = mp(k), bi = mp(h + k);
+        const float sr = hs[k], si = hs[h + k], pr = rp[k] * br, pi = rp[h + k] * bi, orr = ho[k], oi = ho[h + k];
+        ds[k] = gi * (pr * orr + pi * oi);      ds[h + k] = gi * (pr * oi - pi * orr);
+        dp[k] = gi * (sr * orr + si * oi) * br; dp[h + k] = gi * (sr * oi - si * orr) * bi;
+        dob[k] = gi * (sr * pr - pi * si);      dob[h + k] = gi * (pr * si + pi * sr);
+      }
+    }
+  }
+}
+
+// dZ = dH * act'(Zb) in place; per-block partial column sums (64 rows per block) for the bias gradient.
+__global__ __launch_bounds__(256) void lit_act_bwd(float* __restrict__ dH, const float* __restrict__ Zb, int64_t rows, int d, int act,
+                                                    float* __restrict__ psum) {
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < min(rows, r0 + 64); ++r) {
+      float h, dh;
+      act_eval(act, Zb[r * d + k], h, dh);
+      const float v = dH[r * d + k] * dh;
+      dH[r * d + k] = v;
+      s += v;
+    }
+    psum[(int64_t)blockIdx.x * d + k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void lit_colsum(const float* __restrict__ partials, int nb, int n, float* __restrict__ out) {
+  __shared__ double sa[256];
+  const int c = blockIdx.x;
+  double x = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) x += partials[(int64_t)i * n + c];
+  sa[threadIdx.x] = x;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sa[threadIdx.x] += sa[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[c] += (float)sa[0];
+}
+
+// dS[t] = dA[t][:d] * mask(t, role 0), dO[t] = dA[n+t][:d] * mask(t, role 2)
+template <bool DROP>
+__global__ __launch_bounds__(256) void lit_compact(const float* __restrict__ dA, int64_t n, int d, int K1, float* __restrict__ dS,
+                                                    float* __restrict__ dO, uint64_t seed, uint32_t thr, float dscale) {
+  const int64_t total = n * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / d;
+    const int k = (int)(i - t * d);
+    float a = dA[t * K1 + k], b = dA[(n + t) * K1 + k];
+    if (DROP) { a *= drop_mul(drop_key(seed, t, 0), k, thr, dscale); b *= drop_mul(drop_key(seed, t, 2), k, thr, dscale); }
+    dS[i] = a;
+    dO[i] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+#define KGE_BLAS_TRY(expr)                                                                  \
+  do {                                                                                      \
+    rocblas_status s__ = (expr);                                                            \
+    if (s__ != rocblas_status_success) return fail(KGE_EHIP, "%s: rocblas status %d", #expr, (int)s__); \
+  } while (0)
+
+static int64_t l256(int64_t x) { return align_up(x, 256); }
+
+static int lit_check(const kge_model_desc* md, int L, int act) {
+  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX)
+    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE and ComplEx are built)", md->model);
+  if (L <= 0) return fail(KGE_EINVAL, "literal path: literal width %d", L);
+  if (act < 0 || act > 8) return fail(KGE_EUNSUPPORTED, "literal path: activation id %d (softmax and custom callables are not built)", act);
+  return KGE_OK;
+}
+
+// Ehat (rows, d) = act([E | Lit] W + b) for table rows 0..rows-1, inference mode (no dropout)
+int lit_transform(const kge_model_desc* md, int act, const float* E, const float* Lit, int L, int lit_rows_n, const float* theta, int rows,
+                  float* out, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  if (int rc = lit_check(md, L, act)) return rc;
+  const int d = md->d_e, K1 = d + L;
+  const int64_t need = l256((int64_t)rows * K1 * 4) + 512;
+  if (wbytes < need) return fail(KGE_EWORKSPACE, "literal transform: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)need);
+  float* A = reinterpret_cast<float*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL((lit_gather<false>), dim3((int)std::min<int64_t>(cdiv(rows, 4), 4096)), dim3(256), 0, st, E, Lit, (const int32_t*)nullptr, (int64_t)rows,
+                     (const int32_t*)nullptr, (int64_t)0, md->num_entities, lit_rows_n, d, L, A, err, 0, 0u, 1.f);
+  rocblas_handle h = blas_handle_shared();
+  if (!h) return fail(KGE_EHIP, "literal path: rocblas handle could not be created");
+  KGE_BLAS_TRY(rocblas_set_stream(h, st));
+  const float one = 1.f, zero = 0.f;
+  KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, d, rows, K1, &one, theta, d, A, K1, &zero, out, d));
+  hipLaunchKernelGGL(lit_act_fwd, dim3((int)std::min<int64_t>(cdiv((int64_t)rows * d, 256), 8192)), dim3(256), 0, st, out, out, (int64_t)rows, d,
+                     theta + (int64_t)K1 * d, act);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+int64_t lit_transform_workspace_bytes(const kge_model_desc* md, int L, int rows) { return l256((int64_t)rows * (md->d_e + L) * 4) + 1024; }
+
+int64_t lit_workspace_bytes(const kge_model_desc* md, int L, int64_t m_pos, int64_t m_neg) {
+  const int64_t n = m_pos + m_neg, d = md->d_e, K1 = d + L;
+  return pull_header_bytes(md) + 2 * l256(2 * n * K1 * 4) + 3 * l256(2 * n * d * 4) + 3 * l256(n * d * 4) + 2 * l256(n * 4) +
+         l256(cdiv(2 * n, 64) * d * 4) + pull_workspace_bytes(md, n) + l256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096;
+}
+
+template <int MODEL, int NORM, int MODE>
+static void launch_rows(bool drop, int grid, hipStream_t st, const float* Rel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                        const kge_model_desc* md, const float* H, const float* g, float* scores, float* dH, float* dP, uint64_t seed) {
+  const uint32_t thr = drop_thr(md->dropout);
+  const float dscale = 1.f / (1.f - md->dropout);
+  if (drop) hipLaunchKernelGGL((lit_rows<MODEL, NORM, MODE, true>), dim3(grid), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, md->d_e, md->gamma, H, g, scores, dH, dP, seed, thr, dscale);
+  else hipLaunchKernelGGL((lit_rows<MODEL, NORM, MODE, false>), dim3(grid), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, md->d_e, md->gamma, H, g, scores, dH, dP, seed, thr, dscale);
+}
+
+template <int MODE>
+static void launch_rows_model(bool drop, int grid, hipStream_t st, const float* Rel, const int32_t* pos, int64_t m_pos, const int32_t* neg,
+                              int64_t m_neg, const kge_model_desc* md, const float* H, const float* g, float* scores, float* dH, float* dP,
+                              uint64_t seed) {
+  if (md->model == KGE_DISTMULT) launch_rows<KGE_DISTMULT, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+  else if (md->model == KGE_COMPLEX) launch_rows<KGE_COMPLEX, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+  else if (md->norm == 1) launch_rows<KGE_TRANSE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+  else launch_rows<KGE_TRANSE, 2, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+}
+
+int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, const float* E, const float* Rel, const float* Lit, int L,
+                    int lit_rows_n, const float* theta, float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos,
+                    const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err,
+                    hipStream_t st) {
+  if (int rc = lit_check(md, L, act)) return rc;
+  if (wbytes < lit_workspace_bytes(md, L, m_pos, m_neg))
+    return fail(KGE_EWORKSPACE, "literal path: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)lit_workspace_bytes(md, L, m_pos, m_neg));
+  const int64_t n = m_pos + m_neg;
+  const int d = md->d_e, K1 = d + L;
+  char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t bytes) { char* r = q; q += l256(bytes); return r; };
+  void* pull_hdr = take(pull_header_bytes(md));
+  float* A = (float*)take(2 * n * K1 * 4);
+  float* dA = (float*)take(2 * n * K1 * 4);
+  float* Zb = (float*)take(2 * n * d * 4);
+  float* H = (float*)take(2 * n * d * 4);
+  float* dH = (float*)take(2 * n * d * 4);
+  float* dPb = (float*)take(n * d * 4);
+  float* dS = (float*)take(n * d * 4);
+  float* dO = (float*)take(n * d * 4);
+  float* g = (float*)take(n * 4);
+  float* scb = (float*)take(n * 4);
+  const int nb_rows = (int)cdiv(2 * n, 64);
+  float* psum = (float*)take((int64_t)nb_rows * d * 4);
+  void* pull_body = take(pull_workspace_bytes(md, n));
+  const int64_t loss_ws_bytes = train_workspace_bytes(nullptr, m_pos, m_neg);
+  void* loss_ws = take(loss_ws_bytes);
+  float* sc = scores_out ? scores_out : scb;
+  const bool drop = md->dropout > 0.f;
+  const uint32_t thr = drop_thr(md->dropout);
+  const float dscale = 1.f / (1.f - md->dropout);
+  PullPlan plan;
+  if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, pull_hdr, pull_body, st, &plan)) return rc;
+  rocblas_handle hb = blas_handle_shared();
+  if (!hb) return fail(KGE_EHIP, "literal path: rocblas handle could not be created");
+  KGE_BLAS_TRY(rocblas_set_stream(hb, st));
+  const float one = 1.f, zero = 0.f;
+  const int gw = (int)std::min<int64_t>(cdiv(n, 4), 4096);
+  const int gel = (int)std::min<int64_t>(cdiv(2 * n * d, 256), 8192);
+  {
+    ProfScope prof(KGE_PROF_FWD, st);
+    if (drop) hipLaunchKernelGGL((lit_gather<true>), dim3(gw), dim3(256), 0, st, E, Lit, pos, m_pos, neg, m_neg, md->num_entities, lit_rows_n, d, L, A, err, seed, thr, dscale);
+    else hipLaunchKernelGGL((lit_gather<false>), dim3(gw), dim3(256), 0, st, E, Lit, pos, m_pos, neg, m_neg, md->num_entities, lit_rows_n, d, L, A, err, seed, thr, dscale);
+    KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (rocblas_int)(2 * n), K1, &one, theta, d, A, K1, &zero, Zb, d));
+    hipLaunchKernelGGL(lit_act_fwd, dim3(gel), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d, act);
+    launch_rows_model<0>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, nullptr, sc, nullptr, nullptr, seed);
+  }
+  if (int rc = loss_value(ld, sc, m_pos, sc + m_pos, m_neg, loss_out, g, g + m_pos, loss_ws, loss_ws_bytes, st)) return rc;
+  {
+    ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
+    launch_rows_model<1>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, g, nullptr, dH, dPb, seed);
+    hipLaunchKernelGGL(lit_act_bwd, dim3(nb_rows), dim3(256), 0, st, dH, Zb, 2 * n, d, act, psum);
+    hipLaunchKernelGGL(lit_colsum, dim3(d), dim3(256), 0, st, psum, nb_rows, d, gtheta + (int64_t)K1 * d);
+    // dA(2n,K1) = dZ(2n,d) W^T ; dW(K1,d) += A^T dZ   (column-major views as in conve.hip)
+    KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_transpose, rocblas_operation_none, K1, (rocblas_int)(2 * n), d, &one, theta, d, dH, d, &zero, dA, K1));
+    KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_transpose, d, K1, (rocblas_int)(2 * n), &one, dH, d, A, K1, &one, gtheta, d));
+    const int gc = (int)std::min<int64_t>(cdiv(n * d, 256), 8192);
+    if (drop) hipLaunchKernelGGL((lit_compact<true>), dim3(gc), dim3(256), 0, st, dA, n, d, K1, dS, dO, seed, thr, dscale);
+    else hipLaunchKernelGGL((lit_compact<false>), dim3(gc), dim3(256), 0, st, dA, n, d, K1, dS, dO, seed, thr, dscale);
+    if (int rc = pull2_fill_entries(md, pos, m_pos, neg, m_neg, plan, st)) return rc;
+    if (int rc = cv_rowsum_launch(md, gE, gR, plan, dS, dPb, dO, st)) return rc;
+    if (int rc = pull_finish_launch(md, gE, gR, plan, st)) return rc;
+  }
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+}  // namespace kge

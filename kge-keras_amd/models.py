@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, ModelDesc, LossDesc, OptDesc, MODEL_IDS, LOSS_IDS, OPT_IDS
+from ._lib import lib, check, ModelDesc, LossDesc, OptDesc, MODEL_IDS, LOSS_IDS, OPT_IDS, ACT_IDS
 
 
 def _device():
@@ -113,8 +113,6 @@ class EmbeddingModel:
                  literal_activation=None, literals=None, use_batch_norm=False, entity_embedding_args=None,
                  relational_embedding_args=None, init_entities=None, init_relations=None, name='embedding_model',
                  **kwargs):
-        if literal_activation:
-            raise NotImplementedError("the LiteralE input path (models.py:114-120,152-158) is outside the built hot path")
         dev = _device()
         self.device = dev
         self.name = name
@@ -157,6 +155,22 @@ class EmbeddingModel:
         self._err = torch.zeros(1, dtype=torch.int32, device=dev)
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._seed = int(seed) if seed is not None else 0
+        self._lit = None
+        if literal_activation:  # models.py:114-120: frozen literal table + Dense(e_dim, activation) on [embedding ; literal]
+            if self.MODEL not in ("DistMult", "TransE", "ComplEx"):
+                raise NotImplementedError(f"the literal input path is built for DistMult, TransE and ComplEx, not {self.MODEL}")
+            act = literal_activation if isinstance(literal_activation, str) else getattr(literal_activation, "__name__", None)
+            if act not in ACT_IDS:
+                raise NotImplementedError(f"literal_activation {literal_activation!r}: one of {sorted(k for k in ACT_IDS if k)}")
+            lit = torch.as_tensor(np.asarray(literals, dtype=np.float32), device=dev).contiguous()
+            if lit.ndim != 2:
+                raise ValueError("literals must be a (len(literals), L) array")
+            L = int(lit.shape[1])
+            K1 = int(e_dim) + L
+            theta = torch.zeros(K1 * int(e_dim) + int(e_dim), dtype=torch.float32, device=dev)
+            lim = float(np.sqrt(6.0 / (K1 + int(e_dim))))  # Dense: Glorot-uniform kernel, zero bias
+            theta[:K1 * int(e_dim)].uniform_(-lim, lim, generator=gen)
+            self._lit = dict(table=lit, L=L, act=ACT_IDS[act], theta=theta, gtheta=torch.zeros_like(theta), slots=None, ws=None, tws=None)
         self.__dict__.update(kwargs)  # models.py:129: unknown kwargs become attributes
 
     # ------------------------------------------------------------------ descriptors
@@ -184,6 +198,34 @@ class EmbeddingModel:
     def Rel(self):
         return self.relational_embedding.weights
 
+    # ------------------------------------------------------------------ literal input path (models.py:114-120,152-158)
+    def get_literal_dense(self):
+        """(W (e_dim+L, e_dim), b (e_dim)) of the literal Dense layer as numpy arrays."""
+        K1, d = int(self.e_dim) + self._lit["L"], int(self.e_dim)
+        th = self._lit["theta"].cpu().numpy()
+        return th[:K1 * d].reshape(K1, d).copy(), th[K1 * d:].copy()
+
+    def set_literal_dense(self, W, b):
+        th = np.concatenate([np.asarray(W, dtype=np.float32).reshape(-1), np.asarray(b, dtype=np.float32).reshape(-1)])
+        self._lit["theta"].copy_(torch.from_numpy(th))
+
+    def _eval_table(self):
+        """The entity table the scoring / ranking kernels see in inference mode: E itself, or, with the literal path,
+        act(Dense([E ; literals])) of every entity (dropout is the identity outside fit)."""
+        if self._lit is None:
+            return self.E
+        lt = self._lit
+        md = self._model_desc(False)
+        N = self.num_entities
+        need = check(lib.kge_lit_transform_workspace_bytes(C.byref(md), lt["L"], N))
+        if lt["tws"] is None or lt["tws"].numel() < need:
+            lt["tws"] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        out = torch.empty((N, int(self.e_dim)), dtype=torch.float32, device=self.device)
+        check(lib.kge_lit_transform(C.byref(md), lt["act"], self.E.data_ptr(), lt["table"].data_ptr(), lt["L"], lt["table"].shape[0],
+                                    lt["theta"].data_ptr(), N, out.data_ptr(), lt["tws"].data_ptr(), lt["tws"].numel(), self._err.data_ptr(),
+                                    _lib.stream_ptr()))
+        return out
+
     # ------------------------------------------------------------------ forward (models.py:134-162)
     def call(self, inputs, training=False):
         """(n,3) ids -> (n,) scores as a device tensor.  Dropout is only applied inside train_step."""
@@ -191,7 +233,8 @@ class EmbeddingModel:
         n = t.shape[0]
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         md = self._model_desc(False)
-        check(lib.kge_score(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), t.data_ptr(), n, out.data_ptr(),
+        Et = self._eval_table()
+        check(lib.kge_score(C.byref(md), Et.data_ptr(), self.Rel.data_ptr(), t.data_ptr(), n, out.data_ptr(),
                             self._err.data_ptr(), _lib.stream_ptr()))
         return out
 
@@ -259,6 +302,8 @@ class EmbeddingModel:
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
         m_pos, m_neg = pos.shape[0], neg.shape[0]
+        if self._lit is not None:
+            return self._train_step_literal(pos, neg, scores_out)
         md, ld = self._ensure_train_state(m_pos, m_neg)
         self.optimizer.iterations += 1
         od = self._opt_desc()
@@ -267,6 +312,30 @@ class EmbeddingModel:
                                  self._gE.data_ptr(), self._gR.data_ptr(), pos.data_ptr(), m_pos, neg.data_ptr(), m_neg,
                                  self._loss.data_ptr(), scores_out.data_ptr() if scores_out is not None else None,
                                  self._seed, self._ws.data_ptr(), self._ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        return {"loss": self._loss[0]}
+
+    def _train_step_literal(self, pos, neg, scores_out=None):
+        lt, o = self._lit, self.optimizer
+        md, ld = self._ensure_train_state(0, 0)
+        if o.kind == "adam" and lt["slots"] is None:
+            lt["slots"] = (torch.zeros_like(lt["theta"]), torch.zeros_like(lt["theta"]))
+        need = check(lib.kge_lit_workspace_bytes(C.byref(md), lt["L"], pos.shape[0], neg.shape[0]))
+        if lt["ws"] is None or lt["ws"].numel() < need:
+            lt["ws"] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+        o.iterations += 1
+        self._seed += 1
+        check(lib.kge_lit_train_grads(C.byref(md), C.byref(ld), lt["act"], self.E.data_ptr(), self.Rel.data_ptr(), lt["table"].data_ptr(),
+                                      lt["L"], lt["table"].shape[0], lt["theta"].data_ptr(), self._gE.data_ptr(), self._gR.data_ptr(),
+                                      lt["gtheta"].data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0],
+                                      self._loss.data_ptr(), scores_out.data_ptr() if scores_out is not None else None, self._seed,
+                                      lt["ws"].data_ptr(), lt["ws"].numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        od = self._opt_desc()
+        check(lib.kge_opt_apply(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                self._gR.data_ptr(), 1.0, self._loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()))
+        ts = [x.data_ptr() for x in lt["slots"]] if lt["slots"] else [None, None]
+        odv = OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, o.iterations, ts[0], ts[1], None, None)
+        check(lib.kge_opt_apply_vector(C.byref(odv), lt["theta"].data_ptr(), lt["gtheta"].data_ptr(), lt["theta"].numel(), 1.0,
+                                       _lib.stream_ptr()))
         return {"loss": self._loss[0]}
 
     def train_grads(self, data):
@@ -391,8 +460,9 @@ class EmbeddingModel:
         acc = counts is not None
         if counts is None:
             counts = torch.empty(nq, dtype=torch.int32, device=self.device)
-        ec_ptr = self.E.data_ptr() + 4 * int(cand_offset) * int(self.e_dim)
-        check(lib.kge_rank_counts(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), ec_ptr, int(cand_offset), int(cand_rows),
+        Et = self._eval_table() if self._lit is not None else self.E
+        ec_ptr = Et.data_ptr() + 4 * int(cand_offset) * int(self.e_dim)
+        check(lib.kge_rank_counts(C.byref(md), Et.data_ptr(), self.Rel.data_ptr(), ec_ptr, int(cand_offset), int(cand_rows),
                                   t.data_ptr(), nq, int(side), fq.data_ptr() if fq.numel() else None,
                                   fi.data_ptr() if fi.numel() else None, fq.numel(), counts.data_ptr(), 1 if acc else 0, None,
                                   self._rank_ws.data_ptr(), self._rank_ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))

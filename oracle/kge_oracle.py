@@ -642,3 +642,97 @@ def conve_train_step(P, E, Rel, opt, pos, neg, loss="pointwize_hinge", margin=1,
     for k in CONVE_TRAINABLE:
         opt.apply("conve_" + k, P[k], gP[k])
     return L, scores[0], scores[1]
+
+
+# ----------------------------------------------------------------------------------------------
+# LiteralE-style input path (models.py:114-120,152-158; the configuration the reference's own script uses, tests.py:113,125-126):
+#   l = dp(literal_layer(id))            frozen (len(literals), L) table
+#   s = Dense(e_dim, activation)(concat([dp(entity_embedding(id)), l]))      for s and for o, the SAME Dense
+# [TF] Dense: x @ W + b with W Glorot-uniform ((e_dim + L), e_dim), b zeros; Keras activation strings.
+# Dropout multipliers: roles 0/1/2 = s/p/o rows as everywhere, 5/6 = the literal rows of s / o.
+# ----------------------------------------------------------------------------------------------
+ACTIVATIONS = ("linear", "relu", "sigmoid", "tanh", "softplus", "softsign", "elu", "selu", "exponential")
+_SELU_A, _SELU_S = 1.6732632423543772, 1.0507009873554805
+
+
+def activation(name, z):
+    """(act(z), act'(z)) for the Keras activation strings the reference's docstring lists (softmax excluded)."""
+    if name in (None, "linear"):
+        return z, np.ones_like(z)
+    if name == "relu":
+        return np.maximum(z, 0), (z > 0).astype(z.dtype)
+    if name == "sigmoid":
+        h = 1.0 / (1.0 + np.exp(-z))
+        return h, h * (1 - h)
+    if name == "tanh":
+        h = np.tanh(z)
+        return h, 1 - h * h
+    if name == "softplus":
+        return np.logaddexp(0, z), 1.0 / (1.0 + np.exp(-z))
+    if name == "softsign":
+        return z / (1 + np.abs(z)), 1.0 / (1 + np.abs(z)) ** 2
+    if name == "elu":
+        return np.where(z > 0, z, np.exp(np.minimum(z, 0)) - 1), np.where(z > 0, 1.0, np.exp(np.minimum(z, 0)))
+    if name == "selu":
+        e = np.exp(np.minimum(z, 0))
+        return _SELU_S * np.where(z > 0, z, _SELU_A * (e - 1)), _SELU_S * np.where(z > 0, 1.0, _SELU_A * e)
+    if name == "exponential":
+        e = np.exp(z)
+        return e, e
+    raise KeyError(name)
+
+
+def literal_init(e_dim, L, rs, dtype=np.float32):
+    lim = np.sqrt(6.0 / ((e_dim + L) + e_dim))
+    return dict(W=rs.uniform(-lim, lim, (e_dim + L, e_dim)).astype(dtype), b=np.zeros(e_dim, dtype))
+
+
+def literal_transform(H, E, Lit, ids, act, me=None, ml=None):
+    """act([E[ids]*me | Lit[ids]*ml] @ W + b); returns (rows, cache)."""
+    a_e, a_l = E[ids], Lit[ids]
+    if me is not None:
+        a_e, a_l = a_e * me, a_l * ml
+    A = np.concatenate([a_e, a_l], axis=1)
+    Z = A @ H["W"] + H["b"]
+    h, dh = activation(act, Z)
+    return h, dict(A=A, dh=dh)
+
+
+def literal_train_step(model, H, act, E, Rel, Lit, opt, pos, neg, loss="pointwize_hinge", margin=1, negative_samples=1, norm=1, gamma=12,
+                       dropout=0.0, seed=0):
+    """One Keras train step with the literal path in front of `model`'s func.  E, Rel, H['W'], H['b'] are updated in place."""
+    dt = E.dtype
+    pos = np.asarray(pos).reshape(-1, 3).astype(np.int64)
+    neg = np.asarray(neg).reshape(-1, 3).astype(np.int64)
+    d, L = E.shape[1], Lit.shape[1]
+    per = []
+    for t, off in ((pos, 0), (neg, len(pos))):
+        m = len(t)
+        one_e, one_l = np.ones((m, d), dt), np.ones((m, L), dt)
+        if dropout:
+            mk = lambda role, w: dropout_multipliers(seed, m, role, w, dropout, off).astype(dt)  # noqa: E731
+            ms, mp, mo, mls, mlo = mk(0, d), mk(1, Rel.shape[1]), mk(2, d), mk(5, L), mk(6, L)
+        else:
+            ms, mp, mo, mls, mlo = one_e, np.ones((m, Rel.shape[1]), dt), one_e, one_l, one_l
+        s_, cs = literal_transform(H, E, Lit, t[:, 0], act, ms, mls)
+        o_, co = literal_transform(H, E, Lit, t[:, 2], act, mo, mlo)
+        p_ = Rel[t[:, 1]] * mp
+        per.append(dict(t=t, s=s_, p=p_, o=o_, cs=cs, co=co, ms=ms, mp=mp, mo=mo, sc=score_rows(model, s_, p_, o_, norm, gamma).astype(dt)))
+    Lv, gt, gf = loss_value_and_grads(loss, per[0]["sc"], per[1]["sc"], margin, negative_samples)
+    gE, gR = np.zeros_like(E), np.zeros_like(Rel)
+    gW, gb = np.zeros_like(H["W"]), np.zeros_like(H["b"])
+    for c, g in ((per[0], gt), (per[1], gf)):
+        ds, dp, do = score_row_grads(model, c["s"], c["p"], c["o"], g.astype(dt), norm, gamma)
+        _scatter_add(gR, c["t"][:, 1], (dp * c["mp"]).astype(dt))
+        for dh, cache, mask, col in ((ds, c["cs"], c["ms"], 0), (do, c["co"], c["mo"], 2)):
+            dZ = dh * cache["dh"]
+            gW += cache["A"].T @ dZ
+            gb += dZ.sum(0)
+            dA = dZ @ H["W"].T
+            _scatter_add(gE, c["t"][:, col], (dA[:, :d] * mask).astype(dt))
+    opt.begin_step()
+    opt.apply("E", E, gE)
+    opt.apply("R", Rel, gR)
+    opt.apply("lit_W", H["W"], gW)
+    opt.apply("lit_b", H["b"], gb)
+    return Lv, per[0]["sc"], per[1]["sc"]

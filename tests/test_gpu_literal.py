@@ -1,0 +1,88 @@
+"""GPU parity of the LiteralE-style input path (models.py:114-120,152-158 -- the configuration of the reference's own script:
+DistMult + random literals + tanh + pairwize_hinge, tests.py:113-128)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _mk(model, N, R, d, L, act, seed=0, **kw):
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(seed)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    lit = rs.rand(N, L).astype(np.float32)  # tests.py:113 np.random.rand(len(E), 5)
+    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, init_entities=E0, init_relations=R0, literals=lit,
+                            literal_activation=act, **kw)
+    H = O.literal_init(de, L, rs)
+    H["b"] += rs.uniform(-0.1, 0.1, de).astype(np.float32)
+    mdl.set_literal_dense(H["W"], H["b"])
+    return mdl, E0, R0, lit, H, rs
+
+
+def _tri(rs, n, N, R):
+    return np.stack([rs.randint(0, N, n), rs.randint(0, R, n), rs.randint(0, N, n)], 1)
+
+
+def _f64(H):
+    return {k: np.asarray(v, dtype=np.float64).copy() for k, v in H.items()}
+
+
+@pytest.mark.parametrize("act", list(O.ACTIVATIONS))
+def test_literal_predict_parity(act):
+    mdl, E0, R0, lit, H, rs = _mk("DistMult", 40, 5, 32, 5, act, dp=0.0)
+    t = _tri(rs, 300, 40, 5)
+    Hd = _f64(H)
+    s_, _ = O.literal_transform(Hd, E0.astype(np.float64), lit.astype(np.float64), t[:, 0], act)
+    o_, _ = O.literal_transform(Hd, E0.astype(np.float64), lit.astype(np.float64), t[:, 2], act)
+    ref = O.score_rows("DistMult", s_, R0[t[:, 1]].astype(np.float64), o_)
+    np.testing.assert_allclose(mdl.predict(t), ref, atol=TOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})])
+@pytest.mark.parametrize("loss,act", [("pairwize_hinge", "tanh"), ("pointwize_logistic", "relu"), ("pointwize_hinge", "sigmoid")])
+@pytest.mark.parametrize("dp", [0.0, 0.25])
+def test_literal_train_step_parity(model, kw, loss, act, dp):
+    N, R, d, L, m = 30, 4, 16, 5, 200
+    mdl, E0, R0, lit, H, rs = _mk(model, N, R, d, L, act, seed=2, dp=dp, loss_function=loss, margin=0.5, **kw)
+    mdl.compile("adam")
+    Eo, Ro, Ho, Lo = E0.astype(np.float64), R0.astype(np.float64), _f64(H), lit.astype(np.float64)
+    oo = O.AdamTF()
+    for step in range(2):
+        pos, neg = _tri(rs, m, N, R), _tri(rs, m, N, R)
+        sc = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        L_ = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+        Lr, sp, sn = O.literal_train_step(model, Ho, act, Eo, Ro, Lo, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12),
+                                          dropout=dp, seed=mdl._seed)
+        np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
+        assert L_ == pytest.approx(Lr, abs=TOL, rel=1e-4), (step, L_, Lr)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        W, b = mdl.get_literal_dense()
+        np.testing.assert_allclose(W, Ho["W"], atol=TOL)
+        np.testing.assert_allclose(b, Ho["b"], atol=TOL)
+
+
+def test_reference_script_configuration(datasets):
+    """tests.py:96-134 on nations: DistMult, dim from hp, random literals (len(E), 5), tanh, pairwize_hinge, margin 1, Adam;
+    fit runs, the loss falls, validate() ranks on the literal-transformed table."""
+    import random
+    from kge_keras_amd.harness import DataGenerator, build_model
+    from kge_keras_amd.utils import validate
+    tr = [tuple(int(v) for v in t) for t in datasets["nations_train"]]
+    te = [tuple(int(v) for v in t) for t in datasets["nations_test"]]
+    np.random.seed(0)
+    random.seed(0)
+    literals = np.random.rand(14, 5)
+    mdl = build_model({'num_entities': 14, 'num_relations': 55, 'dim': 32, 'embedding_model': 'DistMult', 'literals': literals,
+                       'literal_activation': 'tanh', 'loss_function': 'pairwize_hinge', 'margin': 1, 'seed': 1})
+    h = mdl.fit(DataGenerator(tr, batch_size=32), epochs=6, verbose=0)
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    tes = set(te)
+    met = validate(mdl, te[:60], 14, None, filtering_triples=[t for t in tr if t not in tes])
+    assert len(met) == 15 and 1.0 <= met["mr"] <= 14
