@@ -5,8 +5,9 @@ Workload (BASELINE.json configs[1]): FB15k-237-shaped DistMult d=200, B=2048 pos
 m = 204 800 rows per input array, 409 600 scored triples per step; N=14 541 entities, R=237 relations;
 synthetic uniform-id triples (the train split is a missing blob in the reference), Glorot-uniform tables from
 RandomState(1234); pointwize_hinge (margin 1) + Keras-semantics Adam.  A step = score(pos) + score(neg) + loss +
-gradients + optimizer update on one batch that is already resident in HBM.  Batches come from the bit-exact
-MT19937 builder (np.random.seed(0) / random.seed(0) streams) and are generated before the timed region.
+gradients + optimizer update on one batch resident in HBM.  By default (--sampler device) every batch is ALSO drawn inside
+the timed region by the bit-exact MT19937 HIP sampler (negative sampling + oversampling, the reference's exact draws) on a
+side stream, one batch ahead of training; --sampler pre uses batches built on the host before timing.
 
 N > 1: data-parallel replicas, one process per GPU (torch.distributed, backend nccl = RCCL): every rank runs the
 gradient half on its own batch, the dense gradient tables are all-reduced (mean) over xGMI, every rank applies

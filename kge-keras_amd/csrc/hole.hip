@@ -23,11 +23,6 @@ namespace kge {
 constexpr int kHoleMaxD = 1024;
 constexpr float kEpsH = 1e-6f;
 
-struct HoleLds {  // per-wave LDS slices
-  float* u;   // [dpad]
-  float* w2;  // [2*d + 16]
-};
-
 __device__ __forceinline__ int hole_dpad(int d) { return (d + 3) & ~3; }
 __host__ __device__ __forceinline__ int hole_lds_floats(int d) { return ((d + 3) & ~3) + ((2 * d + 16 + 3) & ~3); }
 

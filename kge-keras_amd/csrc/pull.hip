@@ -1,24 +1,25 @@
-// "pull" gradient path of the training batch: no float atomics.
+// "pull" gradient path of the training batch: no float atomics.  (Generic-list variant; pull2.hip adds the relation-grouped
+// forward for pointwise losses and reuses the scan / pull / finish kernels of this file for the entity rows.)
 //
 // Same contract as the push path in train.hip (forward x2, loss, sparse gradients with duplicates summed;
 // reference: tests.py:63-89, KGEkeras/models.py:134-222, KGEkeras/utils.py:288-319), different dataflow:
 //
-//   hist_kernel     one int atomic per (triple, role): how many gradient contributions every table row receives
-//   scan_kernel     exclusive scans -> list offsets, chunking of long lists, partial-slab slots        (1 block)
+//   hist_kernel     one returning int atomic per (triple, role): the contribution's rank inside its destination row's list
+//                   (relation counters aggregated in LDS per block)
+//   scan_kernel     exclusive scans -> list offsets, chunking of long lists, partial-slab slots        (1 workgroup)
 //   emap_kernel     (row, chunk) of every extra chunk
 //   fwd_kernel      gather 3 rows, score, dL/dscore in registers (pointwise losses), loss partials    [HBM gather]
-//   fill_kernel     per (triple, role) one 16-byte list entry {other row a, other row b, coefficient} at the
-//                   destination row's cursor
+//   fill_kernel     atomic-free: per (triple, role) one 16-byte list entry {other row a, other row b, coefficient, t}
+//                   at  off[destination] + rank
 //   pull_kernel     one wave per (destination row, chunk of <= C entries): re-gathers the two OTHER rows of every
 //                   contribution, forms the gradient term in registers and sums; single-chunk rows add straight
 //                   into the dense gradient table, chunks of long lists (relations, hub entities) write a partial
 //                   row to a slab                                                                      [HBM gather]
-//   pull_finish     sums the slabs of multi-chunk rows in chunk order
+//   pull_finish     sums the slabs of multi-chunk rows in chunk order; leaves the counters zero for the next step
 //
 // Every destination row has exactly one writer, so the only non-determinism left is the order of a row's list
-// (cursor atomics).  Bytes moved per scored triple: forward 3 rows + backward 6 rows + 48 B of list entries,
-// against 3 rows + 3 atomic rows on the push path -- but gathers run at the cache/HBM rate (6-10 TB/s) while
-// float atomics are capped near 1.3 TB/s chip-wide (MI355X_MICROARCH.md, Global float atomics).
+// (rank atomics).  Gathers run at the cache/HBM rate (6-10 TB/s) while float atomics are capped near 1.3 TB/s chip-wide
+// (MI355X_MICROARCH.md, Global float atomics).
 #include "kge_internal.hpp"
 #include "pull.hpp"
 #include "dropout.hpp"

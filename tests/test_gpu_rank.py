@@ -198,3 +198,39 @@ def test_nations_end_to_end_fit_then_validate(datasets):
     assert h.history["loss"][-1] < h.history["loss"][0]
     assert after["mrr"] > before["mrr"] + 0.1 and after["mr"] < 4.0, (before, after)
     assert len(after) == 15
+
+
+def test_rank_yago310_shape_row_sharded(datasets):
+    """BASELINE config 5 shape: YAGO3-10 (N = 123 182 entities, 37 relations), DistMult d=200, the entity table cut into 8 row
+    shards as on an 8-GPU node; per-shard counts add up to the unsharded sweep and match the oracle on real test triples."""
+    from kge_keras_amd.models import DistMult
+    from kge_keras_amd.dist import shard_range
+    N, R, d = 123182, 37, 200
+    rs = np.random.RandomState(1234)
+    E0, R0 = O.glorot_uniform(N, d, rs), O.glorot_uniform(R, d, rs)
+    mdl = DistMult(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0 * 30, init_relations=R0 * 10)
+    Ef, Rf = (E0 * 30).astype(np.float32), (R0 * 10).astype(np.float32)
+    test = np.asarray(datasets["yago310_test"][:64], dtype=np.int32)
+    test[:, 0] %= N
+    test[:, 2] %= N
+    test[:, 1] %= R
+    fq = np.repeat(np.arange(len(test), dtype=np.int32), 2)
+    fi = rs.randint(0, N, 2 * len(test)).astype(np.int32)
+    keep = fi != np.repeat(test[:, 2], 2)
+    fq, fi = fq[keep], fi[keep]
+    full = mdl.rank_counts(test, 0, fq, fi).cpu().numpy()
+    acc = None
+    for r in range(8):
+        lo, hi = shard_range(N, r, 8)
+        acc = mdl.rank_counts(test, 0, fq, fi, cand_offset=lo, cand_rows=hi - lo, counts=acc)
+    assert np.array_equal(full, acc.cpu().numpy())
+    # oracle on the first queries
+    for i in range(8):
+        s, p, o = (int(v) for v in test[i])
+        sc = (Ef[s].astype(np.float64) * Rf[p]) @ Ef.astype(np.float64).T
+        keepm = np.ones(N, bool)
+        keepm[o] = False
+        keepm[fi[fq == i]] = False
+        ref = int(np.sum(sc[keepm] > sc[o]))
+        gap = np.min(np.abs(sc[keepm] - sc[o]))
+        assert full[i] == ref or gap < 1e-5 * np.abs(sc).max(), (i, full[i], ref)

@@ -312,3 +312,40 @@ def test_loss_functions_callable(name):
             loss_function_lookup(name)(t, f, 0.7, 3)
     with pytest.raises(KeyError):
         loss_function_lookup("nope")
+
+
+def test_wn18rr_complex400_train_step(datasets):
+    """BASELINE config 4 shape in training: WN18RR (N = 40 943, R = 11), ComplEx d=400 (rows of 800 floats -> the generic-list
+    pull variant with two float4 chunks per lane), real training triples, one Adam step against the oracle."""
+    from kge_keras_amd.models import ComplEx
+    from kge_keras_amd.sampler import NumpyStream, PythonStream, build_batch
+    N, R, d = 40943, 11, 400
+    rs = np.random.RandomState(7)
+    E0, R0 = O.glorot_uniform(N, 2 * d, rs) * 10, O.glorot_uniform(R, 2 * d, rs) * 3
+    batch = datasets["wn18rr_train"][:256]
+    pos, neg = build_batch(NumpyStream(1), PythonStream(1), batch, 20, N)
+    mdl = ComplEx(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0, loss_function="pointwize_logistic")
+    mdl.compile("adam")
+    L = float(mdl.train_step([pos, neg])["loss"].item())
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    Lo = O.train_step("ComplEx", Eo, Ro, O.AdamTF(), pos, neg, "pointwize_logistic", 1.0)
+    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+
+
+def test_edge_cases_single_row_and_skewed_batches():
+    """m = 1, one relation / one entity receiving every contribution (hub lists split into many chunks), odd widths."""
+    for model, d in (("DistMult", 32), ("TransE", 30), ("ComplEx", 6)):
+        kw = dict(norm=1, gamma=12) if model == "TransE" else {}
+        N, R = 9, 3
+        mdl, E0, R0, rs = _mk(model, N, R, d, loss_function="pointwize_logistic", **kw)
+        mdl.compile("sgd")
+        Eo, Ro, oo = E0.astype(np.float64), R0.astype(np.float64), O.SGDTF()
+        for pos, neg in ((np.array([[0, 0, 1]]), np.array([[2, 1, 3]])),
+                         (np.tile(np.array([[4, 2, 4]]), (1500, 1)), np.tile(np.array([[4, 2, 5]]), (700, 1)))):
+            L = float(mdl.train_step([pos, neg])["loss"].item())
+            Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+            assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (model, len(pos))
+            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=2 * TOL)
+            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=2 * TOL)
