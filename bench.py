@@ -213,7 +213,8 @@ def main():
         if world == 1:
             model.train_step([pos, neg])
         else:  # data-parallel: gradient half, all-reduce of the dense gradient tables over RCCL, optimizer half
-            D.dp_train_step(lambda: model.train_grads([pos, neg]), model.apply_grads, [model._gE, model._gR], model._loss)
+            # gradient tables and the loss word are one flat buffer: ONE all-reduce per step
+            D.dp_train_step(lambda: model.train_grads([pos, neg]), model.apply_grads, [model._gall], None)
         if args.sampler == "device":
             freed[i % 2].record(main_stream)
             produce(i + 2)
@@ -238,7 +239,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     model._raise_on_flag()
-    loss = float(model._loss.item())
+    loss = float(model._loss.item()) / world  # summed over ranks by the flat all-reduce
     s_ms, s_n = _lib.prof_read("sampler")
     i_ms, i_n = _lib.prof_read("index")
     assert int(dsamp.err.item()) == 0, "device sampler: rejection margin ran short"

@@ -270,17 +270,20 @@ class EmbeddingModel:
     # ------------------------------------------------------------------ training (tests.py:63-89,130-134)
     def compile(self, optimizer='adam', loss=None, **kw):
         self.optimizer = optimizer if isinstance(optimizer, _Optimizer) else _Optimizer(optimizer)
-        if self._gE is None:  # dense gradient accumulators (kept all-zero between steps by the optimizer sweep)
-            self._gE = torch.zeros_like(self.E)
-            self._gR = torch.zeros_like(self.Rel)
+        if self._gE is None:
+            # dense gradient accumulators (kept all-zero between steps by the optimizer sweep) and the loss word live in ONE
+            # flat buffer, so that data-parallel training needs a single all-reduce per step (kge_keras_amd.dist)
+            nE, nR = self.E.numel(), self.Rel.numel()
+            pad = (-(nE + nR)) % 4
+            self._gall = torch.zeros(nE + nR + pad + 4, dtype=torch.float32, device=self.device)
+            self._gE = self._gall[:nE].view_as(self.E)
+            self._gR = self._gall[nE:nE + nR].view_as(self.Rel)
+            self._loss = self._gall[nE + nR + pad:nE + nR + pad + 1]
         return self
 
     def _ensure_train_state(self, m_pos, m_neg):
         if self.optimizer is None:
             raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
-        if self._gE is None:
-            self._gE = torch.zeros_like(self.E)
-            self._gR = torch.zeros_like(self.Rel)
         if self.optimizer.kind == "adam" and self.optimizer.slots is None:
             self.optimizer.slots = tuple(torch.zeros_like(x) for x in (self.E, self.E, self.Rel, self.Rel))
         md, ld = self._model_desc(True), self._loss_desc()

@@ -23,6 +23,18 @@ def load_kg(path):
     return out
 
 
+def index_kg(*splits):
+    """Deterministic replacement for tests.py:102-117 (whose entity / relation ids come from enumerating Python sets of strings
+    and so change with PYTHONHASHSEED): ids are the ranks of the sorted strings over all given splits.
+    Returns (entity_map, relation_map, [int32 (n,3) array per split])."""
+    ents = sorted({x for sp in splits for (s, _, o) in sp for x in (s, o)})
+    rels = sorted({p for sp in splits for (_, p, _) in sp})
+    emap = {e: i for i, e in enumerate(ents)}
+    rmap = {r: i for i, r in enumerate(rels)}
+    arrs = [np.asarray([(emap[s], rmap[p], emap[o]) for s, p, o in sp], dtype=np.int32).reshape(-1, 3) for sp in splits]
+    return emap, rmap, arrs
+
+
 def generate_negative(kg, N, negative=2, check_kg=False, corrupt_head=True, corrupt_tail=True):
     """utils.py:114-121.  Consumes NumPy's *global* legacy stream exactly like the reference
     (all `negative*len(kg)` heads, then all tails) and returns the same (negative*len(kg), 3, 1) int64 array."""

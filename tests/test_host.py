@@ -304,3 +304,17 @@ def test_mt19937_jump_ahead_polynomial():
     poly = np.zeros(312, dtype=np.uint64)
     _lib.check(_lib.lib.kge_mt_jump_poly(5, poly.ctypes.data))
     assert int(poly[0]) == 32 and not poly[1:].any()   # x^5 mod phi = x^5
+
+
+def test_index_kg_matches_golden_id_arrays(golden, datasets, tmp_path):
+    """utils.index_kg (sorted-string ids) reproduces the id arrays the golden vectors were generated with."""
+    g = golden("misc")
+    rows = g["misc"]["load_kg_first"]
+    p = tmp_path / "kg.txt"
+    p.write_text("\n".join("\t".join(t) for t in rows) + "\n")
+    kg = U.load_kg(str(p))
+    emap, rmap, (arr,) = U.index_kg(kg)
+    assert arr.dtype == np.int32 and arr.shape == (len(rows), 3)
+    assert sorted(emap, key=emap.get) == sorted(emap) and sorted(rmap, key=rmap.get) == sorted(rmap)
+    for (s, p_, o), (a, b, c) in zip(rows, arr.tolist()):
+        assert emap[s] == a and rmap[p_] == b and emap[o] == c
