@@ -47,10 +47,11 @@ class DataGenerator:
 
 class DeviceDataGenerator:
     """Same batches as DataGenerator, built on the GPU: the training triples and the epoch permutation live in HBM, every
-    batch is produced by kge_build_batch_device (bit-exact MT19937 on the device) and never touches the host.  The two
-    generator states are adopted from NumPy's / Python's global generators at construction and handed back by
-    `release_global()`; the epoch shuffle (sequential Fisher-Yates, tests.py:50-53) runs on the host twin of the
-    NumPy state."""
+    batch is produced by kge_build_batch_device (bit-exact MT19937 on the device) and never touches the host.  Like the
+    reference's generator it draws from NumPy's / Python's GLOBAL generators: their states are uploaded when an epoch's
+    iteration starts (`batches`) and written back when it ends, so `np.random.seed(a); random.seed(b)` + fit() consumes
+    the global streams exactly like the host generator does.  The epoch shuffle (sequential Fisher-Yates, tests.py:50-53)
+    runs on the host."""
 
     def __init__(self, kg, ns=10, batch_size=32, shuffle=True, device=None):
         import torch
@@ -73,22 +74,62 @@ class DeviceDataGenerator:
         import torch
         index = np.arange(self.n, dtype=np.int64)
         if self.shuffle:
-            nps, _ = self.sampler.to_streams()
-            nps.shuffle(index)
-            self.sampler.load_streams(np_stream=nps)
+            st = NumpyStream().adopt_global()
+            st.shuffle(index)  # np.random.shuffle (tests.py:53)
+            st.release_global()
         self.index = torch.from_numpy(index).to(self.device)
 
-    def __getitem__(self, i):
-        sl = self.index[i * self.batch_size:(i + 1) * self.batch_size]
-        batch = self.kg.index_select(0, sl).contiguous()
-        pos, neg = self.sampler.build_batch(batch, self.ns, self.num_e)
-        return [pos, neg], None
+    def _upload_global(self):
+        self.sampler.load_streams(NumpyStream().adopt_global(), PythonStream().adopt_global())
 
     def release_global(self):
         """Write the generator states back into np.random / random (where the reference's generator would stand)."""
         nps, pys = self.sampler.to_streams()
         nps.release_global()
         pys.release_global()
+
+    def __getitem__(self, i):
+        """One batch, synchronously (global states up, batch, global states down): the compatible slow path."""
+        self._upload_global()
+        sl = self.index[i * self.batch_size:(i + 1) * self.batch_size]
+        batch = self.kg.index_select(0, sl).contiguous()
+        pos, neg = self.sampler.build_batch(batch, self.ns, self.num_e)
+        self.release_global()
+        return [pos, neg], None
+
+    def batches(self, order):
+        """Iterate the batches `order` with the sampler running on a side stream one batch ahead of the consumer
+        (double-buffered in HBM, event fork/join): `fit` uses this, so drawing a batch overlaps the previous train step.
+        Same draws, in the same order, as calling self[i] for i in order."""
+        import torch
+        main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+        m = self.batch_size * self.ns
+        bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device=self.device) for _ in range(2)) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+        order = list(order)
+        self._upload_global()
+        side.wait_stream(main)
+
+        def produce(k):
+            with torch.cuda.stream(side):
+                side.wait_event(freed[k % 2])
+                i = order[k]
+                sl = self.index[i * self.batch_size:(i + 1) * self.batch_size]
+                batch = self.kg.index_select(0, sl).contiguous()
+                self.sampler.build_batch(batch, self.ns, self.num_e, *bufs[k % 2])
+                ready[k % 2].record(side)
+
+        for k in range(min(2, len(order))):
+            produce(k)
+        for k in range(len(order)):
+            main.wait_event(ready[k % 2])
+            yield list(bufs[k % 2])
+            freed[k % 2].record(main)
+            if k + 2 < len(order):
+                produce(k + 2)
+        main.wait_stream(side)
+        self.release_global()
 
 
 def build_model(hp):

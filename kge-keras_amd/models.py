@@ -382,8 +382,8 @@ class EmbeddingModel:
             if shuffle:
                 random.shuffle(order)  # Keras shuffles the batch order of a Sequence with Python's `random`
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
-            for i in order:
-                X, _y = x[i]
+            it = x.batches(order) if hasattr(x, "batches") else (x[i][0] for i in order)  # device generators prefetch on a side stream
+            for X in it:
                 tot += self.train_step(X)["loss"].double()
             logs = {"loss": float(tot.item()) / max(1, len(order))}
             self._raise_on_flag()
