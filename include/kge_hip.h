@@ -48,7 +48,8 @@ typedef enum {
   KGE_PAIRWIZE_HINGE = 2,     /* utils.py:300-305 */
   KGE_PAIRWIZE_LOGISTIC = 3,  /* utils.py:307-312 */
   KGE_POINTWIZE_SQUARE = 4,   /* utils.py:294-295 */
-  KGE_PAIRWIZE_SQUARE = 5     /* utils.py:314-319 */
+  KGE_PAIRWIZE_SQUARE = 5,    /* utils.py:314-319 */
+  KGE_POINTWIZE_CROSS_ENTROPY = 6 /* utils.py:297-298 (Keras binary_crossentropy on the raw scores) */
 } kge_loss;
 
 typedef enum { KGE_OPT_SGD = 0, KGE_OPT_ADAM_TF = 1 } kge_opt;
@@ -191,6 +192,12 @@ int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* 
 int64_t kge_loss_workspace_bytes(int64_t m_true, int64_t m_false);
 int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,
                    float* loss_out, float* d_true, float* d_false, void* workspace, int64_t workspace_bytes, kge_stream_t stream);
+
+/* reduce_mean=False of the pairwize losses (utils.py:303-305,310-312,317-319): the raw pair tensor of the NumPy/TF
+ * broadcast of false.reshape(-1, ns) against true: out is (m_false/ns, max(ns, m_true)) row-major, out_elems its size.
+ * KGE_ESHAPE where the reference would raise a broadcast error; KGE_EINVAL for pointwize losses (they always reduce). */
+int kge_loss_pairs(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,
+                   float* out, int64_t out_elems, kge_stream_t stream);
 
 /* Gradient path of kge_train_step / kge_train_grads: 0 (default) = "pull": per-destination-row gather-reduce, no float
  * atomics; 1 = "push": fused forward + no-return fp32 global atomics.  Same results to fp32 rounding. */

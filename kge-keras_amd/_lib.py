@@ -14,7 +14,7 @@ lib = C.CDLL(LIB_PATH)
 KGE_OK, KGE_EINVAL, KGE_ESHAPE, KGE_EHIP, KGE_EWORKSPACE, KGE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4}
 LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, "pairwize_logistic": 3,
-            "pointwize_square_loss": 4, "pairwize_square_loss": 5}
+            "pointwize_square_loss": 4, "pairwize_square_loss": 5, "pointwize_cross_entropy": 6}
 OPT_IDS = {"sgd": 0, "adam": 1}
 ACT_IDS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "softsign": 5, "elu": 6, "selu": 7, "exponential": 8}
 MT_STATE_BYTES = 2504
@@ -61,6 +61,7 @@ SIGNATURES = {
     "kge_rank_sweep_q": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _I32, _P, _I64, _P]),
     "kge_loss_workspace_bytes": (_I64, [_I64, _I64]),
     "kge_loss_value": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P]),
+    "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),

@@ -131,6 +131,7 @@ int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, 
               int64_t, hipStream_t);
 
 int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
+int loss_pairs(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, int64_t, hipStream_t);
 int64_t rank_workspace_bytes(const kge_model_desc*, int64_t);
 int conve_sizes(const kge_model_desc*, int64_t*, int64_t*);
 int64_t conve_workspace_bytes(const kge_model_desc*, int64_t, int64_t);
@@ -331,6 +332,13 @@ int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_
   if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_value: empty score vector (reduce_mean of nothing)");
   return loss_value(ld, true_scores, m_true, false_scores, m_false, loss_out, d_true, d_false, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+int kge_loss_pairs(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,
+                   float* out, int64_t out_elems, kge_stream_t stream) {
+  if (!ld || !true_scores || !false_scores || !out) return fail(KGE_EINVAL, "kge_loss_pairs: null pointer");
+  if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_pairs: empty score vector");
+  return loss_pairs(ld, true_scores, m_true, false_scores, m_false, out, out_elems, static_cast<hipStream_t>(stream));
 }
 
 static int check_conve(const kge_model_desc* md, const char* who) {

@@ -21,7 +21,6 @@
 namespace kge {
 
 constexpr int kHoleMaxD = 1024;
-constexpr float kEpsH = 1e-6f;
 
 __device__ __forceinline__ int hole_dpad(int d) { return (d + 3) & ~3; }
 __host__ __device__ __forceinline__ int hole_lds_floats(int d) { return ((d + 3) & ~3) + ((2 * d + 16 + 3) & ~3); }
@@ -80,24 +79,6 @@ __device__ __forceinline__ void ccorr4(const float* __restrict__ u, const float*
   out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
 }
 
-template <int LOSS>
-__device__ __forceinline__ void pointwise_h(float score, bool is_pos, float margin, float inv, float& g, float& l) {
-  if (LOSS == KGE_POINTWIZE_HINGE) {
-    const float a = is_pos ? margin - score : margin + score;
-    const bool on = a > 0.f;
-    l = on ? a * inv : 0.f;
-    g = on ? (is_pos ? -inv : inv) : 0.f;
-  } else if (LOSS == KGE_POINTWIZE_LOGISTIC) {
-    const float e = expf(is_pos ? -score : score);
-    const float den = kEpsH + 1.f + e;
-    l = logf(den) * inv;
-    g = (is_pos ? -e : e) / den * inv;
-  } else {
-    const float a = is_pos ? margin - score : margin + score;
-    l = a * a * inv;
-    g = (is_pos ? -2.f : 2.f) * a * inv;
-  }
-}
 
 // Forward.  LOSS >= 0: pointwise loss fused; LOSS < 0: scores only (predict, pairwise two-phase path).
 // Dynamic LDS: 4 waves x hole_lds_floats(d) floats.
@@ -149,7 +130,7 @@ __global__ __launch_bounds__(256) void hole_fwd_kernel(const float* __restrict__
       if (scores) scores[t] = score;
       if (LOSS >= 0) {
         float g = 0.f, l = 0.f;
-        if (ok) pointwise_h<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+        if (ok) pointwise_term<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
         lsum += l;
         coef[t] = g;
       }
@@ -305,6 +286,7 @@ int hole_forward(const kge_model_desc* md, int loss, float margin, const float* 
     case KGE_POINTWIZE_HINGE: KGE_HF2(KGE_POINTWIZE_HINGE); break;
     case KGE_POINTWIZE_LOGISTIC: KGE_HF2(KGE_POINTWIZE_LOGISTIC); break;
     case KGE_POINTWIZE_SQUARE: KGE_HF2(KGE_POINTWIZE_SQUARE); break;
+    case KGE_POINTWIZE_CROSS_ENTROPY: KGE_HF2(KGE_POINTWIZE_CROSS_ENTROPY); break;
     default: KGE_HF2(-1); break;
   }
 #undef KGE_HF2

@@ -59,4 +59,34 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats 
   return r;
 }
 
+// dL/dscore (g) and the loss term (l) of one row for the pointwise losses (KGEkeras/utils.py:288-298).
+// `inv` = 1/len(true) or 1/len(false) (reduce_mean).  [TF] relu'(0) = 0; clip_by_value passes the gradient on [lo, hi].
+constexpr float kLossEps = 1e-6f;  // KGEkeras/utils.py:12
+constexpr float kBceEps = 1e-7f;   // keras.backend.epsilon(): binary_crossentropy clips to [eps, 1-eps] and adds eps in the log
+template <int LOSS>
+__device__ __forceinline__ void pointwise_term(float score, bool is_pos, float margin, float inv, float& g, float& l) {
+  if (LOSS == KGE_POINTWIZE_HINGE) {
+    const float a = is_pos ? margin - score : margin + score;
+    const bool on = a > 0.f;
+    l = on ? a * inv : 0.f;
+    g = on ? (is_pos ? -inv : inv) : 0.f;
+  } else if (LOSS == KGE_POINTWIZE_LOGISTIC) {
+    const float e = expf(is_pos ? -score : score);
+    const float den = kLossEps + 1.f + e;
+    l = logf(den) * inv;
+    g = (is_pos ? -e : e) / den * inv;
+  } else if (LOSS == KGE_POINTWIZE_CROSS_ENTROPY) {  // utils.py:297-298: BCE(1, true) + BCE(0, false) on raw scores
+    const float hi = 1.f - kBceEps;
+    const bool in = score >= kBceEps && score <= hi;
+    const float c = fminf(fmaxf(score, kBceEps), hi);
+    const float a = is_pos ? c + kBceEps : 1.f - c + kBceEps;
+    l = -logf(a) * inv;
+    g = in ? (is_pos ? -inv : inv) / a : 0.f;
+  } else {  // KGE_POINTWIZE_SQUARE
+    const float a = is_pos ? margin - score : margin + score;
+    l = a * a * inv;
+    g = (is_pos ? -2.f : 2.f) * a * inv;
+  }
+}
+
 }  // namespace kge

@@ -26,28 +26,9 @@
 
 namespace kge {
 
-constexpr float kEpsP = 1e-6f;  // KGEkeras/utils.py:12
 
 
 
-template <int LOSS>
-__device__ __forceinline__ void pointwise_p(float score, bool is_pos, float margin, float inv, float& g, float& l) {
-  if (LOSS == KGE_POINTWIZE_HINGE) {
-    const float a = is_pos ? margin - score : margin + score;
-    const bool on = a > 0.f;
-    l = on ? a * inv : 0.f;
-    g = on ? (is_pos ? -inv : inv) : 0.f;
-  } else if (LOSS == KGE_POINTWIZE_LOGISTIC) {
-    const float e = expf(is_pos ? -score : score);
-    const float den = kEpsP + 1.f + e;
-    l = logf(den) * inv;
-    g = (is_pos ? -e : e) / den * inv;
-  } else {
-    const float a = is_pos ? margin - score : margin + score;
-    l = a * a * inv;
-    g = (is_pos ? -2.f : 2.f) * a * inv;
-  }
-}
 
 template <int VEC> struct V;
 template <> struct V<4> {
@@ -150,7 +131,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, c
       if (scores) scores[t] = score;
       if (LOSS >= 0) {
         float g = 0.f, l = 0.f;
-        if (ok) pointwise_p<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+        if (ok) pointwise_term<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
         lsum += l;
         if (MODEL == KGE_TRANSE) {
           g = gamma > 0.f ? -g : g;                            // d score / d dist
@@ -543,6 +524,7 @@ static void launch_fwd_loss(int loss, int G, int grid, hipStream_t st, const flo
     case KGE_POINTWIZE_HINGE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_HINGE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
     case KGE_POINTWIZE_LOGISTIC: launch_fwd<MODEL, NORM, KGE_POINTWIZE_LOGISTIC, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
     case KGE_POINTWIZE_SQUARE: launch_fwd<MODEL, NORM, KGE_POINTWIZE_SQUARE, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
+    case KGE_POINTWIZE_CROSS_ENTROPY: launch_fwd<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
     default: launch_fwd<MODEL, NORM, -1, VEC>(G, grid, st, E, Rel, pos, m_pos, neg, m_neg, md, nchunk, margin, coef, scores, partials, err, seed); break;
   }
 }

@@ -20,7 +20,6 @@ namespace kge {
 constexpr int kRelMax = 4096;   // relations handled by the LDS histogram / single-workgroup plan
 constexpr int kRelChunk = 64;   // triples per forward work unit
 constexpr int kRelBlockTriples = 1024;
-constexpr float kEps2 = 1e-6f;
 
 struct Plan2 {
   // relation side
@@ -147,24 +146,6 @@ __global__ __launch_bounds__(256) void ent_fill_kernel(const int32_t* __restrict
   entries[off[o] + erank[n + t]] = make_int4(p | (int)0x80000000, s, cb, (int)t);
 }
 
-template <int LOSS>
-__device__ __forceinline__ void pointwise2(float score, bool is_pos, float margin, float inv, float& g, float& l) {
-  if (LOSS == KGE_POINTWIZE_HINGE) {
-    const float a = is_pos ? margin - score : margin + score;
-    const bool on = a > 0.f;
-    l = on ? a * inv : 0.f;
-    g = on ? (is_pos ? -inv : inv) : 0.f;
-  } else if (LOSS == KGE_POINTWIZE_LOGISTIC) {
-    const float e = expf(is_pos ? -score : score);
-    const float den = kEps2 + 1.f + e;
-    l = logf(den) * inv;
-    g = (is_pos ? -e : e) / den * inv;
-  } else {
-    const float a = is_pos ? margin - score : margin + score;
-    l = a * a * inv;
-    g = (is_pos ? -2.f : 2.f) * a * inv;
-  }
-}
 
 __device__ __forceinline__ float4 f4(float x) { return make_float4(x, x, x, x); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -256,7 +237,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
         score = gamma > 0.f ? gamma - dist : dist;
       }
       float g, l;
-      pointwise2<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+      pointwise_term<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
       if (MODEL == KGE_TRANSE) {
         g = gamma > 0.f ? -g : g;
         if (NORM == 2) g = dist > 0.f ? g / dist : 0.f;
@@ -352,7 +333,9 @@ int pull_chunk();
 
 bool pull2_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
   if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX) return false;
-  if (ld->loss != KGE_POINTWIZE_HINGE && ld->loss != KGE_POINTWIZE_LOGISTIC && ld->loss != KGE_POINTWIZE_SQUARE) return false;
+  if (ld->loss != KGE_POINTWIZE_HINGE && ld->loss != KGE_POINTWIZE_LOGISTIC && ld->loss != KGE_POINTWIZE_SQUARE &&
+      ld->loss != KGE_POINTWIZE_CROSS_ENTROPY)
+    return false;
   if (md->num_relations > kRelMax) return false;
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   return width % 4 == 0 && md->d_e % 4 == 0 && width / 4 <= 64;
@@ -427,7 +410,8 @@ static void launch_fwd_rel_loss(int loss, int nv, bool drop, int grid, hipStream
                                 float* partials, uint64_t seed) {
   if (loss == KGE_POINTWIZE_HINGE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
   else if (loss == KGE_POINTWIZE_LOGISTIC) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
-  else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
+  else if (loss == KGE_POINTWIZE_SQUARE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
+  else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
 }
 
 // `side` may be null (then everything runs on `st`).

@@ -15,28 +15,9 @@
 
 namespace kge {
 
-constexpr float kEps = 1e-6f;  // KGEkeras/utils.py:12
 
 // dL/dscore and the loss term of one row for the pointwise losses (utils.py:288-295).
 // `inv` = 1/len(true) or 1/len(false) (reduce_mean).  [TF] relu'(0) = 0.
-template <int LOSS>
-__device__ __forceinline__ void pointwise(float score, bool is_pos, float margin, float inv, float& g, float& l) {
-  if (LOSS == KGE_POINTWIZE_HINGE) {
-    const float a = is_pos ? margin - score : margin + score;
-    const bool on = a > 0.f;
-    l = on ? a * inv : 0.f;
-    g = on ? (is_pos ? -inv : inv) : 0.f;
-  } else if (LOSS == KGE_POINTWIZE_LOGISTIC) {
-    const float e = expf(is_pos ? -score : score);
-    const float den = kEps + 1.f + e;
-    l = logf(den) * inv;
-    g = (is_pos ? -e : e) / den * inv;
-  } else {  // KGE_POINTWIZE_SQUARE
-    const float a = is_pos ? margin - score : margin + score;
-    l = a * a * inv;
-    g = (is_pos ? -2.f : 2.f) * a * inv;
-  }
-}
 
 // LOSS < 0: dL/dscore comes from gbuf (two-phase pairwise path) and no loss term is produced here.
 template <int MODEL, int NORM, int LOSS, int G, bool DROP>
@@ -90,7 +71,7 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
       score = gamma > 0.f ? gamma - dist : dist;
     }
     float g, l = 0.f;
-    if (LOSS >= 0) pointwise<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+    if (LOSS >= 0) pointwise_term<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
     else g = gbuf[t];
     if (!ok) { g = 0.f; l = 0.f; score = __builtin_nanf(""); }
     if (lane == 0) {
@@ -152,7 +133,7 @@ __device__ __forceinline__ void pair_term(float z, float margin, float& val, flo
     val = y > 0.f ? y : 0.f;
     dz = y > 0.f ? 1.f : 0.f;
   } else if (LOSS == KGE_PAIRWIZE_LOGISTIC) {
-    const float e = expf(z), den = kEps + 1.f + e;
+    const float e = expf(z), den = kLossEps + 1.f + e;
     val = logf(den);
     dz = e / den;
   } else {
@@ -357,15 +338,101 @@ static int push_by_model(int G, const kge_model_desc* md, const kge_loss_desc* l
   }
 }
 
+// Column-aligned broadcast: false.reshape(-1, ns) against true of length ns > 1 (utils.py:301,308,315):
+// tmp[i][j] = phi(F[i][j] - true_j), mean over the m_f entries.  SIDE 0: one thread per false element (g_f, loss partials);
+// SIDE 1: one thread per column j walks the rows in order (g_t[j] = -sum_i dz / m_f; fixed summation order).
+template <int LOSS, int SIDE>
+__global__ __launch_bounds__(256) void pairwise_columns_kernel(const float* __restrict__ tscore, int64_t ns, const float* __restrict__ fscore,
+                                                                int64_t m_f, float margin, float* __restrict__ g_t,
+                                                                float* __restrict__ g_f, float* __restrict__ loss_partials) {
+  __shared__ float red[16];
+  const float inv = 1.f / (float)m_f;
+  if (SIDE == 0) {
+    float lsum = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < m_f; k += (int64_t)gridDim.x * 256) {
+      float val, dz;
+      pair_term<LOSS>(fscore[k] - tscore[k % ns], margin, val, dz);
+      g_f[k] = dz * inv;
+      lsum += val * inv;
+    }
+    const float b = block_sum(lsum, red);
+    if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
+  } else {
+    const int64_t rows = m_f / ns;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < ns; j += (int64_t)gridDim.x * 256) {
+      const float tj = tscore[j];
+      float gs = 0.f;
+      for (int64_t i = 0; i < rows; ++i) {
+        float val, dz;
+        pair_term<LOSS>(fscore[i * ns + j] - tj, margin, val, dz);
+        gs += dz;
+      }
+      g_t[j] = -gs * inv;
+    }
+  }
+}
+
+// NumPy/TF broadcast of false.reshape(-1, ns) (rows, ns) against true (m_t,):
+//   ns == 1 or m_t == 1 -> all pairs;   ns == m_t -> column aligned;   anything else is a broadcast error in the reference.
+static int pairwise_shape(const kge_loss_desc* ld, int64_t m_t, int64_t m_f) {
+  if (ld->negative_samples < 1 || m_f % ld->negative_samples)
+    return fail(KGE_ESHAPE, "pairwize loss: len(false)=%lld is not divisible by negative_samples=%d", (long long)m_f, ld->negative_samples);
+  if (!(ld->negative_samples == 1 || m_t == 1 || ld->negative_samples == m_t))
+    return fail(KGE_ESHAPE, "pairwize loss: (%lld,%d) does not broadcast against (%lld,)", (long long)(m_f / ld->negative_samples),
+                ld->negative_samples, (long long)m_t);
+  return KGE_OK;
+}
+
 template <int LOSS>
-static int launch_pairwise(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float margin, float* g_t, float* g_f,
-                           float* partials, hipStream_t st, int* nb) {
+static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int64_t m_f, int64_t ns, float margin, float* g_t, float* g_f,
+                             float* partials, hipStream_t st, int* nb) {
   const int gf = (int)std::min<int64_t>(cdiv(m_f, 256), kMaxBlocks);
   const int gt = (int)std::min<int64_t>(cdiv(m_t, 256), kMaxBlocks);
   *nb = gf;
   ProfScope prof(KGE_PROF_PAIRWISE, st);
-  hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 0>), dim3(gf), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
-  hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 1>), dim3(gt), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
+  if (ns == 1 || m_t == 1) {
+    hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 0>), dim3(gf), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
+    hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 1>), dim3(gt), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
+  } else {
+    hipLaunchKernelGGL((pairwise_columns_kernel<LOSS, 0>), dim3(gf), dim3(256), 0, st, ts, ns, fs, m_f, margin, g_t, g_f, partials);
+    hipLaunchKernelGGL((pairwise_columns_kernel<LOSS, 1>), dim3(gt), dim3(256), 0, st, ts, ns, fs, m_f, margin, g_t, g_f, partials);
+  }
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+static int launch_pairwise(const kge_loss_desc* ld, const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* g_t, float* g_f,
+                           float* partials, hipStream_t st, int* nb) {
+  const int64_t ns = ld->negative_samples;
+  if (ld->loss == KGE_PAIRWIZE_HINGE) return launch_pairwise_t<KGE_PAIRWIZE_HINGE>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, st, nb);
+  if (ld->loss == KGE_PAIRWIZE_LOGISTIC) return launch_pairwise_t<KGE_PAIRWIZE_LOGISTIC>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, st, nb);
+  return launch_pairwise_t<KGE_PAIRWIZE_SQUARE>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, st, nb);
+}
+
+// reduce_mean=False of the pairwize losses (utils.py:303-305,310-312,317-319): the raw (rows, cols) pair tensor of the
+// broadcast, rows = len(false)/ns, cols = max(ns, len(true)).
+template <int LOSS>
+__global__ __launch_bounds__(256) void pair_tensor_kernel(const float* __restrict__ ts, int64_t m_t, const float* __restrict__ fs, int64_t ns,
+                                                           int64_t rows, int64_t cols, float margin, float* __restrict__ out) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < rows * cols; k += (int64_t)gridDim.x * 256) {
+    const int64_t i = k / cols, j = k - i * cols;
+    float val, dz;
+    pair_term<LOSS>(fs[i * ns + (ns == 1 ? 0 : j)] - ts[m_t == 1 ? 0 : j], margin, val, dz);
+    out[k] = val;
+  }
+}
+
+int loss_pairs(const kge_loss_desc* ld, const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* out, int64_t out_elems, hipStream_t st) {
+  if (ld->loss != KGE_PAIRWIZE_HINGE && ld->loss != KGE_PAIRWIZE_LOGISTIC && ld->loss != KGE_PAIRWIZE_SQUARE)
+    return fail(KGE_EINVAL, "kge_loss_pairs: loss %d is not a pairwize loss (the pointwize ones always reduce)", ld->loss);
+  if (int rc = pairwise_shape(ld, m_t, m_f)) return rc;
+  const int64_t ns = ld->negative_samples, rows = m_f / ns, cols = std::max<int64_t>(ns, m_t);
+  if (out_elems != rows * cols) return fail(KGE_ESHAPE, "kge_loss_pairs: output holds %lld floats, the pair tensor is (%lld, %lld)", (long long)out_elems, (long long)rows, (long long)cols);
+  const int nb = (int)std::min<int64_t>(cdiv(rows * cols, 256), kMaxBlocks);
+  ProfScope prof(KGE_PROF_PAIRWISE, st);
+  if (ld->loss == KGE_PAIRWIZE_HINGE) hipLaunchKernelGGL((pair_tensor_kernel<KGE_PAIRWIZE_HINGE>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, ns, rows, cols, ld->margin, out);
+  else if (ld->loss == KGE_PAIRWIZE_LOGISTIC) hipLaunchKernelGGL((pair_tensor_kernel<KGE_PAIRWIZE_LOGISTIC>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, ns, rows, cols, ld->margin, out);
+  else hipLaunchKernelGGL((pair_tensor_kernel<KGE_PAIRWIZE_SQUARE>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, ns, rows, cols, ld->margin, out);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
@@ -382,7 +449,7 @@ __global__ __launch_bounds__(256) void pointwise_loss_kernel(const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m_t + m_f; i += (int64_t)gridDim.x * 256) {
     const bool is_pos = i < m_t;
     float g, l;
-    pointwise<LOSS>(is_pos ? ts[i] : fs[i - m_t], is_pos, margin, is_pos ? inv_t : inv_f, g, l);
+    pointwise_term<LOSS>(is_pos ? ts[i] : fs[i - m_t], is_pos, margin, is_pos ? inv_t : inv_f, g, l);
     lsum += l;
     if (is_pos) { if (g_t) g_t[i] = g; } else if (g_f) g_f[i - m_t] = g;
   }
@@ -397,23 +464,16 @@ int loss_value(const kge_loss_desc* ld, const float* ts, int64_t m_t, const floa
   int nb = 0;
   const bool pairwise = ld->loss == KGE_PAIRWIZE_HINGE || ld->loss == KGE_PAIRWIZE_LOGISTIC || ld->loss == KGE_PAIRWIZE_SQUARE;
   if (pairwise) {
-    if (ld->negative_samples < 1 || m_f % ld->negative_samples)
-      return fail(KGE_ESHAPE, "pairwize loss: len(false)=%lld is not divisible by negative_samples=%d", (long long)m_f, ld->negative_samples);
-    if (!(ld->negative_samples == 1 || m_t == 1))
-      return fail(ld->negative_samples == m_t ? KGE_EUNSUPPORTED : KGE_ESHAPE, "pairwize loss: (%lld,%d) against (%lld,) is not the all-pairs broadcast",
-                  (long long)(m_f / ld->negative_samples), ld->negative_samples, (long long)m_t);
+    if (int rc = pairwise_shape(ld, m_t, m_f)) return rc;
     float* gt = g_t ? g_t : ws.gbuf;
     float* gf = g_f ? g_f : ws.gbuf + m_t;
-    int rc;
-    if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(ts, m_t, fs, m_f, ld->margin, gt, gf, ws.loss_partials, st, &nb);
-    else if (ld->loss == KGE_PAIRWIZE_LOGISTIC) rc = launch_pairwise<KGE_PAIRWIZE_LOGISTIC>(ts, m_t, fs, m_f, ld->margin, gt, gf, ws.loss_partials, st, &nb);
-    else rc = launch_pairwise<KGE_PAIRWIZE_SQUARE>(ts, m_t, fs, m_f, ld->margin, gt, gf, ws.loss_partials, st, &nb);
-    if (rc) return rc;
+    if (int rc = launch_pairwise(ld, ts, m_t, fs, m_f, gt, gf, ws.loss_partials, st, &nb)) return rc;
   } else {
     nb = (int)std::min<int64_t>(cdiv(m_t + m_f, 256), kMaxBlocks);
     if (ld->loss == KGE_POINTWIZE_HINGE) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_HINGE>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
     else if (ld->loss == KGE_POINTWIZE_LOGISTIC) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_LOGISTIC>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
     else if (ld->loss == KGE_POINTWIZE_SQUARE) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_SQUARE>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
+    else if (ld->loss == KGE_POINTWIZE_CROSS_ENTROPY) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_CROSS_ENTROPY>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
     else return fail(KGE_EINVAL, "unknown loss %d", ld->loss);
   }
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
@@ -428,16 +488,9 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   const bool pairwise = ld->loss == KGE_PAIRWIZE_HINGE || ld->loss == KGE_PAIRWIZE_LOGISTIC || ld->loss == KGE_PAIRWIZE_SQUARE;
   if (pairwise) {
-    // numpy/TF broadcast of false.reshape(-1, ns) against true (m_t,): all-pairs iff ns == 1 or m_t == 1
-    if (ld->negative_samples < 1 || m_neg % ld->negative_samples)
-      return fail(KGE_ESHAPE, "pairwize loss: len(false)=%lld is not divisible by negative_samples=%d", (long long)m_neg, ld->negative_samples);
-    if (!(ld->negative_samples == 1 || m_pos == 1)) {
-      if (ld->negative_samples == m_pos)
-        return fail(KGE_EUNSUPPORTED, "pairwize loss with negative_samples == len(true) (column-aligned broadcast) is not built yet");
-      return fail(KGE_ESHAPE, "pairwize loss: (%lld,%d) does not broadcast against (%lld,)", (long long)(m_neg / ld->negative_samples),
-                  ld->negative_samples, (long long)m_pos);
-    }
-  } else if (ld->loss != KGE_POINTWIZE_HINGE && ld->loss != KGE_POINTWIZE_LOGISTIC && ld->loss != KGE_POINTWIZE_SQUARE) {
+    if (int rc = pairwise_shape(ld, m_pos, m_neg)) return rc;
+  } else if (ld->loss != KGE_POINTWIZE_HINGE && ld->loss != KGE_POINTWIZE_LOGISTIC && ld->loss != KGE_POINTWIZE_SQUARE &&
+             ld->loss != KGE_POINTWIZE_CROSS_ENTROPY) {
     return fail(KGE_EINVAL, "unknown loss %d", ld->loss);
   }
   int nb = 0;
@@ -463,11 +516,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     if (int rc = pull_forward(md, pairwise ? -1 : ld->loss, ld->margin, E, Rel, pos, m_pos, neg, m_neg, plan, sc, ws.loss_partials, &nb, err, seed, st)) return rc;
     if (ss) KGE_HIP_TRY(hipStreamWaitEvent(st, ss->join, 0));
     if (pairwise) {
-      int rc;
-      if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
-      else if (ld->loss == KGE_PAIRWIZE_LOGISTIC) rc = launch_pairwise<KGE_PAIRWIZE_LOGISTIC>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
-      else rc = launch_pairwise<KGE_PAIRWIZE_SQUARE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb);
-      if (rc) return rc;
+      if (int rc = launch_pairwise(ld, sc, m_pos, sc + m_pos, m_neg, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb)) return rc;
     }
     if (int rc = pull_backward(md, E, Rel, gE, gR, pos, m_pos, neg, m_neg, plan, pairwise, sc, seed, st)) return rc;
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
@@ -488,6 +537,9 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     case KGE_POINTWIZE_SQUARE:
       if (int rc = push_by_model<KGE_POINTWIZE_SQUARE>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb, seed)) return rc;
       break;
+    case KGE_POINTWIZE_CROSS_ENTROPY:
+      if (int rc = push_by_model<KGE_POINTWIZE_CROSS_ENTROPY>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, nullptr, scores_out, ws.loss_partials, err, st, &nb, seed)) return rc;
+      break;
     case KGE_PAIRWIZE_HINGE:
     case KGE_PAIRWIZE_LOGISTIC:
     case KGE_PAIRWIZE_SQUARE: {
@@ -497,10 +549,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
       if (int rc = score_dispatch(md, E, Rel, neg, m_neg, sc + m_pos, err, st)) return rc;
       // phase 2: dL/dscore for every row + loss
       int rc;
-      if (ld->loss == KGE_PAIRWIZE_HINGE) rc = launch_pairwise<KGE_PAIRWIZE_HINGE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb);
-      else if (ld->loss == KGE_PAIRWIZE_LOGISTIC) rc = launch_pairwise<KGE_PAIRWIZE_LOGISTIC>(sc, m_pos, sc + m_pos, m_neg, ld->margin, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb);
-      else rc = launch_pairwise<KGE_PAIRWIZE_SQUARE>(sc, m_pos, sc + m_pos, m_neg, ld->margin, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb);
-      if (rc) return rc;
+      if ((rc = launch_pairwise(ld, sc, m_pos, sc + m_pos, m_neg, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb))) return rc;
       // phase 3: gradient rows
       int nb2 = 0;
       if ((rc = push_by_model<-1>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, ws.gbuf, nullptr, nullptr, err, st, &nb2, seed))) return rc;

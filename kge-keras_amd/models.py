@@ -87,8 +87,6 @@ def loss_value(name, true, false, margin=1, negative_samples=1, return_grads=Fal
     """loss_function_lookup(name)(true, false, margin, negative_samples) of the reference (utils.py:288-319) on the GPU:
     a 0-d device tensor (and, with return_grads, d loss/d true and d loss/d false)."""
     if name not in LOSS_IDS:
-        if name == "pointwize_cross_entropy":
-            raise NotImplementedError("pointwize_cross_entropy (utils.py:297-298) is not on the built path")
         raise KeyError(name)
     dev = _device()
     t = torch.as_tensor(true, dtype=torch.float32, device=dev).reshape(-1).contiguous()
@@ -103,6 +101,21 @@ def loss_value(name, true, false, margin=1, negative_samples=1, return_grads=Fal
                              gt.data_ptr() if return_grads else None, gf.data_ptr() if return_grads else None,
                              ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
     return (out[0], gt, gf) if return_grads else out[0]
+
+
+def loss_pairs(name, true, false, margin=1, negative_samples=1):
+    """reduce_mean=False of a pairwize loss (utils.py:303-305,310-312,317-319): the raw pair tensor
+    phi(false.reshape(-1, negative_samples) - true) with the reference's broadcast, as a device tensor."""
+    dev = _device()
+    t = torch.as_tensor(true, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    f = torch.as_tensor(false, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    ns = int(negative_samples)
+    rows, cols = f.numel() // max(ns, 1), max(ns, t.numel())
+    out = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    ld = LossDesc(LOSS_IDS[name], ns, float(margin), 0.0)
+    check(lib.kge_loss_pairs(C.byref(ld), t.data_ptr(), t.numel(), f.data_ptr(), f.numel(), out.data_ptr(), out.numel(),
+                             _lib.stream_ptr()))
+    return out
 
 
 class EmbeddingModel:
@@ -181,8 +194,6 @@ class EmbeddingModel:
 
     def _loss_desc(self):
         if self.loss_function not in LOSS_IDS:
-            if self.loss_function == "pointwize_cross_entropy":
-                raise NotImplementedError("pointwize_cross_entropy (utils.py:297-298) is not on the built training path")
             raise KeyError(self.loss_function)  # utils.py:322-330
         return LossDesc(LOSS_IDS[self.loss_function], int(self.loss_negative_samples), float(self.margin or 1),
                         float(self.regularization))

@@ -95,9 +95,9 @@ class LossFunction:
         self.__name__ = name
 
     def __call__(self, true, false, margin=1, negative_samples=1, reduce_mean=True):
-        from .models import loss_value
-        if not reduce_mean:
-            raise NotImplementedError("reduce_mean=False (raw pair tensor) is not on the training path")
+        from .models import loss_value, loss_pairs
+        if not reduce_mean and self.name.startswith("pairwize"):  # the pointwize ones ignore the flag (utils.py:288-298)
+            return loss_pairs(self.name, true, false, margin, negative_samples)
         return loss_value(self.name, true, false, margin, negative_samples)
 
     def __repr__(self):

@@ -146,6 +146,20 @@ def _unbroadcast(x, shape):
     return x
 
 
+def loss_pairs(name, true, false, margin=1, negative_samples=1):
+    """reduce_mean=False branch of the pairwize losses (utils.py:303-305, 310-312, 317-319): the raw pair tensor."""
+    t = np.asarray(true)
+    F = np.asarray(false).reshape(-1, negative_samples)  # utils.py:301/308/315
+    z = F - t
+    if name == "pairwize_hinge":
+        return np.maximum(t.dtype.type(margin) + z, 0)
+    if name == "pairwize_logistic":
+        return np.log(t.dtype.type(EPSILON) + 1 + np.exp(z))
+    if name == "pairwize_square_loss":
+        return -(z * z)
+    raise KeyError(name)
+
+
 def loss_value_and_grads(name, true, false, margin=1, negative_samples=1):
     """Returns (loss, dL/dtrue, dL/dfalse) for the reduce_mean=True form the harness uses (tests.py:80-81).
 
@@ -172,13 +186,17 @@ def loss_value_and_grads(name, true, false, margin=1, negative_samples=1):
         b = margin + f
         loss = np.mean(a * a) + np.mean(b * b)
         return loss, -2 * a / t.size, 2 * b / f.size
-    if name == "pointwize_cross_entropy":  # utils.py:297-298  [TF] keras BCE clips to [1e-7, 1-1e-7], adds 1e-7 in the log
-        k = dt.type(1e-7)
-        ct = np.clip(t, k, one - k)
-        cf = np.clip(f, k, one - k)
+    if name == "pointwize_cross_entropy":
+        # utils.py:297-298  [TF] keras.backend.binary_crossentropy: clip to [eps, 1 - eps], eps added inside both logs.  TF
+        # evaluates this in float32, and the saturated branches depend on that: fp32(1 - 1e-7) = 1 - 2**-23, so a score >= 1
+        # costs -log(2**-23 + 1e-7) as a negative, not -log(2e-7).  The constants are therefore the float32 ones in every dtype.
+        k = dt.type(np.float32(1e-7))
+        hi = dt.type(np.float32(1) - np.float32(1e-7))
+        ct = np.clip(t, k, hi)
+        cf = np.clip(f, k, hi)
         loss = -np.mean(np.log(ct + k)) - np.mean(np.log(one - cf + k))
-        gt = np.where((t >= k) & (t <= one - k), -one / (ct + k), 0) / t.size
-        gf = np.where((f >= k) & (f <= one - k), one / (one - cf + k), 0) / f.size
+        gt = np.where((t >= k) & (t <= hi), -one / (ct + k), 0) / t.size  # clip_by_value passes the gradient on [lo, hi]
+        gf = np.where((f >= k) & (f <= hi), one / (one - cf + k), 0) / f.size
         return loss, gt.astype(dt), gf.astype(dt)
     if name in ("pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"):
         F = f.reshape(-1, negative_samples)  # utils.py:301/308/315
