@@ -246,6 +246,16 @@ def main():
     k_ms, k_n = _lib.prof_read("train_grads")
     f_ms, f_n = _lib.prof_read("fwd")
     o_ms, o_n = _lib.prof_read("opt")
+    d_ms, d_n = _lib.prof_read("dedup")
+
+    # rows a launch of the gather kernels really processes: with duplicate-row folding on (default; KGE_DEDUP=0 turns it off) the
+    # distinct rows of a batch, counted here (outside the timed region) on the batches the run used
+    def distinct(a):
+        key = (a[:, 0].long() * CFG["R"] + a[:, 1].long()) * CFG["N"] + a[:, 2].long()
+        return int(torch.unique(key).numel())
+    used = list(bufs) if args.sampler == "device" else dev
+    folded = d_n > 0
+    rows_launch = float(np.mean([distinct(p) + distinct(n) for p, n in used])) if folded else float(per_step)
 
     ev = eval_leg(torch, dist, model, rank, world)
 
@@ -257,8 +267,8 @@ def main():
         variant = 1 if os.environ.get("KGE_PULL_VARIANT", "2") == "1" else 2
         if f_n and variant == 2:
             # relation-grouped forward carries the relation-gradient row too; the pull is left with the two entity rows
-            kernels["fwd_rel_kernel (gather+score+loss+relation gradient)"] = (f_ms / f_n * 1e-3, per_step * (A_FWD + 4 * CFG["d"]))
-            kernels["pull_kernel (per-entity-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, per_step * 8 * CFG["d"])
+            kernels["fwd_rel_kernel (gather+score+loss+relation gradient)"] = (f_ms / f_n * 1e-3, rows_launch * (A_FWD + 4 * CFG["d"]))
+            kernels["pull_kernel (per-entity-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, rows_launch * 8 * CFG["d"])
         elif f_n:
             kernels["fwd_kernel (gather+score+loss)"] = (f_ms / f_n * 1e-3, per_step * A_FWD)
             kernels["pull_kernel (per-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, per_step * A_BWD)
@@ -282,6 +292,10 @@ def main():
                          "algorithmic_bytes_per_launch": k_bytes, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
                          "all_kernels": {k: {"avg_ms": v[0] * 1e3, "algorithmic_GBps": v[1] / v[0] / 1e9} for k, v in kernels.items()},
                          "whole_step_algorithmic_GBps": per_step * A_TRAIN / (dt / args.steps) / 1e9,
+                         "rows_per_launch": rows_launch, "batch_rows": per_step,
+                         "duplicate_row_folding": ("on: the gather kernels run on the distinct rows of the batch (hash fold inside the step); "
+                                                   "bytes per launch are priced on those rows" if folded else "off"),
+                         "fold_avg_ms": d_ms / max(1, d_n),
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
                          "sampler_avg_ms": s_ms / max(1, s_n)},
         }

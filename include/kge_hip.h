@@ -185,6 +185,26 @@ int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* 
                      const int32_t* target_ids, const int32_t* filt_query, const int32_t* filt_ids, int64_t n_filt, int32_t* counts,
                      int32_t accumulate, void* workspace, int64_t workspace_bytes, kge_stream_t stream);
 
+/* ---- batch plans: the part of a training step that depends on the batch ids only, built ahead of the step.
+ *      The reference's Keras `fit` prefetches batches from its Sequence (tests.py:29-61,130-134) while the previous step
+ *      runs; here the prefetch stage also folds duplicate rows and builds the per-relation / per-entity gradient lists, so
+ *      that the step proper starts at the forward gather.  A plan is an opaque device buffer:
+ *        kge_batch_plan_bytes   size for (md, ld, m_pos, m_neg); KGE_EUNSUPPORTED where no plan exists (pairwize losses, HolE,
+ *                               ConvE, gradient mode 1) -- callers then use kge_train_step;
+ *        kge_batch_plan_build   asynchronous on `stream` (any stream; the arrays pos / neg are not referenced afterwards);
+ *        kge_train_step_planned = kge_train_step on the batch the plan was built from (same md, ld, m_pos, m_neg), without
+ *                               scores_out.  CONSUMES the plan: one step per build.  The caller orders build -> step
+ *                               (events or same stream).  Workspace as for kge_train_step. */
+int64_t kge_batch_plan_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg);
+int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                         void* plan, int64_t plan_bytes, uint32_t* err_flag, kge_stream_t stream);
+int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
+                            void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace,
+                            int64_t workspace_bytes, kge_stream_t stream);
+int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,
+                           float* gradRel, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed,
+                           void* workspace, int64_t workspace_bytes, kge_stream_t stream);
+
 /* ---- the reference's loss functions as callables on two score vectors (utils.py:288-319, reduce_mean=True):
  *      *loss_out = loss(true, false, margin, negative_samples); d_true / d_false (optional, may be NULL) receive the
  *      derivatives.  Workspace: kge_train_step_workspace_bytes(NULL-free md of any shape, ld, m_true, m_false) suffices;
@@ -203,11 +223,17 @@ int kge_loss_pairs(const kge_loss_desc* ld, const float* true_scores, int64_t m_
  * atomics; 1 = "push": fused forward + no-return fp32 global atomics.  Same results to fp32 rounding. */
 int kge_set_grad_mode(int mode);
 
+/* Duplicate-row folding of the pull path (pointwise losses, no dropout): oversample_data (utils.py:123-147) draws rows
+ * with replacement, identical rows have identical scores and gradient terms, so the step hashes the batch, runs on the
+ * distinct rows and weights each by its multiplicity (same sums up to fp32 order).  0 = off, 1 (default) = batches of at
+ * least 4096 rows, 2 = always. */
+int kge_set_dedup_mode(int mode);
+
 /* ---- in-library kernel timing (bench.py's roofline leg): when enabled, every launcher brackets its dominant
  *      kernel with hipEvents recorded on the launch stream.  kge_prof_read synchronises those events, returns the
  *      summed duration (ms) and launch count for one label and clears that label.  Off by default. */
 typedef enum { KGE_PROF_TRAIN_GRADS = 0, KGE_PROF_OPT = 1, KGE_PROF_SCORE = 2, KGE_PROF_PAIRWISE = 3, KGE_PROF_RANK = 4,
-               KGE_PROF_SAMPLER = 5, KGE_PROF_FWD = 6, KGE_PROF_INDEX = 7, KGE_PROF_NLABELS = 8 } kge_prof_label;
+               KGE_PROF_SAMPLER = 5, KGE_PROF_FWD = 6, KGE_PROF_INDEX = 7, KGE_PROF_DEDUP = 8, KGE_PROF_NLABELS = 9 } kge_prof_label;
 int kge_prof_enable(int on);
 int kge_prof_read(int label, double* total_ms, int64_t* launches);
 

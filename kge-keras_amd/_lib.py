@@ -61,8 +61,13 @@ SIGNATURES = {
     "kge_rank_sweep_q": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _I32, _P, _I64, _P]),
     "kge_loss_workspace_bytes": (_I64, [_I64, _I64]),
     "kge_loss_value": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P]),
+    "kge_batch_plan_bytes": (_I64, [_MD, _LD, _I64, _I64]),
+    "kge_batch_plan_build": (C.c_int, [_MD, _LD, _P, _I64, _P, _I64, _P, _I64, _P, _P]),
+    "kge_train_grads_planned": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
+    "kge_train_step_planned": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
+    "kge_set_dedup_mode": (C.c_int, [C.c_int]),
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),
     "kge_score": (C.c_int, [_MD, _P, _P, _P, _I64, _P, _P, _P]),
@@ -91,7 +96,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 
-PROF_LABELS = {"train_grads": 0, "opt": 1, "score": 2, "pairwise": 3, "rank": 4, "sampler": 5, "fwd": 6, "index": 7}
+PROF_LABELS = {"train_grads": 0, "opt": 1, "score": 2, "pairwise": 3, "rank": 4, "sampler": 5, "fwd": 6, "index": 7, "dedup": 8}
 
 
 def prof_read(label):

@@ -97,6 +97,12 @@ int pull_variant() {
   return v == 1 ? 1 : 2;
 }
 
+static int g_dedup_mode = -1;
+int dedup_mode() {  // 1 (default): fold duplicate rows of batches >= 4096 rows; 0: never; 2: always.  KGE_DEDUP overrides the default.
+  if (g_dedup_mode < 0) { const int v = env_int("KGE_DEDUP", 1); g_dedup_mode = v < 0 || v > 2 ? 1 : v; }
+  return g_dedup_mode;
+}
+
 static int g_grad_mode = -1;
 int grad_mode() {
   if (g_grad_mode < 0) g_grad_mode = env_int("KGE_GRAD_MODE", 0) ? 1 : 0;
@@ -127,6 +133,11 @@ int score_dispatch(const kge_model_desc*, const float*, const float*, const int3
 int64_t train_workspace_bytes(const kge_model_desc*, int64_t, int64_t);
 int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, const int32_t*, int64_t,
                 const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
+bool plan_supported(const kge_model_desc*, const kge_loss_desc*);
+int64_t batch_plan_bytes(const kge_model_desc*, int64_t);
+int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, void*, uint32_t*, hipStream_t);
+int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, void*, int64_t, int64_t, float*,
+                          uint64_t, void*, int64_t, hipStream_t);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
               int64_t, hipStream_t);
 
@@ -268,6 +279,51 @@ int kge_train_step(const kge_model_desc* md, const kge_loss_desc* ld, const kge_
   return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, st);
 }
 
+static int check_plan(const char* who, const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg) {
+  if (int rc = check_model(md, who)) return rc;
+  if (!ld) return fail(KGE_EINVAL, "%s: loss descriptor is null", who);
+  if (m_pos <= 0 || m_neg <= 0) return fail(KGE_EINVAL, "%s: empty batch (m_pos=%lld, m_neg=%lld)", who, (long long)m_pos, (long long)m_neg);
+  if (m_pos + m_neg > 0x7FFFFFFFll) return fail(KGE_EUNSUPPORTED, "%s: batch above 2^31 rows", who);
+  if (!plan_supported(md, ld))
+    return fail(KGE_EUNSUPPORTED, "%s: batch plans exist for the relation-grouped pull path (DistMult / TransE / ComplEx, pointwize losses, "
+                "gradient mode 0); use kge_train_step", who);
+  return KGE_OK;
+}
+
+int64_t kge_batch_plan_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg) {
+  if (int rc = check_plan("kge_batch_plan_bytes", md, ld, m_pos, m_neg)) return rc;
+  return batch_plan_bytes(md, m_pos + m_neg);
+}
+
+int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                         void* plan, int64_t plan_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_plan("kge_batch_plan_build", md, ld, m_pos, m_neg)) return rc;
+  if (!pos || !neg || !plan || !err_flag) return fail(KGE_EINVAL, "kge_batch_plan_build: null pointer");
+  if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
+    return fail(KGE_EWORKSPACE, "kge_batch_plan_build: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
+  return batch_plan_build(md, pos, m_pos, neg, m_neg, plan, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
+                            void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace,
+                            int64_t workspace_bytes, kge_stream_t stream) {
+  if (int rc = check_plan("kge_train_grads_planned", md, ld, m_pos, m_neg)) return rc;
+  if (!E || !Rel || !gradE || !gradRel || !plan || !loss_out) return fail(KGE_EINVAL, "kge_train_grads_planned: null pointer");
+  if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
+    return fail(KGE_EWORKSPACE, "kge_train_grads_planned: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
+  return train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes,
+                               static_cast<hipStream_t>(stream));
+}
+
+int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,
+                           float* gradRel, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed,
+                           void* workspace, int64_t workspace_bytes, kge_stream_t stream) {
+  if (!od) return fail(KGE_EINVAL, "kge_train_step_planned: optimizer descriptor is null");
+  if (int rc = kge_train_grads_planned(md, ld, E, Rel, gradE, gradRel, plan, plan_bytes, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, stream))
+    return rc;
+  return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries) {
   if (check_model(md, "kge_rank_workspace_bytes")) return KGE_EINVAL;
   if (n_queries < 0) return fail(KGE_EINVAL, "negative query count");
@@ -332,6 +388,12 @@ int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_
   if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_value: empty score vector (reduce_mean of nothing)");
   return loss_value(ld, true_scores, m_true, false_scores, m_false, loss_out, d_true, d_false, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+int kge_set_dedup_mode(int mode) {
+  if (mode < 0 || mode > 2) return fail(KGE_EINVAL, "kge_set_dedup_mode: mode %d (0 = off, 1 = batches of 4096+ rows, 2 = always)", mode);
+  g_dedup_mode = mode;
+  return KGE_OK;
 }
 
 int kge_loss_pairs(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,

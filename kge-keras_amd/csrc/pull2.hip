@@ -11,6 +11,16 @@
 //   ent_fill_kernel   entity lists {p | role, other entity, coef, t}
 //   pull_kernel       (pull.hip) over entity keys only
 //   rel_finish_kernel d/dp rows = sum of the relation's slab rows (chunk order); pull_finish for hub entities
+//
+// Duplicate rows.  oversample_data (KGEkeras/utils.py:123-147) draws both arrays WITH replacement: at B=2048, ns=100 the
+// 204 800 positive rows hold at most 2048 distinct triples and the negatives ~63 % distinct ones.  Identical rows have
+// identical scores and identical gradient terms (no dropout), so the step first folds them: an open-addressing hash table
+// in HBM (64-bit keys, one CAS per new triple, a plain load for a repeat) yields the distinct rows with their
+// multiplicities, the whole pipeline above then runs on {s, p, o, +-multiplicity} rows (count known on the device only,
+// grids are sized for the worst case), and the loss / dL/dscore of a row are weighted by its multiplicity.  Same sums as
+// TensorFlow's IndexedSlices accumulation up to fp32 summation order.  Off when dropout is on (every row has its own mask).
+#include <cstdlib>
+
 #include "dropout.hpp"
 #include "kge_internal.hpp"
 #include "pull.hpp"
@@ -21,7 +31,22 @@ constexpr int kRelMax = 4096;   // relations handled by the LDS histogram / sing
 constexpr int kRelChunk = 64;   // triples per forward work unit
 constexpr int kRelBlockTriples = 1024;
 
+struct Dedup {
+  unsigned long long* keys;  // [cap]  0 = empty, else key + 1
+  int32_t* cnt;              // [cap]  multiplicity of the slot's triple
+  int32_t* uid;              // [cap]  folded row id of the slot
+  int32_t* nu;               // [64]   number of folded rows (keys | cnt are one region, cleared at the start of a step)
+  int32_t* slot_of;          // [n]    slot of input row t (-1: ids outside the tables)
+  int32_t* frank;            // [n]    rank of input row t among its block's newly found triples (-1: a repeat)
+  int32_t* bcnt;             // [blocks] newly found triples per block of 256 input rows
+  int4* uniq;                // [n]
+  float* uscore;             // [n]    scores of the folded rows (only when the caller asks for scores)
+  int64_t cap;
+  int64_t clear_bytes;
+};
+
 struct Plan2 {
+  Dedup dd;
   // relation side
   int32_t* rcnt;    // [R]
   int32_t* roff;    // [R]  list start
@@ -37,13 +62,116 @@ struct Plan2 {
   int32_t* erank;   // [2][n]
 };
 
-__global__ __launch_bounds__(256) void rel_hist_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
-                                                        const int32_t* __restrict__ neg, int64_t m_neg, int N, int R,
-                                                        int32_t* __restrict__ rcnt, int32_t* __restrict__ rrank) {
+// Where the step's rows come from: the caller's (pos, neg) arrays, or the folded rows {s, p, o, +-multiplicity}.
+struct Src {
+  const int32_t* pos; int64_t m_pos;
+  const int32_t* neg; int64_t m_neg;
+  const int4* uniq;     // null: no folding
+  const int32_t* nu;    // device count of folded rows
+};
+__device__ __forceinline__ int64_t src_rows(const Src& x) { return x.uniq ? (int64_t)x.nu[0] : x.m_pos + x.m_neg; }
+__device__ __forceinline__ void src_load(const Src& x, int64_t t, int& s, int& p, int& o, int& w) {
+  if (x.uniq) {
+    const int4 e = x.uniq[t];
+    s = e.x; p = e.y; o = e.z; w = e.w;
+  } else {
+    const int32_t* tr = t < x.m_pos ? x.pos + 3 * t : x.neg + 3 * (t - x.m_pos);
+    s = tr[0]; p = tr[1]; o = tr[2]; w = t < x.m_pos ? 1 : -1;
+  }
+}
+
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+
+// One thread per input row: find-or-insert its key.  A slot changes exactly once (0 -> key), so the plain probe load can only
+// see 0 (then the CAS decides) or a final key.  The thread whose CAS installs a key owns the new folded row; its id is
+// block offset + rank inside the block (ballots + LDS, no global counter): frank[t] = rank or -1, bcnt[block] = owners.
+__global__ __launch_bounds__(256) void dedup_insert_kernel(const int32_t* __restrict__ pos, int64_t m_pos, const int32_t* __restrict__ neg,
+                                                            int64_t m_neg, int N, int R, unsigned long long* keys, int32_t* cnt,
+                                                            unsigned long long mask, int32_t* __restrict__ slot_of,
+                                                            int32_t* __restrict__ frank, int32_t* __restrict__ bcnt,
+                                                            uint32_t* __restrict__ err) {
+  __shared__ int wcnt[4];
+  const int64_t n = m_pos + m_neg;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool first = false;
+  if (t < n) {
+    const bool is_pos = t < m_pos;
+    const int32_t* tr = is_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+    const int s = tr[0], p = tr[1], o = tr[2];
+    if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
+      const unsigned long long key = ((((unsigned long long)s * (unsigned)R + (unsigned)p) * (unsigned)N + (unsigned)o) << 1 | (is_pos ? 1ull : 0ull)) + 1ull;
+      unsigned long long slot = mix64(key) & mask;
+      for (;;) {
+        unsigned long long cur = *(volatile unsigned long long*)(keys + slot);
+        if (cur == 0ull) {
+          cur = atomicCAS(keys + slot, 0ull, key);
+          if (cur == 0ull) { first = true; break; }
+        }
+        if (cur == key) break;
+        slot = (slot + 1) & mask;
+      }
+      atomicAdd(cnt + slot, 1);
+      slot_of[t] = (int32_t)slot;
+    } else {
+      slot_of[t] = -1;
+      atomicOr(err, 1u);
+    }
+  }
+  const unsigned long long m = __ballot(first);
+  if (lane == 0) wcnt[wave] = __popcll(m);
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wcnt[w];
+  if (t < n) frank[t] = first ? before + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+  if (threadIdx.x == 0) bcnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// Same grid: block b's folded rows start at sum(bcnt[0..b)) (every block sums that prefix itself; block 0 publishes the total).
+__global__ __launch_bounds__(256) void dedup_rows_kernel(const int32_t* __restrict__ pos, int64_t m_pos, const int32_t* __restrict__ neg,
+                                                          int64_t m_neg, const int32_t* __restrict__ bcnt, const int32_t* __restrict__ frank,
+                                                          const int32_t* __restrict__ slot_of, const int32_t* __restrict__ cnt,
+                                                          int32_t* __restrict__ uid, int4* __restrict__ uniq, int32_t* __restrict__ nu) {
+  __shared__ int red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int upto = blockIdx.x == 0 ? (int)gridDim.x : (int)blockIdx.x;
+  int acc = 0;
+  for (int i = threadIdx.x; i < upto; i += 256) acc += bcnt[i];
+  for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  const int sum = red[0] + red[1] + red[2] + red[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) nu[0] = sum;
+  const int base = blockIdx.x == 0 ? 0 : sum;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m_pos + m_neg) return;
+  const int fr = frank[t];
+  if (fr < 0) return;
+  const bool is_pos = t < m_pos;
+  const int32_t* tr = is_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+  const int sl = slot_of[t];
+  const int w = cnt[sl];
+  uid[sl] = base + fr;
+  uniq[base + fr] = make_int4(tr[0], tr[1], tr[2], is_pos ? w : -w);
+}
+
+__global__ __launch_bounds__(256) void dedup_scores_kernel(const int32_t* __restrict__ slot_of, const int32_t* __restrict__ uid,
+                                                            const float* __restrict__ uscore, int64_t n, float* __restrict__ scores) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int sl = slot_of[t];
+  scores[t] = sl < 0 ? __builtin_nanf("") : uscore[uid[sl]];
+}
+
+__global__ __launch_bounds__(256) void rel_hist_kernel(Src src, int N, int R, int32_t* __restrict__ rcnt, int32_t* __restrict__ rrank) {
   __shared__ int lrel[kRelMax];
   for (int i = threadIdx.x; i < R; i += 256) lrel[i] = 0;
   __syncthreads();
-  const int64_t n = m_pos + m_neg;
+  const int64_t n = src_rows(src);
   const int64_t t0 = (int64_t)blockIdx.x * kRelBlockTriples;
   constexpr int PER = kRelBlockTriples / 256;
   int rp[PER], pp[PER];
@@ -52,8 +180,8 @@ __global__ __launch_bounds__(256) void rel_hist_kernel(const int32_t* __restrict
     const int64_t t = t0 + threadIdx.x + i * 256;
     rp[i] = pp[i] = -1;
     if (t < n) {
-      const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
-      const int s = tr[0], p = tr[1], o = tr[2];
+      int s, p, o, w;
+      src_load(src, t, s, p, o, w);
       if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) { pp[i] = p; rp[i] = atomicAdd(&lrel[p], 1); }
     }
   }
@@ -95,32 +223,27 @@ __global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict
   if (tid == 255) rtotal[0] = rb;
 }
 
-__global__ __launch_bounds__(256) void rel_fill_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
-                                                        const int32_t* __restrict__ neg, int64_t m_neg,
-                                                        const int32_t* __restrict__ roff, const int32_t* __restrict__ rrank,
-                                                        int4* __restrict__ rentries, float* __restrict__ coef,
-                                                        float* __restrict__ scores, uint32_t* __restrict__ err) {
+__global__ __launch_bounds__(256) void rel_fill_kernel(Src src, const int32_t* __restrict__ roff, const int32_t* __restrict__ rrank,
+                                                        int4* __restrict__ rentries, float* __restrict__ scores,
+                                                        uint32_t* __restrict__ err) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= m_pos + m_neg) return;
+  if (t >= src_rows(src)) return;
   const int r = rrank[t];
   if (r < 0) {  // ids outside the tables: the row takes no part in the step, scores NaN, error flag raised
-    coef[t] = 0.f;
     if (scores) scores[t] = __builtin_nanf("");
     atomicOr(err, 1u);
     return;
   }
-  const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
-  rentries[roff[tr[1]] + r] = make_int4(tr[0], tr[2], (int)t, 0);
+  int s, p, o, w;
+  src_load(src, t, s, p, o, w);
+  rentries[roff[p] + r] = make_int4(s, o, (int)t, w);  // w: +multiplicity for a positive row, -multiplicity for a negative one
 }
 
-__global__ __launch_bounds__(256) void ent_hist_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
-                                                        const int32_t* __restrict__ neg, int64_t m_neg, int N, int R,
-                                                        int32_t* __restrict__ cnt, int32_t* __restrict__ erank) {
-  const int64_t n = m_pos + m_neg;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
-  const int s = tr[0], p = tr[1], o = tr[2];
+__global__ __launch_bounds__(256) void ent_hist_kernel(Src src, int64_t n, int N, int R, int32_t* __restrict__ cnt, int32_t* __restrict__ erank) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // n = m_pos + m_neg: stride of the two rank planes
+  if (t >= src_rows(src)) return;
+  int s, p, o, w;
+  src_load(src, t, s, p, o, w);
   int rs = -1, ro = -1;
   if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
     rs = atomicAdd(&cnt[s], 1);
@@ -130,17 +253,14 @@ __global__ __launch_bounds__(256) void ent_hist_kernel(const int32_t* __restrict
   erank[n + t] = ro;
 }
 
-__global__ __launch_bounds__(256) void ent_fill_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
-                                                        const int32_t* __restrict__ neg, int64_t m_neg,
-                                                        const float* __restrict__ coef, const int32_t* __restrict__ off,
+__global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const float* __restrict__ coef, const int32_t* __restrict__ off,
                                                         const int32_t* __restrict__ erank, int4* __restrict__ entries) {
-  const int64_t n = m_pos + m_neg;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+  if (t >= src_rows(src)) return;
   const int r0 = erank[t];
   if (r0 < 0) return;
-  const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
-  const int s = tr[0], p = tr[1], o = tr[2];
+  int s, p, o, w;
+  src_load(src, t, s, p, o, w);
   const int cb = __float_as_int(coef[t]);
   entries[off[s] + r0] = make_int4(p, o, cb, (int)t);
   entries[off[o] + erank[n + t]] = make_int4(p | (int)0x80000000, s, cb, (int)t);
@@ -196,7 +316,8 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
     for (int i = sub; i < len; i += 4) {
       const int4 e = rentries[start + i];
       const int64_t t = e.z;
-      const bool is_pos = t < m_pos;
+      const bool is_pos = e.w > 0;
+      const float mult = fabsf((float)e.w);  // how many input rows this one stands for
       const float* es = E + (int64_t)e.x * d_e;
       const float* eo = E + (int64_t)e.y * d_e;
       DropKey ks{0, 0}, kp{0, 0}, ko{0, 0};
@@ -237,7 +358,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
         score = gamma > 0.f ? gamma - dist : dist;
       }
       float g, l;
-      pointwise_term<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+      pointwise_term<LOSS>(score, is_pos, margin, (is_pos ? inv_pos : inv_neg) * mult, g, l);
       if (MODEL == KGE_TRANSE) {
         g = gamma > 0.f ? -g : g;
         if (NORM == 2) g = dist > 0.f ? g / dist : 0.f;
@@ -330,6 +451,23 @@ __global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR,
 // ---------------------------------------------------------------------------------------------------------------
 static int64_t b256(int64_t x) { return align_up(x, 256); }
 int pull_chunk();
+int dedup_mode();
+
+static int64_t dedup_cap(int64_t n) {
+  int64_t c = 1024;
+  while (c < 2 * n) c <<= 1;
+  return c;
+}
+static int64_t dedup_bytes(int64_t n) {
+  const int64_t cap = dedup_cap(n);
+  return b256(cap * 8) + b256(cap * 4) + 256 + b256(cap * 4) + b256(n * 4) * 2 + b256((n / 256 + 1) * 4) + b256(n * 16) + b256(n * 4);
+}
+// Folding needs the packed key 2*((s*R + p)*N + o) + side + 1 to fit 64 bits, and pays off only on batches of some size.
+static bool dedup_applies(const kge_model_desc* md, int64_t n) {
+  const int mode = dedup_mode();
+  if (mode == 0 || md->dropout > 0.f || (mode == 1 && n < 4096)) return false;
+  return (long double)md->num_entities * md->num_entities * md->num_relations * 2.0L + 2.0L < 1.8e19L;
+}
 
 bool pull2_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
   if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX) return false;
@@ -341,45 +479,80 @@ bool pull2_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
   return width % 4 == 0 && md->d_e % 4 == 0 && width / 4 <= 64;
 }
 
-int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n) {
-  const int64_t R = md->num_relations, N = md->num_entities;
-  const int64_t max_units = n / kRelChunk + R + 1;
-  const int C = pull_chunk();
-  const int64_t max_extra = 2 * n / C + 1;
-  return b256(R * 4) * 3 + 256 + b256(max_units * 8) + b256(n * 4) + b256(n * 16) + b256(max_units * md->d_e * 4) +
-         b256(N * 4) * 4 + 256 + b256(max_extra * 8) + b256(2 * n * 16) + b256(2 * n * 4) + b256(n * 4) + b256(2 * max_extra * md->d_e * 4) + 2048;
+// The per-batch state has two parts.  The PLAN depends on the ids only (folded rows, relation lists, entity offsets and
+// ranks): it can be built ahead of time, on another stream, while the previous step still runs (kge_batch_plan_build).
+// The SCRATCH depends on the parameters (coefficients, list entries carrying them, partial gradient rows).
+struct Sizes { int64_t R, N, n, max_units, max_extra, cap; int C; };
+static Sizes sizes_of(const kge_model_desc* md, int64_t n) {
+  Sizes z;
+  z.R = md->num_relations; z.N = md->num_entities; z.n = n;
+  z.max_units = n / kRelChunk + z.R + 1;
+  z.C = pull_chunk();
+  z.max_extra = 2 * n / z.C + 1;
+  z.cap = dedup_cap(n);
+  return z;
+}
+static int64_t counters_bytes(const Sizes& z) { return b256(z.N * 4) + b256(z.R * 4); }
+static int64_t plan_bytes(const Sizes& z) {
+  return b256(z.R * 4) * 2 + 256 + b256(z.max_units * 8) + b256(z.n * 4) + b256(z.n * 16) +                 // relation side
+         b256(z.N * 4) * 3 + 256 + b256(z.max_extra * 8) + b256(2 * z.n * 4) +                               // entity side
+         b256(z.cap * 8) + b256(z.cap * 4) + 256 + b256(z.cap * 4) + b256(z.n * 4) * 2 + b256((z.n / 256 + 1) * 4) + b256(z.n * 16) + 512;
+}
+static int64_t scratch_bytes(const Sizes& z, int d_e) {
+  return b256(z.max_units * d_e * 4) + b256(2 * z.n * 16) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + 512;
 }
 
-static void carve2(void* hdr, void* ws, const kge_model_desc* md, int64_t n, Plan2* p) {
-  const int64_t R = md->num_relations, N = md->num_entities;
-  const int64_t max_units = n / kRelChunk + R + 1;
-  const int C = pull_chunk();
-  const int64_t max_extra = 2 * n / C + 1;
-  char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n) {
+  const Sizes z = sizes_of(md, n);
+  return plan_bytes(z) + scratch_bytes(z, md->d_e);
+}
+
+// counters: [N] entity counters then [R] relation counters, all zero when a build starts (and left zero by the step)
+static void carve_plan(void* counters, void* region, const kge_model_desc* md, int64_t n, Plan2* p) {
+  const Sizes z = sizes_of(md, n);
+  char* q = reinterpret_cast<char*>(((uintptr_t)region + 255) & ~(uintptr_t)255);
   auto take = [&](int64_t bytes) { char* r = q; q += b256(bytes); return r; };
-  char* hq = reinterpret_cast<char*>(((uintptr_t)hdr + 255) & ~(uintptr_t)255);
-  p->ent.cnt = (int32_t*)hq;                 // header (fixed place, zero on entry, left zero): entity counters ...
-  p->rcnt = (int32_t*)(hq + b256(N * 4));    // ... then relation counters
-  p->roff = (int32_t*)take(R * 4);
-  p->ruoff = (int32_t*)take(R * 4);
+  char* hq = reinterpret_cast<char*>(((uintptr_t)counters + 255) & ~(uintptr_t)255);
+  p->ent.cnt = (int32_t*)hq;
+  p->rcnt = (int32_t*)(hq + b256(z.N * 4));
+  p->roff = (int32_t*)take(z.R * 4);
+  p->ruoff = (int32_t*)take(z.R * 4);
   p->rtotal = (int32_t*)take(16);
-  p->rumap = (int2*)take(max_units * 8);
+  p->rumap = (int2*)take(z.max_units * 8);
   p->rrank = (int32_t*)take(n * 4);
   p->rentries = (int4*)take(n * 16);
-  p->rslab = (float*)take(max_units * md->d_e * 4);
-  p->max_units = (int)max_units;
-  p->ent.off = (int32_t*)take(N * 4);
-  p->ent.eoff = (int32_t*)take(N * 4);
-  p->ent.poff = (int32_t*)take(N * 4);
+  p->max_units = (int)z.max_units;
+  p->ent.off = (int32_t*)take(z.N * 4);
+  p->ent.eoff = (int32_t*)take(z.N * 4);
+  p->ent.poff = (int32_t*)take(z.N * 4);
   p->ent.totals = (int32_t*)take(16);
-  p->ent.emap = (int2*)take(max_extra * 8);
-  p->ent.entries = (int4*)take(2 * n * 16);
+  p->ent.emap = (int2*)take(z.max_extra * 8);
   p->erank = (int32_t*)take(2 * n * 4);
   p->ent.ranks = p->erank;
+  p->ent.max_extra = (int)z.max_extra;
+  p->ent.chunk = z.C;
+  Dedup& d = p->dd;
+  d.cap = z.cap;
+  d.keys = (unsigned long long*)take(d.cap * 8);   // keys | cnt: contiguous, one memset per build
+  d.cnt = (int32_t*)take(d.cap * 4);
+  d.clear_bytes = (char*)d.cnt + b256(d.cap * 4) - (char*)d.keys;
+  d.nu = (int32_t*)take(256);
+  d.uid = (int32_t*)take(d.cap * 4);
+  d.slot_of = (int32_t*)take(n * 4);
+  d.frank = (int32_t*)take(n * 4);
+  d.bcnt = (int32_t*)take((n / 256 + 1) * 4);
+  d.uniq = (int4*)take(n * 16);
+}
+
+static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Plan2* p) {
+  const Sizes z = sizes_of(md, n);
+  char* q = reinterpret_cast<char*>(((uintptr_t)region + 255) & ~(uintptr_t)255);
+  auto take = [&](int64_t bytes) { char* r = q; q += b256(bytes); return r; };
+  p->rslab = (float*)take(z.max_units * md->d_e * 4);
+  p->ent.entries = (int4*)take(2 * n * 16);
   p->ent.coef = (float*)take(n * 4);
-  p->ent.slab = (float*)take(2 * max_extra * md->d_e * 4);
-  p->ent.max_extra = (int)max_extra;
-  p->ent.chunk = C;
+  p->ent.slab = (float*)take(2 * z.max_extra * md->d_e * 4);
+  p->dd.uscore = (float*)take(n * 4);
 }
 
 // kernels of pull.hip reused on the entity keys
@@ -414,49 +587,140 @@ static void launch_fwd_rel_loss(int loss, int nv, bool drop, int grid, hipStream
   else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
 }
 
-// `side` may be null (then everything runs on `st`).
+__global__ __launch_bounds__(256) void rows_copy_kernel(const int32_t* __restrict__ pos, int64_t m_pos, const int32_t* __restrict__ neg,
+                                                         int64_t m_neg, int4* __restrict__ rows, int32_t* __restrict__ nu) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) nu[0] = (int32_t)(m_pos + m_neg);
+  if (t >= m_pos + m_neg) return;
+  const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+  rows[t] = make_int4(tr[0], tr[1], tr[2], t < m_pos ? 1 : -1);
+}
+
+// ---- plan: everything that depends on the ids only.  `own_rows`: the plan must not refer to the caller's arrays afterwards
+// (kge_batch_plan_build), so rows that are not folded are copied.  `side` may be null (then everything runs on `st`).
+static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const Plan2& p, bool own_rows,
+                      Src* src_out, bool* folded, float* scores, uint32_t* err, hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+  const int64_t n = m_pos + m_neg;
+  const int N = md->num_entities, R = md->num_relations;
+  const int tgrid = (int)cdiv(n, 256);
+  Src src{pos, m_pos, neg, m_neg, nullptr, nullptr};
+  const bool fold = dedup_applies(md, n);
+  *folded = fold;
+  const Dedup& d = p.dd;
+  if (fold) {
+    ProfScope prof(KGE_PROF_DEDUP, st);
+    KGE_HIP_TRY(hipMemsetAsync(d.keys, 0, d.clear_bytes, st));
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, R, d.keys, d.cnt,
+                       (unsigned long long)(d.cap - 1), d.slot_of, d.frank, d.bcnt, err);
+    hipLaunchKernelGGL(dedup_rows_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.bcnt, d.frank, d.slot_of, d.cnt, d.uid,
+                       d.uniq, d.nu);
+    src.uniq = d.uniq;
+    src.nu = d.nu;
+  } else if (own_rows) {
+    hipLaunchKernelGGL(rows_copy_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.uniq, d.nu);
+    src.uniq = d.uniq;
+    src.nu = d.nu;
+  }
+  *src_out = src;
+  // entity index (side stream when there is one)
+  hipStream_t es = side ? side : st;
+  if (side) { KGE_HIP_TRY(hipEventRecord(fork, st)); KGE_HIP_TRY(hipStreamWaitEvent(side, fork, 0)); }
+  {
+    ProfScope prof(KGE_PROF_INDEX, es);
+    hipLaunchKernelGGL(ent_hist_kernel, dim3(tgrid), dim3(256), 0, es, src, n, N, R, p.ent.cnt, p.erank);
+    pull2_entity_plan(p.ent, N, es);
+  }
+  if (side) KGE_HIP_TRY(hipEventRecord(join, side));
+  // relation index
+  hipLaunchKernelGGL(rel_hist_kernel, dim3((int)cdiv(n, kRelBlockTriples)), dim3(256), 0, st, src, N, R, p.rcnt, p.rrank);
+  hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
+  hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// ---- step: everything that depends on the parameters.  Consumes the plan (the finish kernels leave its counters zero).
+static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, int64_t m_pos,
+                     int64_t m_neg, const Plan2& p, const Src& src, float* fwd_scores, float* loss_partials, int* n_partials, float* loss_out,
+                     uint64_t seed, hipStream_t st, hipEvent_t join) {
+  const int64_t n = m_pos + m_neg;
+  const int R = md->num_relations;
+  const int tgrid = (int)cdiv(n, 256);
+  const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
+  const int nchunk = width / 4;
+  const bool drop = md->dropout > 0.f;
+  const int fgrid = (int)cdiv(p.max_units, 4);
+  *n_partials = fgrid;
+  {
+    ProfScope prof(KGE_PROF_FWD, st);
+    const int nv = (int)cdiv(nchunk, 16);
+    if (md->model == KGE_DISTMULT) launch_fwd_rel_loss<KGE_DISTMULT, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else if (md->model == KGE_COMPLEX) launch_fwd_rel_loss<KGE_COMPLEX, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else if (md->norm == 1) launch_fwd_rel_loss<KGE_TRANSE, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+  }
+  if (join) KGE_HIP_TRY(hipStreamWaitEvent(st, join, 0));
+  hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.coef, p.ent.off, p.erank, p.ent.entries);
+  if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st)) return rc;
+  hipLaunchKernelGGL(rel_finish_kernel, dim3((int)cdiv(R, 4) + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
+                     *n_partials, loss_out);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// One step with the plan built on the spot (kge_train_step / kge_train_grads).  `side` may be null.
 int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
                       const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* scores, float* loss_partials,
                       int* n_partials, float* loss_out, void* hdr, void* ws, uint32_t* err, uint64_t seed, hipStream_t st, hipStream_t side,
                       hipEvent_t fork, hipEvent_t join) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
-  carve2(hdr, ws, md, n, &p);
-  const int N = md->num_entities, R = md->num_relations;
-  const int tgrid = (int)cdiv(n, 256);
-  const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
-  const int nchunk = width / 4;
-  const bool drop = md->dropout > 0.f;
-  // ---- entity index on the side stream
-  hipStream_t es = side ? side : st;
-  if (side) { KGE_HIP_TRY(hipEventRecord(fork, st)); KGE_HIP_TRY(hipStreamWaitEvent(side, fork, 0)); }
-  {
-    ProfScope prof(KGE_PROF_INDEX, es);
-    hipLaunchKernelGGL(ent_hist_kernel, dim3(tgrid), dim3(256), 0, es, pos, m_pos, neg, m_neg, N, R, p.ent.cnt, p.erank);
-    pull2_entity_plan(p.ent, N, es);
-  }
-  if (side) KGE_HIP_TRY(hipEventRecord(join, side));
-  // ---- relation index + forward on the main stream
-  hipLaunchKernelGGL(rel_hist_kernel, dim3((int)cdiv(n, kRelBlockTriples)), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, R, p.rcnt, p.rrank);
-  hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
-  hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, p.roff, p.rrank, p.rentries, p.ent.coef, scores, err);
-  const int fgrid = (int)cdiv(p.max_units, 4);
-  *n_partials = fgrid;
-  {
-    ProfScope prof(KGE_PROF_FWD, st);
-    const int nv = (int)cdiv(nchunk, 16);
-    if (md->model == KGE_DISTMULT) launch_fwd_rel_loss<KGE_DISTMULT, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, scores, loss_partials, seed);
-    else if (md->model == KGE_COMPLEX) launch_fwd_rel_loss<KGE_COMPLEX, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, scores, loss_partials, seed);
-    else if (md->norm == 1) launch_fwd_rel_loss<KGE_TRANSE, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, scores, loss_partials, seed);
-    else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, scores, loss_partials, seed);
-  }
-  if (side) KGE_HIP_TRY(hipStreamWaitEvent(st, join, 0));
-  hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, p.ent.coef, p.ent.off, p.erank, p.ent.entries);
-  if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st)) return rc;
-  hipLaunchKernelGGL(rel_finish_kernel, dim3((int)cdiv(R, 4) + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
-                     *n_partials, loss_out);
+  carve_plan(hdr, ws, md, n, &p);
+  carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
+  Src src;
+  bool folded = false;
+  // folded rows: the forward writes the scores of the distinct rows, expanded to the caller's rows afterwards
+  const bool fold = dedup_applies(md, n);
+  float* fwd_scores = fold && scores ? p.dd.uscore : scores;
+  if (int rc = plan_build(md, pos, m_pos, neg, m_neg, p, false, &src, &folded, fold ? nullptr : scores, err, st, side, fork, join)) return rc;
+  if (int rc = plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, fwd_scores, loss_partials, n_partials, loss_out, seed, st, side ? join : nullptr))
+    return rc;
+  if (folded && scores) hipLaunchKernelGGL(dedup_scores_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, p.dd.slot_of, p.dd.uid, p.dd.uscore, n, scores);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
+}
+
+// ---- plan built ahead of time (kge_batch_plan_build) and consumed by a later step (kge_train_grads_planned)
+int64_t batch_plan_bytes(const kge_model_desc* md, int64_t n) {
+  const Sizes z = sizes_of(md, n);
+  return counters_bytes(z) + plan_bytes(z) + 512;
+}
+
+static void carve_plan_buffer(void* plan, const kge_model_desc* md, int64_t n, Plan2* p) {
+  char* base = reinterpret_cast<char*>(((uintptr_t)plan + 255) & ~(uintptr_t)255);
+  carve_plan(base, base + counters_bytes(sizes_of(md, n)), md, n, p);
+}
+
+int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* plan, uint32_t* err,
+                     hipStream_t st) {
+  const int64_t n = m_pos + m_neg;
+  Plan2 p;
+  carve_plan_buffer(plan, md, n, &p);
+  KGE_HIP_TRY(hipMemsetAsync(p.ent.cnt, 0, counters_bytes(sizes_of(md, n)), st));
+  Src src;
+  bool folded;
+  return plan_build(md, pos, m_pos, neg, m_neg, p, true, &src, &folded, nullptr, err, st, nullptr, nullptr, nullptr);
+}
+
+int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
+                        int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
+                        hipStream_t st) {
+  const int64_t n = m_pos + m_neg;
+  Plan2 p;
+  carve_plan_buffer(plan, md, n, &p);
+  carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
+  const Src src{nullptr, m_pos, nullptr, m_neg, p.dd.uniq, p.dd.nu};
+  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, nullptr);
 }
 
 }  // namespace kge

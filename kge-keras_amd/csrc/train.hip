@@ -575,6 +575,18 @@ static int launch_opt(bool reg, float* w, float* g, float* m, float* v, int64_t 
   return KGE_OK;
 }
 
+bool plan_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
+  return grad_mode() == 0 && pull_variant() == 2 && pull2_supported(md, ld);
+}
+
+int train_grads_with_plan(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
+                          int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace, int64_t wbytes, hipStream_t st) {
+  Workspace ws;
+  if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
+  int nb = 0;
+  return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st);
+}
+
 int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float gscale, hipStream_t st) {
   int nb = 0;
   if (od->kind == KGE_OPT_ADAM_TF) {

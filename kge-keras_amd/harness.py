@@ -97,38 +97,63 @@ class DeviceDataGenerator:
         self.release_global()
         return [pos, neg], None
 
-    def batches(self, order):
-        """Iterate the batches `order` with the sampler running on a side stream one batch ahead of the consumer
-        (double-buffered in HBM, event fork/join): `fit` uses this, so drawing a batch overlaps the previous train step.
-        Same draws, in the same order, as calling self[i] for i in order."""
+    def batches(self, order, plan=None):
+        """Iterate the batches `order` with the sampler running on a side stream ahead of the consumer (double-buffered in
+        HBM, event fork/join): `fit` uses this, so drawing a batch overlaps the previous train steps.  Same draws, in the
+        same order, as calling self[i] for i in order.  `plan`: optional callable ([pos, neg], out=previous) -> BatchPlan
+        (EmbeddingModel.plan_batch); it runs on a third stream right behind the sampler and the iterator then yields the
+        plans instead of the arrays."""
         import torch
         main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+        pstream = torch.cuda.Stream() if plan is not None else None
         m = self.batch_size * self.ns
         bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device=self.device) for _ in range(2)) for _ in range(2)]
-        ready = [torch.cuda.Event() for _ in range(2)]
-        freed = [torch.cuda.Event() for _ in range(2)]
+        plans = [None, None]
+        ready = [torch.cuda.Event() for _ in range(2)]     # batch arrays drawn
+        freed = [torch.cuda.Event() for _ in range(2)]     # batch arrays no longer needed
+        planned = [torch.cuda.Event() for _ in range(2)]   # plan built
+        pfreed = [torch.cuda.Event() for _ in range(2)]    # plan consumed
         order = list(order)
         self._upload_global()
         side.wait_stream(main)
+        if pstream is not None:
+            pstream.wait_stream(main)
 
         def produce(k):
+            j = k % 2
             with torch.cuda.stream(side):
-                side.wait_event(freed[k % 2])
+                side.wait_event(freed[j])
                 i = order[k]
                 sl = self.index[i * self.batch_size:(i + 1) * self.batch_size]
                 batch = self.kg.index_select(0, sl).contiguous()
-                self.sampler.build_batch(batch, self.ns, self.num_e, *bufs[k % 2])
-                ready[k % 2].record(side)
+                self.sampler.build_batch(batch, self.ns, self.num_e, *bufs[j])
+                ready[j].record(side)
+            if pstream is not None:
+                with torch.cuda.stream(pstream):
+                    pstream.wait_event(ready[j])
+                    pstream.wait_event(pfreed[j])
+                    plans[j] = plan(list(bufs[j]), out=plans[j])
+                    planned[j].record(pstream)
+                    freed[j].record(pstream)
 
         for k in range(min(2, len(order))):
             produce(k)
         for k in range(len(order)):
-            main.wait_event(ready[k % 2])
-            yield list(bufs[k % 2])
-            freed[k % 2].record(main)
+            j = k % 2
+            if pstream is not None:
+                main.wait_event(planned[j])
+                plans[j].buf.record_stream(main)
+                yield plans[j]
+                pfreed[j].record(main)
+            else:
+                main.wait_event(ready[j])
+                yield list(bufs[j])
+                freed[j].record(main)
             if k + 2 < len(order):
                 produce(k + 2)
         main.wait_stream(side)
+        if pstream is not None:
+            main.wait_stream(pstream)
         self.release_global()
 
 

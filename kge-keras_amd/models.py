@@ -118,6 +118,16 @@ def loss_pairs(name, true, false, margin=1, negative_samples=1):
     return out
 
 
+class BatchPlan:
+    """The half of a training step that depends on the batch ids only (duplicate rows folded, per-relation and per-entity
+    gradient lists), built ahead of the step by EmbeddingModel.plan_batch -- typically on a side stream while the previous
+    step runs -- and consumed by exactly one train_step / train_grads (kge_batch_plan_build / kge_train_step_planned)."""
+    __slots__ = ("buf", "m_pos", "m_neg")
+
+    def __init__(self, buf, m_pos, m_neg):
+        self.buf, self.m_pos, self.m_neg = buf, int(m_pos), int(m_neg)
+
+
 class EmbeddingModel:
     MODEL = None
 
@@ -308,9 +318,45 @@ class EmbeddingModel:
         sl = [x.data_ptr() for x in o.slots] if o.slots else [None] * 4
         return OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, o.iterations, *sl)
 
+    def plan_supported(self):
+        """True where a batch plan exists for this model / loss (the relation-grouped pull path of the HIP library)."""
+        if self._lit is not None or type(self).train_step is not EmbeddingModel.train_step:
+            return False
+        md, ld = self._model_desc(True), self._loss_desc()
+        return lib.kge_batch_plan_bytes(C.byref(md), C.byref(ld), 1, 1) > 0
+
+    def plan_batch(self, data, out=None):
+        """Build the BatchPlan of [pos, neg] on the CURRENT stream (asynchronous).  `out`: a BatchPlan whose buffer is reused
+        when large enough.  The caller orders the build before the step that consumes it (same stream, or an event)."""
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        md, ld = self._model_desc(True), self._loss_desc()
+        need = check(lib.kge_batch_plan_bytes(C.byref(md), C.byref(ld), pos.shape[0], neg.shape[0]))
+        buf = out.buf if out is not None and out.buf.numel() >= need else torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        check(lib.kge_batch_plan_build(C.byref(md), C.byref(ld), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0], buf.data_ptr(),
+                                       buf.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        return BatchPlan(buf, pos.shape[0], neg.shape[0])
+
+    def _step_planned(self, plan, apply):
+        md, ld = self._ensure_train_state(plan.m_pos, plan.m_neg)
+        self._seed += 1
+        if not apply:
+            check(lib.kge_train_grads_planned(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                              self._gR.data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), plan.m_pos, plan.m_neg,
+                                              self._loss.data_ptr(), self._seed, self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()))
+            return {"loss": self._loss[0]}
+        self.optimizer.iterations += 1
+        od = self._opt_desc()
+        check(lib.kge_train_step_planned(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                         self._gR.data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), plan.m_pos, plan.m_neg,
+                                         self._loss.data_ptr(), self._seed, self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()))
+        return {"loss": self._loss[0]}
+
     def train_step(self, data, scores_out=None):
-        """Default Keras train_step for the two-input wrapper: data = [pos (m,3), neg (m,3)] (optionally (X, y)).
-        Returns {'loss': 0-d device tensor}."""
+        """Default Keras train_step for the two-input wrapper: data = [pos (m,3), neg (m,3)] (optionally (X, y)), or a BatchPlan
+        built from such a batch.  Returns {'loss': 0-d device tensor}."""
+        if isinstance(data, BatchPlan):
+            return self._step_planned(data, True)
         if isinstance(data, tuple) and len(data) == 2 and (data[1] is None or isinstance(data[0], (list, tuple))):
             data = data[0]
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
@@ -355,6 +401,8 @@ class EmbeddingModel:
     def train_grads(self, data):
         """First half of train_step (forward + loss + gradient accumulation); for data-parallel training an
         all-reduce of `_gE` / `_gR` goes between this and apply_grads."""
+        if isinstance(data, BatchPlan):
+            return self._step_planned(data, False)
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
         md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
@@ -393,7 +441,10 @@ class EmbeddingModel:
             if shuffle:
                 random.shuffle(order)  # Keras shuffles the batch order of a Sequence with Python's `random`
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
-            it = x.batches(order) if hasattr(x, "batches") else (x[i][0] for i in order)  # device generators prefetch on a side stream
+            if hasattr(x, "batches"):  # device generators draw (and, where a plan exists, index) the next batches on side streams
+                it = x.batches(order, plan=self.plan_batch if self.plan_supported() else None)
+            else:
+                it = (x[i][0] for i in order)
             for X in it:
                 tot += self.train_step(X)["loss"].double()
             logs = {"loss": float(tot.item()) / max(1, len(order))}

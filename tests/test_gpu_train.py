@@ -262,6 +262,114 @@ def test_full_size_fb15k237_step(model, kw):
     np.testing.assert_allclose(mdl2.E.cpu().numpy(), mdl.E.cpu().numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})])
+@pytest.mark.parametrize("loss", ["pointwize_hinge", "pointwize_logistic", "pointwize_square_loss"])
+def test_duplicate_row_folding(model, kw, loss):
+    """kge_set_dedup_mode: the step on the distinct rows weighted by multiplicity == the step on every row == the oracle.
+    Batches like oversample_data's (few distinct positives, many repeats), a triple present in BOTH arrays, scores_out
+    expanded back to the input rows, and ids outside the tables (error flag + NaN score, the row takes no part)."""
+    from kge_keras_amd import _lib
+    N, R, d = 50, 7, 32
+    res = {}
+    for mode in (2, 0):
+        _lib.check(_lib.lib.kge_set_dedup_mode(mode))
+        try:
+            mdl, E0, R0, rs = _mk(model, N, R, d, loss_function=loss, margin=0.5, **kw)
+            mdl.compile("adam")
+            Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+            oo = O.AdamTF()
+            out = []
+            for step in range(3):
+                base = _triples(rs, 12, N, R)
+                pos = base[rs.randint(0, 12, 700)]
+                negs = _triples(rs, 400, N, R)
+                neg = np.concatenate([negs[rs.randint(0, 400, 500)], base[:3], base[:3]])  # positives reappear as negatives
+                sc = torch.empty(len(pos) + len(neg), dtype=torch.float32, device="cuda")
+                L = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+                sp = O.call(model, Eo, Ro, pos, kw.get("norm", 1), kw.get("gamma", 12))
+                sn = O.call(model, Eo, Ro, neg, kw.get("norm", 1), kw.get("gamma", 12))
+                np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
+                Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12))
+                assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (mode, step)
+                np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+                np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+                out.append(L)
+            res[mode] = (out, mdl.E.cpu().numpy())
+            # ids outside the tables
+            bad = torch.tensor([[0, 0, 1], [0, R, 1], [-1, 0, 1], [0, 0, 1]], dtype=torch.int32, device="cuda")
+            sc = torch.empty(8, dtype=torch.float32, device="cuda")
+            mdl.train_step([bad, bad], scores_out=sc)
+            v = sc.cpu().numpy()
+            assert np.isfinite(v[[0, 3, 4, 7]]).all() and np.isnan(v[[1, 2, 5, 6]]).all() and v[0] == v[3]
+            with pytest.raises(IndexError):
+                mdl._raise_on_flag()
+        finally:
+            _lib.lib.kge_set_dedup_mode(1)
+    np.testing.assert_allclose(res[2][0], res[0][0], rtol=1e-5)
+    np.testing.assert_allclose(res[2][1], res[0][1], atol=2e-5)
+
+
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})])
+@pytest.mark.parametrize("dp", [0.0, 0.3])
+def test_batch_plan_step_equals_plain_step(model, kw, dp, grad_mode):
+    """kge_batch_plan_build on another stream + kge_train_step_planned == kge_train_step on the same batch == the oracle;
+    a plan is reusable as a buffer; models / losses without a plan say so."""
+    from kge_keras_amd import _lib, models as M
+    if grad_mode == "push":
+        mdl, *_ = _mk(model, 20, 3, 8, **kw)
+        mdl.compile("adam")
+        assert not mdl.plan_supported()
+        with pytest.raises(NotImplementedError):
+            mdl.plan_batch([np.zeros((4, 3), dtype=np.int64)] * 2)
+        return
+    N, R, d = 60, 5, 32
+    for fold_mode in (2, 0):
+        _lib.check(_lib.lib.kge_set_dedup_mode(fold_mode))
+        try:
+            rs = np.random.RandomState(4)
+            de, dr = O.table_dims(model, d, d)
+            E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+            R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+            a, b = (getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=dp, init_entities=E0, init_relations=R0,
+                                      loss_function="pointwize_logistic", **kw) for _ in range(2))
+            a.compile("adam")
+            b.compile("adam")
+            assert a.plan_supported()
+            Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+            oo = O.AdamTF()
+            side = torch.cuda.Stream()
+            plan = None
+            for step in range(3):
+                base = _triples(rs, 30, N, R)
+                pos, neg = base[rs.randint(0, 30, 500)], _triples(rs, 400, N, R)[rs.randint(0, 400, 600)]
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    plan = a.plan_batch([pos, neg], out=plan)
+                torch.cuda.current_stream().wait_stream(side)
+                La = float(a.train_step(plan)["loss"].item())
+                Lb = float(b.train_step([pos, neg])["loss"].item())
+                Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, b._seed)
+                assert La == pytest.approx(Lb, rel=1e-5, abs=1e-6) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), (fold_mode, step)
+                np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-5)
+                np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
+                np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+            # the gradient half alone (data-parallel split) + ids outside the tables raise through the plan too
+            g = a.train_grads(a.plan_batch([pos, neg]))
+            assert np.isfinite(float(g["loss"].item())) and float(a._gE.abs().max()) > 0
+            a.apply_grads()
+            bad = torch.tensor([[0, 0, 1], [0, R, 1]], dtype=torch.int32, device="cuda")
+            a.train_step(a.plan_batch([bad, bad]))
+            with pytest.raises(IndexError):
+                a._raise_on_flag()
+        finally:
+            _lib.lib.kge_set_dedup_mode(1)
+    h = M.HolE(e_dim=8, r_dim=8, num_entities=N, num_relations=R, dp=0.0)
+    h.compile("adam")
+    p2 = M.DistMult(e_dim=8, r_dim=8, num_entities=N, num_relations=R, dp=0.0, loss_function="pairwize_hinge")
+    p2.compile("adam")
+    assert not h.plan_supported() and not p2.plan_supported()
+
+
 @pytest.mark.parametrize("model,kw", CASES)
 @pytest.mark.parametrize("loss", ["pointwize_logistic", "pairwize_hinge"])
 def test_dropout_training_parity(model, kw, loss, grad_mode):
