@@ -142,6 +142,10 @@ def main():
     ap.add_argument("--sampler", default="device", choices=["device", "pre"],
                     help="device: every step's batch is drawn by the bit-exact MT19937 HIP sampler on a side stream, one batch ahead "
                          "(inside the timed region); pre: batches pre-built on the host before timing")
+    ap.add_argument("--plan", default="ahead", choices=["ahead", "step"],
+                    help="ahead: batch plans (ids-only half of the step) built on their own stream ahead of the step; step: inside the step")
+    ap.add_argument("--launch", default="graph", choices=["graph", "stream"],
+                    help="graph: the steady-state pipeline tick is one hipGraph launch per step; stream: every kernel launched from Python")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -188,36 +192,74 @@ def main():
     train_dev, perm_dev = torch.from_numpy(train).cuda(), torch.from_numpy(perm).cuda()
     dsamp = DeviceSampler(nps, PythonStream(rank))
     bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device="cuda") for _ in range(2)) for _ in range(2)]
-    ready = [torch.cuda.Event() for _ in range(2)]
-    freed = [torch.cuda.Event() for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(2)]     # batch arrays drawn
+    freed = [torch.cuda.Event() for _ in range(2)]     # batch arrays no longer needed
+    planned = [torch.cuda.Event() for _ in range(2)]   # batch plan built
+    pfreed = [torch.cuda.Event() for _ in range(2)]    # batch plan consumed
     nb_epoch = CFG["n_train"] // CFG["B"]
+    # --plan ahead (default): the ids-only half of the step (duplicate-row fold, gradient lists) is built on a third stream
+    # right behind the sampler, one to two batches ahead of the step that consumes it; --plan step builds it inside the step
+    plan_ahead = args.plan == "ahead" and model.plan_supported()
+    pstream = torch.cuda.Stream() if plan_ahead else None
+    plans = [None, None]
+    pool_plans = [None] * n_pool
 
     def produce(i):
-        with torch.cuda.stream(side):
-            side.wait_event(freed[i % 2])
-            b = i % nb_epoch
-            batch = train_dev.index_select(0, perm_dev[b * CFG["B"]:(b + 1) * CFG["B"]])
-            dsamp.build_batch(batch, CFG["ns"], CFG["N"], *bufs[i % 2])
-            ready[i % 2].record(side)
-
-    if args.sampler == "device":
-        produce(0)
-        produce(1)
-
-    def step(i):
+        j = i % 2
         if args.sampler == "device":
-            main_stream.wait_event(ready[i % 2])
-            pos, neg = bufs[i % 2]
+            with torch.cuda.stream(side):
+                side.wait_event(freed[j])
+                b = i % nb_epoch
+                batch = train_dev.index_select(0, perm_dev[b * CFG["B"]:(b + 1) * CFG["B"]])
+                dsamp.build_batch(batch, CFG["ns"], CFG["N"], *bufs[j])
+                ready[j].record(side)
+        if plan_ahead:
+            with torch.cuda.stream(pstream):
+                if args.sampler == "device":
+                    pstream.wait_event(ready[j])
+                pstream.wait_event(pfreed[j])
+                plans[j] = model.plan_batch(list(bufs[j]) if args.sampler == "device" else list(dev[i % n_pool]), out=plans[j])
+                planned[j].record(pstream)
+                freed[j].record(pstream)
+
+    def step(i):  # kernel-by-kernel launches (--launch stream, --sampler pre, --plan step)
+        j = i % 2
+        if plan_ahead:
+            main_stream.wait_event(planned[j])
+            data = plans[j]
+        elif args.sampler == "device":
+            main_stream.wait_event(ready[j])
+            data = list(bufs[j])
         else:
-            pos, neg = dev[i % n_pool]
+            data = list(dev[i % n_pool])
         if world == 1:
-            model.train_step([pos, neg])
+            model.train_step(data)
         else:  # data-parallel: gradient half, all-reduce of the dense gradient tables over RCCL, optimizer half
             # gradient tables and the loss word are one flat buffer: ONE all-reduce per step
-            D.dp_train_step(lambda: model.train_grads([pos, neg]), model.apply_grads, [model._gall], None)
-        if args.sampler == "device":
-            freed[i % 2].record(main_stream)
+            D.dp_train_step(lambda: model.train_grads(data), model.apply_grads, [model._gall], None)
+        if plan_ahead:
+            pfreed[j].record(main_stream)
+        elif args.sampler == "device":
+            freed[j].record(main_stream)
+        if args.sampler == "device" or plan_ahead:
             produce(i + 2)
+
+    # default: the three-stage pipeline (draw batch t+2 | plan batch t+1 | train step t) replayed from hipGraphs, one launch per step
+    pipe = None
+    if args.sampler == "device" and plan_ahead and args.launch == "graph":
+        from kge_keras_amd.pipeline import TrainPipeline
+        between = (lambda: (D.allreduce_sum_([model._gall]), 1.0 / world)[1]) if world > 1 else None
+        pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=True, between=between)
+        total = args.warmup + 2 * args.steps + 8
+        pipe.load_epoch(perm_dev, [i % nb_epoch for i in range(total)])
+        pipe.start()
+        step = lambda i: pipe.tick()  # noqa: E731
+    elif args.sampler == "device" or plan_ahead:
+        side.wait_stream(main_stream)
+        if pstream is not None:
+            pstream.wait_stream(main_stream)
+        produce(0)
+        produce(1)
 
     def fence():
         if world > 1:
@@ -227,12 +269,23 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    _lib.lib.kge_prof_enable(1)  # hipEvents around the dominant kernels, recorded on the launch stream
+    if pipe is None:
+        _lib.lib.kge_prof_enable(1)  # hipEvents around the dominant kernels, recorded on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    t_issue = time.perf_counter() - t0  # host time to enqueue the steps (the GPU runs behind it)
     fence()
     dt = time.perf_counter() - t0
+    if pipe is not None:
+        # kernel durations for the roofline object: the same K steps again, launched kernel by kernel (events cannot be read
+        # back from inside a replayed graph), hipEvents recorded by the library on each kernel's own launch stream
+        pipe.use_graphs = False
+        _lib.lib.kge_prof_enable(1)
+        for i in range(args.steps):
+            step(args.warmup + args.steps + i)
+        fence()
+        pipe.finish()
     _lib.lib.kge_prof_enable(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -253,7 +306,7 @@ def main():
     def distinct(a):
         key = (a[:, 0].long() * CFG["R"] + a[:, 1].long()) * CFG["N"] + a[:, 2].long()
         return int(torch.unique(key).numel())
-    used = list(bufs) if args.sampler == "device" else dev
+    used = list(pipe.bufs) if pipe is not None else (list(bufs) if args.sampler == "device" else dev)
     folded = d_n > 0
     rows_launch = float(np.mean([distinct(p) + distinct(n) for p, n in used])) if folded else float(per_step)
 
@@ -297,7 +350,12 @@ def main():
                                                    "bytes per launch are priced on those rows" if folded else "off"),
                          "fold_avg_ms": d_ms / max(1, d_n),
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
-                         "sampler_avg_ms": s_ms / max(1, s_n)},
+                         "sampler_avg_ms": s_ms / max(1, s_n), "host_enqueue_ms_per_step": t_issue / args.steps * 1e3,
+                         "launch": ("one hipGraph launch per step (draw | plan | step stages on three streams inside the graph); kernel durations "
+                                    "above come from a second pass of the same steps launched kernel by kernel" if pipe is not None
+                                    else "kernel-by-kernel stream launches"),
+                         "plan": ("ids-only half of the step (fold + gradient lists) built 1-2 batches ahead on its own stream, inside the timed region"
+                                  if plan_ahead else "built inside the step")},
         }
         res["eval_1vsall"] = ev
         if world == 1 and not args.no_cpu_baseline:

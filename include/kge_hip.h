@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 1
+#define KGE_ABI_VERSION 2
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -80,8 +80,13 @@ typedef struct {
 typedef struct {
   int32_t kind;  /* kge_opt */
   float lr, beta1, beta2, eps;
-  int64_t step;  /* t of THIS update, 1-based */
+  int64_t step;  /* t of THIS update, 1-based (ignored when step_dev is set) */
   float *mE, *vE, *mRel, *vRel; /* Adam slots, same shapes as the tables (unused for SGD) */
+  /* Optional device-resident step state, for steps replayed from a hipGraph where no host value can change between
+   * launches.  16 bytes: {int64 t = updates done so far, float lr_t of update t+1, float running sum of the step losses}.
+   * kge_opt_state_init seeds it from `step`; every kge_opt_apply / kge_train_step* then reads lr_t from it and, as its last
+   * kernel, advances t, prepares the next lr_t and adds *loss_out to the running sum.  NULL: `step` above is used. */
+  int64_t* step_dev;
 } kge_opt_desc;
 
 const char* kge_last_error(void);
@@ -175,6 +180,8 @@ int kge_lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32
                         int32_t L, int32_t lit_rows, const float* theta_l, float* gradE, float* gradRel, float* gtheta_l, const int32_t* pos,
                         int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
                         int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* Seeds the device-resident step state: od->step_dev := {od->step - 1, lr_t(od->step), 0} (see kge_opt_desc). */
+int kge_opt_state_init(const kge_opt_desc* od, kge_stream_t stream);
 /* Keras optimizer update of one flat fp32 vector (w -= ..., g re-zeroed); od->mE / od->vE are its Adam slots. */
 int kge_opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float grad_scale, kge_stream_t stream);
 /* Filtered rank counts for any model whose score is a dot product <q_i, c_j>: Q is (n_queries, K), Cand holds rows

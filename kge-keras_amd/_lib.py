@@ -32,7 +32,8 @@ class LossDesc(C.Structure):
 
 class OptDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("step", C.c_int64), ("mE", C.c_void_p), ("vE", C.c_void_p), ("mRel", C.c_void_p), ("vRel", C.c_void_p)]
+                ("step", C.c_int64), ("mE", C.c_void_p), ("vE", C.c_void_p), ("mRel", C.c_void_p), ("vRel", C.c_void_p),
+                ("step_dev", C.c_void_p)]
 
 
 _P, _I64, _I32, _U64, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float
@@ -56,6 +57,7 @@ SIGNATURES = {
     "kge_lit_transform_workspace_bytes": (_I64, [_MD, _I32, _I32]),
     "kge_lit_transform": (C.c_int, [_MD, _I32, _P, _P, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "kge_lit_train_grads": (C.c_int, [_MD, _LD, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
+    "kge_opt_state_init": (C.c_int, [_OD, _P]),
     "kge_opt_apply_vector": (C.c_int, [_OD, _P, _P, _I64, _F, _P]),
     "kge_rank_sweep_q_workspace_bytes": (_I64, [_I64, _I32]),
     "kge_rank_sweep_q": (C.c_int, [_P, _I64, _I32, _P, _I32, _I32, _P, _P, _P, _I64, _P, _I32, _P, _I64, _P]),

@@ -134,6 +134,7 @@ int64_t train_workspace_bytes(const kge_model_desc*, int64_t, int64_t);
 int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, const int32_t*, int64_t,
                 const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
 bool plan_supported(const kge_model_desc*, const kge_loss_desc*);
+int opt_state_init(const kge_opt_desc*, hipStream_t);
 int64_t batch_plan_bytes(const kge_model_desc*, int64_t);
 int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, void*, uint32_t*, hipStream_t);
 int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, void*, int64_t, int64_t, float*,
@@ -265,6 +266,13 @@ int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_o
   if (!ld || !od || !E || !Rel || !gradE || !gradRel) return fail(KGE_EINVAL, "kge_opt_apply: null pointer");
   return opt_apply(md, ld, od, E, Rel, gradE, gradRel, grad_scale, loss_out, workspace, workspace_bytes,
                    static_cast<hipStream_t>(stream));
+}
+
+int kge_opt_state_init(const kge_opt_desc* od, kge_stream_t stream) {
+  if (!od || !od->step_dev) return fail(KGE_EINVAL, "kge_opt_state_init: optimizer descriptor without step_dev");
+  if (od->kind != KGE_OPT_ADAM_TF && od->kind != KGE_OPT_SGD) return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
+  if (od->step < 1) return fail(KGE_EINVAL, "kge_opt_state_init: step must be >= 1 (the number of the next update)");
+  return opt_state_init(od, static_cast<hipStream_t>(stream));
 }
 
 int kge_train_step(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,

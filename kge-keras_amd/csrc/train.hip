@@ -188,12 +188,11 @@ __global__ __launch_bounds__(256) void pairwise_allpairs_kernel(const float* __r
 // sweep equals the sparse scatter because untouched rows have g == 0 exactly).  Also re-zeroes the accumulator and,
 // when the L3 regulariser is on (models.py:10-11), adds 3w*x*|x| to the gradient and reduces sum|x|^3 for the loss.
 template <int KIND, bool REG>
-__global__ __launch_bounds__(256) void opt_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
-                                                   float eps, float gscale, float regw, float* __restrict__ reg_partials) {
-  __shared__ float red[16];
+__device__ __forceinline__ void opt_sweep(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                          int64_t n, int block, int nblocks, float lr_t, float b1, float b2, float eps, float gscale,
+                                          float regw, float* __restrict__ reg_partials, float* red) {
   float rsum = 0.f;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride = (int64_t)nblocks * blockDim.x;
   const int64_t n4 = n >> 2;
   float4* w4 = reinterpret_cast<float4*>(w);
   float4* g4 = reinterpret_cast<float4*>(g);
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(256) void opt_kernel(float* __restrict__ w, float* 
       wx -= lr_t * gx;
     }
   };
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  for (int64_t i = (int64_t)block * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 wv = w4[i], gv = g4[i], mv, vv;
     if (KIND == KGE_OPT_ADAM_TF) { mv = m4[i]; vv = v4[i]; }
     upd(wv.x, gv.x, mv.x, vv.x);
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(256) void opt_kernel(float* __restrict__ w, float* 
     if (KIND == KGE_OPT_ADAM_TF) { m4[i] = mv; v4[i] = vv; }
   }
   // scalar tail (n % 4)
-  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (int64_t i = (n4 << 2) + (int64_t)block * blockDim.x + threadIdx.x; i < n; i += stride) {
     float wx = w[i], gx = g[i], mx = 0.f, vx = 0.f;
     if (KIND == KGE_OPT_ADAM_TF) { mx = m[i]; vx = v[i]; }
     upd(wx, gx, mx, vx);
@@ -236,8 +235,19 @@ __global__ __launch_bounds__(256) void opt_kernel(float* __restrict__ w, float* 
   }
   if (REG) {
     const float b = block_sum(rsum, red);
-    if (threadIdx.x == 0) reg_partials[blockIdx.x] = b;
+    if (threadIdx.x == 0) reg_partials[block] = b;
   }
+}
+
+// One launch for both tables: blocks [0, grid_a) sweep table a (the entity table; REG applies to it), the rest table b.
+struct OptSeg { float *w, *g, *m, *v; int64_t n; };
+template <int KIND, bool REG>
+__global__ __launch_bounds__(256) void opt_kernel(OptSeg a, OptSeg b, int grid_a, float lr_t, float b1, float b2, float eps, float gscale,
+                                                   float regw, float* __restrict__ reg_partials, const float* __restrict__ lr_dev) {
+  __shared__ float red[16];
+  if (lr_dev) lr_t = lr_dev[0];  // device-resident step counter (graph replay): lr_t of this step
+  if ((int)blockIdx.x < grid_a) opt_sweep<KIND, REG>(a.w, a.g, a.m, a.v, a.n, blockIdx.x, grid_a, lr_t, b1, b2, eps, gscale, regw, reg_partials, red);
+  else opt_sweep<KIND, false>(b.w, b.g, b.m, b.v, b.n, blockIdx.x - grid_a, gridDim.x - grid_a, lr_t, b1, b2, eps, gscale, 0.f, nullptr, red);
 }
 
 // loss_out = (accumulate ? loss_out : 0) + scale * sum(partials[0..n)), fixed order -> run-to-run deterministic
@@ -563,16 +573,49 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   return KGE_OK;
 }
 
-template <int KIND>
-static int launch_opt(bool reg, float* w, float* g, float* m, float* v, int64_t n, float lr_t, const kge_opt_desc* od,
-                      float gscale, float regw, float* reg_partials, hipStream_t st, int* nb) {
-  const int64_t want = cdiv(cdiv(n, 4), 256);
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, kCUs * 8));
-  *nb = grid;
-  if (reg) hipLaunchKernelGGL((opt_kernel<KIND, true>), dim3(grid), dim3(256), 0, st, w, g, m, v, n, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials);
-  else hipLaunchKernelGGL((opt_kernel<KIND, false>), dim3(grid), dim3(256), 0, st, w, g, m, v, n, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials);
+// Device-resident optimizer step state (kge_opt_desc.step_dev, 16 bytes): {int64 t = updates done, float lr_t of update t+1,
+// float running sum of the step losses}.  Advanced by one tiny kernel at the end of every kge_opt_apply.
+__device__ __forceinline__ float lr_of_step(int kind, float lr, float b1, float b2, int64_t t) {
+  if (kind != KGE_OPT_ADAM_TF) return lr;
+  return (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));  // Keras Adam
+}
+__global__ void opt_state_init_kernel(int64_t* step, int64_t done, int kind, float lr, float b1, float b2) {
+  step[0] = done;
+  float* f = reinterpret_cast<float*>(step + 1);
+  f[0] = lr_of_step(kind, lr, b1, b2, done + 1);
+  f[1] = 0.f;
+}
+__global__ void opt_state_post_kernel(int64_t* step, int kind, float lr, float b1, float b2, const float* loss) {
+  const int64_t t = step[0] + 1;
+  step[0] = t;
+  float* f = reinterpret_cast<float*>(step + 1);
+  f[0] = lr_of_step(kind, lr, b1, b2, t + 1);
+  if (loss) f[1] += loss[0];
+}
+
+int opt_state_init(const kge_opt_desc* od, hipStream_t st) {
+  hipLaunchKernelGGL(opt_state_init_kernel, dim3(1), dim3(1), 0, st, od->step_dev, od->step - 1, od->kind, od->lr, od->beta1, od->beta2);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
+}
+
+template <int KIND>
+static int launch_opt(bool reg, OptSeg a, OptSeg b, float lr_t, const kge_opt_desc* od, float gscale, float regw, float* reg_partials,
+                      hipStream_t st, int* nb) {
+  const float* lr_dev = od->step_dev ? reinterpret_cast<const float*>(od->step_dev + 1) : nullptr;
+  auto blocks = [](int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(cdiv(n, 4), 256), kCUs * 8)); };
+  const int ga = blocks(a.n), gb = b.n > 0 ? blocks(b.n) : 0;
+  *nb = ga;
+  if (reg) hipLaunchKernelGGL((opt_kernel<KIND, true>), dim3(ga + gb), dim3(256), 0, st, a, b, ga, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials, lr_dev);
+  else hipLaunchKernelGGL((opt_kernel<KIND, false>), dim3(ga + gb), dim3(256), 0, st, a, b, ga, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials, lr_dev);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+static float host_lr_t(const kge_opt_desc* od) {
+  if (od->kind != KGE_OPT_ADAM_TF) return od->lr;
+  const double t = (double)od->step;
+  return (float)((double)od->lr * std::sqrt(1.0 - std::pow((double)od->beta2, t)) / (1.0 - std::pow((double)od->beta1, t)));
 }
 
 bool plan_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
@@ -589,14 +632,14 @@ int train_grads_with_plan(const kge_model_desc* md, const kge_loss_desc* ld, con
 
 int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float gscale, hipStream_t st) {
   int nb = 0;
+  if (od->step_dev) return fail(KGE_EUNSUPPORTED, "kge_opt_apply_vector: device-resident step counters cover kge_opt_apply only");
+  const OptSeg none{nullptr, nullptr, nullptr, nullptr, 0};
   if (od->kind == KGE_OPT_ADAM_TF) {
     if (!od->mE || !od->vE) return fail(KGE_EINVAL, "adam: moment buffers (mE, vE) are null");
     if (od->step < 1) return fail(KGE_EINVAL, "adam: step must be >= 1");
-    const double t = (double)od->step;
-    const float lr_t = (float)((double)od->lr * std::sqrt(1.0 - std::pow((double)od->beta2, t)) / (1.0 - std::pow((double)od->beta1, t)));
-    return launch_opt<KGE_OPT_ADAM_TF>(false, w, g, od->mE, od->vE, n, lr_t, od, gscale, 0.f, nullptr, st, &nb);
+    return launch_opt<KGE_OPT_ADAM_TF>(false, OptSeg{w, g, od->mE, od->vE, n}, none, host_lr_t(od), od, gscale, 0.f, nullptr, st, &nb);
   }
-  if (od->kind == KGE_OPT_SGD) return launch_opt<KGE_OPT_SGD>(false, w, g, nullptr, nullptr, n, od->lr, od, gscale, 0.f, nullptr, st, &nb);
+  if (od->kind == KGE_OPT_SGD) return launch_opt<KGE_OPT_SGD>(false, OptSeg{w, g, nullptr, nullptr, n}, none, od->lr, od, gscale, 0.f, nullptr, st, &nb);
   return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
 }
 
@@ -606,25 +649,24 @@ int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_d
   if (int rc = carve(workspace, wbytes, md, 0, 0, &ws)) return rc;
   const int64_t nE = (int64_t)md->num_entities * md->d_e, nR = (int64_t)md->num_relations * md->d_r;
   const bool reg = ld->regularization != 0.f;
-  int nb = 0, nb2 = 0;
-  ProfScope prof(KGE_PROF_OPT, st);
-  if (od->kind == KGE_OPT_ADAM_TF) {
-    if (!od->mE || !od->vE || !od->mRel || !od->vRel) return fail(KGE_EINVAL, "adam: moment buffers are null");
-    if (od->step < 1) return fail(KGE_EINVAL, "adam: step must be >= 1");
-    const double t = (double)od->step;
-    const float lr_t = (float)((double)od->lr * std::sqrt(1.0 - std::pow((double)od->beta2, t)) / (1.0 - std::pow((double)od->beta1, t)));
-    if (int rc = launch_opt<KGE_OPT_ADAM_TF>(reg, E, gE, od->mE, od->vE, nE, lr_t, od, gscale, ld->regularization, ws.reg_partials, st, &nb)) return rc;
-    if (int rc = launch_opt<KGE_OPT_ADAM_TF>(false, Rel, gR, od->mRel, od->vRel, nR, lr_t, od, gscale, 0.f, nullptr, st, &nb2)) return rc;
-  } else if (od->kind == KGE_OPT_SGD) {
-    if (int rc = launch_opt<KGE_OPT_SGD>(reg, E, gE, nullptr, nullptr, nE, od->lr, od, gscale, ld->regularization, ws.reg_partials, st, &nb)) return rc;
-    if (int rc = launch_opt<KGE_OPT_SGD>(false, Rel, gR, nullptr, nullptr, nR, od->lr, od, gscale, 0.f, nullptr, st, &nb2)) return rc;
-  } else {
-    return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
+  int nb = 0;
+  {
+    ProfScope prof(KGE_PROF_OPT, st);
+    if (od->kind == KGE_OPT_ADAM_TF) {
+      if (!od->mE || !od->vE || !od->mRel || !od->vRel) return fail(KGE_EINVAL, "adam: moment buffers are null");
+      if (!od->step_dev && od->step < 1) return fail(KGE_EINVAL, "adam: step must be >= 1");
+      if (int rc = launch_opt<KGE_OPT_ADAM_TF>(reg, OptSeg{E, gE, od->mE, od->vE, nE}, OptSeg{Rel, gR, od->mRel, od->vRel, nR}, host_lr_t(od), od, gscale,
+                                               ld->regularization, ws.reg_partials, st, &nb)) return rc;
+    } else if (od->kind == KGE_OPT_SGD) {
+      if (int rc = launch_opt<KGE_OPT_SGD>(reg, OptSeg{E, gE, nullptr, nullptr, nE}, OptSeg{Rel, gR, nullptr, nullptr, nR}, od->lr, od, gscale,
+                                           ld->regularization, ws.reg_partials, st, &nb)) return rc;
+    } else {
+      return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
+    }
   }
-  if (reg && loss_out) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.reg_partials, nb, ld->regularization, 1, loss_out);
-    KGE_HIP_TRY(hipGetLastError());
-  }
+  if (reg && loss_out) hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.reg_partials, nb, ld->regularization, 1, loss_out);
+  if (od->step_dev) hipLaunchKernelGGL(opt_state_post_kernel, dim3(1), dim3(1), 0, st, od->step_dev, od->kind, od->lr, od->beta1, od->beta2, loss_out);
+  KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
 

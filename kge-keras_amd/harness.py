@@ -97,6 +97,20 @@ class DeviceDataGenerator:
         self.release_global()
         return [pos, neg], None
 
+    def run_epoch(self, model, order, graphs=True):
+        """One epoch of model training over the batches `order` through the three-stage GPU pipeline (pipeline.TrainPipeline:
+        draw batch t+2 | plan batch t+1 | train step t, steady state replayed from hipGraphs).  Same draws and the same
+        updates as `for i in order: model.train_step(self[i][0])`.  Returns the summed loss (device tensor)."""
+        from .pipeline import TrainPipeline
+        pipe = getattr(self, "_pipe", None)
+        if pipe is None or pipe.model is not model or pipe.use_graphs != (bool(graphs) and float(model.dp or 0.0) == 0.0):
+            pipe = self._pipe = TrainPipeline(model, self.kg, self.n, self.batch_size, self.ns, self.num_e, self.sampler, graphs=graphs)
+        self._upload_global()
+        try:
+            return pipe.run_epoch(self.index, order)
+        finally:
+            self.release_global()
+
     def batches(self, order, plan=None):
         """Iterate the batches `order` with the sampler running on a side stream ahead of the consumer (double-buffered in
         HBM, event fork/join): `fit` uses this, so drawing a batch overlaps the previous train steps.  Same draws, in the

@@ -316,7 +316,8 @@ class EmbeddingModel:
     def _opt_desc(self):
         o = self.optimizer
         sl = [x.data_ptr() for x in o.slots] if o.slots else [None] * 4
-        return OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, o.iterations, *sl)
+        sd = getattr(self, "_step_dev", None)  # device-resident step counter while a hipGraph pipeline drives the steps
+        return OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, max(1, o.iterations), *sl, sd.data_ptr() if sd is not None else None)
 
     def plan_supported(self):
         """True where a batch plan exists for this model / loss (the relation-grouped pull path of the HIP library)."""
@@ -441,12 +442,13 @@ class EmbeddingModel:
             if shuffle:
                 random.shuffle(order)  # Keras shuffles the batch order of a Sequence with Python's `random`
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
-            if hasattr(x, "batches"):  # device generators draw (and, where a plan exists, index) the next batches on side streams
-                it = x.batches(order, plan=self.plan_batch if self.plan_supported() else None)
+            if hasattr(x, "run_epoch") and self.plan_supported():
+                # device generator + a model with batch plans: draw | plan | step pipelined on the GPU, replayed from hipGraphs
+                tot = x.run_epoch(self, order)
             else:
-                it = (x[i][0] for i in order)
-            for X in it:
-                tot += self.train_step(X)["loss"].double()
+                it = x.batches(order) if hasattr(x, "batches") else (x[i][0] for i in order)  # device generators prefetch on a side stream
+                for X in it:
+                    tot += self.train_step(X)["loss"].double()
             logs = {"loss": float(tot.item()) / max(1, len(order))}
             self._raise_on_flag()
             if validation_data is not None:
