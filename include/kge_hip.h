@@ -198,13 +198,16 @@ int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* 
  *      that the step proper starts at the forward gather.  A plan is an opaque device buffer:
  *        kge_batch_plan_bytes   size for (md, ld, m_pos, m_neg); KGE_EUNSUPPORTED where no plan exists (pairwize losses, HolE,
  *                               ConvE, gradient mode 1) -- callers then use kge_train_step;
- *        kge_batch_plan_build   asynchronous on `stream` (any stream; the arrays pos / neg are not referenced afterwards);
+ *        kge_batch_plan_build   asynchronous on `stream` (any stream; the arrays pos / neg are not referenced once part 1 is
+ *                               done).  parts: 1 = rows (duplicates folded, counters cleared), 2 = entity lists, 4 = relation
+ *                               lists; 7 = everything.  2 and 4 need 1 and are independent of each other, so a caller may
+ *                               run them on two streams (fork after 1, join before the step);
  *        kge_train_step_planned = kge_train_step on the batch the plan was built from (same md, ld, m_pos, m_neg), without
  *                               scores_out.  CONSUMES the plan: one step per build.  The caller orders build -> step
  *                               (events or same stream).  Workspace as for kge_train_step. */
 int64_t kge_batch_plan_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg);
 int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
-                         void* plan, int64_t plan_bytes, uint32_t* err_flag, kge_stream_t stream);
+                         void* plan, int64_t plan_bytes, int32_t parts, uint32_t* err_flag, kge_stream_t stream);
 int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
                             void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace,
                             int64_t workspace_bytes, kge_stream_t stream);
@@ -280,6 +283,14 @@ int kge_sampler_plan_host(int64_t B, int64_t ns, int64_t num_e, void* plan_host)
 int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t* batch_dev, int64_t B, int64_t ns,
                            int64_t num_e, int32_t* pos_out_dev, int32_t* neg_out_dev, const void* plan_dev, void* workspace,
                            int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* Same, with the positives read in place: row i of the batch is kg[index[starts[*cursor] * B + i]] (kg: all training
+ * triples (n,3) int32; index: the epoch permutation, int64; starts: batch numbers in drawing order, int64; cursor: one
+ * int64 on the device) -- the slice DataGenerator.__getitem__ takes (tests.py:43-47,55-56).  The last kernel adds one to
+ * *cursor, so consecutive calls (or replays of a hipGraph holding the call) walk through `starts`. */
+int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const int32_t* kg_dev, const int64_t* index_dev,
+                                   const int64_t* starts_dev, int64_t* cursor_dev, int64_t B, int64_t ns, int64_t num_e,
+                                   int32_t* pos_out_dev, int32_t* neg_out_dev, const void* plan_dev, void* workspace,
+                                   int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
 /* GF(2) jump-ahead primitives (host): out[312] uint64 = coefficients of x^J mod phi; kge_mt_jump_host replaces the 624
  * state words by raw words [J, J+624) of the stream (bits 0..30 of word 0 are not state and not guaranteed). */
 int kge_mt_jump_poly(int64_t J, uint64_t* out_host);

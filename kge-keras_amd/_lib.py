@@ -64,7 +64,7 @@ SIGNATURES = {
     "kge_loss_workspace_bytes": (_I64, [_I64, _I64]),
     "kge_loss_value": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "kge_batch_plan_bytes": (_I64, [_MD, _LD, _I64, _I64]),
-    "kge_batch_plan_build": (C.c_int, [_MD, _LD, _P, _I64, _P, _I64, _P, _I64, _P, _P]),
+    "kge_batch_plan_build": (C.c_int, [_MD, _LD, _P, _I64, _P, _I64, _P, _I64, _I32, _P, _P]),
     "kge_train_grads_planned": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_train_step_planned": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
@@ -88,6 +88,7 @@ SIGNATURES = {
     "kge_sampler_plan_bytes": (_I64, []),
     "kge_sampler_plan_host": (C.c_int, [_I64, _I64, _I64, _P]),
     "kge_build_batch_device": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P]),
+    "kge_build_batch_device_indexed": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P]),
     "kge_mt_jump_poly": (C.c_int, [_I64, _P]),
     "kge_mt_jump_host": (C.c_int, [_P, _I64]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),

@@ -136,7 +136,7 @@ int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const
 bool plan_supported(const kge_model_desc*, const kge_loss_desc*);
 int opt_state_init(const kge_opt_desc*, hipStream_t);
 int64_t batch_plan_bytes(const kge_model_desc*, int64_t);
-int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, void*, uint32_t*, hipStream_t);
+int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, void*, int, uint32_t*, hipStream_t);
 int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, void*, int64_t, int64_t, float*,
                           uint64_t, void*, int64_t, hipStream_t);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
@@ -167,7 +167,7 @@ int rank_chain_scores(const kge_model_desc*, const float*, const float*, const i
                       uint32_t*, hipStream_t);
 
 int64_t sampler_workspace_bytes(int64_t, int64_t, int64_t);
-int build_batch_device(void*, void*, const int32_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, const void*, void*, int64_t, uint32_t*,
+int build_batch_device(void*, void*, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int64_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, const void*, void*, int64_t, uint32_t*,
                        hipStream_t);
 int sampler_plan_host(int64_t, int64_t, int64_t, uint64_t*);
 int64_t sampler_plan_bytes();
@@ -304,12 +304,13 @@ int64_t kge_batch_plan_bytes(const kge_model_desc* md, const kge_loss_desc* ld, 
 }
 
 int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
-                         void* plan, int64_t plan_bytes, uint32_t* err_flag, kge_stream_t stream) {
+                         void* plan, int64_t plan_bytes, int32_t parts, uint32_t* err_flag, kge_stream_t stream) {
   if (int rc = check_plan("kge_batch_plan_build", md, ld, m_pos, m_neg)) return rc;
   if (!pos || !neg || !plan || !err_flag) return fail(KGE_EINVAL, "kge_batch_plan_build: null pointer");
   if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
     return fail(KGE_EWORKSPACE, "kge_batch_plan_build: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
-  return batch_plan_build(md, pos, m_pos, neg, m_neg, plan, err_flag, static_cast<hipStream_t>(stream));
+  if (parts < 1 || parts > 7) return fail(KGE_EINVAL, "kge_batch_plan_build: parts mask %d outside 1..7", parts);
+  return batch_plan_build(md, pos, m_pos, neg, m_neg, plan, parts, err_flag, static_cast<hipStream_t>(stream));
 }
 
 int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
@@ -381,8 +382,20 @@ int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t
   if (!np_state_dev || !py_state_dev || !batch_dev || !pos_out_dev || !neg_out_dev || !workspace || !err_flag)
     return fail(KGE_EINVAL, "kge_build_batch_device: null pointer");
   if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_build_batch_device: bad sizes");
-  return build_batch_device(np_state_dev, py_state_dev, batch_dev, B, ns, num_e, pos_out_dev, neg_out_dev, plan_dev, workspace,
-                            workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+  return build_batch_device(np_state_dev, py_state_dev, batch_dev, nullptr, nullptr, nullptr, nullptr, B, ns, num_e, pos_out_dev, neg_out_dev,
+                            plan_dev, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const int32_t* kg_dev, const int64_t* index_dev,
+                                   const int64_t* starts_dev, int64_t* cursor_dev, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out_dev,
+                                   int32_t* neg_out_dev, const void* plan_dev, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                                   kge_stream_t stream) {
+  if (!np_state_dev || !py_state_dev || !kg_dev || !index_dev || !starts_dev || !cursor_dev || !pos_out_dev || !neg_out_dev || !workspace || !err_flag)
+    return fail(KGE_EINVAL, "kge_build_batch_device_indexed: null pointer");
+  if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll)
+    return fail(KGE_EINVAL, "kge_build_batch_device_indexed: bad sizes");
+  return build_batch_device(np_state_dev, py_state_dev, nullptr, kg_dev, index_dev, starts_dev, cursor_dev, B, ns, num_e, pos_out_dev, neg_out_dev,
+                            plan_dev, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
 }
 
 int64_t kge_loss_workspace_bytes(int64_t m_true, int64_t m_false) {

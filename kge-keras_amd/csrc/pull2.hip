@@ -515,6 +515,17 @@ static void carve_plan(void* counters, void* region, const kge_model_desc* md, i
   char* hq = reinterpret_cast<char*>(((uintptr_t)counters + 255) & ~(uintptr_t)255);
   p->ent.cnt = (int32_t*)hq;
   p->rcnt = (int32_t*)(hq + b256(z.N * 4));
+  Dedup& d = p->dd;
+  d.cap = z.cap;
+  d.keys = (unsigned long long*)take(d.cap * 8);   // keys | cnt first: contiguous with the counters of a plan buffer, one memset
+  d.cnt = (int32_t*)take(d.cap * 4);
+  d.clear_bytes = (char*)d.cnt + b256(d.cap * 4) - (char*)d.keys;
+  d.nu = (int32_t*)take(256);
+  d.uid = (int32_t*)take(d.cap * 4);
+  d.slot_of = (int32_t*)take(n * 4);
+  d.frank = (int32_t*)take(n * 4);
+  d.bcnt = (int32_t*)take((n / 256 + 1) * 4);
+  d.uniq = (int4*)take(n * 16);
   p->roff = (int32_t*)take(z.R * 4);
   p->ruoff = (int32_t*)take(z.R * 4);
   p->rtotal = (int32_t*)take(16);
@@ -531,17 +542,6 @@ static void carve_plan(void* counters, void* region, const kge_model_desc* md, i
   p->ent.ranks = p->erank;
   p->ent.max_extra = (int)z.max_extra;
   p->ent.chunk = z.C;
-  Dedup& d = p->dd;
-  d.cap = z.cap;
-  d.keys = (unsigned long long*)take(d.cap * 8);   // keys | cnt: contiguous, one memset per build
-  d.cnt = (int32_t*)take(d.cap * 4);
-  d.clear_bytes = (char*)d.cnt + b256(d.cap * 4) - (char*)d.keys;
-  d.nu = (int32_t*)take(256);
-  d.uid = (int32_t*)take(d.cap * 4);
-  d.slot_of = (int32_t*)take(n * 4);
-  d.frank = (int32_t*)take(n * 4);
-  d.bcnt = (int32_t*)take((n / 256 + 1) * 4);
-  d.uniq = (int4*)take(n * 16);
 }
 
 static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Plan2* p) {
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(const int32_t* __restric
 // ---- plan: everything that depends on the ids only.  `own_rows`: the plan must not refer to the caller's arrays afterwards
 // (kge_batch_plan_build), so rows that are not folded are copied.  `side` may be null (then everything runs on `st`).
 static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const Plan2& p, bool own_rows,
-                      Src* src_out, bool* folded, float* scores, uint32_t* err, hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+                      bool clear_counters, int parts, Src* src_out, bool* folded, float* scores, uint32_t* err, hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
   const int64_t n = m_pos + m_neg;
   const int N = md->num_entities, R = md->num_relations;
   const int tgrid = (int)cdiv(n, 256);
@@ -607,34 +607,38 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
   const bool fold = dedup_applies(md, n);
   *folded = fold;
   const Dedup& d = p.dd;
-  if (fold) {
-    ProfScope prof(KGE_PROF_DEDUP, st);
-    KGE_HIP_TRY(hipMemsetAsync(d.keys, 0, d.clear_bytes, st));
-    hipLaunchKernelGGL(dedup_insert_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, R, d.keys, d.cnt,
-                       (unsigned long long)(d.cap - 1), d.slot_of, d.frank, d.bcnt, err);
-    hipLaunchKernelGGL(dedup_rows_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.bcnt, d.frank, d.slot_of, d.cnt, d.uid,
-                       d.uniq, d.nu);
-    src.uniq = d.uniq;
-    src.nu = d.nu;
-  } else if (own_rows) {
-    hipLaunchKernelGGL(rows_copy_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.uniq, d.nu);
-    src.uniq = d.uniq;
-    src.nu = d.nu;
-  }
+  if (fold || own_rows) { src.uniq = d.uniq; src.nu = d.nu; }
   *src_out = src;
-  // entity index (side stream when there is one)
-  hipStream_t es = side ? side : st;
-  if (side) { KGE_HIP_TRY(hipEventRecord(fork, st)); KGE_HIP_TRY(hipStreamWaitEvent(side, fork, 0)); }
-  {
-    ProfScope prof(KGE_PROF_INDEX, es);
-    hipLaunchKernelGGL(ent_hist_kernel, dim3(tgrid), dim3(256), 0, es, src, n, N, R, p.ent.cnt, p.erank);
-    pull2_entity_plan(p.ent, N, es);
+  if (parts & 1) {  // rows: fold duplicates (or copy), counters cleared
+    // a plan buffer keeps its counters right in front of the hash table: one memset clears both
+    const int64_t cbytes = clear_counters ? (char*)d.keys - (char*)p.ent.cnt : 0;
+    if (!fold && clear_counters) KGE_HIP_TRY(hipMemsetAsync(p.ent.cnt, 0, cbytes, st));
+    if (fold) {
+      ProfScope prof(KGE_PROF_DEDUP, st);
+      KGE_HIP_TRY(hipMemsetAsync(clear_counters ? (void*)p.ent.cnt : (void*)d.keys, 0, cbytes + d.clear_bytes, st));
+      hipLaunchKernelGGL(dedup_insert_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, R, d.keys, d.cnt,
+                         (unsigned long long)(d.cap - 1), d.slot_of, d.frank, d.bcnt, err);
+      hipLaunchKernelGGL(dedup_rows_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.bcnt, d.frank, d.slot_of, d.cnt, d.uid,
+                         d.uniq, d.nu);
+    } else if (own_rows) {
+      hipLaunchKernelGGL(rows_copy_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.uniq, d.nu);
+    }
   }
-  if (side) KGE_HIP_TRY(hipEventRecord(join, side));
-  // relation index
-  hipLaunchKernelGGL(rel_hist_kernel, dim3((int)cdiv(n, kRelBlockTriples)), dim3(256), 0, st, src, N, R, p.rcnt, p.rrank);
-  hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
-  hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
+  if (parts & 2) {  // entity index (side stream when there is one)
+    hipStream_t es = side ? side : st;
+    if (side) { KGE_HIP_TRY(hipEventRecord(fork, st)); KGE_HIP_TRY(hipStreamWaitEvent(side, fork, 0)); }
+    {
+      ProfScope prof(KGE_PROF_INDEX, es);
+      hipLaunchKernelGGL(ent_hist_kernel, dim3(tgrid), dim3(256), 0, es, src, n, N, R, p.ent.cnt, p.erank);
+      pull2_entity_plan(p.ent, N, es);
+    }
+    if (side) KGE_HIP_TRY(hipEventRecord(join, side));
+  }
+  if (parts & 4) {  // relation index
+    hipLaunchKernelGGL(rel_hist_kernel, dim3((int)cdiv(n, kRelBlockTriples)), dim3(256), 0, st, src, N, R, p.rcnt, p.rrank);
+    hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
+    hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
+  }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
@@ -682,7 +686,7 @@ int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const f
   // folded rows: the forward writes the scores of the distinct rows, expanded to the caller's rows afterwards
   const bool fold = dedup_applies(md, n);
   float* fwd_scores = fold && scores ? p.dd.uscore : scores;
-  if (int rc = plan_build(md, pos, m_pos, neg, m_neg, p, false, &src, &folded, fold ? nullptr : scores, err, st, side, fork, join)) return rc;
+  if (int rc = plan_build(md, pos, m_pos, neg, m_neg, p, false, false, 7, &src, &folded, fold ? nullptr : scores, err, st, side, fork, join)) return rc;
   if (int rc = plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, fwd_scores, loss_partials, n_partials, loss_out, seed, st, side ? join : nullptr))
     return rc;
   if (folded && scores) hipLaunchKernelGGL(dedup_scores_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, p.dd.slot_of, p.dd.uid, p.dd.uscore, n, scores);
@@ -701,15 +705,16 @@ static void carve_plan_buffer(void* plan, const kge_model_desc* md, int64_t n, P
   carve_plan(base, base + counters_bytes(sizes_of(md, n)), md, n, p);
 }
 
-int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* plan, uint32_t* err,
-                     hipStream_t st) {
+// parts: bit 0 = rows (fold / copy; clears the counters), bit 1 = entity index, bit 2 = relation index.  Bits 1 and 2 need
+// bit 0 done and are independent of each other (the caller may run them on two streams).
+int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* plan, int parts,
+                     uint32_t* err, hipStream_t st) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
   carve_plan_buffer(plan, md, n, &p);
-  KGE_HIP_TRY(hipMemsetAsync(p.ent.cnt, 0, counters_bytes(sizes_of(md, n)), st));
   Src src;
   bool folded;
-  return plan_build(md, pos, m_pos, neg, m_neg, p, true, &src, &folded, nullptr, err, st, nullptr, nullptr, nullptr);
+  return plan_build(md, pos, m_pos, neg, m_neg, p, true, true, parts, &src, &folded, nullptr, err, st, nullptr, nullptr, nullptr);
 }
 
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,

@@ -190,8 +190,10 @@ __global__ __launch_bounds__(256) void np_count_kernel(const MTDev* __restrict__
 }
 
 // exclusive scan of up to 1024*per tile counts, one workgroup
-__global__ __launch_bounds__(256) void np_scan_kernel(int32_t* __restrict__ tile_cnt, int ntiles, int32_t* __restrict__ total) {
+__global__ __launch_bounds__(256) void np_scan_kernel(int32_t* __restrict__ tile_cnt, int ntiles, int32_t* __restrict__ total,
+                                                       int64_t* __restrict__ consumed) {
   __shared__ int wsum[4];
+  if (threadIdx.x == 0) *consumed = -1;  // "fewer than 2m accepted draws" until np_scatter_kernel finds the 2m-th
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (ntiles + 255) / 256;
   const int k0 = tid * per, k1 = min(ntiles, k0 + per);
@@ -247,8 +249,21 @@ __device__ __forceinline__ int64_t py_choice(const MTDev* st, const uint32_t* U,
   return (int64_t)floor(r * n);
 }
 
+// The positives of the batch: a (B,3) array, or rows index[starts[*cursor] * B + i] of the training triples (the slice
+// DataGenerator.__getitem__ takes of its epoch permutation, tests.py:43-47,55-56) read in place.
+struct BatchSrc {
+  const int32_t* batch;
+  const int32_t* kg;
+  const int64_t* index;
+  const int64_t* starts;
+  const int64_t* cursor;
+};
+__device__ __forceinline__ const int32_t* batch_row(const BatchSrc& b, int64_t B, int64_t a) {
+  return b.batch ? b.batch + 3 * a : b.kg + 3 * b.index[b.starts[b.cursor[0]] * B + a];
+}
+
 __global__ __launch_bounds__(256) void py_assemble_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U,
-                                                           const int32_t* __restrict__ batch, int64_t B, int64_t ns,
+                                                           BatchSrc batch, int64_t B, int64_t ns,
                                                            const int32_t* __restrict__ fs, const int32_t* __restrict__ fo,
                                                            int32_t* __restrict__ pos_out, int32_t* __restrict__ neg_out) {
   const int64_t m = B * ns;
@@ -257,33 +272,45 @@ __global__ __launch_bounds__(256) void py_assemble_kernel(const MTDev* __restric
   const int p0 = st->pos;
   if (i < m) {  // choices over the positives (len B) come first in the stream
     const int64_t a = py_choice(st, U, p0, i, (double)B);
-    pos_out[3 * i + 0] = batch[3 * a + 0];
-    pos_out[3 * i + 1] = batch[3 * a + 1];
-    pos_out[3 * i + 2] = batch[3 * a + 2];
+    const int32_t* row = batch_row(batch, B, a);
+    pos_out[3 * i + 0] = row[0];
+    pos_out[3 * i + 1] = row[1];
+    pos_out[3 * i + 2] = row[2];
   } else {      // then over the negatives (len m); row j of generate_negative carries the relation of positive j // ns
     const int64_t j = py_choice(st, U, p0, i, (double)m);
     const int64_t o = i - m;
     neg_out[3 * o + 0] = fs[j];
-    neg_out[3 * o + 1] = batch[3 * (j / ns) + 1];
+    neg_out[3 * o + 1] = batch_row(batch, B, j / ns)[1];
     neg_out[3 * o + 2] = fo[j];
   }
 }
 
 // New state after consuming `c` words: the block of U the consumption stopped in (NumPy/CPython keep pos = 624 at a
 // block end and regenerate lazily, which is the representation kept here).
-__global__ __launch_bounds__(256) void mt_advance_kernel(MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
-                                                          const int64_t* __restrict__ consumed_ptr, int64_t consumed_fixed,
-                                                          int64_t need, uint32_t* __restrict__ err) {
+struct AdvanceArgs {
+  MTDev* st;
+  const uint32_t* U;
+  int64_t L_u;
+  const int64_t* consumed_ptr;  // data-dependent word count (NumPy stream), or null
+  int64_t consumed_fixed;       // fixed word count (Python stream)
+};
+
+// One workgroup per generator.  The last kernel of a batch: also moves the batch cursor on (when there is one).
+__global__ __launch_bounds__(256) void mt_advance_kernel(AdvanceArgs a0, AdvanceArgs a1, int64_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ err) {
   __shared__ int64_t c_s;
-  if (threadIdx.x == 0) c_s = consumed_ptr ? *consumed_ptr : consumed_fixed;
+  const AdvanceArgs& A = blockIdx.x == 0 ? a0 : a1;
+  if (blockIdx.x == 1 && threadIdx.x == 0 && cursor) cursor[0] += 1;
+  MTDev* st = A.st;
+  if (!st) return;
+  if (threadIdx.x == 0) c_s = A.consumed_ptr ? *A.consumed_ptr : A.consumed_fixed;
   __syncthreads();
   int64_t c = c_s;
   const int p0 = st->pos;
-  if (consumed_ptr && c < 0) {  // fewer than `need` accepted draws in the buffer
+  if (A.consumed_ptr && c < 0) {  // fewer than the needed accepted draws in the buffer
     if (threadIdx.x == 0) atomicOr(err, 2u);
-    c = (624 - p0) + L_u;
+    c = (624 - p0) + A.L_u;
   }
-  (void)need;
   const int64_t a = p0 + c;  // absolute position counted from the start of the current state block
   if (a <= 624) {
     __syncthreads();
@@ -293,7 +320,7 @@ __global__ __launch_bounds__(256) void mt_advance_kernel(MTDev* __restrict__ st,
   const int64_t idx = a - 624;             // words consumed out of U (idx >= 1)
   const int64_t blk = (idx - 1) / 624;     // block holding the last consumed word
   const int newpos = (int)(idx - blk * 624);
-  const uint32_t* src = U + blk * 624;
+  const uint32_t* src = A.U + blk * 624;
   uint32_t tmp[3];
   for (int i = threadIdx.x, k = 0; i < 624; i += 256, ++k) tmp[k] = src[i];
   __syncthreads();
@@ -301,7 +328,6 @@ __global__ __launch_bounds__(256) void mt_advance_kernel(MTDev* __restrict__ st,
   if (threadIdx.x == 0) st->pos = newpos;
 }
 
-__global__ void set_i64_kernel(int64_t* p, int64_t v) { *p = v; }
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -370,8 +396,10 @@ int sampler_plan_host(int64_t B, int64_t ns, int64_t num_e, uint64_t* polys_host
 }
 int64_t sampler_plan_bytes() { return (int64_t)2 * (kSeg - 1) * kPolyWords * 8; }
 
-int build_batch_device(void* np_state, void* py_state, const int32_t* batch, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out,
-                       int32_t* neg_out, const void* plan_dev, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+// batch != null: the positives as a (B,3) array.  Otherwise rows index[starts[*cursor] * B + i] of kg, and *cursor += 1 at the end.
+int build_batch_device(void* np_state, void* py_state, const int32_t* batch, const int32_t* kg, const int64_t* index, const int64_t* starts,
+                       int64_t* cursor, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out, int32_t* neg_out, const void* plan_dev,
+                       void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
   if (wbytes < sampler_workspace_bytes(B, ns, num_e))
     return fail(KGE_EWORKSPACE, "kge_build_batch_device: workspace has %lld bytes, needs %lld", (long long)wbytes,
                 (long long)sampler_workspace_bytes(B, ns, num_e));
@@ -391,17 +419,18 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, int
   }
   if (rng) {
     const int64_t L_u = p.K_np * 624;
-    hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, p.consumed, (int64_t)-1);
     hipLaunchKernelGGL(np_count_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt);
-    hipLaunchKernelGGL(np_scan_kernel, dim3(1), dim3(256), 0, st, p.tile_cnt, (int)p.ntiles, p.total);
+    hipLaunchKernelGGL(np_scan_kernel, dim3(1), dim3(256), 0, st, p.tile_cnt, (int)p.ntiles, p.total, p.consumed);
     hipLaunchKernelGGL(np_scatter_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt, m, p.fs, p.fo, p.consumed);
   } else {  // a range of one: numpy draws nothing
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fs, m, 0);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fo, m, 0);
   }
-  hipLaunchKernelGGL(py_assemble_kernel, dim3((int)cdiv(2 * m, 256)), dim3(256), 0, st, pys, p.U_py, batch, B, ns, p.fs, p.fo, pos_out, neg_out);
-  if (rng) hipLaunchKernelGGL(mt_advance_kernel, dim3(1), dim3(256), 0, st, nps, p.U_np, p.K_np * 624, p.consumed, (int64_t)0, 2 * m, err);
-  hipLaunchKernelGGL(mt_advance_kernel, dim3(1), dim3(256), 0, st, pys, p.U_py, p.K_py * 624, (const int64_t*)nullptr, 4 * m, 4 * m, err);
+  hipLaunchKernelGGL(py_assemble_kernel, dim3((int)cdiv(2 * m, 256)), dim3(256), 0, st, pys, p.U_py, BatchSrc{batch, kg, index, starts, cursor}, B, ns, p.fs, p.fo, pos_out,
+                     neg_out);
+  const AdvanceArgs adv_np{rng ? nps : nullptr, p.U_np, p.K_np * 624, p.consumed, 0};
+  const AdvanceArgs adv_py{pys, p.U_py, p.K_py * 624, nullptr, 4 * m};
+  hipLaunchKernelGGL(mt_advance_kernel, dim3(2), dim3(256), 0, st, adv_np, adv_py, batch ? nullptr : cursor, err);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

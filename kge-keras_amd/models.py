@@ -326,16 +326,17 @@ class EmbeddingModel:
         md, ld = self._model_desc(True), self._loss_desc()
         return lib.kge_batch_plan_bytes(C.byref(md), C.byref(ld), 1, 1) > 0
 
-    def plan_batch(self, data, out=None):
+    def plan_batch(self, data, out=None, parts=7):
         """Build the BatchPlan of [pos, neg] on the CURRENT stream (asynchronous).  `out`: a BatchPlan whose buffer is reused
-        when large enough.  The caller orders the build before the step that consumes it (same stream, or an event)."""
+        when large enough.  The caller orders the build before the step that consumes it (same stream, or an event).
+        parts: 1 = rows, 2 = entity lists, 4 = relation lists (2 and 4 may run on two streams once 1 is done); 7 = all."""
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
         md, ld = self._model_desc(True), self._loss_desc()
         need = check(lib.kge_batch_plan_bytes(C.byref(md), C.byref(ld), pos.shape[0], neg.shape[0]))
         buf = out.buf if out is not None and out.buf.numel() >= need else torch.empty(int(need), dtype=torch.uint8, device=self.device)
         check(lib.kge_batch_plan_build(C.byref(md), C.byref(ld), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0], buf.data_ptr(),
-                                       buf.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+                                       buf.numel(), int(parts), self._err.data_ptr(), _lib.stream_ptr()))
         return BatchPlan(buf, pos.shape[0], neg.shape[0])
 
     def _step_planned(self, plan, apply):

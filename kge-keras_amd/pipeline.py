@@ -1,17 +1,17 @@
-"""The training hot path as a three-stage software pipeline on the GPU, replayed from hipGraphs.
+"""The training hot path as a three-stage software pipeline on the GPU, every stage replayed from a hipGraph.
 
 What Keras does for the reference (tests.py:130-134: `fit` over a `Sequence`, batches prefetched by worker threads while the
-previous step runs) becomes, per tick t:
+previous step runs) becomes three streams that run one to two batches apart:
 
-    stage S (stream 1)  draw batch t+2 on the device: bit-exact NumPy / CPython MT19937 streams (utils.py:114-147)
-    stage P (stream 2)  plan of batch t+1: fold duplicate rows, per-relation / per-entity gradient lists (ids only)
-    stage T (main)      train step t on the plan of batch t: forward, loss, gradients, optimizer (tests.py:63-89)
+    stage S (stream 1)  draw batch k: bit-exact NumPy / CPython MT19937 streams on the device (utils.py:114-147)
+    stage P (stream 2)  plan of batch k: fold duplicate rows, per-relation / per-entity gradient lists (ids only)
+    stage T (main)      train step k on the plan of batch k: forward, loss, gradients, optimizer (tests.py:63-89)
 
-The three chains are independent inside a tick (double-buffered batches and plans) and meet at its end.  A tick is ~35 short
-kernels, so launching it kernel by kernel is bound by the host; the steady-state tick is therefore captured once per buffer
-parity into a hipGraph and replayed with one launch.  Everything that changes from step to step lives on the device: the
-generator states, the batch cursor, the Adam step counter (kge_opt_desc.step_dev).  The last two ticks of an epoch draw no
-further batches (the random streams must stop where the reference's would), so they are launched stage by stage.
+with double-buffered batches and plans and four events per buffer pair (drawn / arrays free / planned / plan free).  A stage is
+6-10 short kernels, so launching them one by one is bound by the host; each stage is therefore captured once per buffer
+parity into a hipGraph and a training step costs three graph launches.  (One graph holding all three stages as branches
+does not overlap them on ROCm 7.2; separate graphs on separate streams do.)  Everything that changes from step to step lives
+on the device: the generator states, the batch cursor, the optimizer step state (kge_opt_desc.step_dev).
 """
 import torch
 
@@ -28,8 +28,9 @@ class TrainPipeline:
         self.model, self.kg, self.B, self.ns, self.num_e, self.sampler = model, kg, int(batch_size), int(ns), int(num_e), sampler
         self.dev = kg.device
         self.between = between
-        # a captured step cannot change its dropout seed: graphs only without dropout
-        self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0
+        # a captured step cannot change its dropout seed: graphs only without dropout; with a collective between the halves of
+        # the step (one process per GPU) the stages are launched kernel by kernel
+        self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0 and between is None
         m = self.B * self.ns
         self.bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device=self.dev) for _ in range(2)) for _ in range(2)]
         md, ld = model._model_desc(True), model._loss_desc()
@@ -39,45 +40,39 @@ class TrainPipeline:
         self.index = torch.zeros(int(n_rows), dtype=torch.int64, device=self.dev)   # epoch permutation (tests.py:50-53)
         self.starts = None                                                          # batch numbers in drawing order
         self.cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.ar = torch.arange(self.B, dtype=torch.int64, device=self.dev)
         self.loss_sum = torch.zeros((), dtype=torch.float64, device=self.dev)
         self.step_dev = torch.zeros(2, dtype=torch.int64, device=self.dev)          # kge_opt_desc.step_dev: {t, lr_t, sum of losses}
-        self.s1, self.s2 = torch.cuda.Stream(), torch.cuda.Stream()
-        self.graphs = [None, None]
+        self.s1, self.s2, self.s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        self.ready = [torch.cuda.Event() for _ in range(2)]     # batch arrays drawn
+        self.freed = [torch.cuda.Event() for _ in range(2)]     # batch arrays no longer needed (their plan is built)
+        self.planned = [torch.cuda.Event() for _ in range(2)]   # plan built
+        self.pfreed = [torch.cuda.Event() for _ in range(2)]    # plan consumed
+        self.graphs = {}
         self._sig = None
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
-        b = self.starts.index_select(0, self.cursor)
-        rows = self.index.index_select(0, b * self.B + self.ar)
-        batch = self.kg.index_select(0, rows)
-        self.sampler.build_batch(batch, self.ns, self.num_e, *self.bufs[slot])
-        self.cursor.add_(1)
+        # positives read in place (kg[index[starts[cursor] * B + i]]); the sampler's last kernel moves the cursor on
+        self.sampler.build_batch(None, self.ns, self.num_e, *self.bufs[slot], indexed=(self.kg, self.index, self.starts, self.cursor, self.B))
 
-    def _stage_P(self, slot):
-        self.plans[slot] = self.model.plan_batch(list(self.bufs[slot]), out=self.plans[slot])
+    def _stage_P(self, slot, fork=None):
+        """rows first, then the entity lists and the relation lists -- side by side on `fork` (a stream that already follows
+        the caller's origin stream and is joined by the caller) when given: they only share the rows."""
+        cur, b, pl = torch.cuda.current_stream(), list(self.bufs[slot]), self.plans[slot]
+        if fork is None:
+            self.model.plan_batch(b, out=pl, parts=7)
+            return
+        self.model.plan_batch(b, out=pl, parts=1)
+        fork.wait_stream(cur)
+        with torch.cuda.stream(fork):
+            self.model.plan_batch(b, out=pl, parts=2)
+        self.model.plan_batch(b, out=pl, parts=4)
 
     def _stage_T(self, slot):
         if self.between is None:
             self.model.train_step(self.plans[slot])  # the step's last kernel adds its loss to the device step state
         else:
             self.model.train_grads(self.plans[slot])
-
-    def _tick(self, j, do_S, do_P):
-        cur = torch.cuda.current_stream()
-        if do_S:
-            self.s1.wait_stream(cur)
-            with torch.cuda.stream(self.s1):
-                self._stage_S(j)
-        if do_P:
-            self.s2.wait_stream(cur)
-            with torch.cuda.stream(self.s2):
-                self._stage_P(1 - j)
-        self._stage_T(j)
-        if do_S:
-            cur.wait_stream(self.s1)
-        if do_P:
-            cur.wait_stream(self.s2)
 
     def _after(self):
         if self.between is not None:
@@ -94,17 +89,39 @@ class TrainPipeline:
         return tuple(x.data_ptr() for x in t if x is not None) + (mo.optimizer.kind, mo.optimizer.lr, mo.loss_function, float(mo.margin or 1))
 
     def _capture(self):
-        """Capture the steady-state tick for both buffer parities.  Capturing enqueues nothing; host-side counters the stages
-        bump (dropout seed, iterations) are restored."""
+        """Capture the three stages for both buffer parities.  Capturing enqueues nothing; host-side counters the stages bump
+        (dropout seed, iterations) are restored."""
         mo = self.model
         seed, it = mo._seed, mo.optimizer.iterations
+        self.graphs = {}
         for j in (0, 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._tick(j, True, True)
-            self.graphs[j] = g
+            for name, fn in (("S", lambda j=j: self._stage_S(j)), ("P", lambda j=j: self._stage_P(j)), ("T", lambda j=j: self._stage_T(j))):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                self.graphs[name, j] = g
         mo._seed, mo.optimizer.iterations = seed, it
         self._sig = self._signature()
+
+    def _stage_P_forked(self, slot):
+        """Stage P with its two list builds side by side (kernel-by-kernel launches only: replaying a stage graph that holds
+        this fork from another stream crashes the ROCm 7.2 runtime, and the stage is not the longest of the three anyway)."""
+        cur = torch.cuda.current_stream()
+        self.s3.wait_stream(cur)
+        self._stage_P(slot, fork=self.s3)
+        cur.wait_stream(self.s3)
+
+    def _run(self, name, slot):
+        if self.use_graphs:
+            if not self.graphs or self._sig != self._signature():
+                self._capture()
+            self.graphs[name, slot].replay()
+        elif name == "S":
+            self._stage_S(slot)
+        elif name == "P":
+            self._stage_P_forked(slot)
+        else:
+            self._stage_T(slot)
 
     # ------------------------------------------------------------------ driving
     def load_epoch(self, index, order):
@@ -119,9 +136,26 @@ class TrainPipeline:
         self.loss_sum.zero_()
         self.t = 0
 
+    def _produce(self, k):
+        """Issue the draw and the plan of batch k on their streams."""
+        if k >= self.n:
+            return
+        j = k % 2
+        with torch.cuda.stream(self.s1):
+            self.s1.wait_event(self.freed[j])
+            self._run("S", j)
+            self.ready[j].record(self.s1)
+        with torch.cuda.stream(self.s2):
+            self.s2.wait_event(self.ready[j])
+            self.s2.wait_event(self.pfreed[j])
+            self._run("P", j)
+            self.planned[j].record(self.s2)
+            self.freed[j].record(self.s2)
+
     def start(self):
-        """Prologue: batch 0 drawn and planned, batch 1 drawn.  Switches the optimizer to the device step counter."""
+        """Prologue: batches 0 and 1 on their way.  Switches the optimizer to the device step state."""
         mo = self.model
+        main = torch.cuda.current_stream()
         mo._ensure_train_state(self.B * self.ns, self.B * self.ns)
         if self.between is None:
             mo._step_dev = self.step_dev
@@ -129,27 +163,30 @@ class TrainPipeline:
             od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, int(o.iterations) + 1, None, None, None, None,
                               self.step_dev.data_ptr())
             _lib.check(_lib.lib.kge_opt_state_init(_lib.C.byref(od), _lib.stream_ptr()))
-        if self.n >= 1:
-            self._stage_S(0)
-            self._stage_P(0)
-        if self.n >= 2:
-            self._stage_S(1)
+        self.sampler.prepare(self.B, self.ns, self.num_e)  # workspace + jump polynomials: nothing is allocated inside a capture
+        if self.use_graphs and (not self.graphs or self._sig != self._signature()):
+            self._capture()
+        for st in (self.s1, self.s2, self.s3):
+            st.wait_stream(main)
+        self._produce(0)
+        self._produce(1)
 
     def tick(self):
-        """One training step (and the stages of the next two batches that run beside it)."""
-        t, j = self.t, self.t % 2
-        do_P, do_S = t + 1 < self.n, t + 2 < self.n
-        if self.use_graphs and do_S and do_P:
-            if self.graphs[j] is None or self._sig != self._signature():
-                self._capture()
-            self.graphs[j].replay()
-        else:
-            self._tick(j, do_S, do_P)
+        """One training step; then the draw and the plan of the batch two steps ahead are issued."""
+        main = torch.cuda.current_stream()
+        j = self.t % 2
+        main.wait_event(self.planned[j])
+        self._run("T", j)
         self._after()
+        self.pfreed[j].record(main)
+        self._produce(self.t + 2)
         self.t += 1
 
     def finish(self):
         mo = self.model
+        main = torch.cuda.current_stream()
+        for st in (self.s1, self.s2, self.s3):
+            main.wait_stream(st)
         if getattr(mo, "_step_dev", None) is not None:
             mo.optimizer.iterations = int(self.step_dev[0].item())
             mo._step_dev = None

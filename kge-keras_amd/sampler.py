@@ -143,10 +143,25 @@ class DeviceSampler:
         if py_stream is not None:
             self.py_state.copy_(torch.from_numpy(py_stream._buf.view(np.uint8).copy()))
 
-    def build_batch(self, batch, ns, num_e, pos_out=None, neg_out=None):
+    def prepare(self, B, ns, num_e):
+        """Allocate the workspace and compute / upload the jump polynomials for this batch shape (what build_batch does lazily
+        on its first call), so that later calls allocate nothing -- needed before capturing build_batch into a hipGraph."""
+        import torch
+        need = check(lib.kge_sampler_workspace_bytes(int(B), int(ns), int(num_e)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        key = (int(B), int(ns), int(num_e))
+        if self.segmented and key not in self._plans:
+            buf = np.empty(int(lib.kge_sampler_plan_bytes()) // 8, dtype=np.uint64)
+            check(lib.kge_sampler_plan_host(int(B), int(ns), int(num_e), buf.ctypes.data))
+            self._plans[key] = torch.from_numpy(buf.view(np.int64)).to(self.device)
+
+    def build_batch(self, batch, ns, num_e, pos_out=None, neg_out=None, indexed=None):
+        """batch: (B,3) int32 device rows -- or None with indexed=(kg, index, starts, cursor, B): the positives are read in
+        place as kg[index[starts[cursor] * B + i]] and the device cursor moves on by one (kge_build_batch_device_indexed)."""
         import torch
         from . import _lib
-        B = batch.shape[0]
+        B = batch.shape[0] if indexed is None else int(indexed[4])
         m = B * int(ns)
         need = check(lib.kge_sampler_workspace_bytes(B, int(ns), int(num_e)))
         if self._ws is None or self._ws.numel() < need:
@@ -162,6 +177,13 @@ class DeviceSampler:
                 check(lib.kge_sampler_plan_host(B, int(ns), int(num_e), buf.ctypes.data))
                 self._plans[key] = torch.from_numpy(buf.view(np.int64)).to(self.device)
             plan_ptr = self._plans[key].data_ptr()
+        if indexed is not None:
+            kg, index, starts, cursor = indexed[:4]
+            check(lib.kge_build_batch_device_indexed(self.np_state.data_ptr(), self.py_state.data_ptr(), kg.data_ptr(), index.data_ptr(),
+                                                     starts.data_ptr(), cursor.data_ptr(), B, int(ns), int(num_e), pos_out.data_ptr(),
+                                                     neg_out.data_ptr(), plan_ptr, self._ws.data_ptr(), self._ws.numel(), self.err.data_ptr(),
+                                                     _lib.stream_ptr()))
+            return pos_out, neg_out
         check(lib.kge_build_batch_device(self.np_state.data_ptr(), self.py_state.data_ptr(), batch.data_ptr(), B, int(ns), int(num_e),
                                          pos_out.data_ptr(), neg_out.data_ptr(), plan_ptr, self._ws.data_ptr(), self._ws.numel(),
                                          self.err.data_ptr(), _lib.stream_ptr()))
