@@ -297,9 +297,12 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if pipe is not None:
-        # kernel durations for the roofline object: the same K steps again, launched kernel by kernel (events cannot be read
-        # back from inside a replayed graph), hipEvents recorded by the library on each kernel's own launch stream
+        # kernel durations for the roofline object: the same K steps again, launched kernel by kernel on ONE stream (events cannot
+        # be read back from inside a replayed graph, and kernels of concurrent stages stretch each other: the roofline is about
+        # the kernel, so it is timed alone, like rocprofv3's kernel trace does), hipEvents recorded by the library on that stream
+        fence()
         pipe.use_graphs = False
+        pipe.serial = True
         _lib.lib.kge_prof_enable(1)
         for i in range(args.steps):
             step(base + args.steps + i)
@@ -371,7 +374,7 @@ def main():
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
                          "sampler_avg_ms": s_ms / max(1, s_n), "host_enqueue_ms_per_step": t_issue / args.steps * 1e3,
                          "launch": ("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams); kernel durations "
-                                    "above come from a second pass of the same steps launched kernel by kernel" if pipe is not None
+                                    "above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)" if pipe is not None
                                     else "kernel-by-kernel stream launches"),
                          "plan": ("ids-only half of the step (fold + gradient lists) built 1-2 batches ahead on its own stream, inside the timed region"
                                   if plan_ahead else "built inside the step")},

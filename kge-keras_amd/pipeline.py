@@ -49,6 +49,7 @@ class TrainPipeline:
         self.pfreed = [torch.cuda.Event() for _ in range(2)]    # plan consumed
         self.graphs = {}
         self._sig = None
+        self.serial = False  # True: every stage on the caller's stream, nothing overlaps (clean per-kernel timings)
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
@@ -119,7 +120,7 @@ class TrainPipeline:
         elif name == "S":
             self._stage_S(slot)
         elif name == "P":
-            self._stage_P_forked(slot)
+            self._stage_P(slot) if self.serial else self._stage_P_forked(slot)
         else:
             self._stage_T(slot)
 
@@ -141,16 +142,17 @@ class TrainPipeline:
         if k >= self.n:
             return
         j = k % 2
-        with torch.cuda.stream(self.s1):
-            self.s1.wait_event(self.freed[j])
+        s1, s2 = (self.s1, self.s2) if not self.serial else (torch.cuda.current_stream(),) * 2
+        with torch.cuda.stream(s1):
+            s1.wait_event(self.freed[j])
             self._run("S", j)
-            self.ready[j].record(self.s1)
-        with torch.cuda.stream(self.s2):
-            self.s2.wait_event(self.ready[j])
-            self.s2.wait_event(self.pfreed[j])
+            self.ready[j].record(s1)
+        with torch.cuda.stream(s2):
+            s2.wait_event(self.ready[j])
+            s2.wait_event(self.pfreed[j])
             self._run("P", j)
-            self.planned[j].record(self.s2)
-            self.freed[j].record(self.s2)
+            self.planned[j].record(s2)
+            self.freed[j].record(s2)
 
     def start(self):
         """Prologue: batches 0 and 1 on their way.  Switches the optimizer to the device step state."""
