@@ -418,33 +418,10 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
   }
 }
 
-// One wave per key; multi-chunk keys add their slab rows, in chunk order, into the gradient table.
-// Also leaves cnt all-zero for the next step: the workspace is self-cleaning (it is zeroed once, at allocation).
 __global__ __launch_bounds__(256) void pull_finish_kernel(float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,
                                                            int32_t* __restrict__ cnt, const int32_t* __restrict__ poff,
                                                            const float* __restrict__ slab, int C) {
-  const int key = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (key >= NK) return;
-  const int lane = threadIdx.x & 63;
-  const int c = cnt[key];
-  if (lane == 0 && c) cnt[key] = 0;
-  const int nch = (c + C - 1) / C;
-  if (nch <= 1) return;
-  float* dst = key >= N ? gR + (int64_t)(key - N) * d_e : gE + (int64_t)key * d_e;
-  const float* src = slab + (int64_t)poff[key] * d_e;
-  for (int k = lane; k < d_e; k += 64) {
-    float s = 0.f;
-    int j = 0;
-    for (; j + 8 <= nch; j += 8) {  // eight independent loads in flight, summed in chunk order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(j + u) * d_e + k];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; j < nch; ++j) s += src[(int64_t)j * d_e + k];
-    dst[k] += s;
-  }
+  pull_finish_wave(blockIdx.x * 4 + (threadIdx.x >> 6), gE, gR, N, NK, d_e, cnt, poff, slab, C);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -656,6 +633,7 @@ void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st) {
   hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(N, 256)), dim3(256), 0, st, e.cnt, e.eoff, N, e.chunk, e.max_extra, e.emap);
 }
 
+// (the finish of the entity keys is fused into pull2.hip's rel_finish_kernel)
 int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const PullPlan& e, uint64_t seed,
                       hipStream_t st) {
   const int N = md->num_entities;
@@ -668,7 +646,6 @@ int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel
     else if (md->norm == 1) launch_pull<KGE_TRANSE, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
     else launch_pull<KGE_TRANSE, 2, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
   }
-  hipLaunchKernelGGL(pull_finish_kernel, dim3((int)cdiv(N, 4)), dim3(256), 0, st, gE, gR, N, N, md->d_e, e.cnt, e.poff, e.slab, e.chunk);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

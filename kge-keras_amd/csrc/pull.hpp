@@ -23,6 +23,34 @@ struct PullPlan {
   int chunk;
 };
 
+// One wave per key; multi-chunk keys add their slab rows, in chunk order, into the gradient table.
+// Also leaves cnt all-zero for the next step: the workspace is self-cleaning (it is zeroed once, at allocation).
+__device__ __forceinline__ void pull_finish_wave(int key, float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,
+                                                 int32_t* __restrict__ cnt, const int32_t* __restrict__ poff, const float* __restrict__ slab,
+                                                 int C) {
+  if (key >= NK) return;
+  const int lane = threadIdx.x & 63;
+  const int c = cnt[key];
+  if (lane == 0 && c) cnt[key] = 0;
+  const int nch = (c + C - 1) / C;
+  if (nch <= 1) return;
+  float* dst = key >= N ? gR + (int64_t)(key - N) * d_e : gE + (int64_t)key * d_e;
+  const float* src = slab + (int64_t)poff[key] * d_e;
+  for (int k = lane; k < d_e; k += 64) {
+    float s = 0.f;
+    int j = 0;
+    for (; j + 8 <= nch; j += 8) {  // eight independent loads in flight, summed in chunk order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(j + u) * d_e + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; j < nch; ++j) s += src[(int64_t)j * d_e + k];
+    dst[k] += s;
+  }
+}
+
 bool pull_supported(const kge_model_desc* md);
 int64_t pull_workspace_bytes(const kge_model_desc* md, int64_t n);
 // histogram of destination rows + scans + chunk map (depends on the ids only)

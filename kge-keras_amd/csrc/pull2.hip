@@ -412,11 +412,19 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
 // gR[p] += sum of the relation's slab rows, in chunk order (one wave per relation, 8 independent loads in flight)
 // Also: leaves rcnt all-zero for the next step (the workspace is self-cleaning; it is zeroed once at allocation), and the
 // extra last block reduces the forward's loss partials (fixed order) into *loss_out.
+// Blocks [0, ent_blocks): the finish of the entity keys (hub rows: slab rows summed in chunk order; counters left zero).
 __global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR, int R, int d_e, int32_t* __restrict__ rcnt,
                                                           const int32_t* __restrict__ ruoff, const float* __restrict__ rslab,
                                                           const float* __restrict__ loss_partials, int n_partials,
-                                                          float* __restrict__ loss_out) {
+                                                          float* __restrict__ loss_out, int ent_blocks, float* __restrict__ gE, int N,
+                                                          int32_t* __restrict__ ecnt, const int32_t* __restrict__ epoff,
+                                                          const float* __restrict__ eslab, int C) {
   __shared__ float red[16];
+  if ((int)blockIdx.x < ent_blocks) {
+    pull_finish_wave(blockIdx.x * 4 + (threadIdx.x >> 6), gE, gR, N, N, d_e, ecnt, epoff, eslab, C);
+    return;
+  }
+  const int rb = blockIdx.x - ent_blocks;
   if (blockIdx.x == gridDim.x - 1) {  // loss = sum of block partials
     float s = 0.f;
     for (int i = threadIdx.x; i < n_partials; i += 256) s += loss_partials[i];
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR,
     if (threadIdx.x == 0) loss_out[0] = b;
     return;
   }
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int p = rb * 4 + (threadIdx.x >> 6);
   if (p >= R) return;
   const int lane = threadIdx.x & 63;
   const int c = rcnt[p];
@@ -666,8 +674,9 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
   if (join) KGE_HIP_TRY(hipStreamWaitEvent(st, join, 0));
   hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.coef, p.ent.off, p.erank, p.ent.entries);
   if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st)) return rc;
-  hipLaunchKernelGGL(rel_finish_kernel, dim3((int)cdiv(R, 4) + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
-                     *n_partials, loss_out);
+  const int eb = (int)cdiv(md->num_entities, 4);
+  hipLaunchKernelGGL(rel_finish_kernel, dim3(eb + (int)cdiv(R, 4) + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
+                     *n_partials, loss_out, eb, gE, md->num_entities, p.ent.cnt, p.ent.poff, p.ent.slab, p.ent.chunk);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

@@ -7,9 +7,9 @@
 // embarrassingly parallel:
 //
 //   mt_generate_kernel   2 workgroups (NumPy stream, Python stream): K blocks of raw state words each  -> U_np, U_py
-//   np_count_kernel      temper + mask + accept (NumPy's masked rejection, utils.py:118-119) -> per-tile accept counts
-//   np_scan_kernel       exclusive scan of the tile counts (one workgroup)
-//   np_scatter_kernel    the first m accepted draws -> fs, the next m -> fo; position of the 2m-th -> words consumed
+//   np_select_kernel     temper + mask + accept (NumPy's masked rejection, utils.py:118-119), per-tile accept counts published
+//                        and summed in the same pass; the first m accepted draws -> fs, the next m -> fo; position of the
+//                        2m-th -> words consumed
 //   py_assemble_kernel   choices: idx = floor(((a>>5)*2^26 + (b>>6)) / 2^53 * n) from word pairs (utils.py:136),
 //                        then pos_out[i] = batch[idxA[i]], neg_out[i] = (fs[j], batch[j/ns].p, fo[j]), j = idxB[i]
 //   mt_advance_kernel    new generator states (the block the consumption stopped in + position inside it)
@@ -173,47 +173,18 @@ __device__ __forceinline__ uint32_t stream_word(const MTDev* st, const uint32_t*
 
 constexpr int kTileW = 1024;  // stream words per tile (256 threads x 4)
 
-__global__ __launch_bounds__(256) void np_count_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
-                                                        uint32_t rng, uint32_t mask, int32_t* __restrict__ tile_cnt) {
-  __shared__ int red[4];
-  const int p0 = st->pos;
-  const int64_t L = (624 - p0) + L_u;
-  const int64_t base = (int64_t)blockIdx.x * kTileW + threadIdx.x * 4;
-  int c = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (base + j < L) c += ((stream_word(st, U, p0, base + j) & mask) <= rng) ? 1 : 0;
-  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// exclusive scan of up to 1024*per tile counts, one workgroup
-__global__ __launch_bounds__(256) void np_scan_kernel(int32_t* __restrict__ tile_cnt, int ntiles, int32_t* __restrict__ total,
-                                                       int64_t* __restrict__ consumed) {
+// NumPy's masked rejection (utils.py:118-119) in ONE pass: every tile of 1024 stream words tempers + masks + tests its words,
+// publishes its accept count tagged with the batch epoch, sums the counts of all tiles before it (they publish as soon as
+// they have counted and wait for nothing, and workgroups are dispatched in order, so the wait always ends) and scatters its
+// accepted draws: the first m -> fs, the next m -> fo; the position of the 2m-th gives the words consumed.
+// tile_agg[b] = epoch << 32 | count.  The epoch lives in the (zero-initialised) workspace and is advanced by mt_advance_kernel.
+__global__ __launch_bounds__(256) void np_select_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
+                                                         uint32_t rng, uint32_t mask, unsigned long long* tile_agg,
+                                                         const uint32_t* __restrict__ epoch_ptr, int64_t m, int32_t* __restrict__ fs,
+                                                         int32_t* __restrict__ fo, int64_t* __restrict__ consumed) {
   __shared__ int wsum[4];
-  if (threadIdx.x == 0) *consumed = -1;  // "fewer than 2m accepted draws" until np_scatter_kernel finds the 2m-th
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (ntiles + 255) / 256;
-  const int k0 = tid * per, k1 = min(ntiles, k0 + per);
-  int s = 0;
-  for (int k = k0; k < k1; ++k) s += tile_cnt[k];
-  int inc = s;
-  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  int pre = inc - s;
-  for (int w = 0; w < wave; ++w) pre += wsum[w];
-  for (int k = k0; k < k1; ++k) { const int v = tile_cnt[k]; tile_cnt[k] = pre; pre += v; }
-  if (tid == 255) *total = pre;
-}
-
-__global__ __launch_bounds__(256) void np_scatter_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
-                                                          uint32_t rng, uint32_t mask, const int32_t* __restrict__ tile_off,
-                                                          int64_t m, int32_t* __restrict__ fs, int32_t* __restrict__ fo,
-                                                          int64_t* __restrict__ consumed) {
-  __shared__ int wsum[4];
+  __shared__ long long pre_s[4];
+  const unsigned long long ep = (unsigned long long)(epoch_ptr[0] + 1u);
   const int p0 = st->pos;
   const int64_t L = (624 - p0) + L_u;
   const int64_t base = (int64_t)blockIdx.x * kTileW + threadIdx.x * 4;
@@ -230,14 +201,27 @@ __global__ __launch_bounds__(256) void np_scatter_kernel(const MTDev* __restrict
   for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  int64_t r = (int64_t)tile_off[blockIdx.x] + inc - c;
+  if (threadIdx.x == 0)
+    __hip_atomic_store(tile_agg + blockIdx.x, ep << 32 | (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // counts of the tiles in front of this one
+  long long before = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
+    unsigned long long s;
+    do { s = __hip_atomic_load(tile_agg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((s >> 32) != ep);
+    before += (long long)(s & 0xFFFFFFFFull);
+  }
+  for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) pre_s[wave] = before;
+  __syncthreads();
+  int64_t r = pre_s[0] + pre_s[1] + pre_s[2] + pre_s[3] + inc - c;
   for (int w = 0; w < wave; ++w) r += wsum[w];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (!a[j]) continue;
     if (r < m) fs[r] = (int32_t)v[j];
     else if (r < 2 * m) fo[r - m] = (int32_t)v[j];
-    if (r == 2 * m - 1) *consumed = base + j + 1;
+    if (r == 2 * m - 1) { consumed[0] = base + j + 1; consumed[1] = (int64_t)ep; }  // tagged: no reset between batches
     ++r;
   }
 }
@@ -297,14 +281,18 @@ struct AdvanceArgs {
 
 // One workgroup per generator.  The last kernel of a batch: also moves the batch cursor on (when there is one).
 __global__ __launch_bounds__(256) void mt_advance_kernel(AdvanceArgs a0, AdvanceArgs a1, int64_t* __restrict__ cursor,
-                                                          uint32_t* __restrict__ err) {
+                                                          uint32_t* __restrict__ epoch, uint32_t* __restrict__ err) {
   __shared__ int64_t c_s;
   const AdvanceArgs& A = blockIdx.x == 0 ? a0 : a1;
   if (blockIdx.x == 1 && threadIdx.x == 0 && cursor) cursor[0] += 1;
   MTDev* st = A.st;
-  if (!st) return;
-  if (threadIdx.x == 0) c_s = A.consumed_ptr ? *A.consumed_ptr : A.consumed_fixed;
+  if (threadIdx.x == 0 && st) {
+    c_s = A.consumed_fixed;
+    if (A.consumed_ptr) c_s = A.consumed_ptr[1] == (int64_t)(epoch[0] + 1u) ? A.consumed_ptr[0] : -1;  // -1: the 2m-th draw was not reached
+  }
   __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) epoch[0] += 1;  // this batch is done (block 0 owns the NumPy side, the only reader)
+  if (!st) return;
   int64_t c = c_s;
   const int p0 = st->pos;
   if (A.consumed_ptr && c < 0) {  // fewer than the needed accepted draws in the buffer
@@ -338,8 +326,8 @@ struct SamplerPlan {
   int64_t K_np, K_py, ntiles;
   uint32_t* U_np;
   uint32_t* U_py;
-  int32_t* tile_cnt;
-  int32_t* total;
+  unsigned long long* tile_agg;
+  uint32_t* epoch;
   int64_t* consumed;
   int32_t* fs;
   int32_t* fo;
@@ -366,8 +354,8 @@ static SamplerPlan plan_sampler(int64_t B, int64_t ns, int64_t num_e, void* ws) 
   auto take = [&](int64_t bytes) { char* r = q; q += align_up(bytes, 256); return r; };
   p.U_np = (uint32_t*)take(std::max<int64_t>(1, p.K_np) * 624 * 4);
   p.U_py = (uint32_t*)take(p.K_py * 624 * 4);
-  p.tile_cnt = (int32_t*)take(p.ntiles * 4);
-  p.total = (int32_t*)take(256);
+  p.tile_agg = (unsigned long long*)take(p.ntiles * 8);
+  p.epoch = (uint32_t*)take(256);
   p.consumed = (int64_t*)take(256);
   p.fs = (int32_t*)take(m * 4);
   p.fo = (int32_t*)take(m * 4);
@@ -419,9 +407,8 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
   }
   if (rng) {
     const int64_t L_u = p.K_np * 624;
-    hipLaunchKernelGGL(np_count_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt);
-    hipLaunchKernelGGL(np_scan_kernel, dim3(1), dim3(256), 0, st, p.tile_cnt, (int)p.ntiles, p.total, p.consumed);
-    hipLaunchKernelGGL(np_scatter_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_cnt, m, p.fs, p.fo, p.consumed);
+    hipLaunchKernelGGL(np_select_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_agg, p.epoch, m, p.fs, p.fo,
+                       p.consumed);
   } else {  // a range of one: numpy draws nothing
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fs, m, 0);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fo, m, 0);
@@ -430,7 +417,7 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
                      neg_out);
   const AdvanceArgs adv_np{rng ? nps : nullptr, p.U_np, p.K_np * 624, p.consumed, 0};
   const AdvanceArgs adv_py{pys, p.U_py, p.K_py * 624, nullptr, 4 * m};
-  hipLaunchKernelGGL(mt_advance_kernel, dim3(2), dim3(256), 0, st, adv_np, adv_py, batch ? nullptr : cursor, err);
+  hipLaunchKernelGGL(mt_advance_kernel, dim3(2), dim3(256), 0, st, adv_np, adv_py, batch ? nullptr : cursor, p.epoch, err);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

@@ -149,7 +149,7 @@ class DeviceSampler:
         import torch
         need = check(lib.kge_sampler_workspace_bytes(int(B), int(ns), int(num_e)))
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            self._ws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)  # zero-filled once (kge_hip.h)
         key = (int(B), int(ns), int(num_e))
         if self.segmented and key not in self._plans:
             buf = np.empty(int(lib.kge_sampler_plan_bytes()) // 8, dtype=np.uint64)
@@ -165,7 +165,7 @@ class DeviceSampler:
         m = B * int(ns)
         need = check(lib.kge_sampler_workspace_bytes(B, int(ns), int(num_e)))
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            self._ws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)  # zero-filled once (kge_hip.h)
         if pos_out is None:
             pos_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
             neg_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
