@@ -208,6 +208,14 @@ int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* 
 int64_t kge_batch_plan_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg);
 int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
                          void* plan, int64_t plan_bytes, int32_t parts, uint32_t* err_flag, kge_stream_t stream);
+/* The same plan from a batch given in folded form: cand_rows ((n_pos_cand + n_neg_cand), 3), positives first, with their
+ * multiplicities cand_counts laid out as (pos_lanes * n_pos_cand + n_neg_cand) int32 (count of positive a = sum over lanes l of
+ * cand_counts[l * n_pos_cand + a]; pos_lanes = 1 for a plain count vector, KGE_CAND_POS_LANES for the sampler's output).  Rows
+ * with count 0 are skipped; the counts of the positives sum to m_pos, those of the negatives to m_neg.  No hash table is
+ * needed.  Buffer size as for (m_pos, m_neg); requires n_pos_cand + n_neg_cand <= m_pos + m_neg. */
+int kge_batch_plan_build_counted(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* cand_rows, const int32_t* cand_counts,
+                                 int32_t pos_lanes, int64_t n_pos_cand, int64_t n_neg_cand, int64_t m_pos, int64_t m_neg, void* plan,
+                                 int64_t plan_bytes, int32_t parts, uint32_t* err_flag, kge_stream_t stream);
 int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
                             void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace,
                             int64_t workspace_bytes, kge_stream_t stream);
@@ -287,11 +295,19 @@ int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t
 /* Same, with the positives read in place: row i of the batch is kg[index[starts[*cursor] * B + i]] (kg: all training
  * triples (n,3) int32; index: the epoch permutation, int64; starts: batch numbers in drawing order, int64; cursor: one
  * int64 on the device) -- the slice DataGenerator.__getitem__ takes (tests.py:43-47,55-56).  The last kernel adds one to
- * *cursor, so consecutive calls (or replays of a hipGraph holding the call) walk through `starts`. */
+ * *cursor, so consecutive calls (or replays of a hipGraph holding the call) walk through `starts`.
+ * cand_rows / cand_counts (optional, both or neither): the batch BEFORE oversampling as ((B + B*ns), 3) int32 rows -- the B
+ * positives, then the B*ns rows of generate_negative (utils.py:114-121) -- and how often random.choices picked each row
+ * (utils.py:136): the oversampled batch in folded form, a by-product of drawing it (kge_batch_plan_build_counted).
+ * cand_counts holds KGE_CAND_POS_LANES*B + B*ns int32: the count of positive a is the sum over lanes l of
+ * cand_counts[l*B + a] (B bins take B*ns picks, so their counters are striped to spread the same-address atomics); the count
+ * of generated negative j is cand_counts[KGE_CAND_POS_LANES*B + j]. */
+#define KGE_CAND_POS_LANES 16
 int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const int32_t* kg_dev, const int64_t* index_dev,
                                    const int64_t* starts_dev, int64_t* cursor_dev, int64_t B, int64_t ns, int64_t num_e,
-                                   int32_t* pos_out_dev, int32_t* neg_out_dev, const void* plan_dev, void* workspace,
-                                   int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+                                   int32_t* pos_out_dev, int32_t* neg_out_dev, int32_t* cand_rows_dev, int32_t* cand_counts_dev,
+                                   const void* plan_dev, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                                   kge_stream_t stream);
 /* GF(2) jump-ahead primitives (host): out[312] uint64 = coefficients of x^J mod phi; kge_mt_jump_host replaces the 624
  * state words by raw words [J, J+624) of the stream (bits 0..30 of word 0 are not state and not guaranteed). */
 int kge_mt_jump_poly(int64_t J, uint64_t* out_host);

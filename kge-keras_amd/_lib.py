@@ -18,6 +18,7 @@ LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, 
 OPT_IDS = {"sgd": 0, "adam": 1}
 ACT_IDS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "softsign": 5, "elu": 6, "selu": 7, "exponential": 8}
 MT_STATE_BYTES = 2504
+CAND_POS_LANES = 16  # KGE_CAND_POS_LANES
 
 
 class ModelDesc(C.Structure):
@@ -65,6 +66,7 @@ SIGNATURES = {
     "kge_loss_value": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "kge_batch_plan_bytes": (_I64, [_MD, _LD, _I64, _I64]),
     "kge_batch_plan_build": (C.c_int, [_MD, _LD, _P, _I64, _P, _I64, _P, _I64, _I32, _P, _P]),
+    "kge_batch_plan_build_counted": (C.c_int, [_MD, _LD, _P, _P, _I32, _I64, _I64, _I64, _I64, _P, _I64, _I32, _P, _P]),
     "kge_train_grads_planned": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_train_step_planned": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
@@ -88,7 +90,7 @@ SIGNATURES = {
     "kge_sampler_plan_bytes": (_I64, []),
     "kge_sampler_plan_host": (C.c_int, [_I64, _I64, _I64, _P]),
     "kge_build_batch_device": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P]),
-    "kge_build_batch_device_indexed": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P]),
+    "kge_build_batch_device_indexed": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "kge_mt_jump_poly": (C.c_int, [_I64, _P]),
     "kge_mt_jump_host": (C.c_int, [_P, _I64]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),

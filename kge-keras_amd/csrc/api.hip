@@ -136,7 +136,8 @@ int train_grads(const kge_model_desc*, const kge_loss_desc*, const float*, const
 bool plan_supported(const kge_model_desc*, const kge_loss_desc*);
 int opt_state_init(const kge_opt_desc*, hipStream_t);
 int64_t batch_plan_bytes(const kge_model_desc*, int64_t);
-int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, void*, int, uint32_t*, hipStream_t);
+int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int, int64_t, int64_t, void*,
+                     int, uint32_t*, hipStream_t);
 int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, void*, int64_t, int64_t, float*,
                           uint64_t, void*, int64_t, hipStream_t);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
@@ -167,7 +168,7 @@ int rank_chain_scores(const kge_model_desc*, const float*, const float*, const i
                       uint32_t*, hipStream_t);
 
 int64_t sampler_workspace_bytes(int64_t, int64_t, int64_t);
-int build_batch_device(void*, void*, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int64_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, const void*, void*, int64_t, uint32_t*,
+int build_batch_device(void*, void*, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int64_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, int32_t*, int32_t*, const void*, void*, int64_t, uint32_t*,
                        hipStream_t);
 int sampler_plan_host(int64_t, int64_t, int64_t, uint64_t*);
 int64_t sampler_plan_bytes();
@@ -310,7 +311,25 @@ int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, cons
   if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
     return fail(KGE_EWORKSPACE, "kge_batch_plan_build: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
   if (parts < 1 || parts > 7) return fail(KGE_EINVAL, "kge_batch_plan_build: parts mask %d outside 1..7", parts);
-  return batch_plan_build(md, pos, m_pos, neg, m_neg, plan, parts, err_flag, static_cast<hipStream_t>(stream));
+  return batch_plan_build(md, pos, m_pos, neg, m_neg, nullptr, nullptr, 1, 0, 0, plan, parts, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_batch_plan_build_counted(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* cand_rows, const int32_t* cand_counts,
+                                 int32_t pos_lanes, int64_t n_pos_cand, int64_t n_neg_cand, int64_t m_pos, int64_t m_neg, void* plan,
+                                 int64_t plan_bytes, int32_t parts, uint32_t* err_flag, kge_stream_t stream) {
+  if (pos_lanes < 1 || pos_lanes > 64) return fail(KGE_EINVAL, "kge_batch_plan_build_counted: pos_lanes %d outside 1..64", pos_lanes);
+  if (int rc = check_plan("kge_batch_plan_build_counted", md, ld, m_pos, m_neg)) return rc;
+  if (!cand_rows || !cand_counts || !plan || !err_flag) return fail(KGE_EINVAL, "kge_batch_plan_build_counted: null pointer");
+  if (n_pos_cand <= 0 || n_neg_cand <= 0 || n_pos_cand + n_neg_cand > m_pos + m_neg)
+    return fail(KGE_EINVAL, "kge_batch_plan_build_counted: %lld + %lld candidate rows for %lld + %lld batch rows", (long long)n_pos_cand,
+                (long long)n_neg_cand, (long long)m_pos, (long long)m_neg);
+  if (md->dropout > 0.f) return fail(KGE_EUNSUPPORTED, "kge_batch_plan_build_counted: folded batches and dropout exclude each other (every row has its own mask)");
+  if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
+    return fail(KGE_EWORKSPACE, "kge_batch_plan_build_counted: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes,
+                (long long)batch_plan_bytes(md, m_pos + m_neg));
+  if (parts < 1 || parts > 7) return fail(KGE_EINVAL, "kge_batch_plan_build_counted: parts mask %d outside 1..7", parts);
+  return batch_plan_build(md, nullptr, m_pos, nullptr, m_neg, cand_rows, cand_counts, pos_lanes, n_pos_cand, n_neg_cand, plan, parts, err_flag,
+                          static_cast<hipStream_t>(stream));
 }
 
 int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
@@ -383,19 +402,21 @@ int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t
     return fail(KGE_EINVAL, "kge_build_batch_device: null pointer");
   if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_build_batch_device: bad sizes");
   return build_batch_device(np_state_dev, py_state_dev, batch_dev, nullptr, nullptr, nullptr, nullptr, B, ns, num_e, pos_out_dev, neg_out_dev,
-                            plan_dev, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+                            nullptr, nullptr, plan_dev, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
 }
 
 int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const int32_t* kg_dev, const int64_t* index_dev,
                                    const int64_t* starts_dev, int64_t* cursor_dev, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out_dev,
-                                   int32_t* neg_out_dev, const void* plan_dev, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
-                                   kge_stream_t stream) {
+                                   int32_t* neg_out_dev, int32_t* cand_rows_dev, int32_t* cand_counts_dev, const void* plan_dev, void* workspace,
+                                   int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if ((cand_rows_dev == nullptr) != (cand_counts_dev == nullptr))
+    return fail(KGE_EINVAL, "kge_build_batch_device_indexed: cand_rows and cand_counts go together");
   if (!np_state_dev || !py_state_dev || !kg_dev || !index_dev || !starts_dev || !cursor_dev || !pos_out_dev || !neg_out_dev || !workspace || !err_flag)
     return fail(KGE_EINVAL, "kge_build_batch_device_indexed: null pointer");
   if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll)
     return fail(KGE_EINVAL, "kge_build_batch_device_indexed: bad sizes");
   return build_batch_device(np_state_dev, py_state_dev, nullptr, kg_dev, index_dev, starts_dev, cursor_dev, B, ns, num_e, pos_out_dev, neg_out_dev,
-                            plan_dev, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+                            cand_rows_dev, cand_counts_dev, plan_dev, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
 }
 
 int64_t kge_loss_workspace_bytes(int64_t m_true, int64_t m_false) {

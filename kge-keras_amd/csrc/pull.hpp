@@ -76,8 +76,10 @@ int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const f
 
 // plan built ahead of the step (ids only) and consumed by it
 int64_t batch_plan_bytes(const kge_model_desc* md, int64_t n);
-int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* plan, int parts,
-                     uint32_t* err, hipStream_t st);
+// pos / neg arrays, or (cand_rows != null) the batch in folded form: candidate rows + multiplicities
+int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const int32_t* cand_rows,
+                     const int32_t* cand_cnt, int pos_lanes, int64_t n_pos_cand, int64_t n_neg_cand, void* plan, int parts, uint32_t* err,
+                     hipStream_t st);
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
                         hipStream_t st);

@@ -525,10 +525,10 @@ static void carve_plan(void* counters, void* region, const kge_model_desc* md, i
   p->rcnt = (int32_t*)(hq + b256(z.N * 4));
   Dedup& d = p->dd;
   d.cap = z.cap;
-  d.keys = (unsigned long long*)take(d.cap * 8);   // keys | cnt first: contiguous with the counters of a plan buffer, one memset
+  d.nu = (int32_t*)take(256);                      // nu | keys | cnt first: contiguous with the counters of a plan buffer, one memset
+  d.keys = (unsigned long long*)take(d.cap * 8);
   d.cnt = (int32_t*)take(d.cap * 4);
   d.clear_bytes = (char*)d.cnt + b256(d.cap * 4) - (char*)d.keys;
-  d.nu = (int32_t*)take(256);
   d.uid = (int32_t*)take(d.cap * 4);
   d.slot_of = (int32_t*)take(n * 4);
   d.frank = (int32_t*)take(n * 4);
@@ -595,6 +595,43 @@ static void launch_fwd_rel_loss(int loss, int nv, bool drop, int grid, hipStream
   else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
 }
 
+// Batch given in folded form (the sampler's candidates + pick counts): keep the rows with a count, dense ids from a ballot
+// per wave and one atomicAdd per workgroup on the row counter (zeroed with the plan's counters).
+__global__ __launch_bounds__(256) void counted_rows_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ cnt, int lanes,
+                                                            int64_t n_pos, int64_t n_all, int N, int R, int4* __restrict__ uniq, int32_t* nu,
+                                                            uint32_t* __restrict__ err) {
+  __shared__ int wbase[4];
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int s = 0, p = 0, o = 0, w = 0;
+  bool keep = false;
+  if (c < n_all) {
+    if (c < n_pos) { for (int l = 0; l < lanes; ++l) w += cnt[l * n_pos + c]; }  // striped counters of the positives
+    else w = cnt[(int64_t)(lanes - 1) * n_pos + c];
+    if (w > 0) {
+      s = rows[3 * c]; p = rows[3 * c + 1]; o = rows[3 * c + 2];
+      keep = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+      if (!keep) atomicOr(err, 1u);
+    }
+  }
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wbase[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wbase[0] + wbase[1] + wbase[2] + wbase[3];
+    const int base = tot ? atomicAdd(nu, tot) : 0;
+    int acc = base;
+    for (int i = 0; i < 4; ++i) { const int v = wbase[i]; wbase[i] = acc; acc += v; }
+  }
+  __syncthreads();
+  if (keep) uniq[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(s, p, o, c < n_pos ? w : -w);
+}
+
+__global__ __launch_bounds__(256) void zero_words_kernel(int32_t* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void rows_copy_kernel(const int32_t* __restrict__ pos, int64_t m_pos, const int32_t* __restrict__ neg,
                                                          int64_t m_neg, int4* __restrict__ rows, int32_t* __restrict__ nu) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -606,22 +643,29 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(const int32_t* __restric
 
 // ---- plan: everything that depends on the ids only.  `own_rows`: the plan must not refer to the caller's arrays afterwards
 // (kge_batch_plan_build), so rows that are not folded are copied.  `side` may be null (then everything runs on `st`).
+struct Counted { const int32_t* rows; const int32_t* cnt; int lanes; int64_t n_pos, n_all; };  // batch in folded form (rows == null: not given)
+
 static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const Plan2& p, bool own_rows,
-                      bool clear_counters, int parts, Src* src_out, bool* folded, float* scores, uint32_t* err, hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+                      bool clear_counters, int parts, const Counted& cd, Src* src_out, bool* folded, float* scores, uint32_t* err, hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
   const int64_t n = m_pos + m_neg;
   const int N = md->num_entities, R = md->num_relations;
   const int tgrid = (int)cdiv(n, 256);
   Src src{pos, m_pos, neg, m_neg, nullptr, nullptr};
-  const bool fold = dedup_applies(md, n);
+  const bool fold = !cd.rows && dedup_applies(md, n);
   *folded = fold;
   const Dedup& d = p.dd;
-  if (fold || own_rows) { src.uniq = d.uniq; src.nu = d.nu; }
+  if (fold || own_rows || cd.rows) { src.uniq = d.uniq; src.nu = d.nu; }
   *src_out = src;
   if (parts & 1) {  // rows: fold duplicates (or copy), counters cleared
-    // a plan buffer keeps its counters right in front of the hash table: one memset clears both
+    // a plan buffer keeps its counters right in front of the row counter and the hash table: one memset clears what is needed
     const int64_t cbytes = clear_counters ? (char*)d.keys - (char*)p.ent.cnt : 0;
-    if (!fold && clear_counters) KGE_HIP_TRY(hipMemsetAsync(p.ent.cnt, 0, cbytes, st));
-    if (fold) {
+    // (small clears by kernel: two replayed hipGraphs that both hold memset nodes stall each other's launches on ROCm 7.2)
+    if (!fold && clear_counters) hipLaunchKernelGGL(zero_words_kernel, dim3((int)cdiv(cbytes / 4, 256)), dim3(256), 0, st, (int32_t*)p.ent.cnt, cbytes / 4);
+    if (cd.rows) {
+      ProfScope prof(KGE_PROF_DEDUP, st);
+      hipLaunchKernelGGL(counted_rows_kernel, dim3((int)cdiv(cd.n_all, 256)), dim3(256), 0, st, cd.rows, cd.cnt, cd.lanes, cd.n_pos, cd.n_all, N, R,
+                         d.uniq, d.nu, err);
+    } else if (fold) {
       ProfScope prof(KGE_PROF_DEDUP, st);
       KGE_HIP_TRY(hipMemsetAsync(clear_counters ? (void*)p.ent.cnt : (void*)d.keys, 0, cbytes + d.clear_bytes, st));
       hipLaunchKernelGGL(dedup_insert_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, R, d.keys, d.cnt,
@@ -695,7 +739,7 @@ int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const f
   // folded rows: the forward writes the scores of the distinct rows, expanded to the caller's rows afterwards
   const bool fold = dedup_applies(md, n);
   float* fwd_scores = fold && scores ? p.dd.uscore : scores;
-  if (int rc = plan_build(md, pos, m_pos, neg, m_neg, p, false, false, 7, &src, &folded, fold ? nullptr : scores, err, st, side, fork, join)) return rc;
+  if (int rc = plan_build(md, pos, m_pos, neg, m_neg, p, false, false, 7, Counted{nullptr, nullptr, 1, 0, 0}, &src, &folded, fold ? nullptr : scores, err, st, side, fork, join)) return rc;
   if (int rc = plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, fwd_scores, loss_partials, n_partials, loss_out, seed, st, side ? join : nullptr))
     return rc;
   if (folded && scores) hipLaunchKernelGGL(dedup_scores_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, p.dd.slot_of, p.dd.uid, p.dd.uscore, n, scores);
@@ -716,14 +760,16 @@ static void carve_plan_buffer(void* plan, const kge_model_desc* md, int64_t n, P
 
 // parts: bit 0 = rows (fold / copy; clears the counters), bit 1 = entity index, bit 2 = relation index.  Bits 1 and 2 need
 // bit 0 done and are independent of each other (the caller may run them on two streams).
-int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, void* plan, int parts,
-                     uint32_t* err, hipStream_t st) {
+int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const int32_t* cand_rows,
+                     const int32_t* cand_cnt, int pos_lanes, int64_t n_pos_cand, int64_t n_neg_cand, void* plan, int parts, uint32_t* err,
+                     hipStream_t st) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
   carve_plan_buffer(plan, md, n, &p);
   Src src;
   bool folded;
-  return plan_build(md, pos, m_pos, neg, m_neg, p, true, true, parts, &src, &folded, nullptr, err, st, nullptr, nullptr, nullptr);
+  return plan_build(md, pos, m_pos, neg, m_neg, p, true, true, parts, Counted{cand_rows, cand_cnt, pos_lanes, n_pos_cand, n_pos_cand + n_neg_cand}, &src, &folded,
+                    nullptr, err, st, nullptr, nullptr, nullptr);
 }
 
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,

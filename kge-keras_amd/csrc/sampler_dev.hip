@@ -181,9 +181,12 @@ constexpr int kTileW = 1024;  // stream words per tile (256 threads x 4)
 __global__ __launch_bounds__(256) void np_select_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U, int64_t L_u,
                                                          uint32_t rng, uint32_t mask, unsigned long long* tile_agg,
                                                          const uint32_t* __restrict__ epoch_ptr, int64_t m, int32_t* __restrict__ fs,
-                                                         int32_t* __restrict__ fo, int64_t* __restrict__ consumed) {
+                                                         int32_t* __restrict__ fo, int64_t* __restrict__ consumed,
+                                                         int32_t* __restrict__ zero_p, int64_t zero_n) {
   __shared__ int wsum[4];
   __shared__ long long pre_s[4];
+  // (the pick counters py_assemble_kernel adds into are cleared here, on the way)
+  for (int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * blockDim.x) zero_p[z] = 0;
   const unsigned long long ep = (unsigned long long)(epoch_ptr[0] + 1u);
   const int p0 = st->pos;
   const int64_t L = (624 - p0) + L_u;
@@ -246,10 +249,14 @@ __device__ __forceinline__ const int32_t* batch_row(const BatchSrc& b, int64_t B
   return b.batch ? b.batch + 3 * a : b.kg + 3 * b.index[b.starts[b.cursor[0]] * B + a];
 }
 
+// cand_rows / cand_cnt (optional): the batch BEFORE oversampling -- rows [0,B) the positives, rows [B, B+m) the generated
+// negatives -- and how often random.choices picked each of them (cand_cnt zeroed by the caller of the kernel): the batch in
+// folded form, a by-product of drawing it.
 __global__ __launch_bounds__(256) void py_assemble_kernel(const MTDev* __restrict__ st, const uint32_t* __restrict__ U,
                                                            BatchSrc batch, int64_t B, int64_t ns,
                                                            const int32_t* __restrict__ fs, const int32_t* __restrict__ fo,
-                                                           int32_t* __restrict__ pos_out, int32_t* __restrict__ neg_out) {
+                                                           int32_t* __restrict__ pos_out, int32_t* __restrict__ neg_out,
+                                                           int32_t* __restrict__ cand_rows, int32_t* __restrict__ cand_cnt) {
   const int64_t m = B * ns;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * m) return;
@@ -260,12 +267,22 @@ __global__ __launch_bounds__(256) void py_assemble_kernel(const MTDev* __restric
     pos_out[3 * i + 0] = row[0];
     pos_out[3 * i + 1] = row[1];
     pos_out[3 * i + 2] = row[2];
+    if (cand_rows) {
+      atomicAdd(cand_cnt + (i & (KGE_CAND_POS_LANES - 1)) * B + a, 1);  // striped: B bins take m picks, ~ns hits per bin
+      if (i < B) {
+        const int32_t* r = batch_row(batch, B, i);
+        cand_rows[3 * i + 0] = r[0]; cand_rows[3 * i + 1] = r[1]; cand_rows[3 * i + 2] = r[2];
+      }
+      int32_t* g = cand_rows + 3 * (B + i);  // generated negative i (generate_negative's row i, utils.py:114-121)
+      g[0] = fs[i]; g[1] = batch_row(batch, B, i / ns)[1]; g[2] = fo[i];
+    }
   } else {      // then over the negatives (len m); row j of generate_negative carries the relation of positive j // ns
     const int64_t j = py_choice(st, U, p0, i, (double)m);
     const int64_t o = i - m;
     neg_out[3 * o + 0] = fs[j];
     neg_out[3 * o + 1] = batch_row(batch, B, j / ns)[1];
     neg_out[3 * o + 2] = fo[j];
+    if (cand_rows) atomicAdd(cand_cnt + KGE_CAND_POS_LANES * B + j, 1);
   }
 }
 
@@ -315,6 +332,7 @@ __global__ __launch_bounds__(256) void mt_advance_kernel(AdvanceArgs a0, Advance
   for (int i = threadIdx.x, k = 0; i < 624; i += 256, ++k) st->mt[i] = tmp[k];
   if (threadIdx.x == 0) st->pos = newpos;
 }
+
 
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,8 +404,8 @@ int64_t sampler_plan_bytes() { return (int64_t)2 * (kSeg - 1) * kPolyWords * 8; 
 
 // batch != null: the positives as a (B,3) array.  Otherwise rows index[starts[*cursor] * B + i] of kg, and *cursor += 1 at the end.
 int build_batch_device(void* np_state, void* py_state, const int32_t* batch, const int32_t* kg, const int64_t* index, const int64_t* starts,
-                       int64_t* cursor, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out, int32_t* neg_out, const void* plan_dev,
-                       void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+                       int64_t* cursor, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out, int32_t* neg_out, int32_t* cand_rows,
+                       int32_t* cand_cnt, const void* plan_dev, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
   if (wbytes < sampler_workspace_bytes(B, ns, num_e))
     return fail(KGE_EWORKSPACE, "kge_build_batch_device: workspace has %lld bytes, needs %lld", (long long)wbytes,
                 (long long)sampler_workspace_bytes(B, ns, num_e));
@@ -397,6 +415,8 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
   MTDev* pys = static_cast<MTDev*>(py_state);
   const uint32_t rng = (uint32_t)(num_e - 1), mask = (uint32_t)smear64(rng);
   ProfScope prof(KGE_PROF_SAMPLER, st);
+  const int64_t n_cnt = cand_cnt ? KGE_CAND_POS_LANES * B + m : 0;
+  if (cand_cnt && !rng) hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(n_cnt, 256)), dim3(256), 0, st, cand_cnt, n_cnt, 0);
   const int sb_np = plan_dev ? p.segb_np : 0, sb_py = plan_dev ? p.segb_py : 0;
   hipLaunchKernelGGL(mt_generate_kernel, dim3(2), dim3(256), 0, st, nps, pys, p.U_np, sb_np ? kJumpBlocks : (int)p.K_np, p.U_py,
                      sb_py ? kJumpBlocks : (int)p.K_py, (sb_np || sb_py) ? p.Jst : nullptr);
@@ -408,13 +428,13 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
   if (rng) {
     const int64_t L_u = p.K_np * 624;
     hipLaunchKernelGGL(np_select_kernel, dim3((int)p.ntiles), dim3(256), 0, st, nps, p.U_np, L_u, rng, mask, p.tile_agg, p.epoch, m, p.fs, p.fo,
-                       p.consumed);
+                       p.consumed, cand_cnt, n_cnt);
   } else {  // a range of one: numpy draws nothing
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fs, m, 0);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fo, m, 0);
   }
   hipLaunchKernelGGL(py_assemble_kernel, dim3((int)cdiv(2 * m, 256)), dim3(256), 0, st, pys, p.U_py, BatchSrc{batch, kg, index, starts, cursor}, B, ns, p.fs, p.fo, pos_out,
-                     neg_out);
+                     neg_out, cand_rows, cand_cnt);
   const AdvanceArgs adv_np{rng ? nps : nullptr, p.U_np, p.K_np * 624, p.consumed, 0};
   const AdvanceArgs adv_py{pys, p.U_py, p.K_py * 624, nullptr, 4 * m};
   hipLaunchKernelGGL(mt_advance_kernel, dim3(2), dim3(256), 0, st, adv_np, adv_py, batch ? nullptr : cursor, p.epoch, err);

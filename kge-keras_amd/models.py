@@ -326,6 +326,19 @@ class EmbeddingModel:
         md, ld = self._model_desc(True), self._loss_desc()
         return lib.kge_batch_plan_bytes(C.byref(md), C.byref(ld), 1, 1) > 0
 
+    def plan_batch_counted(self, cand_rows, cand_counts, n_pos_cand, m_pos, m_neg, out=None, parts=7, pos_lanes=1):
+        """BatchPlan of a batch given in folded form: cand_rows (rows of the batch before oversampling, positives first) with
+        their multiplicities cand_counts (DeviceSampler.build_batch(..., counted=...): pos_lanes = _lib.CAND_POS_LANES striped
+        counters for the positives); no hash table involved."""
+        md, ld = self._model_desc(True), self._loss_desc()
+        need = check(lib.kge_batch_plan_bytes(C.byref(md), C.byref(ld), int(m_pos), int(m_neg)))
+        buf = out.buf if out is not None and out.buf.numel() >= need else torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        n_neg_cand = int(cand_counts.numel()) - int(pos_lanes) * int(n_pos_cand)
+        check(lib.kge_batch_plan_build_counted(C.byref(md), C.byref(ld), cand_rows.data_ptr(), cand_counts.data_ptr(), int(pos_lanes),
+                                               int(n_pos_cand), n_neg_cand, int(m_pos), int(m_neg), buf.data_ptr(), buf.numel(), int(parts),
+                                               self._err.data_ptr(), _lib.stream_ptr()))
+        return BatchPlan(buf, m_pos, m_neg)
+
     def plan_batch(self, data, out=None, parts=7):
         """Build the BatchPlan of [pos, neg] on the CURRENT stream (asynchronous).  `out`: a BatchPlan whose buffer is reused
         when large enough.  The caller orders the build before the step that consumes it (same stream, or an event).

@@ -33,6 +33,11 @@ class TrainPipeline:
         self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0 and between is None
         m = self.B * self.ns
         self.bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device=self.dev) for _ in range(2)) for _ in range(2)]
+        # the batch before oversampling + how often each row was picked: the sampler's by-product the plans are built from when
+        # there is no dropout (with dropout every oversampled row has its own mask and the plan takes the arrays as they are)
+        self.counted = float(getattr(model, "dp", 0.0) or 0.0) == 0.0
+        self.cand = [(torch.empty((self.B + m, 3), dtype=torch.int32, device=self.dev), torch.zeros(_lib.CAND_POS_LANES * self.B + m, dtype=torch.int32, device=self.dev))
+                     for _ in range(2)] if self.counted else [None, None]
         md, ld = model._model_desc(True), model._loss_desc()
         need = _lib.check(_lib.lib.kge_batch_plan_bytes(_lib.C.byref(md), _lib.C.byref(ld), m, m))
         from .models import BatchPlan
@@ -48,26 +53,33 @@ class TrainPipeline:
         self.planned = [torch.cuda.Event() for _ in range(2)]   # plan built
         self.pfreed = [torch.cuda.Event() for _ in range(2)]    # plan consumed
         self.graphs = {}
+        self._done = {}  # (stage, slot) -> event recorded behind the last replay of that graph
         self._sig = None
         self.serial = False  # True: every stage on the caller's stream, nothing overlaps (clean per-kernel timings)
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
         # positives read in place (kg[index[starts[cursor] * B + i]]); the sampler's last kernel moves the cursor on
-        self.sampler.build_batch(None, self.ns, self.num_e, *self.bufs[slot], indexed=(self.kg, self.index, self.starts, self.cursor, self.B))
+        self.sampler.build_batch(None, self.ns, self.num_e, *self.bufs[slot], indexed=(self.kg, self.index, self.starts, self.cursor, self.B),
+                                 counted=self.cand[slot])
 
     def _stage_P(self, slot, fork=None):
         """rows first, then the entity lists and the relation lists -- side by side on `fork` (a stream that already follows
         the caller's origin stream and is joined by the caller) when given: they only share the rows."""
         cur, b, pl = torch.cuda.current_stream(), list(self.bufs[slot]), self.plans[slot]
+        m = self.B * self.ns
+        if self.counted:
+            build = lambda parts: self.model.plan_batch_counted(*self.cand[slot], self.B, m, m, out=pl, parts=parts, pos_lanes=_lib.CAND_POS_LANES)  # noqa: E731
+        else:
+            build = lambda parts: self.model.plan_batch(b, out=pl, parts=parts)  # noqa: E731
         if fork is None:
-            self.model.plan_batch(b, out=pl, parts=7)
+            build(7)
             return
-        self.model.plan_batch(b, out=pl, parts=1)
+        build(1)
         fork.wait_stream(cur)
         with torch.cuda.stream(fork):
-            self.model.plan_batch(b, out=pl, parts=2)
-        self.model.plan_batch(b, out=pl, parts=4)
+            build(2)
+        build(4)
 
     def _stage_T(self, slot):
         if self.between is None:
@@ -85,6 +97,7 @@ class TrainPipeline:
     def _signature(self):
         mo, sa = self.model, self.sampler
         t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.starts]
+        t += [x for c in self.cand if c is not None for x in c]
         if mo.optimizer.slots:
             t += list(mo.optimizer.slots)
         return tuple(x.data_ptr() for x in t if x is not None) + (mo.optimizer.kind, mo.optimizer.lr, mo.loss_function, float(mo.margin or 1))
@@ -116,7 +129,16 @@ class TrainPipeline:
         if self.use_graphs:
             if not self.graphs or self._sig != self._signature():
                 self._capture()
+            # A graph exec cannot run twice at once: launching it again while its previous launch is still in flight blocks
+            # inside the runtime, and that wait sleeps (milliseconds on a busy host).  Spin on an event instead.
+            ev = self._done.get((name, slot))
+            if ev is not None:
+                while not ev.query():
+                    pass
+            else:
+                ev = self._done[name, slot] = torch.cuda.Event()
             self.graphs[name, slot].replay()
+            ev.record(torch.cuda.current_stream())
         elif name == "S":
             self._stage_S(slot)
         elif name == "P":

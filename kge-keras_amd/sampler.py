@@ -156,9 +156,11 @@ class DeviceSampler:
             check(lib.kge_sampler_plan_host(int(B), int(ns), int(num_e), buf.ctypes.data))
             self._plans[key] = torch.from_numpy(buf.view(np.int64)).to(self.device)
 
-    def build_batch(self, batch, ns, num_e, pos_out=None, neg_out=None, indexed=None):
+    def build_batch(self, batch, ns, num_e, pos_out=None, neg_out=None, indexed=None, counted=None):
         """batch: (B,3) int32 device rows -- or None with indexed=(kg, index, starts, cursor, B): the positives are read in
-        place as kg[index[starts[cursor] * B + i]] and the device cursor moves on by one (kge_build_batch_device_indexed)."""
+        place as kg[index[starts[cursor] * B + i]] and the device cursor moves on by one (kge_build_batch_device_indexed).
+        counted=(cand_rows ((B + B*ns), 3) int32, cand_counts (B + B*ns) int32), with `indexed`: also emit the batch before
+        oversampling and how often each of its rows was picked (the batch in folded form)."""
         import torch
         from . import _lib
         B = batch.shape[0] if indexed is None else int(indexed[4])
@@ -181,8 +183,9 @@ class DeviceSampler:
             kg, index, starts, cursor = indexed[:4]
             check(lib.kge_build_batch_device_indexed(self.np_state.data_ptr(), self.py_state.data_ptr(), kg.data_ptr(), index.data_ptr(),
                                                      starts.data_ptr(), cursor.data_ptr(), B, int(ns), int(num_e), pos_out.data_ptr(),
-                                                     neg_out.data_ptr(), plan_ptr, self._ws.data_ptr(), self._ws.numel(), self.err.data_ptr(),
-                                                     _lib.stream_ptr()))
+                                                     neg_out.data_ptr(), counted[0].data_ptr() if counted else None,
+                                                     counted[1].data_ptr() if counted else None, plan_ptr, self._ws.data_ptr(),
+                                                     self._ws.numel(), self.err.data_ptr(), _lib.stream_ptr()))
             return pos_out, neg_out
         check(lib.kge_build_batch_device(self.np_state.data_ptr(), self.py_state.data_ptr(), batch.data_ptr(), B, int(ns), int(num_e),
                                          pos_out.data_ptr(), neg_out.data_ptr(), plan_ptr, self._ws.data_ptr(), self._ws.numel(),

@@ -86,3 +86,70 @@ def test_indexed_batch_builder_walks_the_epoch(datasets):
         assert torch.equal(pa, pb) and torch.equal(na, nb)
         assert int(cursor.item()) == k + 1
     assert torch.equal(a.np_state, b.np_state) and torch.equal(a.py_state, b.py_state)
+
+
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("ComplEx", {})])
+def test_counted_plan_equals_plain_step(model, kw):
+    """kge_batch_plan_build_counted: a batch given as candidate rows + multiplicities (what the device sampler emits next to the
+    oversampled arrays; no hash table) trains exactly like the expanded arrays.  Plain count vector (pos_lanes = 1), rows with
+    count 0, a row outside the tables."""
+    from kge_keras_amd import models as M
+    N, R, d = 40, 5, 16
+    rs = np.random.RandomState(8)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    a, b = (getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0,
+                              loss_function="pointwize_logistic", **kw) for _ in range(2))
+    a.compile("adam")
+    b.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.AdamTF()
+    for step in range(2):
+        n_pos, n_neg = 20, 300
+        cand = np.stack([rs.randint(0, N, n_pos + n_neg), rs.randint(0, R, n_pos + n_neg), rs.randint(0, N, n_pos + n_neg)], 1).astype(np.int32)
+        cnt = rs.randint(0, 6, n_pos + n_neg).astype(np.int32)  # zeros included
+        cnt[0] = max(cnt[0], 1)
+        cnt[n_pos] = max(cnt[n_pos], 1)
+        pos, neg = np.repeat(cand[:n_pos], cnt[:n_pos], axis=0), np.repeat(cand[n_pos:], cnt[n_pos:], axis=0)
+        rs.shuffle(pos)
+        plan = a.plan_batch_counted(torch.from_numpy(cand).cuda(), torch.from_numpy(cnt).cuda(), n_pos, len(pos), len(neg))
+        La = float(a.train_step(plan)["loss"].item())
+        Lb = float(b.train_step([pos, neg])["loss"].item())
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+        assert La == pytest.approx(Lb, rel=1e-5, abs=1e-6) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), step
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+        np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-5)
+    cand[3, 0] = N  # a picked row outside the tables: error flag, the row takes no part
+    cnt[3] = 2
+    a.train_step(a.plan_batch_counted(torch.from_numpy(cand).cuda(), torch.from_numpy(cnt).cuda(), n_pos, int(cnt[:n_pos].sum()), int(cnt[n_pos:].sum())))
+    with pytest.raises(IndexError):
+        a._raise_on_flag()
+
+
+def test_sampler_candidates_and_pick_counts(datasets):
+    """DeviceSampler.build_batch(..., counted=...): the candidate rows are the batch before oversampling and expanding them by
+    their pick counts gives the same multiset of rows as the oversampled arrays."""
+    from kge_keras_amd import _lib
+    from kge_keras_amd.sampler import DeviceSampler, NumpyStream, PythonStream
+    kg = torch.from_numpy(np.ascontiguousarray(datasets["nations_train"], dtype=np.int32)).cuda()
+    n, B, ns, N, L = kg.shape[0], 64, 9, 14, _lib.CAND_POS_LANES
+    m = B * ns
+    index = torch.from_numpy(np.random.RandomState(3).permutation(n)).cuda()
+    starts = torch.tensor([2, 5], dtype=torch.int64, device="cuda")
+    cursor = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ds = DeviceSampler(NumpyStream(7), PythonStream(8))
+    cand = torch.empty((B + m, 3), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(L * B + m, dtype=torch.int32, device="cuda")
+    for k in range(2):
+        pos, neg = ds.build_batch(None, ns, N, indexed=(kg, index, starts, cursor, B), counted=(cand, cnt))
+        c = cnt.cpu().numpy()
+        cp, cn = c[:L * B].reshape(L, B).sum(0), c[L * B:]
+        assert cp.sum() == m and cn.sum() == m
+        s0 = int(starts[k]) * B
+        assert torch.equal(cand[:B], kg.index_select(0, index[s0:s0 + B]))
+        rows = cand.cpu().numpy()
+        key = lambda a: sorted(map(tuple, a.tolist()))  # noqa: E731
+        assert key(np.repeat(rows[:B], cp, axis=0)) == key(pos.cpu().numpy())
+        assert key(np.repeat(rows[B:], cn, axis=0)) == key(neg.cpu().numpy())
