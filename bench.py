@@ -146,8 +146,8 @@ def main():
                     help="ahead: batch plans (ids-only half of the step) built on their own stream ahead of the step; step: inside the step")
     ap.add_argument("--settle", type=int, default=1000, help="upper bound of the extra untimed steps run until the step time is stable")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "stream"],
-                    help="graph: every pipeline stage is one hipGraph launch per step; stream: every kernel launched from Python; "
-                         "auto: graph on one GPU, stream under torch.distributed")
+                    help="graph / auto: the TrainPipeline object (every stage one hipGraph launch per step on one GPU; kernel-by-kernel "
+                         "launches of the same stages under torch.distributed); stream: the plain double-buffered loop of this file")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -248,7 +248,9 @@ def main():
 
     # default: the three-stage pipeline (draw batch t+2 | plan batch t+1 | train step t) replayed from hipGraphs, one launch per step
     pipe = None
-    launch = args.launch if args.launch != "auto" else ("graph" if world == 1 else "stream")
+    # auto: the pipeline object in both cases; under torch.distributed it launches its stages kernel by kernel (the gradient
+    # all-reduce sits between the two halves of the step and stays outside any graph)
+    launch = args.launch if args.launch != "auto" else "graph"
     if args.sampler == "device" and plan_ahead and launch == "graph":
         from kge_keras_amd.pipeline import TrainPipeline
         between = (lambda: (D.allreduce_sum_([model._gall]), 1.0 / world)[1]) if world > 1 else None
@@ -373,8 +375,10 @@ def main():
                          "fold_avg_ms": d_ms / max(1, d_n),
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
                          "sampler_avg_ms": s_ms / max(1, s_n), "host_enqueue_ms_per_step": t_issue / args.steps * 1e3,
-                         "launch": ("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams); kernel durations "
-                                    "above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)" if pipe is not None
+                         "launch": (("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams)" if world == 1 else
+                                     "draw | plan | step stages on three streams, launched kernel by kernel (collective between the halves of the step)")
+                                    + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)"
+                                    if pipe is not None
                                     else "kernel-by-kernel stream launches"),
                          "plan": ("ids-only half of the step (fold + gradient lists) built 1-2 batches ahead on its own stream, inside the timed region"
                                   if plan_ahead else "built inside the step")},
