@@ -170,10 +170,12 @@ def main():
     from kge_keras_amd import _lib
     from kge_keras_amd import dist as D
     from kge_keras_amd.models import DistMult
-    import oracle as O
 
     rs = np.random.RandomState(1234)
-    E0, R0 = O.glorot_uniform(CFG["N"], CFG["d"], rs), O.glorot_uniform(CFG["R"], CFG["d"], rs)
+    def glorot(rows, cols):  # Keras GlorotUniform on an Embedding matrix (models.py:87-93): U(-l, l), l = sqrt(6 / (rows + cols))
+        lim = np.sqrt(6.0 / (rows + cols))
+        return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
+    E0, R0 = glorot(CFG["N"], CFG["d"]), glorot(CFG["R"], CFG["d"])
     model = DistMult(e_dim=CFG["d"], r_dim=CFG["d"], num_entities=CFG["N"], num_relations=CFG["R"], dp=0.0,
                      init_entities=E0, init_relations=R0, loss_function="pointwize_hinge", margin=1)
     model.compile("adam")
