@@ -206,7 +206,6 @@ def main():
     plan_ahead = args.plan == "ahead" and model.plan_supported()
     pstream = torch.cuda.Stream() if plan_ahead else None
     plans = [None, None]
-    pool_plans = [None] * n_pool
 
     def produce(i):
         j = i % 2

@@ -31,5 +31,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 _lib.lib.kge_prof_enable(0)
 out = {k: _lib.prof_read(k) for k in ("dedup", "index", "fwd", "train_grads", "opt")}
-print(f"V={os.environ.get('KGE_DEDUP_V', '0')} DEDUP={os.environ.get('KGE_DEDUP', '1')}: {dt*1e3:.3f} ms/step {2*B*ns/dt/1e6:.0f} M/s  " +
+print(f"KGE_DEDUP={os.environ.get('KGE_DEDUP', '1')}: {dt*1e3:.3f} ms/step {2*B*ns/dt/1e6:.0f} M/s  " +
       "  ".join(f"{k} {ms/max(1,n)*1e3:.1f}us" for k, (ms, n) in out.items()))
