@@ -318,3 +318,9 @@ def test_index_kg_matches_golden_id_arrays(golden, datasets, tmp_path):
     assert sorted(emap, key=emap.get) == sorted(emap) and sorted(rmap, key=rmap.get) == sorted(rmap)
     for (s, p_, o), (a, b, c) in zip(rows, arr.tolist()):
         assert emap[s] == a and rmap[p_] == b and emap[o] == c
+
+
+def test_graft_entry_build_contract():
+    """__graft_entry__.build() is the driver's "does it build" check: run it here (incremental make, import, ABI version)."""
+    import __graft_entry__ as g
+    g.build()
