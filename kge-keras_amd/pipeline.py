@@ -220,7 +220,11 @@ class TrainPipeline:
     def run_epoch(self, index, order):
         """All batches of one epoch; returns the summed loss (0-d float64 device tensor)."""
         self.load_epoch(index, order)
-        self.start()
-        for _ in range(self.n):
-            self.tick()
+        try:
+            self.start()
+            for _ in range(self.n):
+                self.tick()
+        except BaseException:
+            self.model._step_dev = None  # never leave the model on the device step state
+            raise
         return self.finish()
