@@ -144,7 +144,7 @@ def main():
                          "(inside the timed region); pre: batches pre-built on the host before timing")
     ap.add_argument("--plan", default="ahead", choices=["ahead", "step"],
                     help="ahead: batch plans (ids-only half of the step) built on their own stream ahead of the step; step: inside the step")
-    ap.add_argument("--settle", type=int, default=1000, help="upper bound of the extra untimed steps run until the step time is stable")
+    ap.add_argument("--settle", type=int, default=20000, help="upper bound of the extra untimed steps run until the step time is stable")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "stream"],
                     help="graph / auto: the TrainPipeline object (every stage one hipGraph launch per step on one GPU; kernel-by-kernel "
                          "launches of the same stages under torch.distributed); stream: the plain double-buffered loop of this file")
@@ -275,11 +275,15 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    # settle (untimed, bounded): the first process on a fresh box runs several times slower for its first few hundred steps
-    # (clocks / paging); keep stepping in blocks of 20 until a block is within 15 % of the best one seen, at most ~2 s
+    # settle (untimed, bounded): the first process on a fresh box can run several times slower for its first tenths of a second
+    # (the image is still paging in: a cold host, not a cold GPU).  Keep stepping in blocks of 20 for at least 0.6 s and until a
+    # block is within 15 % of the best one seen, at most 3 s.  Under torch.distributed every rank runs the same fixed count.
     settle, best, t_settle = 0, None, time.perf_counter()
-    while settle < args.settle and (world > 1 or time.perf_counter() - t_settle < 2.0):
-        if world > 1 and settle >= min(args.settle, 200):  # every rank must run the same number of (collective) steps
+    while settle + 20 <= args.settle:
+        el = time.perf_counter() - t_settle
+        if world > 1 and settle >= min(args.settle, 2000):
+            break
+        if world == 1 and el > 3.0:
             break
         tb = time.perf_counter()
         for i in range(20):
@@ -287,7 +291,7 @@ def main():
         fence()
         tb = time.perf_counter() - tb
         settle += 20
-        if world == 1 and best is not None and settle >= 60 and tb <= 1.15 * best:
+        if world == 1 and best is not None and el >= 0.6 and tb <= 1.15 * best:
             break
         best = tb if best is None else min(best, tb)
     base = args.warmup + settle

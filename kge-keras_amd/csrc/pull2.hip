@@ -28,7 +28,7 @@
 namespace kge {
 
 constexpr int kRelMax = 4096;   // relations handled by the LDS histogram / single-workgroup plan
-constexpr int kRelChunk = 64;   // triples per forward work unit
+constexpr int kRelChunk = 32;   // triples per forward work unit
 constexpr int kRelBlockTriples = 1024;
 
 struct Dedup {
