@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "stream"],
                     help="graph / auto: the TrainPipeline object (every stage one hipGraph launch per step on one GPU; kernel-by-kernel "
                          "launches of the same stages under torch.distributed); stream: the plain double-buffered loop of this file")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling aid: run the pipeline stages one after the other on one stream, kernel by kernel, in every phase "
+                         "(what the roofline leg does), so that a rocprofv3 kernel trace of the run times every kernel alone")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -257,6 +260,8 @@ def main():
         between = (lambda: (D.allreduce_sum_([model._gall]), 1.0 / world)[1]) if world > 1 else None
         pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=True, between=between)
         total = args.warmup + args.settle + 2 * args.steps + 8
+        if args.serial:
+            pipe.use_graphs, pipe.serial = False, True
         pipe.load_epoch(perm_dev, [i % nb_epoch for i in range(total)])
         pipe.start()
         step = lambda i: pipe.tick()  # noqa: E731
