@@ -95,7 +95,7 @@ def eval_leg(torch, dist, model, rank, world, reps=3):
     fq = np.repeat(np.arange(nq, dtype=np.int32), 3)
     fi = rs.randint(0, CFG["N"], 3 * nq).astype(np.int32)
     keep = (fi != np.repeat(mine[:, 2], 3)) & (fi != np.repeat(mine[:, 0], 3))
-    fq, fi = fq[keep], fi[keep]
+    fq, fi = torch.from_numpy(fq[keep]).cuda(), torch.from_numpy(fi[keep]).cuda()  # the filter index is resident, like the tables
     tq = torch.from_numpy(mine).cuda()
     from kge_keras_amd import dist as D
     lo, hi = D.shard_range(CFG["N"], rank, world)

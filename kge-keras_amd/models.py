@@ -536,8 +536,11 @@ class EmbeddingModel:
         need = check(lib.kge_rank_workspace_bytes(C.byref(md), nq))
         if getattr(self, "_rank_ws", None) is None or self._rank_ws.numel() < need:
             self._rank_ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-        fq = torch.from_numpy(np.ascontiguousarray(filt_q, dtype=np.int32)).to(self.device)
-        fi = torch.from_numpy(np.ascontiguousarray(filt_ids, dtype=np.int32)).to(self.device)
+        def dev_i32(a):  # device tensors are taken as they are (no host round trip per call)
+            if isinstance(a, torch.Tensor) and a.device.type == "cuda":
+                return a.to(dtype=torch.int32).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+        fq, fi = dev_i32(filt_q), dev_i32(filt_ids)
         acc = counts is not None
         if counts is None:
             counts = torch.empty(nq, dtype=torch.int32, device=self.device)
