@@ -32,6 +32,29 @@ constexpr int kTile = 128;  // block tile: 128 queries x 128 candidates, 4 waves
 
 __device__ __forceinline__ float chain_dot(const float* __restrict__ q, const float* __restrict__ e, int K, int Kpad) {
   float acc = 0.f;
+  // rows of K % 4 == 0 floats on 16-byte boundaries (every table the sweeps see): 128-bit loads, the next block of 8 in flight
+  // behind the 8 dependent FMAs of the current one.  Same operations in the same order as the scalar loop below.
+  if ((K & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(e)) & 15) == 0) {
+    const float4* q4 = reinterpret_cast<const float4*>(q);
+    const float4* e4 = reinterpret_cast<const float4*>(e);
+    const int K4 = K >> 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 qa = q4[0], qb = q4[1], ea = e4[0], eb = 1 < K4 ? e4[1] : z;
+    for (int b = 0; b < Kpad / 8; ++b) {
+      float4 nqa = z, nqb = z, nea = z, neb = z;
+      if (b + 1 < Kpad / 8) {
+        nqa = q4[2 * b + 2]; nqb = q4[2 * b + 3];
+        nea = 2 * b + 2 < K4 ? e4[2 * b + 2] : z;
+        neb = 2 * b + 3 < K4 ? e4[2 * b + 3] : z;
+      }
+      acc = __fmaf_rn(qa.x, ea.x, acc); acc = __fmaf_rn(qb.x, eb.x, acc);
+      acc = __fmaf_rn(qa.y, ea.y, acc); acc = __fmaf_rn(qb.y, eb.y, acc);
+      acc = __fmaf_rn(qa.z, ea.z, acc); acc = __fmaf_rn(qb.z, eb.z, acc);
+      acc = __fmaf_rn(qa.w, ea.w, acc); acc = __fmaf_rn(qb.w, eb.w, acc);
+      qa = nqa; qb = nqb; ea = nea; eb = neb;
+    }
+    return acc;
+  }
   for (int k0 = 0; k0 < Kpad; k0 += 8) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
