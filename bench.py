@@ -340,9 +340,13 @@ def main():
     def distinct(a):
         key = (a[:, 0].long() * CFG["R"] + a[:, 1].long()) * CFG["N"] + a[:, 2].long()
         return int(torch.unique(key).numel())
-    used = list(pipe.bufs) if pipe is not None else (list(bufs) if args.sampler == "device" else dev)
     folded = d_n > 0
-    rows_launch = float(np.mean([distinct(p) + distinct(n) for p, n in used])) if folded else float(per_step)
+    if pipe is not None and pipe.counted:  # rows with a pick count (the sampler's folded form of the last two batches)
+        L = _lib.CAND_POS_LANES * CFG["B"]
+        rows_launch = float(np.mean([int((c[:L].view(_lib.CAND_POS_LANES, CFG["B"]).sum(0) > 0).sum() + (c[L:] > 0).sum()) for _r, c in pipe.cand]))
+    else:
+        used = list(pipe.bufs) if pipe is not None else (list(bufs) if args.sampler == "device" else dev)
+        rows_launch = float(np.mean([distinct(p) + distinct(n) for p, n in used])) if folded else float(per_step)
 
     ev = eval_leg(torch, dist, model, rank, world)
 

@@ -301,7 +301,8 @@ int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t
  * (utils.py:136): the oversampled batch in folded form, a by-product of drawing it (kge_batch_plan_build_counted).
  * cand_counts holds KGE_CAND_POS_LANES*B + B*ns int32: the count of positive a is the sum over lanes l of
  * cand_counts[l*B + a] (B bins take B*ns picks, so their counters are striped to spread the same-address atomics); the count
- * of generated negative j is cand_counts[KGE_CAND_POS_LANES*B + j]. */
+ * of generated negative j is cand_counts[KGE_CAND_POS_LANES*B + j].  With the folded form requested, pos_out / neg_out may
+ * both be NULL (the oversampled arrays are then not materialised; the generator states advance all the same). */
 #define KGE_CAND_POS_LANES 16
 int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const int32_t* kg_dev, const int64_t* index_dev,
                                    const int64_t* starts_dev, int64_t* cursor_dev, int64_t B, int64_t ns, int64_t num_e,

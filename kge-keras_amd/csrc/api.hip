@@ -411,8 +411,10 @@ int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const
                                    int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
   if ((cand_rows_dev == nullptr) != (cand_counts_dev == nullptr))
     return fail(KGE_EINVAL, "kge_build_batch_device_indexed: cand_rows and cand_counts go together");
-  if (!np_state_dev || !py_state_dev || !kg_dev || !index_dev || !starts_dev || !cursor_dev || !pos_out_dev || !neg_out_dev || !workspace || !err_flag)
+  if (!np_state_dev || !py_state_dev || !kg_dev || !index_dev || !starts_dev || !cursor_dev || !workspace || !err_flag)
     return fail(KGE_EINVAL, "kge_build_batch_device_indexed: null pointer");
+  if ((pos_out_dev == nullptr) != (neg_out_dev == nullptr) || (!pos_out_dev && !cand_rows_dev))
+    return fail(KGE_EINVAL, "kge_build_batch_device_indexed: give pos_out and neg_out, or cand_rows and cand_counts, or both");
   if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll)
     return fail(KGE_EINVAL, "kge_build_batch_device_indexed: bad sizes");
   return build_batch_device(np_state_dev, py_state_dev, nullptr, kg_dev, index_dev, starts_dev, cursor_dev, B, ns, num_e, pos_out_dev, neg_out_dev,

@@ -263,10 +263,12 @@ __global__ __launch_bounds__(256) void py_assemble_kernel(const MTDev* __restric
   const int p0 = st->pos;
   if (i < m) {  // choices over the positives (len B) come first in the stream
     const int64_t a = py_choice(st, U, p0, i, (double)B);
-    const int32_t* row = batch_row(batch, B, a);
-    pos_out[3 * i + 0] = row[0];
-    pos_out[3 * i + 1] = row[1];
-    pos_out[3 * i + 2] = row[2];
+    if (pos_out) {
+      const int32_t* row = batch_row(batch, B, a);
+      pos_out[3 * i + 0] = row[0];
+      pos_out[3 * i + 1] = row[1];
+      pos_out[3 * i + 2] = row[2];
+    }
     if (cand_rows) {
       atomicAdd(cand_cnt + (i & (KGE_CAND_POS_LANES - 1)) * B + a, 1);  // striped: B bins take m picks, ~ns hits per bin
       if (i < B) {
@@ -279,9 +281,11 @@ __global__ __launch_bounds__(256) void py_assemble_kernel(const MTDev* __restric
   } else {      // then over the negatives (len m); row j of generate_negative carries the relation of positive j // ns
     const int64_t j = py_choice(st, U, p0, i, (double)m);
     const int64_t o = i - m;
-    neg_out[3 * o + 0] = fs[j];
-    neg_out[3 * o + 1] = batch_row(batch, B, j / ns)[1];
-    neg_out[3 * o + 2] = fo[j];
+    if (neg_out) {
+      neg_out[3 * o + 0] = fs[j];
+      neg_out[3 * o + 1] = batch_row(batch, B, j / ns)[1];
+      neg_out[3 * o + 2] = fo[j];
+    }
     if (cand_rows) atomicAdd(cand_cnt + KGE_CAND_POS_LANES * B + j, 1);
   }
 }

@@ -60,7 +60,9 @@ class TrainPipeline:
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
         # positives read in place (kg[index[starts[cursor] * B + i]]); the sampler's last kernel moves the cursor on
-        self.sampler.build_batch(None, self.ns, self.num_e, *self.bufs[slot], indexed=(self.kg, self.index, self.starts, self.cursor, self.B),
+        # (with the folded form the oversampled arrays themselves are not needed and not written)
+        pos, neg = (False, None) if self.counted else self.bufs[slot]
+        self.sampler.build_batch(None, self.ns, self.num_e, pos, neg, indexed=(self.kg, self.index, self.starts, self.cursor, self.B),
                                  counted=self.cand[slot])
 
     def _stage_P(self, slot, fork=None):

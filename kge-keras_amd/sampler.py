@@ -160,7 +160,8 @@ class DeviceSampler:
         """batch: (B,3) int32 device rows -- or None with indexed=(kg, index, starts, cursor, B): the positives are read in
         place as kg[index[starts[cursor] * B + i]] and the device cursor moves on by one (kge_build_batch_device_indexed).
         counted=(cand_rows ((B + B*ns), 3) int32, cand_counts (B + B*ns) int32), with `indexed`: also emit the batch before
-        oversampling and how often each of its rows was picked (the batch in folded form)."""
+        oversampling and how often each of its rows was picked (the batch in folded form); pos_out=False then skips the
+        oversampled arrays altogether."""
         import torch
         from . import _lib
         B = batch.shape[0] if indexed is None else int(indexed[4])
@@ -168,7 +169,10 @@ class DeviceSampler:
         need = check(lib.kge_sampler_workspace_bytes(B, int(ns), int(num_e)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)  # zero-filled once (kge_hip.h)
-        if pos_out is None:
+        arrays = not (counted is not None and pos_out is False)  # pos_out=False with counted=...: folded form only
+        if not arrays:
+            pos_out = neg_out = None
+        elif pos_out is None:
             pos_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
             neg_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
         plan_ptr = None
@@ -182,8 +186,9 @@ class DeviceSampler:
         if indexed is not None:
             kg, index, starts, cursor = indexed[:4]
             check(lib.kge_build_batch_device_indexed(self.np_state.data_ptr(), self.py_state.data_ptr(), kg.data_ptr(), index.data_ptr(),
-                                                     starts.data_ptr(), cursor.data_ptr(), B, int(ns), int(num_e), pos_out.data_ptr(),
-                                                     neg_out.data_ptr(), counted[0].data_ptr() if counted else None,
+                                                     starts.data_ptr(), cursor.data_ptr(), B, int(ns), int(num_e),
+                                                     pos_out.data_ptr() if arrays else None, neg_out.data_ptr() if arrays else None,
+                                                     counted[0].data_ptr() if counted else None,
                                                      counted[1].data_ptr() if counted else None, plan_ptr, self._ws.data_ptr(),
                                                      self._ws.numel(), self.err.data_ptr(), _lib.stream_ptr()))
             return pos_out, neg_out
