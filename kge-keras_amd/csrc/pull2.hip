@@ -28,7 +28,11 @@
 namespace kge {
 
 constexpr int kRelMax = 4096;   // relations handled by the LDS histogram / single-workgroup plan
-constexpr int kRelChunk = 32;   // triples per forward work unit
+constexpr int kRelChunk = 32;   // rows per forward work unit ...
+// ... of a relation with up to 4096 rows in the batch; 128 above that, so that a dominant relation (real graphs: the top
+// relation of FB15k-237 carries 16 % of the triples) leaves a few hundred partial gradient rows to sum, not thousands
+__host__ __device__ __forceinline__ int rel_chunk_rows(int c) { return c > 4096 ? 4 * kRelChunk : kRelChunk; }
+__host__ __device__ __forceinline__ int rel_units(int c) { const int ch = rel_chunk_rows(c); return (c + ch - 1) / ch; }
 constexpr int kRelBlockTriples = 1024;
 
 struct Dedup {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict
   const int per = (R + 255) / 256;  // <= 16
   const int k0 = tid * per, k1 = min(R, k0 + per);
   int a = 0, b = 0;
-  for (int k = k0; k < k1; ++k) { const int c = rcnt[k]; a += c; b += (c + kRelChunk - 1) / kRelChunk; }
+  for (int k = k0; k < k1; ++k) { const int c = rcnt[k]; a += c; b += rel_units(c); }
   int ia = a, ib = b;
   for (int d = 1; d < 64; d <<= 1) {
     const int ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict
   int ra = ia - a, rb = ib - b;
   for (int w = 0; w < wave; ++w) { ra += wa[w]; rb += wb[w]; }
   for (int k = k0; k < k1; ++k) {
-    const int c = rcnt[k], nch = (c + kRelChunk - 1) / kRelChunk;
+    const int c = rcnt[k], nch = rel_units(c);
     roff[k] = ra; ruoff[k] = rb;
     for (int j = 0; j < nch; ++j) if (rb + j < max_units) rumap[rb + j] = make_int2(k, j);
     ra += c; rb += nch;
@@ -239,18 +243,57 @@ __global__ __launch_bounds__(256) void rel_fill_kernel(Src src, const int32_t* _
   rentries[roff[p] + r] = make_int4(s, o, (int)t, w);  // w: +multiplicity for a positive row, -multiplicity for a negative one
 }
 
+// Rank of every (row, role) inside its destination entity's list.  Entities of real graphs are heavy tailed: a hub would take
+// thousands of same-address returning atomics per batch, which serialise (0.48 ms measured on a Zipf batch of 409 600 rows).
+// Each workgroup therefore first aggregates its 1024 rows in an LDS hash table (key -> occurrences so far), then issues ONE
+// global returning atomic per distinct key, and adds the returned base to the local ranks.
+constexpr int kEntRows = 1024;   // rows per workgroup (4 per thread)
+constexpr int kEntSlots = 4096;  // LDS hash slots (2 * kEntRows keys at most -> load factor <= 0.5)
 __global__ __launch_bounds__(256) void ent_hist_kernel(Src src, int64_t n, int N, int R, int32_t* __restrict__ cnt, int32_t* __restrict__ erank) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // n = m_pos + m_neg: stride of the two rank planes
-  if (t >= src_rows(src)) return;
-  int s, p, o, w;
-  src_load(src, t, s, p, o, w);
-  int rs = -1, ro = -1;
-  if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
-    rs = atomicAdd(&cnt[s], 1);
-    ro = atomicAdd(&cnt[o], 1);
+  __shared__ int hkey[kEntSlots];
+  __shared__ int hcnt[kEntSlots];
+  for (int i = threadIdx.x; i < kEntSlots; i += 256) { hkey[i] = -1; hcnt[i] = 0; }
+  __syncthreads();
+  const int64_t rows = src_rows(src);
+  const int64_t t0 = (int64_t)blockIdx.x * kEntRows;
+  int slot[8], lrank[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t t = t0 + threadIdx.x + i * 256;  // n = m_pos + m_neg: stride of the two rank planes
+    slot[2 * i] = slot[2 * i + 1] = -1;
+    if (t < rows) {
+      int s, p, o, w;
+      src_load(src, t, s, p, o, w);
+      if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
+#pragma unroll
+        for (int role = 0; role < 2; ++role) {
+          const int key = role == 0 ? s : o;
+          int h = (int)(((unsigned)key * 2654435761u) >> 20) & (kEntSlots - 1);
+          for (;;) {
+            const int cur = atomicCAS(&hkey[h], -1, key);
+            if (cur == -1 || cur == key) break;
+            h = (h + 1) & (kEntSlots - 1);
+          }
+          slot[2 * i + role] = h;
+          lrank[2 * i + role] = atomicAdd(&hcnt[h], 1);
+        }
+      }
+    }
   }
-  erank[t] = rs;
-  erank[n + t] = ro;
+  __syncthreads();
+  for (int i = threadIdx.x; i < kEntSlots; i += 256) {
+    const int key = hkey[i];
+    if (key >= 0) hcnt[i] = atomicAdd(&cnt[key], hcnt[i]);  // base of this workgroup's occurrences in the key's list
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t t = t0 + threadIdx.x + i * 256;
+    if (t < rows) {
+      erank[t] = slot[2 * i] >= 0 ? hcnt[slot[2 * i]] + lrank[2 * i] : -1;
+      erank[n + t] = slot[2 * i + 1] >= 0 ? hcnt[slot[2 * i + 1]] + lrank[2 * i + 1] : -1;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const float* __restrict__ coef, const int32_t* __restrict__ off,
@@ -302,8 +345,9 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
     const int2 pc = rumap[unit];
     const int p = pc.x;
     const int c = rcnt[p];
-    const int start = roff[p] + pc.y * kRelChunk;
-    const int len = min(kRelChunk, c - pc.y * kRelChunk);
+    const int chunk = rel_chunk_rows(c);
+    const int start = roff[p] + pc.y * chunk;
+    const int len = min(chunk, c - pc.y * chunk);
     const float* rp = Rel + (int64_t)p * d_e;
     float4 pv[NA], acc[NA];
 #pragma unroll
@@ -409,7 +453,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
 }
 
-// gR[p] += sum of the relation's slab rows, in chunk order (one wave per relation, 8 independent loads in flight)
+// gR[p] += sum of the relation's slab rows (one workgroup per relation)
 // Also: leaves rcnt all-zero for the next step (the workspace is self-cleaning; it is zeroed once at allocation), and the
 // extra last block reduces the forward's loss partials (fixed order) into *loss_out.
 // Blocks [0, ent_blocks): the finish of the entity keys (hub rows: slab rows summed in chunk order; counters left zero).
@@ -420,6 +464,7 @@ __global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR,
                                                           int32_t* __restrict__ ecnt, const int32_t* __restrict__ epoff,
                                                           const float* __restrict__ eslab, int C) {
   __shared__ float red[16];
+  __shared__ float part[4][512];  // relation rows of this path are at most 512 floats wide (pull2_supported)
   if ((int)blockIdx.x < ent_blocks) {
     pull_finish_wave(blockIdx.x * 4 + (threadIdx.x >> 6), gE, gR, N, N, d_e, ecnt, epoff, eslab, C);
     return;
@@ -432,28 +477,33 @@ __global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR,
     if (threadIdx.x == 0) loss_out[0] = b;
     return;
   }
-  const int p = rb * 4 + (threadIdx.x >> 6);
+  // one workgroup per relation: the four waves take every fourth slab row (eight loads in flight each) and meet in LDS,
+  // summed in wave order -> the result does not depend on timing
+  const int p = rb;
   if (p >= R) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = rcnt[p];
-  if (lane == 0) rcnt[p] = 0;
-  const int nch = (c + kRelChunk - 1) / kRelChunk;
+  __syncthreads();
+  if (threadIdx.x == 0) rcnt[p] = 0;
+  const int nch = rel_units(c);
   if (nch == 0) return;
   const float* src = rslab + (int64_t)ruoff[p] * d_e;
   float* dst = gR + (int64_t)p * d_e;
   for (int k = lane; k < d_e; k += 64) {
     float s = 0.f;
-    int j = 0;
-    for (; j + 8 <= nch; j += 8) {
+    int j = wave;
+    for (; j + 28 < nch; j += 32) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(j + u) * d_e + k];
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(j + 4 * u) * d_e + k];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; j < nch; ++j) s += src[(int64_t)j * d_e + k];
-    dst[k] += s;
+    for (; j < nch; j += 4) s += src[(int64_t)j * d_e + k];
+    part[wave][k] = s;
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < d_e; k += 256) dst[k] += (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -681,7 +731,7 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
     if (side) { KGE_HIP_TRY(hipEventRecord(fork, st)); KGE_HIP_TRY(hipStreamWaitEvent(side, fork, 0)); }
     {
       ProfScope prof(KGE_PROF_INDEX, es);
-      hipLaunchKernelGGL(ent_hist_kernel, dim3(tgrid), dim3(256), 0, es, src, n, N, R, p.ent.cnt, p.erank);
+      hipLaunchKernelGGL(ent_hist_kernel, dim3((int)cdiv(n, kEntRows)), dim3(256), 0, es, src, n, N, R, p.ent.cnt, p.erank);
       pull2_entity_plan(p.ent, N, es);
     }
     if (side) KGE_HIP_TRY(hipEventRecord(join, side));
@@ -719,7 +769,7 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
   hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.coef, p.ent.off, p.erank, p.ent.entries);
   if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st)) return rc;
   const int eb = (int)cdiv(md->num_entities, 4);
-  hipLaunchKernelGGL(rel_finish_kernel, dim3(eb + (int)cdiv(R, 4) + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
+  hipLaunchKernelGGL(rel_finish_kernel, dim3(eb + R + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
                      *n_partials, loss_out, eb, gE, md->num_entities, p.ent.cnt, p.ent.poff, p.ent.slab, p.ent.chunk);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;

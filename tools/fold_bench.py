@@ -16,7 +16,12 @@ mdl.compile("adam")
 rs = np.random.RandomState(0)
 batches = []
 for k in range(4):
-    b = np.stack([rs.randint(0, N, B), rs.randint(0, R, B), rs.randint(0, N, B)], 1)
+    if os.environ.get("SKEW"):  # relation and entity frequencies like a real graph: a few dominate (Zipf-like)
+        pr = 1.0 / np.arange(1, R + 1) ** 1.1
+        pe = 1.0 / np.arange(1, N + 1) ** 0.9
+        b = np.stack([rs.choice(N, B, p=pe / pe.sum()), rs.choice(R, B, p=pr / pr.sum()), rs.choice(N, B, p=pe / pe.sum())], 1)
+    else:
+        b = np.stack([rs.randint(0, N, B), rs.randint(0, R, B), rs.randint(0, N, B)], 1)
     p, n = build_batch(NumpyStream(k), PythonStream(k), b, ns, N)
     batches.append((torch.from_numpy(p.astype(np.int32)).cuda(), torch.from_numpy(n.astype(np.int32)).cuda()))
 for i in range(5):
