@@ -486,6 +486,44 @@ def test_pairwise_column_aligned_train_step(model):
             np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
 
 
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})])
+@pytest.mark.parametrize("dp", [0.0, 0.2])
+def test_heavy_tailed_batch(model, kw, dp, grad_mode):
+    """Real graphs are heavy tailed.  A batch where one relation carries 80 % of the rows (> 4096 of them: the forward
+    switches to 128-row units and the relation's partial gradient rows are summed by a whole workgroup) and entity ids are
+    Zipf distributed (hub rows split into chunks; the entity histogram aggregates in LDS), with and without dropout."""
+    N, R, d, m = 300, 3, 32, 6000
+    rs = np.random.RandomState(21)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    from kge_keras_amd import models as M
+    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=dp, init_entities=E0, init_relations=R0,
+                            loss_function="pointwize_logistic", seed=2, **kw)
+    mdl.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.AdamTF()
+    pe = 1.0 / np.arange(1, N + 1) ** 1.0
+    pe /= pe.sum()
+
+    def draw(n):
+        return np.stack([rs.choice(N, n, p=pe), rs.choice(R, n, p=[0.8, 0.15, 0.05]), rs.choice(N, n, p=pe)], 1)
+    for step in range(2):
+        pos, neg = draw(m), draw(m)
+        L = float(mdl.train_step([pos, neg])["loss"].item())
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, mdl._seed)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), step
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    if grad_mode == "pull":  # the same through a plan built ahead
+        pos, neg = draw(m), draw(m)
+        L = float(mdl.train_step(mdl.plan_batch([pos, neg]))["loss"].item())
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, mdl._seed)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+
+
 def test_wn18rr_complex400_train_step(datasets):
     """BASELINE config 4 shape in training: WN18RR (N = 40 943, R = 11), ComplEx d=400 (rows of 800 floats -> the generic-list
     pull variant with two float4 chunks per lane), real training triples, one Adam step against the oracle."""
