@@ -184,3 +184,24 @@ def build_model(hp):
     model.loss_negative_samples = 1
     model.compile(optimizer='adam', loss=None)
     return model
+
+
+def main(train, valid, test, dim=100, bs=2048, epochs=100, verbose=2, device_generator=False, **hp):
+    """tests.py:96-134 (the reference's training script): id maps over the three splits, random 5-d literals behind a tanh
+    Dense, DistMult, pairwize_hinge, Adam, `fit` over the generator with the validation split.  train / valid / test: paths
+    (utils.load_kg) or lists of (s, p, o) string triples.  Keyword arguments override the script's hyper-parameters;
+    device_generator=True draws the batches on the GPU (same draws).  Returns (model, history)."""
+    from .utils import load_kg, index_kg
+    splits = [load_kg(x) if isinstance(x, str) else list(x) for x in (train, valid, test)]
+    ents, rels, (train, valid, test) = index_kg(*splits)
+    literals = np.random.rand(len(ents), 5)  # tests.py:113
+    params = {'num_entities': len(ents), 'num_relations': len(rels), 'dim': dim, 'embedding_model': 'DistMult', 'literals': literals,
+              'literal_activation': 'tanh', 'loss_function': 'pairwize_hinge', 'margin': 1}
+    params.update(hp)
+    if params.get('literal_activation') is None:
+        params.pop('literals', None)
+    model = build_model(params)
+    gen = DeviceDataGenerator if device_generator else DataGenerator
+    history = model.fit(gen(train, batch_size=bs), validation_data=DataGenerator(valid, batch_size=bs), epochs=epochs, batch_size=bs,
+                        verbose=verbose)
+    return model, history

@@ -86,3 +86,20 @@ def test_reference_script_configuration(datasets):
     tes = set(te)
     met = validate(mdl, te[:60], 14, None, filtering_triples=[t for t in tr if t not in tes])
     assert len(met) == 15 and 1.0 <= met["mr"] <= 14
+
+
+def test_reference_training_script_flow(datasets):
+    """harness.main == tests.py:96-134 (id maps, random literals behind a tanh Dense, DistMult, pairwize_hinge with the
+    harness's all-pairs broadcast, Adam, fit with a validation split) on the nations triples: it runs and learns."""
+    from kge_keras_amd.harness import main
+
+    def strs(a):
+        return [(f"e{s}", f"r{p}", f"e{o}") for s, p, o in a.tolist()]
+    np.random.seed(1)
+    import random
+    random.seed(2)
+    model, h = main(strs(datasets["nations_train"]), strs(datasets["nations_valid"]), strs(datasets["nations_test"]),
+                    dim=16, bs=64, epochs=4, verbose=0)
+    assert model.num_entities == 14 and len(h.history["loss"]) == 4 and len(h.history["val_loss"]) == 4
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    assert np.all(np.isfinite(h.history["val_loss"]))
