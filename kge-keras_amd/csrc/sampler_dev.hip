@@ -131,10 +131,17 @@ __global__ __launch_bounds__(256) void mt_jump_kernel(const MTDev* __restrict__ 
   for (int wi = wave; wi < WPS; wi += 4) {
     const int w = slice * WPS + wi;
     if (w >= kPolyWords) break;
-    const uint64_t gw = poly[w];  // wave-uniform
+    // the polynomial word is the same for the whole wave: keep it in scalar registers, so that a coefficient test is one scalar
+    // bit compare (as a vector value it costs a 64-bit vector shift, a compare and an exec-mask dance per bit: 4x slower)
+    const uint64_t gwv = poly[w];
+    const uint32_t g[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gwv),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gwv >> 32))};
     const uint32_t* src = win + wi * 64 + lane;  // conflict-free: consecutive lanes, consecutive words
+#pragma unroll
+    for (int hw = 0; hw < 2; ++hw) {
 #pragma unroll 16
-    for (int bit = 0; bit < 64; ++bit) acc ^= ((gw >> bit) & 1ull) ? src[bit] : 0u;
+      for (int bit = 0; bit < 32; ++bit) acc ^= ((g[hw] >> bit) & 1u) ? src[32 * hw + bit] : 0u;
+    }
   }
   part[wave][lane] = acc;
   __syncthreads();
