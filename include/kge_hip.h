@@ -284,7 +284,7 @@ int kge_filter_coo_host(const int32_t* test_host, int64_t n_queries, int32_t sid
  * is allocated (it holds a batch epoch that tags the in-flight tile counts); the library keeps it consistent afterwards. */
 /* plan (optional): MT19937's word stream is sequential, but the state J words ahead is a GF(2)-linear function of the
  * current one.  kge_sampler_plan_host computes, for this batch shape, the jump polynomials x^J mod phi of the starts of
- * 8 segments per stream (host, ~0.1-1 s once, cached); uploaded and passed as plan_dev, the generator then runs as 8
+ * 16 segments per stream (host, ~0.2-2 s once, cached); uploaded and passed as plan_dev, the generator then runs as 16
  * workgroups per stream after one short sequential pre-pass.  plan_dev == NULL: fully sequential generation.  Same bits. */
 int64_t kge_sampler_workspace_bytes(int64_t B, int64_t ns, int64_t num_e);
 int64_t kge_sampler_plan_bytes(void);

@@ -83,7 +83,7 @@ __device__ __forceinline__ void mt_regen_blocks(uint32_t (*buf)[624], uint32_t* 
 }
 
 // blockIdx.x == 0: NumPy stream (K0 blocks), 1: Python stream (K1 blocks), generated sequentially from the state.
-constexpr int kSeg = 8;
+constexpr int kSeg = 16;
 __global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
                                                            uint32_t* __restrict__ U_np, int K0, uint32_t* __restrict__ U_py, int K1,
                                                            uint32_t* __restrict__ Jst_zero) {
