@@ -110,12 +110,18 @@ class TrainPipeline:
         mo = self.model
         seed, it = mo._seed, mo.optimizer.iterations
         self.graphs = {}
-        for j in (0, 1):
-            for name, fn in (("S", lambda j=j: self._stage_S(j)), ("P", lambda j=j: self._stage_P(j)), ("T", lambda j=j: self._stage_T(j))):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    fn()
-                self.graphs[name, j] = g
+        try:
+            for j in (0, 1):
+                for name, fn in (("S", lambda j=j: self._stage_S(j)), ("P", lambda j=j: self._stage_P(j)), ("T", lambda j=j: self._stage_T(j))):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        fn()
+                    self.graphs[name, j] = g
+        except Exception as e:  # a runtime that cannot capture these stages: launch them kernel by kernel instead
+            import warnings
+            warnings.warn(f"TrainPipeline: hipGraph capture failed ({e!r}); falling back to stream launches")
+            self.graphs, self.use_graphs = {}, False
+            torch.cuda.synchronize()
         mo._seed, mo.optimizer.iterations = seed, it
         self._sig = self._signature()
 
@@ -128,9 +134,9 @@ class TrainPipeline:
         cur.wait_stream(self.s3)
 
     def _run(self, name, slot):
+        if self.use_graphs and (not self.graphs or self._sig != self._signature()):
+            self._capture()  # may switch use_graphs off (capture not possible on this runtime)
         if self.use_graphs:
-            if not self.graphs or self._sig != self._signature():
-                self._capture()
             # A graph exec cannot run twice at once: launching it again while its previous launch is still in flight blocks
             # inside the runtime, and that wait sleeps (milliseconds on a busy host).  Spin on an event instead.
             ev = self._done.get((name, slot))
