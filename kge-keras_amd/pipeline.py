@@ -32,10 +32,11 @@ class TrainPipeline:
         # the step (one process per GPU) the stages are launched kernel by kernel
         self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0 and between is None
         m = self.B * self.ns
-        self.bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device=self.dev) for _ in range(2)) for _ in range(2)]
         # the batch before oversampling + how often each row was picked: the sampler's by-product the plans are built from when
         # there is no dropout (with dropout every oversampled row has its own mask and the plan takes the arrays as they are)
         self.counted = float(getattr(model, "dp", 0.0) or 0.0) == 0.0
+        self.bufs = [None, None] if self.counted else [tuple(torch.empty((m, 3), dtype=torch.int32, device=self.dev) for _ in range(2))
+                                                        for _ in range(2)]
         self.cand = [(torch.empty((self.B + m, 3), dtype=torch.int32, device=self.dev), torch.zeros(_lib.CAND_POS_LANES * self.B + m, dtype=torch.int32, device=self.dev))
                      for _ in range(2)] if self.counted else [None, None]
         md, ld = model._model_desc(True), model._loss_desc()
@@ -68,7 +69,8 @@ class TrainPipeline:
     def _stage_P(self, slot, fork=None):
         """rows first, then the entity lists and the relation lists -- side by side on `fork` (a stream that already follows
         the caller's origin stream and is joined by the caller) when given: they only share the rows."""
-        cur, b, pl = torch.cuda.current_stream(), list(self.bufs[slot]), self.plans[slot]
+        cur, pl = torch.cuda.current_stream(), self.plans[slot]
+        b = None if self.counted else list(self.bufs[slot])
         m = self.B * self.ns
         if self.counted:
             build = lambda parts: self.model.plan_batch_counted(*self.cand[slot], self.B, m, m, out=pl, parts=parts, pos_lanes=_lib.CAND_POS_LANES)  # noqa: E731
