@@ -3,7 +3,7 @@
 tag=$1; shift
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $root/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/bench.py --steps 100 --warmup 3 --no-cpu-baseline "$@" > $root/gpurun_out/prof_$tag.log 2>&1
 cd $root
 python3 - <<EOF
 import csv,glob
