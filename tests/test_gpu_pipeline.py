@@ -153,3 +153,43 @@ def test_sampler_candidates_and_pick_counts(datasets):
         key = lambda a: sorted(map(tuple, a.tolist()))  # noqa: E731
         assert key(np.repeat(rows[:B], cp, axis=0)) == key(pos.cpu().numpy())
         assert key(np.repeat(rows[B:], cn, axis=0)) == key(neg.cpu().numpy())
+
+
+def test_randomised_paths_agree_with_oracle():
+    """Seeded sweep over random shapes: table sizes, row widths (all float4-chunk counts of the kernels' dispatch tables), batch
+    sizes around the folding threshold, duplicate-heavy and duplicate-free batches, every pointwise loss.  One step through a
+    plan built ahead must match the oracle and the plain step."""
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(2024)
+    losses = ["pointwize_hinge", "pointwize_logistic", "pointwize_square_loss"]
+    for case in range(24):
+        model = ["DistMult", "TransE", "ComplEx"][case % 3]
+        kw = dict(norm=int(rs.randint(1, 3)), gamma=float(rs.choice([12.0, 0.0]))) if model == "TransE" else {}
+        N, R = int(rs.randint(2, 400)), int(rs.randint(1, 25))
+        d = int(rs.choice([4, 8, 12, 32, 36, 64, 100, 128, 200, 256]))
+        m_pos, m_neg = int(rs.choice([1, 7, 300, 2500, 5000])), int(rs.choice([1, 9, 700, 2100, 6000]))
+        loss = losses[case % 3]
+        de, dr = O.table_dims(model, d, d)
+        E0 = rs.uniform(-0.4, 0.4, (N, de)).astype(np.float32)
+        R0 = rs.uniform(-0.4, 0.4, (R, dr)).astype(np.float32)
+        a, b = (getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0,
+                                  loss_function=loss, margin=0.7, **kw) for _ in range(2))
+        a.compile("adam")
+        b.compile("adam")
+
+        def draw(n):
+            if rs.rand() < 0.5:  # oversampled: few distinct rows
+                base = np.stack([rs.randint(0, N, 17), rs.randint(0, R, 17), rs.randint(0, N, 17)], 1)
+                return base[rs.randint(0, 17, n)]
+            return np.stack([rs.randint(0, N, n), rs.randint(0, R, n), rs.randint(0, N, n)], 1)
+        pos, neg = draw(m_pos), draw(m_neg)
+        Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+        Lo = O.train_step(model, Eo, Ro, O.AdamTF(), pos, neg, loss, 0.7, 1, kw.get("norm", 1), kw.get("gamma", 12))
+        La = float(a.train_step(a.plan_batch([pos, neg]))["loss"].item())
+        Lb = float(b.train_step([pos, neg])["loss"].item())
+        tag = (case, model, kw, N, R, d, m_pos, m_neg, loss)
+        assert La == pytest.approx(Lo, abs=TOL, rel=1e-5) and Lb == pytest.approx(Lo, abs=TOL, rel=1e-5), tag
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL, err_msg=str(tag))
+        np.testing.assert_allclose(b.E.cpu().numpy(), Eo, atol=TOL, err_msg=str(tag))
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL, err_msg=str(tag))
+        np.testing.assert_allclose(b.Rel.cpu().numpy(), Ro, atol=TOL, err_msg=str(tag))
