@@ -152,7 +152,9 @@ class TrainPipeline:
         elif name == "S":
             self._stage_S(slot)
         elif name == "P":
-            self._stage_P(slot) if self.serial else self._stage_P_forked(slot)
+            # kernel-by-kernel launches are bound by the host: the forked variant (shorter chain, more launches and event
+            # traffic) only pays where nothing else sits on the step's critical path
+            self._stage_P(slot) if (self.serial or self.between is not None) else self._stage_P_forked(slot)
         else:
             self._stage_T(slot)
 
