@@ -81,7 +81,7 @@ def cpu_baseline(batches, E0, R0, budget_s=15.0):
                 sample=f"{steps} full-size steps ({n} scored triples) of the C oracle (oracle/kge_oracle_c.c, fp32, OpenMP x{c_port.threads()}) in {dt:.1f}s")
 
 
-def eval_leg(torch, dist, model, rank, world, reps=3):
+def eval_leg(torch, dist, model, rank, world, reps=3, dist_on=False):
     """1-vs-all ranks/sec on the same FB15k-237-shaped tables: 40 932 queries (20 466 test triples x head/tail),
     filters = 3 random ids per query.  N > 1: every rank holds a row shard of E, the shards are all-gathered over
     RCCL into a full table, and the queries are split across ranks (SURVEY 8(e) schedule i)."""
@@ -102,7 +102,7 @@ def eval_leg(torch, dist, model, rank, world, reps=3):
     shard_at_rest = model.E[lo:hi].clone()
 
     def sweep():
-        if world > 1:  # all-gather of the row shards into the full table (kge_keras_amd.dist.allgather_rows)
+        if dist_on:  # all-gather of the row shards into the full table (kge_keras_amd.dist.allgather_rows)
             model.E.copy_(D.allgather_rows(shard_at_rest, CFG["N"]))
         c0 = model.rank_counts(tq, 0, fq, fi)
         c1 = model.rank_counts(tq, 1, fq, fi)
@@ -110,18 +110,18 @@ def eval_leg(torch, dist, model, rank, world, reps=3):
 
     sweep()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     _lib.lib.kge_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(reps):
         c0, c1 = sweep()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     _lib.lib.kge_prof_enable(0)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: run the pipeline stages one after the other on one stream, kernel by kernel, in every phase "
                          "(what the roofline leg does), so that a rocprofv3 kernel trace of the run times every kernel alone")
+    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed code paths even with WORLD_SIZE=1 (rehearsal on one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -159,12 +160,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --force-dist: rehearse the torch.distributed code paths (RCCL process group, all-reduce between the halves of a step,
+    # sharded eval) with a world of one process, on a box that has a single GPU
+    dist_on = world > 1 or args.force_dist
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.force_dist and world == 1:
+            for k, v in (("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -238,7 +245,7 @@ def main():
             data = list(bufs[j])
         else:
             data = list(dev[i % n_pool])
-        if world == 1:
+        if not dist_on:
             model.train_step(data)
         else:  # data-parallel: gradient half, all-reduce of the dense gradient tables over RCCL, optimizer half
             # gradient tables and the loss word are one flat buffer: ONE all-reduce per step
@@ -257,7 +264,8 @@ def main():
     launch = args.launch if args.launch != "auto" else "graph"
     if args.sampler == "device" and plan_ahead and launch == "graph":
         from kge_keras_amd.pipeline import TrainPipeline
-        between = (lambda: (D.allreduce_sum_([model._gall]), 1.0 / world)[1]) if world > 1 else None
+        # gradient tables and the loss word are one flat buffer: ONE all-reduce per step (= dist.allreduce_sum_([model._gall]))
+        between = (lambda: (dist.all_reduce(model._gall, op=dist.ReduceOp.SUM), 1.0 / world)[1]) if dist_on else None
         pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=True, between=between)
         total = args.warmup + args.settle + 2 * args.steps + 8
         if args.serial:
@@ -273,7 +281,7 @@ def main():
         produce(1)
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -286,9 +294,9 @@ def main():
     settle, best, t_settle = 0, None, time.perf_counter()
     while settle + 20 <= args.settle:
         el = time.perf_counter() - t_settle
-        if world > 1 and settle >= min(args.settle, 2000):
+        if dist_on and settle >= min(args.settle, 2000):
             break
-        if world == 1 and el > 3.0:
+        if not dist_on and el > 3.0:
             break
         tb = time.perf_counter()
         for i in range(20):
@@ -296,7 +304,7 @@ def main():
         fence()
         tb = time.perf_counter() - tb
         settle += 20
-        if world == 1 and best is not None and el >= 0.6 and tb <= 1.15 * best:
+        if not dist_on and best is not None and el >= 0.6 and tb <= 1.15 * best:
             break
         best = tb if best is None else min(best, tb)
     base = args.warmup + settle
@@ -321,7 +329,7 @@ def main():
         fence()
         pipe.finish()
     _lib.lib.kge_prof_enable(0)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -348,7 +356,7 @@ def main():
         used = list(pipe.bufs) if pipe is not None else (list(bufs) if args.sampler == "device" else dev)
         rows_launch = float(np.mean([distinct(p) + distinct(n) for p, n in used])) if folded else float(per_step)
 
-    ev = eval_leg(torch, dist, model, rank, world)
+    ev = eval_leg(torch, dist, model, rank, world, dist_on=dist_on)
 
     if rank == 0:
         value = per_step * world * args.steps / dt
@@ -376,7 +384,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "FB15k-237 DistMult d=200, B=2048, 100 negatives (409600 scored triples/step), pointwize_hinge + Adam(TF semantics)",
                        "N": CFG["N"], "R": CFG["R"], "d": CFG["d"], "B": CFG["B"], "ns": CFG["ns"],
-                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "parallelism": f"dp{world}" if dist_on else "single",
                        "sampler": ("bit-exact MT19937 HIP sampler inside the timed region (side stream, one batch ahead)" if args.sampler == "device"
                                    else "bit-exact MT19937 batches pre-built on host, resident in HBM"),
                        "final_loss": loss},
@@ -391,7 +399,7 @@ def main():
                          "fold_avg_ms": d_ms / max(1, d_n),
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
                          "sampler_avg_ms": s_ms / max(1, s_n), "host_enqueue_ms_per_step": t_issue / args.steps * 1e3,
-                         "launch": (("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams)" if world == 1 else
+                         "launch": (("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams)" if not dist_on else
                                      "draw | plan | step stages on three streams, launched kernel by kernel (collective between the halves of the step)")
                                     + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)"
                                     if pipe is not None
@@ -400,10 +408,10 @@ def main():
                                   if plan_ahead else "built inside the step")},
         }
         res["eval_1vsall"] = ev
-        if world == 1 and not args.no_cpu_baseline:
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(host_batches, E0, R0)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
