@@ -28,9 +28,11 @@ class TrainPipeline:
         self.model, self.kg, self.B, self.ns, self.num_e, self.sampler = model, kg, int(batch_size), int(ns), int(num_e), sampler
         self.dev = kg.device
         self.between = between
-        # a captured step cannot change its dropout seed: graphs only without dropout; with a collective between the halves of
-        # the step (one process per GPU) the stages are launched kernel by kernel
-        self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0 and between is None
+        # a captured step cannot change its dropout seed: graphs only without dropout.  With a collective between the halves of
+        # the step (one process per GPU) the draw and plan stages are still graph replays; the step itself (gradient half,
+        # collective, optimizer half) is launched kernel by kernel, so that no collective ever sits inside a captured graph
+        self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0
+        self.graph_stages = ("S", "P", "T") if between is None else ("S", "P")
         m = self.B * self.ns
         # the batch before oversampling + how often each row was picked: the sampler's by-product the plans are built from when
         # there is no dropout (with dropout every oversampled row has its own mask and the plan takes the arrays as they are)
@@ -115,6 +117,8 @@ class TrainPipeline:
         try:
             for j in (0, 1):
                 for name, fn in (("S", lambda j=j: self._stage_S(j)), ("P", lambda j=j: self._stage_P(j)), ("T", lambda j=j: self._stage_T(j))):
+                    if name not in self.graph_stages:
+                        continue
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         fn()
@@ -138,7 +142,7 @@ class TrainPipeline:
     def _run(self, name, slot):
         if self.use_graphs and (not self.graphs or self._sig != self._signature()):
             self._capture()  # may switch use_graphs off (capture not possible on this runtime)
-        if self.use_graphs:
+        if self.use_graphs and name in self.graph_stages:
             # A graph exec cannot run twice at once: launching it again while its previous launch is still in flight blocks
             # inside the runtime, and that wait sleeps (milliseconds on a busy host).  Spin on an event instead.
             ev = self._done.get((name, slot))
