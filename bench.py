@@ -400,7 +400,7 @@ def main():
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
                          "sampler_avg_ms": s_ms / max(1, s_n), "host_enqueue_ms_per_step": t_issue / args.steps * 1e3,
                          "launch": (("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams)" if not dist_on else
-                                     "draw | plan | step stages on three streams, launched kernel by kernel (collective between the halves of the step)")
+                                     "draw and plan stages replayed from hipGraphs on their streams; the step (gradient half, all-reduce, optimizer half) launched kernel by kernel")
                                     + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)"
                                     if pipe is not None
                                     else "kernel-by-kernel stream launches"),
