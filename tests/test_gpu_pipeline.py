@@ -193,3 +193,29 @@ def test_randomised_paths_agree_with_oracle():
         np.testing.assert_allclose(b.E.cpu().numpy(), Eo, atol=TOL, err_msg=str(tag))
         np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL, err_msg=str(tag))
         np.testing.assert_allclose(b.Rel.cpu().numpy(), Ro, atol=TOL, err_msg=str(tag))
+
+
+def test_pipeline_with_a_hook_between_the_halves(datasets):
+    """TrainPipeline(between=...): the data-parallel shape of the pipeline (draw and plan stages as graph replays, the step as
+    gradient half -> hook (the all-reduce) -> optimizer half with the host step counter).  With a hook that does nothing but
+    return the gradient scale 1 it must train exactly like the plain pipeline."""
+    from kge_keras_amd.harness import DeviceDataGenerator, build_model
+    from kge_keras_amd.pipeline import TrainPipeline
+    hp = dict(num_entities=14, num_relations=55, dim=32, embedding_model="DistMult", loss_function="pointwize_logistic", margin=1, dp=0.0, seed=4)
+    out = []
+    for hooked in (False, True):
+        np.random.seed(21)
+        random.seed(22)
+        mdl = build_model(hp)
+        gen = DeviceDataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+        calls = []
+        pipe = TrainPipeline(mdl, gen.kg, gen.n, gen.batch_size, gen.ns, gen.num_e, gen.sampler,
+                             between=(lambda: calls.append(1) or 1.0) if hooked else None)
+        gen._upload_global()
+        tot = pipe.run_epoch(gen.index, list(range(len(gen))))
+        gen.release_global()
+        assert pipe.use_graphs and (("T", 0) in pipe.graphs) == (not hooked) and ("S", 0) in pipe.graphs
+        assert len(calls) == (len(gen) if hooked else 0) and mdl.optimizer.iterations == len(gen)
+        out.append((mdl.E.cpu().numpy(), float(tot.item())))
+    np.testing.assert_allclose(out[0][0], out[1][0], atol=2e-5)
+    assert out[0][1] == pytest.approx(out[1][1], rel=1e-5)
