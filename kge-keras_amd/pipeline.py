@@ -120,7 +120,9 @@ class TrainPipeline:
                     if name not in self.graph_stages:
                         continue
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # thread_local: other threads of the process (e.g. the watchdog of an RCCL process group) may keep calling
+                    # into the runtime while this thread captures
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         fn()
                     self.graphs[name, j] = g
         except Exception as e:  # a runtime that cannot capture these stages: launch them kernel by kernel instead
