@@ -166,49 +166,67 @@ __global__ void coef_from_g_kernel(const float* __restrict__ scores, float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ index build
-// Relation keys are hot (R addresses receive n increments: ~1700 each at FB15k-237 sizes), so they are counted in an LDS
-// histogram per block and flushed with one global atomic per (block, relation); entity keys go straight to L2 atomics.
-// Every atomic returns the contribution's rank inside its destination list, so the later list fill needs no atomics.
+// Relation keys are hot (R addresses receive n increments: ~1700 each at FB15k-237 sizes) and so are the hub entities of a
+// real graph (heavy-tailed degrees): same-address returning atomics serialise.  Every workgroup therefore counts its 1024
+// triples locally first -- relations in an LDS histogram, entities in an LDS hash table (key -> occurrences so far) -- and
+// issues one global returning atomic per distinct key; the returned base plus the local rank is the contribution's rank inside
+// its destination list, so the later list fill needs no atomics.
 constexpr int kRelLds = 4096;           // relations counted in LDS when R <= kRelLds
 constexpr int kIdxBlockTriples = 1024;  // triples per block of the index-build kernel
+constexpr int kIdxSlots = 4096;         // LDS hash slots for the 2 * 1024 entity keys of a block
 
 __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ pos, int64_t m_pos,
                                                     const int32_t* __restrict__ neg, int64_t m_neg, int N, int R,
                                                     int32_t* __restrict__ cnt, int32_t* __restrict__ ranks /* [3][n] */) {
   __shared__ int lrel[kRelLds];
+  __shared__ int hkey[kIdxSlots];
+  __shared__ int hcnt[kIdxSlots];
   const bool lds = R <= kRelLds;
   if (lds) for (int i = threadIdx.x; i < R; i += 256) lrel[i] = 0;
+  for (int i = threadIdx.x; i < kIdxSlots; i += 256) { hkey[i] = -1; hcnt[i] = 0; }
   __syncthreads();
   const int64_t n = m_pos + m_neg;
   const int64_t t0 = (int64_t)blockIdx.x * kIdxBlockTriples;
   constexpr int PER = kIdxBlockTriples / 256;
-  int rs[PER], ro[PER], rp[PER], pp[PER];
+  int rs[PER], ro[PER], rp[PER], pp[PER], hs[PER], ho[PER];
+  auto local = [&](int key, int& slot) {
+    int h = (int)(((unsigned)key * 2654435761u) >> 20) & (kIdxSlots - 1);
+    for (;;) {
+      const int cur = atomicCAS(&hkey[h], -1, key);
+      if (cur == -1 || cur == key) break;
+      h = (h + 1) & (kIdxSlots - 1);
+    }
+    slot = h;
+    return atomicAdd(&hcnt[h], 1);
+  };
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int64_t t = t0 + threadIdx.x + i * 256;
-    rs[i] = ro[i] = rp[i] = pp[i] = -1;
+    rs[i] = ro[i] = rp[i] = pp[i] = hs[i] = ho[i] = -1;
     if (t < n) {
       const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
       const int s = tr[0], p = tr[1], o = tr[2];
       if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
-        rs[i] = atomicAdd(&cnt[s], 1);
-        ro[i] = atomicAdd(&cnt[o], 1);
+        rs[i] = local(s, hs[i]);
+        ro[i] = local(o, ho[i]);
         pp[i] = p;
         rp[i] = lds ? atomicAdd(&lrel[p], 1) : atomicAdd(&cnt[N + p], 1);
       }
     }
   }
-  if (lds) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < R; i += 256) { const int v = lrel[i]; lrel[i] = v ? atomicAdd(&cnt[N + i], v) : 0; }
-    __syncthreads();
+  __syncthreads();
+  for (int i = threadIdx.x; i < kIdxSlots; i += 256) {
+    const int key = hkey[i];
+    if (key >= 0) hcnt[i] = atomicAdd(&cnt[key], hcnt[i]);  // base of this block's occurrences in the key's list
   }
+  if (lds) for (int i = threadIdx.x; i < R; i += 256) { const int v = lrel[i]; lrel[i] = v ? atomicAdd(&cnt[N + i], v) : 0; }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int64_t t = t0 + threadIdx.x + i * 256;
     if (t < n) {
-      ranks[t] = rs[i];
-      ranks[n + t] = ro[i];
+      ranks[t] = hs[i] < 0 ? -1 : hcnt[hs[i]] + rs[i];
+      ranks[n + t] = ho[i] < 0 ? -1 : hcnt[ho[i]] + ro[i];
       ranks[2 * n + t] = pp[i] < 0 ? -1 : (lds ? lrel[pp[i]] + rp[i] : rp[i]);
     }
   }
