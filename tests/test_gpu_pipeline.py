@@ -219,3 +219,26 @@ def test_pipeline_with_a_hook_between_the_halves(datasets):
         out.append((mdl.E.cpu().numpy(), float(tot.item())))
     np.testing.assert_allclose(out[0][0], out[1][0], atol=2e-5)
     assert out[0][1] == pytest.approx(out[1][1], rel=1e-5)
+
+
+def test_device_generator_end_to_end_with_validation_and_callback(datasets):
+    """The reference's workflow on the GPU-resident pipeline: build_model -> fit(DeviceDataGenerator, validation_data, callback)
+    over many epochs (graph replays for the steps, plain steps for the validation loss, ranking in the callback) -> validate."""
+    from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
+    from kge_keras_amd.utils import validate, KGEValidateCallback
+    tr, va, te = ([tuple(int(v) for v in t) for t in datasets["nations_" + k].tolist()] for k in ("train", "valid", "test"))
+    np.random.seed(0)
+    random.seed(0)
+    mdl = build_model(dict(num_entities=14, num_relations=55, dim=32, embedding_model="DistMult", loss_function="pointwize_logistic",
+                           margin=1, dp=0.0, seed=1))
+    tes = set(te) | set(va)
+    filt = [t for t in tr if t not in tes]
+    before = validate(mdl, te, 14, None, filtering_triples=filt)
+    cb = KGEValidateCallback(va, train_data=tr, period=10)
+    gen = DeviceDataGenerator(tr, ns=10, batch_size=32)
+    h = mdl.fit(gen, epochs=30, verbose=0, callbacks=[cb], validation_data=DataGenerator(va, ns=10, batch_size=32))
+    after = validate(mdl, te, 14, None, filtering_triples=filt)
+    assert gen._pipe.use_graphs and mdl.optimizer.iterations == 30 * len(gen) and getattr(mdl, "_step_dev", None) is None
+    assert len(h.history["loss"]) == 30 and len(h.history["val_loss"]) == 30
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    assert after["mrr"] > before["mrr"] + 0.1 and after["mr"] < 4.0, (before, after)
