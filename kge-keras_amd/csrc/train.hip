@@ -144,27 +144,33 @@ __device__ __forceinline__ void pair_term(float z, float margin, float& val, flo
 
 // side 0: one thread per false j, sweeps true  -> g_f[j] = +sum_i dz / (m_f m_t), loss partials
 // side 1: one thread per true  i, sweeps false -> g_t[i] = -sum_j dz / (m_f m_t)
+// The sweep over the other vector is cut into gridDim.y column chunks (a row per thread alone leaves the chip idle: m = 20 480
+// rows are 80 workgroups): chunk c of row idx leaves its partial sums in part[c][idx] (and lpart[c][idx] for the loss on
+// side 0); pairwise_finish_kernel adds the chunks in order.  part == nullptr: one chunk, results written directly.
 template <int LOSS, int SIDE>
 __global__ __launch_bounds__(256) void pairwise_allpairs_kernel(const float* __restrict__ tscore, int64_t m_t,
                                                                  const float* __restrict__ fscore, int64_t m_f,
                                                                  float margin, float* __restrict__ g_t,
-                                                                 float* __restrict__ g_f, float* __restrict__ loss_partials) {
+                                                                 float* __restrict__ g_f, float* __restrict__ loss_partials,
+                                                                 float* __restrict__ part, float* __restrict__ lpart, int64_t chunk_len) {
   __shared__ float tile[256];
   __shared__ float red[16];
   const float* mine = SIDE == 0 ? fscore : tscore;
   const float* other = SIDE == 0 ? tscore : fscore;
   const int64_t n_mine = SIDE == 0 ? m_f : m_t, n_other = SIDE == 0 ? m_t : m_f;
   const float inv = 1.f / ((float)m_f * (float)m_t);
+  const int64_t o0 = part ? (int64_t)blockIdx.y * chunk_len : 0;
+  const int64_t o1 = part ? (o0 + chunk_len < n_other ? o0 + chunk_len : n_other) : n_other;
   float lsum = 0.f;
   for (int64_t base = (int64_t)blockIdx.x * 256; base < n_mine; base += (int64_t)gridDim.x * 256) {
     const int64_t idx = base + threadIdx.x;
     const float v = idx < n_mine ? mine[idx] : 0.f;
     float gs = 0.f, ls = 0.f;
-    for (int64_t ob = 0; ob < n_other; ob += 256) {
+    for (int64_t ob = o0; ob < o1; ob += 256) {
       __syncthreads();
-      tile[threadIdx.x] = ob + threadIdx.x < n_other ? other[ob + threadIdx.x] : 0.f;
+      tile[threadIdx.x] = ob + threadIdx.x < o1 ? other[ob + threadIdx.x] : 0.f;
       __syncthreads();
-      const int cnt = (int)(n_other - ob < 256 ? n_other - ob : 256);
+      const int cnt = (int)(o1 - ob < 256 ? o1 - ob : 256);
       for (int q = 0; q < cnt; ++q) {
         const float z = SIDE == 0 ? v - tile[q] : tile[q] - v;
         float val, dz;
@@ -174,9 +180,32 @@ __global__ __launch_bounds__(256) void pairwise_allpairs_kernel(const float* __r
       }
     }
     if (idx < n_mine) {
-      if (SIDE == 0) { g_f[idx] = gs * inv; lsum += ls * inv; }
+      if (part) {
+        part[(int64_t)blockIdx.y * n_mine + idx] = gs;
+        if (SIDE == 0) lpart[(int64_t)blockIdx.y * n_mine + idx] = ls;
+      } else if (SIDE == 0) { g_f[idx] = gs * inv; lsum += ls * inv; }
       else g_t[idx] = -gs * inv;
     }
+  }
+  if (SIDE == 0 && !part) {
+    const float b = block_sum(lsum, red);
+    if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
+  }
+}
+
+template <int SIDE>
+__global__ __launch_bounds__(256) void pairwise_finish_kernel(const float* __restrict__ part, const float* __restrict__ lpart, int nchunk,
+                                                               int64_t n_mine, float inv, float* __restrict__ g, float* __restrict__ loss_partials) {
+  __shared__ float red[16];
+  float lsum = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n_mine; idx += (int64_t)gridDim.x * 256) {
+    float gs = 0.f, ls = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+      gs += part[(int64_t)c * n_mine + idx];
+      if (SIDE == 0) ls += lpart[(int64_t)c * n_mine + idx];
+    }
+    g[idx] = (SIDE == 0 ? gs : -gs) * inv;
+    lsum += ls * inv;
   }
   if (SIDE == 0) {
     const float b = block_sum(lsum, red);
@@ -270,6 +299,7 @@ struct Workspace {
   float* reg_partials;   // kMaxBlocks
   float* gbuf;           // m_pos + m_neg (pairwise, push path)
   float* sbuf;           // m_pos + m_neg (pairwise, when scores_out is null)
+  float* pair;           // all-pairs partial sums (null when the batch is too large for it)
   void* pull_hdr;        // pull-path counters: fixed place, zero on entry, left zero by every step
   void* pull;            // pull-path plan and lists
 };
@@ -279,7 +309,12 @@ struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
 int pull_variant();          // api.hip: 2 (default) = relation-grouped forward (pull2.hip), 1 = generic lists (pull.hip)
 SideStream* side_stream();  // api.hip: lazily created helper stream (nullptr when disabled by KGE_NO_SIDE_STREAM=1)
 
-static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 2 * align_up(n, 64); }
+// all-pairs pairwise losses: partial sums of up to kPairChunks column chunks per row (two planes for the `false` side: gradient
+// and loss), reserved for batches small enough for an O(m_f * m_t) loss to be usable at all
+constexpr int kPairChunks = 16;
+constexpr int64_t kPairMaxRows = 131072;
+static int64_t pair_floats(int64_t n) { return n <= kPairMaxRows ? 3 * kPairChunks * align_up(n, 64) : 0; }
+static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 2 * align_up(n, 64) + pair_floats(n); }
 
 int64_t train_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
   return (int64_t)sizeof(float) * base_floats(m_pos + m_neg) + 512 +
@@ -299,6 +334,7 @@ static int carve(void* ws, int64_t bytes, const kge_model_desc* md, int64_t m_po
   out->reg_partials = f + kMaxBlocks;
   out->gbuf = f + 2 * kMaxBlocks;
   out->sbuf = out->gbuf + align_up(m_pos + m_neg, 64);
+  out->pair = pair_floats(m_pos + m_neg) ? out->sbuf + align_up(m_pos + m_neg, 64) : nullptr;
   out->pull = f + base_floats(m_pos + m_neg);
   return KGE_OK;
 }
@@ -395,14 +431,25 @@ static int pairwise_shape(const kge_loss_desc* ld, int64_t m_t, int64_t m_f) {
 
 template <int LOSS>
 static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int64_t m_f, int64_t ns, float margin, float* g_t, float* g_f,
-                             float* partials, hipStream_t st, int* nb) {
+                             float* partials, float* pair, hipStream_t st, int* nb) {
   const int gf = (int)std::min<int64_t>(cdiv(m_f, 256), kMaxBlocks);
   const int gt = (int)std::min<int64_t>(cdiv(m_t, 256), kMaxBlocks);
   *nb = gf;
   ProfScope prof(KGE_PROF_PAIRWISE, st);
   if (ns == 1 || m_t == 1) {
-    hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 0>), dim3(gf), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
-    hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 1>), dim3(gt), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials);
+    // column chunks of at least 1024 scores, at most kPairChunks of them (scratch: pair = [chunks][m_f] g | [chunks][m_f] loss | [chunks][m_t] g)
+    auto chunks = [](int64_t n_other) { return (int)std::max<int64_t>(1, std::min<int64_t>(kPairChunks, n_other / 1024)); };
+    const int cf = pair ? chunks(m_t) : 1, ct = pair ? chunks(m_f) : 1;
+    const int64_t stride = align_up(m_t + m_f, 64);
+    float* pf = pair && cf > 1 ? pair : nullptr;
+    float* lf = pf ? pair + kPairChunks * stride : nullptr;
+    float* pt = pair && ct > 1 ? pair + 2 * kPairChunks * stride : nullptr;
+    const int64_t lenf = align_up(cdiv(m_t, cf), 256), lent = align_up(cdiv(m_f, ct), 256);
+    const float inv = 1.f / ((float)m_f * (float)m_t);
+    hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 0>), dim3(gf, pf ? (int)cdiv(m_t, lenf) : 1), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials, pf, lf, lenf);
+    if (pf) hipLaunchKernelGGL((pairwise_finish_kernel<0>), dim3(gf), dim3(256), 0, st, pf, lf, (int)cdiv(m_t, lenf), m_f, inv, g_f, partials);
+    hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 1>), dim3(gt, pt ? (int)cdiv(m_f, lent) : 1), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials, pt, (float*)nullptr, lent);
+    if (pt) hipLaunchKernelGGL((pairwise_finish_kernel<1>), dim3(gt), dim3(256), 0, st, pt, (const float*)nullptr, (int)cdiv(m_f, lent), m_t, inv, g_t, partials);
   } else {
     hipLaunchKernelGGL((pairwise_columns_kernel<LOSS, 0>), dim3(gf), dim3(256), 0, st, ts, ns, fs, m_f, margin, g_t, g_f, partials);
     hipLaunchKernelGGL((pairwise_columns_kernel<LOSS, 1>), dim3(gt), dim3(256), 0, st, ts, ns, fs, m_f, margin, g_t, g_f, partials);
@@ -412,11 +459,11 @@ static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int6
 }
 
 static int launch_pairwise(const kge_loss_desc* ld, const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* g_t, float* g_f,
-                           float* partials, hipStream_t st, int* nb) {
+                           float* partials, float* pair, hipStream_t st, int* nb) {
   const int64_t ns = ld->negative_samples;
-  if (ld->loss == KGE_PAIRWIZE_HINGE) return launch_pairwise_t<KGE_PAIRWIZE_HINGE>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, st, nb);
-  if (ld->loss == KGE_PAIRWIZE_LOGISTIC) return launch_pairwise_t<KGE_PAIRWIZE_LOGISTIC>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, st, nb);
-  return launch_pairwise_t<KGE_PAIRWIZE_SQUARE>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, st, nb);
+  if (ld->loss == KGE_PAIRWIZE_HINGE) return launch_pairwise_t<KGE_PAIRWIZE_HINGE>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, pair, st, nb);
+  if (ld->loss == KGE_PAIRWIZE_LOGISTIC) return launch_pairwise_t<KGE_PAIRWIZE_LOGISTIC>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, pair, st, nb);
+  return launch_pairwise_t<KGE_PAIRWIZE_SQUARE>(ts, m_t, fs, m_f, ns, ld->margin, g_t, g_f, partials, pair, st, nb);
 }
 
 // reduce_mean=False of the pairwize losses (utils.py:303-305,310-312,317-319): the raw (rows, cols) pair tensor of the
@@ -477,7 +524,7 @@ int loss_value(const kge_loss_desc* ld, const float* ts, int64_t m_t, const floa
     if (int rc = pairwise_shape(ld, m_t, m_f)) return rc;
     float* gt = g_t ? g_t : ws.gbuf;
     float* gf = g_f ? g_f : ws.gbuf + m_t;
-    if (int rc = launch_pairwise(ld, ts, m_t, fs, m_f, gt, gf, ws.loss_partials, st, &nb)) return rc;
+    if (int rc = launch_pairwise(ld, ts, m_t, fs, m_f, gt, gf, ws.loss_partials, ws.pair, st, &nb)) return rc;
   } else {
     nb = (int)std::min<int64_t>(cdiv(m_t + m_f, 256), kMaxBlocks);
     if (ld->loss == KGE_POINTWIZE_HINGE) hipLaunchKernelGGL((pointwise_loss_kernel<KGE_POINTWIZE_HINGE>), dim3(nb), dim3(256), 0, st, ts, m_t, fs, m_f, ld->margin, g_t, g_f, ws.loss_partials);
@@ -526,7 +573,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
     if (int rc = pull_forward(md, pairwise ? -1 : ld->loss, ld->margin, E, Rel, pos, m_pos, neg, m_neg, plan, sc, ws.loss_partials, &nb, err, seed, st)) return rc;
     if (ss) KGE_HIP_TRY(hipStreamWaitEvent(st, ss->join, 0));
     if (pairwise) {
-      if (int rc = launch_pairwise(ld, sc, m_pos, sc + m_pos, m_neg, plan.coef, plan.coef + m_pos, ws.loss_partials, st, &nb)) return rc;
+      if (int rc = launch_pairwise(ld, sc, m_pos, sc + m_pos, m_neg, plan.coef, plan.coef + m_pos, ws.loss_partials, ws.pair, st, &nb)) return rc;
     }
     if (int rc = pull_backward(md, E, Rel, gE, gR, pos, m_pos, neg, m_neg, plan, pairwise, sc, seed, st)) return rc;
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.loss_partials, nb, 1.f, 0, loss_out);
@@ -559,7 +606,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
       if (int rc = score_dispatch(md, E, Rel, neg, m_neg, sc + m_pos, err, st)) return rc;
       // phase 2: dL/dscore for every row + loss
       int rc;
-      if ((rc = launch_pairwise(ld, sc, m_pos, sc + m_pos, m_neg, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, st, &nb))) return rc;
+      if ((rc = launch_pairwise(ld, sc, m_pos, sc + m_pos, m_neg, ws.gbuf, ws.gbuf + m_pos, ws.loss_partials, ws.pair, st, &nb))) return rc;
       // phase 3: gradient rows
       int nb2 = 0;
       if ((rc = push_by_model<-1>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, ws.gbuf, nullptr, nullptr, err, st, &nb2, seed))) return rc;

@@ -524,6 +524,33 @@ def test_heavy_tailed_batch(model, kw, dp, grad_mode):
         np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
 
 
+@pytest.mark.parametrize("loss", ["pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"])
+def test_pairwise_allpairs_at_script_scale(loss):
+    """The all-pairs broadcast at sizes where the sweep over the other score vector is cut into column chunks (the reference's
+    own script trains with pairwize_hinge on 20 480-row arrays, tests.py:119-134): loss value / gradients of the callable and
+    one Adam step, against the oracle."""
+    from kge_keras_amd.utils import loss_function_lookup
+    from kge_keras_amd.models import loss_value
+    rs = np.random.RandomState(5)
+    t, f = rs.uniform(-2, 2, 5000), rs.uniform(-2, 2, 3100)
+    L = float(loss_function_lookup(loss)(t, f, 0.7, 1).item())
+    Lo, gto, gfo = O.loss_value_and_grads(loss, t, f, 0.7, 1)
+    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+    _, gt, gf = loss_value(loss, t, f, 0.7, 1, return_grads=True)
+    np.testing.assert_allclose(gt.cpu().numpy(), gto, atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(gf.cpu().numpy(), gfo, atol=1e-7, rtol=1e-4)
+    N, R, d, m = 60, 5, 16, 2600
+    mdl, E0, R0, rs = _mk("DistMult", N, R, d, loss_function=loss, margin=0.5)
+    mdl.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    pos, neg = _triples(rs, m, N, R), _triples(rs, m + 300, N, R)
+    Ls = float(mdl.train_step([pos, neg])["loss"].item())
+    Lso = O.train_step("DistMult", Eo, Ro, O.AdamTF(), pos, neg, loss, 0.5, 1)
+    assert Ls == pytest.approx(Lso, abs=TOL, rel=1e-5)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+
+
 def test_wn18rr_complex400_train_step(datasets):
     """BASELINE config 4 shape in training: WN18RR (N = 40 943, R = 11), ComplEx d=400 (rows of 800 floats -> the generic-list
     pull variant with two float4 chunks per lane), real training triples, one Adam step against the oracle."""
