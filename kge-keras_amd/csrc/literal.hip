@@ -236,9 +236,25 @@ int lit_transform(const kge_model_desc* md, int act, const float* E, const float
 
 int64_t lit_transform_workspace_bytes(const kge_model_desc* md, int L, int rows) { return l256((int64_t)rows * (md->d_e + L) * 4) + 1024; }
 
+// The weight gradient dW (d x K1) = dZ^T A contracts over all 2n stacked rows: one output tile, i.e. ONE workgroup in a plain
+// GEMM (2.2 ms at 2n = 81 920).  It is computed as `splits` slabs of the contraction (strided-batched GEMM, one tile each)
+// whose partial matrices a small kernel adds up in slab order.
+static int lit_splits(int64_t rows2n, int64_t d, int64_t K1) {
+  const int64_t by_rows = rows2n / 512, by_bytes = (32ll << 20) / std::max<int64_t>(1, d * K1 * 4);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(by_rows, by_bytes), 256));
+}
+
+__global__ __launch_bounds__(256) void lit_splitk_sum(const float* __restrict__ part, int splits, int64_t elems, float* __restrict__ acc) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < elems; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * elems + i];
+    acc[i] += s;
+  }
+}
+
 int64_t lit_workspace_bytes(const kge_model_desc* md, int L, int64_t m_pos, int64_t m_neg) {
   const int64_t n = m_pos + m_neg, d = md->d_e, K1 = d + L;
-  return pull_header_bytes(md) + 2 * l256(2 * n * K1 * 4) + 3 * l256(2 * n * d * 4) + 3 * l256(n * d * 4) + 2 * l256(n * 4) +
+  return l256((int64_t)lit_splits(2 * n, d, K1) * d * K1 * 4) + pull_header_bytes(md) + 2 * l256(2 * n * K1 * 4) + 3 * l256(2 * n * d * 4) + 3 * l256(n * d * 4) + 2 * l256(n * 4) +
          l256(cdiv(2 * n, 64) * d * 4) + pull_workspace_bytes(md, n) + l256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096;
 }
 
@@ -288,6 +304,8 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
   void* pull_body = take(pull_workspace_bytes(md, n));
   const int64_t loss_ws_bytes = train_workspace_bytes(nullptr, m_pos, m_neg);
   void* loss_ws = take(loss_ws_bytes);
+  const int splits = lit_splits(2 * n, d, K1);
+  float* wpart = (float*)take((int64_t)splits * d * K1 * 4);
   float* sc = scores_out ? scores_out : scb;
   const bool drop = md->dropout > 0.f;
   const uint32_t thr = drop_thr(md->dropout);
@@ -316,7 +334,16 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
     hipLaunchKernelGGL(lit_colsum, dim3(d), dim3(256), 0, st, psum, nb_rows, d, gtheta + (int64_t)K1 * d);
     // dA(2n,K1) = dZ(2n,d) W^T ; dW(K1,d) += A^T dZ   (column-major views as in conve.hip)
     KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_transpose, rocblas_operation_none, K1, (rocblas_int)(2 * n), d, &one, theta, d, dH, d, &zero, dA, K1));
-    KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_transpose, d, K1, (rocblas_int)(2 * n), &one, dH, d, A, K1, &one, gtheta, d));
+    if (splits > 1) {
+      const int64_t kc = (2 * n) / splits, tail = 2 * n - kc * splits;
+      KGE_BLAS_TRY(rocblas_sgemm_strided_batched(hb, rocblas_operation_none, rocblas_operation_transpose, d, K1, (rocblas_int)kc, &one, dH, d, kc * d, A, K1,
+                                                 kc * K1, &zero, wpart, d, (rocblas_stride)d * K1, splits));
+      hipLaunchKernelGGL(lit_splitk_sum, dim3((int)cdiv((int64_t)d * K1, 256)), dim3(256), 0, st, wpart, splits, (int64_t)d * K1, gtheta);
+      if (tail) KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_transpose, d, K1, (rocblas_int)tail, &one, dH + kc * splits * d, d,
+                                           A + kc * splits * K1, K1, &one, gtheta, d));
+    } else {
+      KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_transpose, d, K1, (rocblas_int)(2 * n), &one, dH, d, A, K1, &one, gtheta, d));
+    }
     const int gc = (int)std::min<int64_t>(cdiv(n * d, 256), 8192);
     if (drop) hipLaunchKernelGGL((lit_compact<true>), dim3(gc), dim3(256), 0, st, dA, n, d, K1, dS, dO, seed, thr, dscale);
     else hipLaunchKernelGGL((lit_compact<false>), dim3(gc), dim3(256), 0, st, dA, n, d, K1, dS, dO, seed, thr, dscale);

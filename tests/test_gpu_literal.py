@@ -68,6 +68,25 @@ def test_literal_train_step_parity(model, kw, loss, act, dp):
         np.testing.assert_allclose(b, Ho["b"], atol=TOL)
 
 
+def test_literal_weight_gradient_split_contraction():
+    """Batches large enough for the Dense layer's weight gradient to be computed as slabs of the contraction over the stacked
+    rows (strided-batched GEMM + ordered sum, plus a tail GEMM for the rows that do not fill a slab): 2n = 3110 rows."""
+    N, R, d, L = 50, 4, 16, 5
+    mdl, E0, R0, lit, H, rs = _mk("DistMult", N, R, d, L, "tanh", seed=3, dp=0.0, loss_function="pointwize_logistic", margin=0.5)
+    mdl.compile("adam")
+    Eo, Ro, Ho, Lo = E0.astype(np.float64), R0.astype(np.float64), _f64(H), lit.astype(np.float64)
+    oo = O.AdamTF()
+    for step in range(2):
+        pos, neg = _tri(rs, 800, N, R), _tri(rs, 755, N, R)
+        L_ = float(mdl.train_step([pos, neg])["loss"].item())
+        Lr, _, _ = O.literal_train_step("DistMult", Ho, "tanh", Eo, Ro, Lo, oo, pos, neg, "pointwize_logistic", 0.5, 1)
+        assert L_ == pytest.approx(Lr, abs=TOL, rel=1e-4), step
+        W, b = mdl.get_literal_dense()
+        np.testing.assert_allclose(W, Ho["W"], atol=TOL)
+        np.testing.assert_allclose(b, Ho["b"], atol=TOL)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+
+
 def test_reference_script_configuration(datasets):
     """tests.py:96-134 on nations: DistMult, dim from hp, random literals (len(E), 5), tanh, pairwize_hinge, margin 1, Adam;
     fit runs, the loss falls, validate() ranks on the literal-transformed table."""
