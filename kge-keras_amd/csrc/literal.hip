@@ -240,7 +240,7 @@ int64_t lit_transform_workspace_bytes(const kge_model_desc* md, int L, int rows)
 // GEMM (2.2 ms at 2n = 81 920).  It is computed as `splits` slabs of the contraction (strided-batched GEMM, one tile each)
 // whose partial matrices a small kernel adds up in slab order.
 static int lit_splits(int64_t rows2n, int64_t d, int64_t K1) {
-  const int64_t by_rows = rows2n / 512, by_bytes = (32ll << 20) / std::max<int64_t>(1, d * K1 * 4);
+  const int64_t by_rows = rows2n / 2048, by_bytes = (32ll << 20) / std::max<int64_t>(1, d * K1 * 4);
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(by_rows, by_bytes), 256));
 }
 

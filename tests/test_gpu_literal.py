@@ -70,14 +70,14 @@ def test_literal_train_step_parity(model, kw, loss, act, dp):
 
 def test_literal_weight_gradient_split_contraction():
     """Batches large enough for the Dense layer's weight gradient to be computed as slabs of the contraction over the stacked
-    rows (strided-batched GEMM + ordered sum, plus a tail GEMM for the rows that do not fill a slab): 2n = 3110 rows."""
+    rows (strided-batched GEMM + ordered sum, plus a tail GEMM for the rows that do not fill a slab): 2n = 8310 rows = 4 slabs of 2077 + a tail of 2."""
     N, R, d, L = 50, 4, 16, 5
     mdl, E0, R0, lit, H, rs = _mk("DistMult", N, R, d, L, "tanh", seed=3, dp=0.0, loss_function="pointwize_logistic", margin=0.5)
     mdl.compile("adam")
     Eo, Ro, Ho, Lo = E0.astype(np.float64), R0.astype(np.float64), _f64(H), lit.astype(np.float64)
     oo = O.AdamTF()
     for step in range(2):
-        pos, neg = _tri(rs, 800, N, R), _tri(rs, 755, N, R)
+        pos, neg = _tri(rs, 2100, N, R), _tri(rs, 2055, N, R)
         L_ = float(mdl.train_step([pos, neg])["loss"].item())
         Lr, _, _ = O.literal_train_step("DistMult", Ho, "tanh", Eo, Ro, Lo, oo, pos, neg, "pointwize_logistic", 0.5, 1)
         assert L_ == pytest.approx(Lr, abs=TOL, rel=1e-4), step
