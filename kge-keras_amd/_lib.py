@@ -2,6 +2,12 @@
 import ctypes as C
 import os
 
+# PyTorch-ROCm owns the device memory and the streams, so libkge_hip.so must talk to the SAME HIP runtime instance PyTorch
+# loaded.  PyTorch wheels bundle their own libamdhip64 / librocblas; loading ours first would pull /opt/rocm's copies into the
+# process beside them, and every launch on a torch pointer would then fail with "no ROCm-capable device is detected".  With
+# torch imported first the loader resolves our DT_NEEDED entries (same SONAMEs) to the copies already in the process.
+import torch  # noqa: F401  (must precede the CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkge_hip.so")
 

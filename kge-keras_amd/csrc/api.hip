@@ -21,7 +21,12 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// hipGetLastError() is per thread and sticky across callers: an error some other library left behind (PyTorch probing the
+// platform at start-up has been seen to leave "no ROCm-capable device") must not be reported as ours after the next launch.
+static inline void clear_stale_error() { (void)hipGetLastError(); }
+
 int check_model(const kge_model_desc* md, const char* who) {
+  clear_stale_error();
   if (!md) return fail(KGE_EINVAL, "%s: model descriptor is null", who);
   if (md->model < KGE_DISTMULT || md->model > KGE_CONVE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
   if (md->num_entities <= 0 || md->num_relations <= 0 || md->d_e <= 0 || md->d_r <= 0)
@@ -270,6 +275,7 @@ int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_o
 }
 
 int kge_opt_state_init(const kge_opt_desc* od, kge_stream_t stream) {
+  clear_stale_error();
   if (!od || !od->step_dev) return fail(KGE_EINVAL, "kge_opt_state_init: optimizer descriptor without step_dev");
   if (od->kind != KGE_OPT_ADAM_TF && od->kind != KGE_OPT_SGD) return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
   if (od->step < 1) return fail(KGE_EINVAL, "kge_opt_state_init: step must be >= 1 (the number of the next update)");
@@ -398,6 +404,7 @@ int kge_sampler_plan_host(int64_t B, int64_t ns, int64_t num_e, void* plan_host)
 int kge_build_batch_device(void* np_state_dev, void* py_state_dev, const int32_t* batch_dev, int64_t B, int64_t ns, int64_t num_e,
                            int32_t* pos_out_dev, int32_t* neg_out_dev, const void* plan_dev, void* workspace, int64_t workspace_bytes,
                            uint32_t* err_flag, kge_stream_t stream) {
+  clear_stale_error();
   if (!np_state_dev || !py_state_dev || !batch_dev || !pos_out_dev || !neg_out_dev || !workspace || !err_flag)
     return fail(KGE_EINVAL, "kge_build_batch_device: null pointer");
   if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "kge_build_batch_device: bad sizes");
@@ -409,6 +416,7 @@ int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const
                                    const int64_t* starts_dev, int64_t* cursor_dev, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out_dev,
                                    int32_t* neg_out_dev, int32_t* cand_rows_dev, int32_t* cand_counts_dev, const void* plan_dev, void* workspace,
                                    int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  clear_stale_error();
   if ((cand_rows_dev == nullptr) != (cand_counts_dev == nullptr))
     return fail(KGE_EINVAL, "kge_build_batch_device_indexed: cand_rows and cand_counts go together");
   if (!np_state_dev || !py_state_dev || !kg_dev || !index_dev || !starts_dev || !cursor_dev || !workspace || !err_flag)
@@ -428,6 +436,7 @@ int64_t kge_loss_workspace_bytes(int64_t m_true, int64_t m_false) {
 
 int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,
                    float* loss_out, float* d_true, float* d_false, void* workspace, int64_t workspace_bytes, kge_stream_t stream) {
+  clear_stale_error();
   if (!ld || !true_scores || !false_scores || !loss_out || !workspace) return fail(KGE_EINVAL, "kge_loss_value: null pointer");
   if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_value: empty score vector (reduce_mean of nothing)");
   return loss_value(ld, true_scores, m_true, false_scores, m_false, loss_out, d_true, d_false, workspace, workspace_bytes,
@@ -442,6 +451,7 @@ int kge_set_dedup_mode(int mode) {
 
 int kge_loss_pairs(const kge_loss_desc* ld, const float* true_scores, int64_t m_true, const float* false_scores, int64_t m_false,
                    float* out, int64_t out_elems, kge_stream_t stream) {
+  clear_stale_error();
   if (!ld || !true_scores || !false_scores || !out) return fail(KGE_EINVAL, "kge_loss_pairs: null pointer");
   if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_pairs: empty score vector");
   return loss_pairs(ld, true_scores, m_true, false_scores, m_false, out, out_elems, static_cast<hipStream_t>(stream));
@@ -500,6 +510,7 @@ int kge_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, con
 }
 
 int kge_opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float grad_scale, kge_stream_t stream) {
+  clear_stale_error();
   if (!od || !w || !g || n < 0) return fail(KGE_EINVAL, "kge_opt_apply_vector: bad arguments");
   return opt_apply_vector(od, w, g, n, grad_scale, static_cast<hipStream_t>(stream));
 }
@@ -512,6 +523,7 @@ int64_t kge_rank_sweep_q_workspace_bytes(int64_t n_queries, int32_t K) {
 int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* Cand, int32_t cand_offset, int32_t cand_rows,
                      const int32_t* target_ids, const int32_t* filt_query, const int32_t* filt_ids, int64_t n_filt, int32_t* counts,
                      int32_t accumulate, void* workspace, int64_t workspace_bytes, kge_stream_t stream) {
+  clear_stale_error();
   if (n_queries == 0) return KGE_OK;
   if (n_queries < 0 || K <= 0 || !Q || !Cand || !target_ids || !counts || !workspace || cand_rows <= 0 || cand_offset < 0 || n_filt < 0 ||
       (n_filt && (!filt_query || !filt_ids)))

@@ -186,8 +186,7 @@ def validate(model, test_data, num_entities, bs, filtering_triples=None):
     if hasattr(model, "rank_triples"):  # GPU ranker + C++ filter index: no per-query Python work
         if filtering_triples is None:
             raise TypeError("'NoneType' object is not iterable")  # the reference iterates over it (utils.py:203)
-        filt = np.asarray([tuple(int(v) for v in t) for t in filtering_triples] if not isinstance(filtering_triples, np.ndarray)
-                          else filtering_triples, dtype=np.int32).reshape(-1, 3)
+        filt = np.asarray(filtering_triples if isinstance(filtering_triples, np.ndarray) else list(filtering_triples), dtype=np.int32).reshape(-1, 3)
         tail_ranks, head_ranks = model.rank_triples(np.asarray(test_data, dtype=np.int32).reshape(-1, 3), num_entities, filt)
         return metrics_from_ranks(tail_ranks, head_ranks)
     filter_h = defaultdict(set)
