@@ -280,8 +280,9 @@ int kge_filter_coo_host(const int32_t* test_host, int64_t n_queries, int32_t sid
 /* The same batch builder on the GPU: states are the same 2504-byte blobs resident in device memory, batch (B,3) int32 on
  * the device, pos_out / neg_out (B*ns,3) int32 on the device.  Bit-identical to kge_build_batch_host, including the
  * generator states left behind.  err_flag bit 1 is set if the rejection-sampling margin of the raw buffer ever ran
- * short (never observed; the states are then left at the end of the buffer).  The workspace must be zero-filled once when it
- * is allocated (it holds a batch epoch that tags the in-flight tile counts); the library keeps it consistent afterwards. */
+ * short (never observed; the states are then left at the end of the buffer).  The workspace must be zero-filled when it is
+ * allocated and again whenever (B, ns, num_e) changes (its layout depends on them and it holds a batch epoch that tags the
+ * in-flight tile counts); between calls of one shape the library keeps it consistent. */
 /* plan (optional): MT19937's word stream is sequential, but the state J words ahead is a GF(2)-linear function of the
  * current one.  kge_sampler_plan_host computes, for this batch shape, the jump polynomials x^J mod phi of the starts of
  * 16 segments per stream (host, ~0.2-2 s once, cached); uploaded and passed as plan_dev, the generator then runs as 16

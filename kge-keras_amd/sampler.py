@@ -143,13 +143,23 @@ class DeviceSampler:
         if py_stream is not None:
             self.py_state.copy_(torch.from_numpy(py_stream._buf.view(np.uint8).copy()))
 
+    def _workspace(self, B, ns, num_e):
+        """The library's scratch: zero-filled when allocated and again whenever the batch shape changes (the layout depends on
+        it, and the batch epoch that tags in-flight tile counts must not be read from stale bytes)."""
+        import torch
+        need = check(lib.kge_sampler_workspace_bytes(B, ns, num_e))
+        shape = (B, ns, num_e)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+        elif getattr(self, "_ws_shape", shape) != shape:
+            self._ws.zero_()
+        self._ws_shape = shape
+
     def prepare(self, B, ns, num_e):
         """Allocate the workspace and compute / upload the jump polynomials for this batch shape (what build_batch does lazily
         on its first call), so that later calls allocate nothing -- needed before capturing build_batch into a hipGraph."""
         import torch
-        need = check(lib.kge_sampler_workspace_bytes(int(B), int(ns), int(num_e)))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)  # zero-filled once (kge_hip.h)
+        self._workspace(int(B), int(ns), int(num_e))
         key = (int(B), int(ns), int(num_e))
         if self.segmented and key not in self._plans:
             buf = np.empty(int(lib.kge_sampler_plan_bytes()) // 8, dtype=np.uint64)
@@ -166,9 +176,7 @@ class DeviceSampler:
         from . import _lib
         B = batch.shape[0] if indexed is None else int(indexed[4])
         m = B * int(ns)
-        need = check(lib.kge_sampler_workspace_bytes(B, int(ns), int(num_e)))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)  # zero-filled once (kge_hip.h)
+        self._workspace(B, int(ns), int(num_e))
         arrays = not (counted is not None and pos_out is False)  # pos_out=False with counted=...: folded form only
         if not arrays:
             pos_out = neg_out = None
