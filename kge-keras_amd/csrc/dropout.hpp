@@ -25,14 +25,14 @@ __host__ __device__ __forceinline__ DropKey drop_key(uint64_t seed, int64_t t, i
   return DropKey{(uint32_t)z, (uint32_t)(z >> 32)};
 }
 
-// 32 mask bits for elements 2w and 2w+1 (16 bits each)
+// 32 mask bits for elements 2w and 2w+1 (16 bits each): a Weyl sequence whose start and (odd) stride are the two halves of
+// the row's key -- both already well mixed by splitmix64 -- followed by one multiply-xorshift round.  Six integer operations
+// per two elements: the masks are regenerated for every gathered row in the forward AND in the gradient kernels, where a
+// murmur3-style finaliser (sixteen operations) made the dropout step ALU bound.
 __host__ __device__ __forceinline__ uint32_t drop_word(DropKey k, uint32_t w) {
-  uint32_t x = (w * 0x9E3779B1u) ^ k.lo;
-  x ^= x >> 16; x *= 0x85EBCA6Bu;
-  x ^= x >> 13; x *= 0xC2B2AE35u;
-  x ^= x >> 16; x += k.hi;
-  x ^= x >> 15; x *= 0x2C1B3C6Du;
-  x ^= x >> 12;
+  uint32_t x = k.lo + w * (k.hi | 1u);
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15;
   return x;
 }
 

@@ -289,12 +289,9 @@ def dropout_multipliers(seed, n_rows, role, width, rate, row_offset=0):
         hi = (z >> np.uint64(32)).astype(np.uint32)[:, None]
         nw = (width + 1) // 2
         w = np.arange(nw, dtype=np.uint32)[None, :]
-        x = (w * np.uint32(0x9E3779B1)) ^ lo
-        x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x85EBCA6B)
-        x = x ^ (x >> np.uint32(13)); x = x * np.uint32(0xC2B2AE35)
-        x = x ^ (x >> np.uint32(16)); x = x + hi
-        x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x2C1B3C6D)
-        x = x ^ (x >> np.uint32(12))
+        x = lo + w * (hi | np.uint32(1))  # Weyl sequence: start lo, odd stride hi | 1 (uint32 wrap-around)
+        x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x7FEB352D)
+        x = x ^ (x >> np.uint32(15))
     bits = np.empty((n_rows, 2 * nw), dtype=np.uint32)
     bits[:, 0::2] = x & np.uint32(0xFFFF)
     bits[:, 1::2] = x >> np.uint32(16)
