@@ -189,16 +189,6 @@ __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ p
   const int64_t t0 = (int64_t)blockIdx.x * kIdxBlockTriples;
   constexpr int PER = kIdxBlockTriples / 256;
   int rs[PER], ro[PER], rp[PER], pp[PER], hs[PER], ho[PER];
-  auto local = [&](int key, int& slot) {
-    int h = (int)(((unsigned)key * 2654435761u) >> 20) & (kIdxSlots - 1);
-    for (;;) {
-      const int cur = atomicCAS(&hkey[h], -1, key);
-      if (cur == -1 || cur == key) break;
-      h = (h + 1) & (kIdxSlots - 1);
-    }
-    slot = h;
-    return atomicAdd(&hcnt[h], 1);
-  };
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int64_t t = t0 + threadIdx.x + i * 256;
@@ -207,8 +197,18 @@ __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ p
       const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
       const int s = tr[0], p = tr[1], o = tr[2];
       if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
-        rs[i] = local(s, hs[i]);
-        ro[i] = local(o, ho[i]);
+#pragma unroll
+        for (int role = 0; role < 2; ++role) {
+          const int key = role == 0 ? s : o;
+          int h = (int)(((unsigned)key * 2654435761u) >> 20) & (kIdxSlots - 1);
+          for (;;) {
+            const int cur = atomicCAS(&hkey[h], -1, key);
+            if (cur == -1 || cur == key) break;
+            h = (h + 1) & (kIdxSlots - 1);
+          }
+          const int lr = atomicAdd(&hcnt[h], 1);
+          if (role == 0) { hs[i] = h; rs[i] = lr; } else { ho[i] = h; ro[i] = lr; }
+        }
         pp[i] = p;
         rp[i] = lds ? atomicAdd(&lrel[p], 1) : atomicAdd(&cnt[N + p], 1);
       }
