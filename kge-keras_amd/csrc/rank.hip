@@ -247,6 +247,167 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
   if (tid < kTile && q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
 }
 
+// Same sweep for rows of K % 4 == 0 floats on 16-byte boundaries (every table the models hand over), built so that the
+// matrix pipe is the only thing a wave waits for:
+//   * candidate tile / k chunk are nested loops, the four accumulators are zeroed and consumed once per tile, so they stay in
+//     accumulator registers for the whole tile (the flattened loop of the generic kernel makes the compiler carry them in
+//     VGPRs and copy 64 registers in and out of the accumulator file every chunk);
+//   * the staging slots of a thread (tile row, float4 column) are loop invariant; rows past the end are clamped to the last
+//     valid row instead of predicated (queries past nq never store, candidates past cand_rows are masked in the epilogue), so
+//     the prefetch of the next chunk is 10 address computations + 10 loads with no branch and can be scheduled between MFMAs;
+//   * the prefetch after the last chunk re-reads the block's first chunk (no branch; the values are dropped).
+// The k order of every accumulation chain is the one documented at the top of the file (same LDS image, same reads).
+template <int BK, bool TAIL>
+__global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
+                                                           int64_t nq, const float* __restrict__ Ec, int K, int Kpad,
+                                                           int cand_rows, int tiles_per_block, int32_t* __restrict__ counts) {
+  constexpr int LS = BK + 4;
+  constexpr int C4 = BK / 4;
+  constexpr int PF = kTile * C4 / 256;
+  static_assert(kTile * C4 % 256 == 0, "staging slots must divide evenly");
+  __shared__ __attribute__((aligned(16))) float As[kTile * LS];
+  __shared__ __attribute__((aligned(16))) float Bs[kTile * LS];
+  __shared__ int cnt_s[kTile];
+  __shared__ float tg_s[kTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int64_t q0 = (int64_t)blockIdx.x * kTile;
+  const int nct = (cand_rows + kTile - 1) / kTile;
+  const int ct_begin = blockIdx.y * tiles_per_block;
+  const int ct_end = min(nct, ct_begin + tiles_per_block);
+  if (ct_begin >= ct_end) return;
+
+  int cnt[2][16];  // one counter per accumulator row (both candidate halves of the wave tile add into it)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cnt[rt][r] = 0;
+  if (tid < kTile) {
+    cnt_s[tid] = 0;
+    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : __builtin_inff();
+  }
+
+  // loop-invariant staging slots; named scalars (PF is 4 or 5), slot 4 is compiled out when PF == 4
+  static_assert(PF == 4 || PF == 5, "staging code is written for 4 or 5 slots per thread");
+  const int last_row = cand_rows - 1;
+  const int nchunk = Kpad / BK;
+#define KGE_SLOT(U)                                                                  \
+  const int r##U = (tid + U * 256) / C4, cB##U = ((tid + U * 256) - r##U * C4) * 4;  \
+  const float* const pA##U = Qv + min(q0 + r##U, nq - 1) * Kpad + cB##U;             \
+  const int lo##U = r##U * LS + cB##U;                                               \
+  float4 pa##U, pb##U;
+  KGE_SLOT(0) KGE_SLOT(1) KGE_SLOT(2) KGE_SLOT(3) KGE_SLOT(4)
+#undef KGE_SLOT
+#define KGE_PF1(U, C0, K0)                                                                                         \
+  if (U < PF) {                                                                                                    \
+    pa##U = *reinterpret_cast<const float4*>(pA##U + (K0));                                                        \
+    const int row_ = min((C0) + r##U, last_row);                                                                   \
+    if (TAIL) { /* K % 4 == 0: a float4 is inside the row or entirely in the padding */                            \
+      const bool in_ = (K0) + cB##U < K;                                                                           \
+      const float4 v_ = *reinterpret_cast<const float4*>(Ec + (int64_t)row_ * K + (in_ ? (K0) + cB##U : 0));      \
+      pb##U = in_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+    } else {                                                                                                       \
+      pb##U = *reinterpret_cast<const float4*>(Ec + (int64_t)row_ * K + (K0) + cB##U);                             \
+    }                                                                                                              \
+  }
+#define KGE_PREFETCH(CT, KC)                                                                                       \
+  {                                                                                                                \
+    const int c0_ = (CT) * kTile, k0_ = (KC) * BK;                                                                 \
+    KGE_PF1(0, c0_, k0_) KGE_PF1(1, c0_, k0_) KGE_PF1(2, c0_, k0_) KGE_PF1(3, c0_, k0_) KGE_PF1(4, c0_, k0_)       \
+  }
+#define KGE_ST1(U)                                                   \
+  if (U < PF) {                                                      \
+    *reinterpret_cast<float4*>(As + lo##U) = pa##U;                  \
+    *reinterpret_cast<float4*>(Bs + lo##U) = pb##U;                  \
+  }
+  const float* a_rd = As + (wq * 64 + l31) * LS + 4 * half;
+  const float* b_rd = Bs + (wc * 64 + l31) * LS + 4 * half;
+
+  KGE_PREFETCH(ct_begin, 0)
+  for (int ct = ct_begin; ct < ct_end; ++ct) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int kc = 0; kc < nchunk; ++kc) {
+      __syncthreads();  // everyone is done reading the previous chunk
+      KGE_ST1(0) KGE_ST1(1) KGE_ST1(2) KGE_ST1(3) KGE_ST1(4)
+      __syncthreads();
+      // next chunk (after the last one: the block's first chunk again, dropped); its loads are issued one staging slot per
+      // group of 16 MFMAs, between scheduling barriers, so the address arithmetic runs in the shadow of the matrix pipe and
+      // every load has at least one full group ahead of it before the chunk ends
+      int nk = kc + 1, nt = ct;
+      if (nk == nchunk) { nk = 0; nt = ct + 1 < ct_end ? ct + 1 : ct_begin; }
+      const int nc0 = nt * kTile, nk0 = nk * BK;
+      float4 fa[2][2], fb[2][2];  // [buffer][row tile]: the fragments of group j+1 are read while group j multiplies
+#define KGE_FRAG(BUF, J)                                                                          \
+  _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                 \
+    fa[BUF][x] = *reinterpret_cast<const float4*>(a_rd + x * 32 * LS + 8 * (J));                  \
+    fb[BUF][x] = *reinterpret_cast<const float4*>(b_rd + x * 32 * LS + 8 * (J));                  \
+  }
+#define KGE_STEP(BUF, comp)                                                                                           \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][0].comp, acc[0][0], 0, 0, 0);             \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][1].comp, acc[0][1], 0, 0, 0);             \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][0].comp, acc[1][0], 0, 0, 0);             \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][1].comp, acc[1][1], 0, 0, 0);
+      KGE_FRAG(0, 0)
+#pragma unroll
+      for (int j = 0; j < BK / 8; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < BK / 8) {
+          if ((j & 1) == 0) { KGE_FRAG(1, j + 1) } else { KGE_FRAG(0, j + 1) }
+        }
+        if (j == 0) { KGE_PF1(0, nc0, nk0) }
+        if (j == 1) { KGE_PF1(1, nc0, nk0) }
+        if (j == 2) { KGE_PF1(2, nc0, nk0) }
+        if (j == 3) { KGE_PF1(3, nc0, nk0) }
+        if (j == 4) { KGE_PF1(4, nc0, nk0) }
+        __builtin_amdgcn_sched_barrier(0);
+        if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
+        else { KGE_STEP(1, x) KGE_STEP(1, y) KGE_STEP(1, z) KGE_STEP(1, w) }
+      }
+#undef KGE_STEP
+#undef KGE_FRAG
+    }
+    // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
+    const int c0 = ct * kTile;
+    if (c0 + kTile <= cand_rows) {  // uniform: every candidate column of the tile exists
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+          cnt[rt][r] += (acc[rt][0][r] > tgv ? 1 : 0) + (acc[rt][1][r] > tgv ? 1 : 0);
+        }
+    } else {
+      const bool v0 = c0 + wc * 64 + l31 < cand_rows, v1 = c0 + wc * 64 + 32 + l31 < cand_rows;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+          cnt[rt][r] += ((v0 && acc[rt][0][r] > tgv) ? 1 : 0) + ((v1 && acc[rt][1][r] > tgv) ? 1 : 0);
+        }
+    }
+  }
+#undef KGE_PREFETCH
+#undef KGE_PF1
+#undef KGE_ST1
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
+    }
+  __syncthreads();
+  if (tid < kTile && q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
+}
+
 // One thread per CSR entry (query pair_q[e], filtered global id filt_ids[e]); un-counts it if it was counted.
 __global__ __launch_bounds__(256) void rank_filter_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                            const float* __restrict__ Ec, int cand_offset, int cand_rows,
@@ -415,6 +576,26 @@ static int pick_bk(int K) {
   return best;
 }
 
+static int sweep_variant() {  // KGE_RANK_SWEEP=1 selects the generic (predicated) kernel for aligned tables too
+  static const int v = [] { const char* e = getenv("KGE_RANK_SWEEP"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float* Qv, const float* tgt, int64_t nq, const float* Ec,
+                         int K, int Kpad, int cand_rows, int tpb, int32_t* counts) {
+  if (nq <= 0 || cand_rows <= 0) return;
+#define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
+  if (v4 && sweep_variant() == 0) {
+    const bool tail = Kpad != K;
+    if (BK == 40) { if (tail) KGE_SWEEP(rank_sweep4_kernel, 40, true); else KGE_SWEEP(rank_sweep4_kernel, 40, false); }
+    else { if (tail) KGE_SWEEP(rank_sweep4_kernel, 32, true); else KGE_SWEEP(rank_sweep4_kernel, 32, false); }
+  } else {
+    if (BK == 40) { if (v4) KGE_SWEEP(rank_sweep_kernel, 40, true); else KGE_SWEEP(rank_sweep_kernel, 40, false); }
+    else { if (v4) KGE_SWEEP(rank_sweep_kernel, 32, true); else KGE_SWEEP(rank_sweep_kernel, 32, false); }
+  }
+#undef KGE_SWEEP
+}
+
 int rank_kpad(int K) { return (int)align_up(K, pick_bk(K)); }
 static int rank_kpad_model(const kge_model_desc* md) { return md->model == KGE_TRANSE ? (int)align_up(md->d_e, 32) : rank_kpad(md->d_e); }
 
@@ -476,10 +657,7 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
     splits = (int)cdiv(nct, tpb);
     const bool v4 = (K % 4 == 0) && ((uintptr_t)Ec % 16 == 0);
     dim3 grid(nqt, splits);
-#define KGE_SWEEP(BKV, V4) hipLaunchKernelGGL((rank_sweep_kernel<BKV, V4>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
-    if (BK == 40) { if (v4) KGE_SWEEP(40, true); else KGE_SWEEP(40, false); }
-    else { if (v4) KGE_SWEEP(32, true); else KGE_SWEEP(32, false); }
-#undef KGE_SWEEP
+    launch_sweep(BK, v4, grid, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
   }
   if (npairs > 0)
     hipLaunchKernelGGL(rank_filter_kernel, dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
@@ -527,10 +705,7 @@ int rank_sweep_q(const float* Q, int64_t nq, int K, const float* Ec, int cand_of
     splits = (int)cdiv(nct, tpb);
     const bool v4 = (K % 4 == 0) && ((uintptr_t)Ec % 16 == 0);
     dim3 grid(nqt, splits);
-#define KGE_SWEEP(BKV, V4) hipLaunchKernelGGL((rank_sweep_kernel<BKV, V4>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
-    if (BK == 40) { if (v4) KGE_SWEEP(40, true); else KGE_SWEEP(40, false); }
-    else { if (v4) KGE_SWEEP(32, true); else KGE_SWEEP(32, false); }
-#undef KGE_SWEEP
+    launch_sweep(BK, v4, grid, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
   }
   if (npairs > 0)
     hipLaunchKernelGGL(rank_filter_kernel, dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
