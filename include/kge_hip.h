@@ -166,6 +166,17 @@ int kge_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, con
                           float* stats, float* gradE, float* gradRel, float* gtheta, const int32_t* pos, int64_t m_pos,
                           const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
                           int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* ---- HolE without dropout in the frequency domain (models.py:231-237: real(ifft(conj(fft(s)) * fft(o))) . p).  By Parseval the
+ *      score is the ComplEx score (models.py:218-222) of the half spectra of the three rows, so a step transforms the two tables
+ *      (kge_hole_spec_forward: out (rows, w) = X (rows, d) * W (d, w), w = kge_hole_spec_width(d) = 2 * roundup4(d/2 + 1), layout
+ *      [real | imag]), runs kge_train_grads with model = KGE_COMPLEX, d_e = d_r = w on the spectra, and carries the gradients
+ *      back (kge_hole_spec_adjoint: G (rows, d) += Ghat (rows, w) * W^T; zero_hat != 0 re-zeroes Ghat).  kge_hole_spec_basis
+ *      fills the two bases: WE for the entity table, WR (columns weighted by the Hermitian multiplicity / d) for the relation
+ *      table.  Dropout steps keep the direct correlation kernels (every triple masks its own rows). */
+int32_t kge_hole_spec_width(int32_t d);
+int kge_hole_spec_basis(int32_t d, float* WE, float* WR, kge_stream_t stream);
+int kge_hole_spec_forward(const float* X, int64_t rows, int32_t d, const float* W, float* out, kge_stream_t stream);
+int kge_hole_spec_adjoint(float* Ghat, int64_t rows, int32_t d, const float* W, float* G, int32_t zero_hat, kge_stream_t stream);
 /* ---- LiteralE-style input path (models.py:114-120,152-158; tests.py:113,125-126): s_hat = act(Dense([dp(E[s]) ; dp(Lit[s])])),
  *      o_hat likewise with the same Dense, score = func(s_hat, dp(Rel[p]), o_hat).  Lit is the frozen (lit_rows, L) literal table,
  *      theta_l = [W (d_e + L, d_e) row-major | b (d_e)], act = 0 linear, 1 relu, 2 sigmoid, 3 tanh, 4 softplus, 5 softsign, 6 elu,

@@ -160,6 +160,10 @@ int conve_train_grads(const kge_model_desc*, const kge_loss_desc*, const float*,
                       const int32_t*, int64_t, const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
 int opt_apply_vector(const kge_opt_desc*, float*, float*, int64_t, float, hipStream_t);
 int64_t lit_workspace_bytes(const kge_model_desc*, int, int64_t, int64_t);
+int hole_spec_half(int);
+int hole_spec_basis(int, float*, float*, hipStream_t);
+int hole_spec_forward(const float*, int64_t, int, const float*, float*, hipStream_t);
+int hole_spec_adjoint(float*, int64_t, int, const float*, float*, int, hipStream_t);
 int64_t lit_transform_workspace_bytes(const kge_model_desc*, int, int);
 int lit_transform(const kge_model_desc*, int, const float*, const float*, int, int, const float*, int, float*, void*, int64_t, uint32_t*, hipStream_t);
 int lit_train_grads(const kge_model_desc*, const kge_loss_desc*, int, const float*, const float*, const float*, int, int, const float*, float*, float*,
@@ -530,6 +534,29 @@ int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* 
     return fail(KGE_EINVAL, "kge_rank_sweep_q: bad arguments");
   return rank_sweep_q(Q, n_queries, K, Cand, cand_offset, cand_rows, target_ids, filt_query, filt_ids, n_filt, counts, accumulate, workspace,
                       workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int32_t kge_hole_spec_width(int32_t d) {
+  if (d <= 0) return fail(KGE_EINVAL, "kge_hole_spec_width: d must be positive");
+  return 2 * hole_spec_half(d);
+}
+
+int kge_hole_spec_basis(int32_t d, float* WE, float* WR, kge_stream_t stream) {
+  clear_stale_error();
+  if (d <= 0 || !WE || !WR) return fail(KGE_EINVAL, "kge_hole_spec_basis: bad arguments");
+  return hole_spec_basis(d, WE, WR, static_cast<hipStream_t>(stream));
+}
+
+int kge_hole_spec_forward(const float* X, int64_t rows, int32_t d, const float* W, float* out, kge_stream_t stream) {
+  clear_stale_error();
+  if (rows < 0 || rows > 0x7fffffffLL || d <= 0 || (rows && (!X || !W || !out))) return fail(KGE_EINVAL, "kge_hole_spec_forward: bad arguments");
+  return hole_spec_forward(X, rows, d, W, out, static_cast<hipStream_t>(stream));
+}
+
+int kge_hole_spec_adjoint(float* Ghat, int64_t rows, int32_t d, const float* W, float* G, int32_t zero_hat, kge_stream_t stream) {
+  clear_stale_error();
+  if (rows < 0 || rows > 0x7fffffffLL || d <= 0 || (rows && (!Ghat || !W || !G))) return fail(KGE_EINVAL, "kge_hole_spec_adjoint: bad arguments");
+  return hole_spec_adjoint(Ghat, rows, d, W, G, zero_hat, static_cast<hipStream_t>(stream));
 }
 
 int64_t kge_lit_workspace_bytes(const kge_model_desc* md, int32_t L, int64_t m_pos, int64_t m_neg) {

@@ -93,4 +93,10 @@ int hole_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
 int hole_build_q(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side, int Kpad,
                  float* Qv, uint32_t* err, hipStream_t st);
 
+// hole_spec.hip: HolE without dropout as ComplEx on half spectra
+int hole_spec_half(int d);
+int hole_spec_basis(int d, float* WE, float* WR, hipStream_t st);
+int hole_spec_forward(const float* X, int64_t rows, int d, const float* W, float* out, hipStream_t st);
+int hole_spec_adjoint(float* Ghat, int64_t rows, int d, const float* W, float* G, int zero_hat, hipStream_t st);
+
 }  // namespace kge

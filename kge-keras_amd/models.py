@@ -413,7 +413,7 @@ class EmbeddingModel:
                                        _lib.stream_ptr()))
         return {"loss": self._loss[0]}
 
-    def train_grads(self, data):
+    def train_grads(self, data, scores_out=None):
         """First half of train_step (forward + loss + gradient accumulation); for data-parallel training an
         all-reduce of `_gE` / `_gR` goes between this and apply_grads."""
         if isinstance(data, BatchPlan):
@@ -424,8 +424,8 @@ class EmbeddingModel:
         self._seed += 1
         check(lib.kge_train_grads(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
                                   self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0],
-                                  self._loss.data_ptr(), None, self._seed, self._ws.data_ptr(), self._ws.numel(),
-                                  self._err.data_ptr(), _lib.stream_ptr()))
+                                  self._loss.data_ptr(), scores_out.data_ptr() if scores_out is not None else None, self._seed,
+                                  self._ws.data_ptr(), self._ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
         return {"loss": self._loss[0]}
 
     def apply_grads(self, grad_scale=1.0):
@@ -637,12 +637,82 @@ class ComplEx(EmbeddingModel):
 
 
 class HolE(EmbeddingModel):
-    """models.py:224-237: score = sum_k p_k * ccorr(s, o)_k, computed directly (O(d^2) per triple) in LDS-tiled VALU kernels;
-    1-vs-all ranking reuses the MFMA sweep with query vectors conv(p, s) / ccorr(p, o) (csrc/hole.hip)."""
+    """models.py:224-237: score = sum_k p_k * ccorr(s, o)_k.
+
+    Training steps without dropout run in the frequency domain (csrc/hole_spec.hip): by Parseval the score is the ComplEx score of
+    the half spectra of the three rows, so a step transforms the two tables once (one GEMM each with the real DFT basis), runs
+    the O(d) ComplEx-shaped kernels -- batch plans and the pipeline included -- on the spectra and carries the gradient tables
+    back through the transposed bases; the optimizer (and the L3 regulariser) act on the real tables as before.
+    Steps with dropout (every triple masks its own rows before the correlation), predict and the query vectors of the 1-vs-all
+    sweep use the direct O(d^2) LDS-tiled kernels of csrc/hole.hip.  `spectral=False` (or KGE_HOLE_SPECTRAL=0) keeps the direct
+    kernels for every step."""
     MODEL = "HolE"
 
     def __init__(self, name='HolE', **kwargs):
         super().__init__(name=name, **kwargs)
+        self._spec = None
+
+    # ---- frequency-domain training path
+    def _spectral_on(self):
+        import os
+        if self.dp != 0 or self._lit is not None or int(self.e_dim) != int(self.r_dim):
+            return False
+        if not getattr(self, "spectral", True) or os.environ.get("KGE_HOLE_SPECTRAL", "1") == "0":
+            return False
+        return lib.kge_hole_spec_width(int(self.e_dim)) // 2 <= 256  # row width the relation-grouped ComplEx kernels take
+
+    def _spec_state(self):
+        if self.optimizer is None:
+            raise RuntimeError("You must compile your model before training/testing. Use `model.compile(optimizer, loss)`.")
+        if self._spec is None:
+            d = int(self.e_dim)
+            w = int(lib.kge_hole_spec_width(d))
+            WE = torch.empty(d, w, dtype=torch.float32, device=self.device)
+            WR = torch.empty(d, w, dtype=torch.float32, device=self.device)
+            check(lib.kge_hole_spec_basis(d, WE.data_ptr(), WR.data_ptr(), _lib.stream_ptr()))
+            inner = ComplEx(e_dim=w // 2, r_dim=w // 2, num_entities=self.num_entities, num_relations=self.num_relations, dp=0,
+                            loss_function=self.loss_function, margin=self.margin, seed=0, name=self.name + '_spectra')
+            inner.compile('sgd')  # allocates the spectral gradient accumulators; its optimizer is never applied
+            inner._loss = self._loss  # the loss word and the error flag of the step are the outer model's
+            inner._err = self._err
+            self._spec = dict(WE=WE, WR=WR, inner=inner, w=w)
+        sp = self._spec
+        inner = sp["inner"]
+        inner.loss_function, inner.margin, inner.loss_negative_samples = self.loss_function, self.margin, self.loss_negative_samples
+        return sp
+
+    def plan_supported(self):
+        return self._spectral_on() and self.optimizer is not None and self._spec_state()["inner"].plan_supported()
+
+    def plan_batch(self, data, out=None, parts=7):
+        return self._spec_state()["inner"].plan_batch(data, out=out, parts=parts)
+
+    def plan_batch_counted(self, *a, **kw):
+        return self._spec_state()["inner"].plan_batch_counted(*a, **kw)
+
+    def train_grads(self, data, scores_out=None):
+        if not self._spectral_on():
+            if isinstance(data, BatchPlan):
+                raise ValueError("a BatchPlan exists for HolE only on the frequency-domain path (dp == 0)")
+            return super().train_grads(data, scores_out)
+        sp = self._spec_state()
+        inner, d, st = sp["inner"], int(self.e_dim), _lib.stream_ptr()
+        self._ensure_train_state(1, 1)  # optimizer slots + the workspace of kge_opt_apply
+        check(lib.kge_hole_spec_forward(self.E.data_ptr(), self.num_entities, d, sp["WE"].data_ptr(), inner.E.data_ptr(), st))
+        check(lib.kge_hole_spec_forward(self.Rel.data_ptr(), self.num_relations, d, sp["WR"].data_ptr(), inner.Rel.data_ptr(), st))
+        inner.train_grads(data, scores_out)
+        check(lib.kge_hole_spec_adjoint(inner._gE.data_ptr(), self.num_entities, d, sp["WE"].data_ptr(), self._gE.data_ptr(), 1, st))
+        check(lib.kge_hole_spec_adjoint(inner._gR.data_ptr(), self.num_relations, d, sp["WR"].data_ptr(), self._gR.data_ptr(), 1, st))
+        return {"loss": self._loss[0]}
+
+    def train_step(self, data, scores_out=None):
+        if not self._spectral_on():
+            return super().train_step(data, scores_out)
+        if isinstance(data, tuple) and len(data) == 2 and (data[1] is None or isinstance(data[0], (list, tuple))):
+            data = data[0]
+        self.train_grads(data, scores_out)
+        self.apply_grads()
+        return {"loss": self._loss[0]}
 
 
 class ConvE(EmbeddingModel):
