@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
 //     the prefetch of the next chunk is 10 address computations + 10 loads with no branch and can be scheduled between MFMAs;
 //   * the prefetch after the last chunk re-reads the block's first chunk (no branch; the values are dropped).
 // The k order of every accumulation chain is the one documented at the top of the file (same LDS image, same reads).
-template <int BK, bool TAIL>
+template <int BK, bool TAIL, int DBG = 0>
 __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                            int64_t nq, const float* __restrict__ Ec, int K, int Kpad,
                                                            int cand_rows, int tiles_per_block, int32_t* __restrict__ counts) {
@@ -333,9 +333,13 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     for (int kc = 0; kc < nchunk; ++kc) {
-      __syncthreads();  // everyone is done reading the previous chunk
-      KGE_ST1(0) KGE_ST1(1) KGE_ST1(2) KGE_ST1(3) KGE_ST1(4)
-      __syncthreads();
+      if (!(DBG & 1)) __syncthreads();  // everyone is done reading the previous chunk
+      if (!(DBG & 5)) {
+        KGE_ST1(0) KGE_ST1(1) KGE_ST1(2) KGE_ST1(3) KGE_ST1(4)
+      } else if (pa0.x + pb0.x + pa1.x + pb1.x + pa2.x + pb2.x + pa3.x + pb3.x + pa4.x + pb4.x == 1.2345e30f) {
+        As[tid] = 0.f;  // timing experiments only: keeps the loads alive
+      }
+      if (!(DBG & 1)) __syncthreads();
       // next chunk (after the last one: the block's first chunk again, dropped); its loads are issued one staging slot per
       // group of 16 MFMAs, between scheduling barriers, so the address arithmetic runs in the shadow of the matrix pipe and
       // every load has at least one full group ahead of it before the chunk ends
@@ -360,11 +364,13 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
         if (j + 1 < BK / 8) {
           if ((j & 1) == 0) { KGE_FRAG(1, j + 1) } else { KGE_FRAG(0, j + 1) }
         }
-        if (j == 0) { KGE_PF1(0, nc0, nk0) }
-        if (j == 1) { KGE_PF1(1, nc0, nk0) }
-        if (j == 2) { KGE_PF1(2, nc0, nk0) }
-        if (j == 3) { KGE_PF1(3, nc0, nk0) }
-        if (j == 4) { KGE_PF1(4, nc0, nk0) }
+        if (!(DBG & 2)) {
+          if (j == 0) { KGE_PF1(0, nc0, nk0) }
+          if (j == 1) { KGE_PF1(1, nc0, nk0) }
+          if (j == 2) { KGE_PF1(2, nc0, nk0) }
+          if (j == 3) { KGE_PF1(3, nc0, nk0) }
+          if (j == 4) { KGE_PF1(4, nc0, nk0) }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
         else { KGE_STEP(1, x) KGE_STEP(1, y) KGE_STEP(1, z) KGE_STEP(1, w) }
@@ -587,6 +593,14 @@ static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float
 #define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
   if (v4 && sweep_variant() == 0) {
     const bool tail = Kpad != K;
+    static const int dbg = [] { const char* e = getenv("KGE_RANK_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg && BK == 40 && !tail) {  // TIMING EXPERIMENTS (wrong results)
+      if (dbg == 1) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 1>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
+      if (dbg == 2) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 2>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
+      if (dbg == 3) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 3>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
+      if (dbg == 4) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 4>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
+      return;
+    }
     if (BK == 40) { if (tail) KGE_SWEEP(rank_sweep4_kernel, 40, true); else KGE_SWEEP(rank_sweep4_kernel, 40, false); }
     else { if (tail) KGE_SWEEP(rank_sweep4_kernel, 32, true); else KGE_SWEEP(rank_sweep4_kernel, 32, false); }
   } else {
