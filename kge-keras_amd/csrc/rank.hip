@@ -115,6 +115,68 @@ __global__ __launch_bounds__(256) void rank_target_kernel(const float* __restric
   if (zero_counts) counts[q] = 0;
 }
 
+// Target scores for rows of K % 4 == 0 floats on 16-byte boundaries: one wave per 64 queries.  A thread per query alone
+// (rank_target_kernel) is latency bound -- 1.25 waves per CU at 20 466 queries, every load instruction touching 64 different
+// rows (63-75 us).  Here the wave copies the 64 query rows and the 64 target rows chunk by chunk into LDS with coalesced 128-bit
+// loads (ten consecutive lanes read 160 contiguous bytes of one row), the next chunk in flight in registers behind the current
+// one, and every lane then runs ITS query's chain from LDS -- the same fmaf sequence in the same k order as chain_dot().
+template <int BK>
+__global__ __launch_bounds__(64) void rank_target4_kernel(const float* __restrict__ Qv, const float* __restrict__ E,
+                                                           const int32_t* __restrict__ triples, int nq, int side, int N, int K,
+                                                           int Kpad, float* __restrict__ tgt, int32_t* __restrict__ counts,
+                                                           int zero_counts) {
+  constexpr int LS = BK + 4, C4 = BK / 4, PF = C4;  // 64 rows x C4 float4 per operand per chunk = C4 per lane
+  __shared__ __attribute__((aligned(16))) float Aq[64 * LS];
+  __shared__ __attribute__((aligned(16))) float Ae[64 * LS];
+  __shared__ int trow[64];
+  const int lane = threadIdx.x;
+  const int q0 = blockIdx.x * 64;
+  const int q = q0 + lane;
+  int t = -1;
+  if (q < nq) t = triples[3 * (int64_t)q + (side == 0 ? 2 : 0)];
+  const bool ok = (unsigned)t < (unsigned)N;
+  trow[lane] = ok ? t : 0;
+  __syncthreads();
+  const int last_q = nq - 1, nchunk = Kpad / BK;
+  float4 pa[PF], pb[PF];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = lane + u * 64, r = idx / C4, c = (idx - r * C4) * 4, k = kc * BK + c;
+      pa[u] = *reinterpret_cast<const float4*>(Qv + (int64_t)min(q0 + r, last_q) * Kpad + k);
+      const bool in = k < K;  // K % 4 == 0: inside the row or entirely in the padding
+      const float4 v = *reinterpret_cast<const float4*>(E + (int64_t)trow[r] * K + (in ? k : 0));
+      pb[u] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(0);
+  float acc = 0.f;
+  for (int kc = 0; kc < nchunk; ++kc) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = lane + u * 64, r = idx / C4, c = (idx - r * C4) * 4;
+      *reinterpret_cast<float4*>(Aq + r * LS + c) = pa[u];
+      *reinterpret_cast<float4*>(Ae + r * LS + c) = pb[u];
+    }
+    __syncthreads();
+    if (kc + 1 < nchunk) fetch(kc + 1);
+#pragma unroll
+    for (int b = 0; b < BK / 8; ++b) {
+      const float4 qa = *reinterpret_cast<const float4*>(Aq + lane * LS + 8 * b), qb = *reinterpret_cast<const float4*>(Aq + lane * LS + 8 * b + 4);
+      const float4 ea = *reinterpret_cast<const float4*>(Ae + lane * LS + 8 * b), eb = *reinterpret_cast<const float4*>(Ae + lane * LS + 8 * b + 4);
+      acc = __fmaf_rn(qa.x, ea.x, acc); acc = __fmaf_rn(qb.x, eb.x, acc);
+      acc = __fmaf_rn(qa.y, ea.y, acc); acc = __fmaf_rn(qb.y, eb.y, acc);
+      acc = __fmaf_rn(qa.z, ea.z, acc); acc = __fmaf_rn(qb.z, eb.z, acc);
+      acc = __fmaf_rn(qa.w, ea.w, acc); acc = __fmaf_rn(qb.w, eb.w, acc);
+    }
+  }
+  if (q < nq) {
+    tgt[q] = ok ? acc : __builtin_nanf("");
+    if (zero_counts) counts[q] = 0;
+  }
+}
+
 template <int BK, bool VEC4>
 __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                           int64_t nq, const float* __restrict__ Ec, int K, int Kpad,
@@ -249,33 +311,44 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
 
 // Same sweep for rows of K % 4 == 0 floats on 16-byte boundaries (every table the models hand over), built so that the
 // matrix pipe is the only thing a wave waits for:
-//   * candidate tile / k chunk are nested loops, the four accumulators are zeroed and consumed once per tile, so they stay in
-//     accumulator registers for the whole tile (the flattened loop of the generic kernel makes the compiler carry them in
-//     VGPRs and copy 64 registers in and out of the accumulator file every chunk);
+//   * PERSISTENT and BALANCED: the grid is one workgroup per residency slot (2 per CU); the (query tile, candidate tile) units,
+//     query-major, are cut into gridDim.x equal contiguous ranges (+-1 unit), so there is no partially filled last round of
+//     workgroups (3680 workgroups over 512 slots lost ~10 % there) and the per-workgroup prologue is paid once.  A range that
+//     crosses into the next query tile flushes its counters (LDS -> one global atomic per query row) and reloads the targets.
+//     Workgroup b takes the logical range (b mod 8)*(grid/8) + b/8: workgroups are dealt round-robin to the 8 XCDs, so each
+//     XCD's L2 sees ~20 neighbouring query tiles and, across them, the same few candidate tiles at a time;
+//   * candidate tile / k chunk are nested loops, the four accumulators are zeroed and consumed once per tile and (VGPR-form
+//     MFMA, see the Makefile) never move (the flattened loop of the generic kernel makes the compiler carry them in VGPRs and
+//     copy 64 registers in and out of the accumulator file every chunk);
 //   * the staging slots of a thread (tile row, float4 column) are loop invariant; rows past the end are clamped to the last
 //     valid row instead of predicated (queries past nq never store, candidates past cand_rows are masked in the epilogue), so
-//     the prefetch of the next chunk is 10 address computations + 10 loads with no branch and can be scheduled between MFMAs;
-//   * the prefetch after the last chunk re-reads the block's first chunk (no branch; the values are dropped).
+//     the prefetch of the next chunk is 10 address computations + 10 loads with no branch, issued one slot per group of 16
+//     MFMAs between scheduling barriers; the LDS fragments of group j+1 are read while group j multiplies;
+//   * the prefetch after the very last chunk re-reads the current unit's first chunk (no branch; the values are dropped).
 // The k order of every accumulation chain is the one documented at the top of the file (same LDS image, same reads).
-template <int BK, bool TAIL, int DBG = 0>
+template <int BK, bool TAIL>
 __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
-                                                           int64_t nq, const float* __restrict__ Ec, int K, int Kpad,
-                                                           int cand_rows, int tiles_per_block, int32_t* __restrict__ counts) {
+                                                           int nq, const float* __restrict__ Ec, int K, int Kpad,
+                                                           int cand_rows, int32_t* __restrict__ counts) {
   constexpr int LS = BK + 4;
   constexpr int C4 = BK / 4;
   constexpr int PF = kTile * C4 / 256;
   static_assert(kTile * C4 % 256 == 0, "staging slots must divide evenly");
+  static_assert(PF == 4 || PF == 5, "staging code is written for 4 or 5 slots per thread");
   __shared__ __attribute__((aligned(16))) float As[kTile * LS];
   __shared__ __attribute__((aligned(16))) float Bs[kTile * LS];
   __shared__ int cnt_s[kTile];
   __shared__ float tg_s[kTile];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
-  const int64_t q0 = (int64_t)blockIdx.x * kTile;
-  const int nct = (cand_rows + kTile - 1) / kTile;
-  const int ct_begin = blockIdx.y * tiles_per_block;
-  const int ct_end = min(nct, ct_begin + tiles_per_block);
-  if (ct_begin >= ct_end) return;
+  const int nqt = (nq + kTile - 1) / kTile, nct = (cand_rows + kTile - 1) / kTile;
+  const int64_t total = (int64_t)nqt * nct;
+  const int nb = gridDim.x;
+  const int lb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int64_t u_begin = total * lb / nb, u_end = total * (lb + 1) / nb;
+  if (u_begin >= u_end) return;
+  int qt = (int)(u_begin / nct), ct = (int)(u_begin - (int64_t)qt * nct);
+  int q0 = qt * kTile;
 
   int cnt[2][16];  // one counter per accumulator row (both candidate halves of the wave tile add into it)
 #pragma unroll
@@ -284,23 +357,22 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
     for (int r = 0; r < 16; ++r) cnt[rt][r] = 0;
   if (tid < kTile) {
     cnt_s[tid] = 0;
-    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : __builtin_inff();
+    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : __builtin_inff();  // nothing is > +inf; NaN targets count nothing either
   }
 
   // loop-invariant staging slots; named scalars (PF is 4 or 5), slot 4 is compiled out when PF == 4
-  static_assert(PF == 4 || PF == 5, "staging code is written for 4 or 5 slots per thread");
-  const int last_row = cand_rows - 1;
+  const int last_row = cand_rows - 1, last_q = nq - 1;
   const int nchunk = Kpad / BK;
 #define KGE_SLOT(U)                                                                  \
   const int r##U = (tid + U * 256) / C4, cB##U = ((tid + U * 256) - r##U * C4) * 4;  \
-  const float* const pA##U = Qv + min(q0 + r##U, nq - 1) * Kpad + cB##U;             \
   const int lo##U = r##U * LS + cB##U;                                               \
   float4 pa##U, pb##U;
   KGE_SLOT(0) KGE_SLOT(1) KGE_SLOT(2) KGE_SLOT(3) KGE_SLOT(4)
 #undef KGE_SLOT
-#define KGE_PF1(U, C0, K0)                                                                                         \
+#define KGE_PF1(U, Q0, C0, K0)                                                                                     \
   if (U < PF) {                                                                                                    \
-    pa##U = *reinterpret_cast<const float4*>(pA##U + (K0));                                                        \
+    const int qrow_ = min((Q0) + r##U, last_q);                                                                    \
+    pa##U = *reinterpret_cast<const float4*>(Qv + (int64_t)qrow_ * Kpad + (K0) + cB##U);                           \
     const int row_ = min((C0) + r##U, last_row);                                                                   \
     if (TAIL) { /* K % 4 == 0: a float4 is inside the row or entirely in the padding */                            \
       const bool in_ = (K0) + cB##U < K;                                                                           \
@@ -310,11 +382,6 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
       pb##U = *reinterpret_cast<const float4*>(Ec + (int64_t)row_ * K + (K0) + cB##U);                             \
     }                                                                                                              \
   }
-#define KGE_PREFETCH(CT, KC)                                                                                       \
-  {                                                                                                                \
-    const int c0_ = (CT) * kTile, k0_ = (KC) * BK;                                                                 \
-    KGE_PF1(0, c0_, k0_) KGE_PF1(1, c0_, k0_) KGE_PF1(2, c0_, k0_) KGE_PF1(3, c0_, k0_) KGE_PF1(4, c0_, k0_)       \
-  }
 #define KGE_ST1(U)                                                   \
   if (U < PF) {                                                      \
     *reinterpret_cast<float4*>(As + lo##U) = pa##U;                  \
@@ -323,8 +390,18 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
   const float* a_rd = As + (wq * 64 + l31) * LS + 4 * half;
   const float* b_rd = Bs + (wc * 64 + l31) * LS + 4 * half;
 
-  KGE_PREFETCH(ct_begin, 0)
-  for (int ct = ct_begin; ct < ct_end; ++ct) {
+  {
+    const int c0_ = ct * kTile;
+    KGE_PF1(0, q0, c0_, 0) KGE_PF1(1, q0, c0_, 0) KGE_PF1(2, q0, c0_, 0) KGE_PF1(3, q0, c0_, 0) KGE_PF1(4, q0, c0_, 0)
+  }
+  for (int64_t u = u_begin; u < u_end; ++u) {
+    // coordinates of the next unit of this workgroup's range (after the last one: this unit again, its values are dropped)
+    const bool has_next = u + 1 < u_end;
+    int nqt_ = qt, nct_ = ct;
+    if (has_next) {
+      nct_ = ct + 1;
+      if (nct_ == nct) { nct_ = 0; nqt_ = qt + 1; }
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -333,19 +410,13 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     for (int kc = 0; kc < nchunk; ++kc) {
-      if (!(DBG & 1)) __syncthreads();  // everyone is done reading the previous chunk
-      if (!(DBG & 5)) {
-        KGE_ST1(0) KGE_ST1(1) KGE_ST1(2) KGE_ST1(3) KGE_ST1(4)
-      } else if (pa0.x + pb0.x + pa1.x + pb1.x + pa2.x + pb2.x + pa3.x + pb3.x + pa4.x + pb4.x == 1.2345e30f) {
-        As[tid] = 0.f;  // timing experiments only: keeps the loads alive
-      }
-      if (!(DBG & 1)) __syncthreads();
-      // next chunk (after the last one: the block's first chunk again, dropped); its loads are issued one staging slot per
-      // group of 16 MFMAs, between scheduling barriers, so the address arithmetic runs in the shadow of the matrix pipe and
-      // every load has at least one full group ahead of it before the chunk ends
-      int nk = kc + 1, nt = ct;
-      if (nk == nchunk) { nk = 0; nt = ct + 1 < ct_end ? ct + 1 : ct_begin; }
-      const int nc0 = nt * kTile, nk0 = nk * BK;
+      __syncthreads();  // everyone is done reading the previous chunk
+      KGE_ST1(0) KGE_ST1(1) KGE_ST1(2) KGE_ST1(3) KGE_ST1(4)
+      __syncthreads();
+      // next chunk: its loads are issued one staging slot per group of 16 MFMAs, between scheduling barriers, so the address
+      // arithmetic runs in the shadow of the matrix pipe and every load has at least one full group ahead of it
+      const bool wrap = kc + 1 == nchunk;
+      const int nq0 = wrap ? nqt_ * kTile : q0, nc0 = (wrap ? nct_ : ct) * kTile, nk0 = wrap ? 0 : (kc + 1) * BK;
       float4 fa[2][2], fb[2][2];  // [buffer][row tile]: the fragments of group j+1 are read while group j multiplies
 #define KGE_FRAG(BUF, J)                                                                          \
   _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                 \
@@ -364,13 +435,11 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
         if (j + 1 < BK / 8) {
           if ((j & 1) == 0) { KGE_FRAG(1, j + 1) } else { KGE_FRAG(0, j + 1) }
         }
-        if (!(DBG & 2)) {
-          if (j == 0) { KGE_PF1(0, nc0, nk0) }
-          if (j == 1) { KGE_PF1(1, nc0, nk0) }
-          if (j == 2) { KGE_PF1(2, nc0, nk0) }
-          if (j == 3) { KGE_PF1(3, nc0, nk0) }
-          if (j == 4) { KGE_PF1(4, nc0, nk0) }
-        }
+        if (j == 0) { KGE_PF1(0, nq0, nc0, nk0) }
+        if (j == 1) { KGE_PF1(1, nq0, nc0, nk0) }
+        if (j == 2) { KGE_PF1(2, nq0, nc0, nk0) }
+        if (j == 3) { KGE_PF1(3, nq0, nc0, nk0) }
+        if (j == 4) { KGE_PF1(4, nq0, nc0, nk0) }
         __builtin_amdgcn_sched_barrier(0);
         if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
         else { KGE_STEP(1, x) KGE_STEP(1, y) KGE_STEP(1, z) KGE_STEP(1, w) }
@@ -398,20 +467,31 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
           cnt[rt][r] += ((v0 && acc[rt][0][r] > tgv) ? 1 : 0) + ((v1 && acc[rt][1][r] > tgv) ? 1 : 0);
         }
     }
+    if (!has_next || nqt_ != qt) {  // uniform: the range leaves this query tile -> flush its counters
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
+          cnt[rt][r] = 0;
+        }
+      __syncthreads();
+      if (tid < kTile) {
+        if (q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
+        if (has_next) {  // read again after the two barriers of the next chunk
+          const int nq0_ = nqt_ * kTile;
+          cnt_s[tid] = 0;
+          tg_s[tid] = nq0_ + tid < nq ? tgt[nq0_ + tid] : __builtin_inff();
+        }
+      }
+    }
+    qt = nqt_;
+    ct = nct_;
+    q0 = qt * kTile;
   }
-#undef KGE_PREFETCH
 #undef KGE_PF1
 #undef KGE_ST1
-  __syncthreads();
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
-    }
-  __syncthreads();
-  if (tid < kTile && q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
 }
 
 // One thread per CSR entry (query pair_q[e], filtered global id filt_ids[e]); un-counts it if it was counted.
@@ -587,22 +667,23 @@ static int sweep_variant() {  // KGE_RANK_SWEEP=1 selects the generic (predicate
   return v;
 }
 
+static int sweep_slots() {  // workgroups of the persistent sweep: two per CU (register and LDS budget of rank_sweep4_kernel)
+  static const int v = [] { const char* e = getenv("KGE_RANK_SLOTS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 2 * kCUs; }();
+  return v;
+}
+
 static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float* Qv, const float* tgt, int64_t nq, const float* Ec,
                          int K, int Kpad, int cand_rows, int tpb, int32_t* counts) {
   if (nq <= 0 || cand_rows <= 0) return;
 #define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
-  if (v4 && sweep_variant() == 0) {
+  if (v4 && sweep_variant() == 0 && nq < (int64_t)1 << 30) {
     const bool tail = Kpad != K;
-    static const int dbg = [] { const char* e = getenv("KGE_RANK_DBG"); return e ? atoi(e) : 0; }();
-    if (dbg && BK == 40 && !tail) {  // TIMING EXPERIMENTS (wrong results)
-      if (dbg == 1) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 1>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
-      if (dbg == 2) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 2>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
-      if (dbg == 3) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 3>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
-      if (dbg == 4) hipLaunchKernelGGL((rank_sweep4_kernel<40, false, 4>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
-      return;
-    }
-    if (BK == 40) { if (tail) KGE_SWEEP(rank_sweep4_kernel, 40, true); else KGE_SWEEP(rank_sweep4_kernel, 40, false); }
-    else { if (tail) KGE_SWEEP(rank_sweep4_kernel, 32, true); else KGE_SWEEP(rank_sweep4_kernel, 32, false); }
+    const int64_t units = cdiv(nq, kTile) * cdiv(cand_rows, kTile);
+    const dim3 pgrid((unsigned)std::min<int64_t>(units, sweep_slots()));
+#define KGE_SWEEP4(BKV, FLAG) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts)
+    if (BK == 40) { if (tail) KGE_SWEEP4(40, true); else KGE_SWEEP4(40, false); }
+    else { if (tail) KGE_SWEEP4(32, true); else KGE_SWEEP4(32, false); }
+#undef KGE_SWEEP4
   } else {
     if (BK == 40) { if (v4) KGE_SWEEP(rank_sweep_kernel, 40, true); else KGE_SWEEP(rank_sweep_kernel, 40, false); }
     else { if (v4) KGE_SWEEP(rank_sweep_kernel, 32, true); else KGE_SWEEP(rank_sweep_kernel, 32, false); }
@@ -662,7 +743,12 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
-  hipLaunchKernelGGL(rank_target_kernel, dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
+  if ((K % 4 == 0) && ((uintptr_t)E % 16 == 0) && nq < (int64_t)1 << 30 && sweep_variant() == 0) {
+    if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
+    else hipLaunchKernelGGL((rank_target4_kernel<32>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
+  } else {
+    hipLaunchKernelGGL(rank_target_kernel, dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
+  }
   {
     const int nqt = (int)cdiv(nq, kTile), nct = (int)cdiv(cand_rows, kTile);
     int splits = (int)cdiv(rank_blocks_target(), nqt);  // >= ~16 blocks per CU so the last, partially filled round is short
