@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 2
+#define KGE_ABI_VERSION 3
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -60,11 +60,13 @@ typedef struct {
   int32_t num_entities;  /* rows of E */
   int32_t num_relations; /* rows of Rel */
   int32_t d_e, d_r;      /* row widths in floats (ComplEx: 2*e_dim, models.py:208-209) */
-  int32_t norm;          /* TransE: 1 or 2 (models.py:178,188) */
+  int32_t norm;          /* TransE: 1 or 2 (models.py:178,188); 3 = the phase distance of pRotatE (models.py:479-489):
+                          * dist = modulus * sum_k |sin((s_k + p_k - o_k) / 2)|, same gamma convention (models.py:486-489) */
   float gamma;           /* TransE (models.py:179,187-190): score = gamma - dist if gamma > 0 else +dist */
   float dropout;         /* Dropout(dp) on the three gathered rows, training only (models.py:122,144-148) */
   int32_t conv_filters;  /* ConvE: Conv2D filters (models.py:242; 8 is built) */
   float hidden_dropout;  /* ConvE: Dropout(hidden_dp) after each batch norm (models.py:241,257,262) */
+  float modulus;         /* norm 3 only (models.py:476: modulus * embedding_range) */
 } kge_model_desc;
 
 /* loss_function(true, false, margin, negative_samples) as called at tests.py:80-81. */

@@ -34,7 +34,8 @@ int check_model(const kge_model_desc* md, const char* who) {
   // s*p*o, s+p-o and the ComplEx products broadcast row-against-row: TensorFlow rejects unequal widths
   if (md->d_e != md->d_r) return fail(KGE_ESHAPE, "%s: e_dim %d and r_dim %d do not broadcast", who, md->d_e, md->d_r);
   if (md->model == KGE_COMPLEX && (md->d_e & 1)) return fail(KGE_ESHAPE, "%s: ComplEx rows must split in two halves (tf.split), width %d", who, md->d_e);
-  if (md->model == KGE_TRANSE && md->norm != 1 && md->norm != 2) return fail(KGE_EUNSUPPORTED, "%s: TransE norm %d (only 1 and 2 are built)", who, md->norm);
+  if (md->model == KGE_TRANSE && md->norm != 1 && md->norm != 2 && md->norm != 3)
+    return fail(KGE_EUNSUPPORTED, "%s: TransE norm %d (1, 2 and the pRotatE phase distance 3 are built)", who, md->norm);
   if (!(md->dropout >= 0.f && md->dropout < 1.f)) return fail(KGE_EINVAL, "%s: dropout rate %f outside [0,1)", who, md->dropout);
   return KGE_OK;
 }

@@ -44,6 +44,16 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// pRotatE phase distance (models.py:479-489; TransE kernels with NORM == 3): per element |sin(x/2)| with x = s + p - o.
+// d|sin(x/2)|/dx = sign(sin(x/2)) * cos(x/2) / 2 (sign(0) = 0 as in TF); the constant modulus/2 is folded into the
+// per-triple coefficient by the forward kernels, phase_dterm() is the element factor.
+__device__ __forceinline__ float phase_abs(float x) { return fabsf(sinf(0.5f * x)); }
+__device__ __forceinline__ float phase_dterm(float x) {
+  float sn, cs;
+  sincosf(0.5f * x, &sn, &cs);
+  return sn > 0.f ? cs : (sn < 0.f ? -cs : 0.f);
+}
+
 // Block-wide sum of one float per thread (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
 __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats */) {
   v = group_sum<64>(v);

@@ -60,6 +60,10 @@ __device__ __forceinline__ float4 vabs(float4 a) { return KGE_F4(fabsf(a.x), fab
 __device__ __forceinline__ float sgn1(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 __device__ __forceinline__ float vsgn(float a) { return sgn1(a); }
 __device__ __forceinline__ float4 vsgn(float4 a) { return KGE_F4(sgn1(a.x), sgn1(a.y), sgn1(a.z), sgn1(a.w)); }
+__device__ __forceinline__ float vphase_abs(float a) { return phase_abs(a); }
+__device__ __forceinline__ float4 vphase_abs(float4 a) { return KGE_F4(phase_abs(a.x), phase_abs(a.y), phase_abs(a.z), phase_abs(a.w)); }
+__device__ __forceinline__ float vphase_dterm(float a) { return phase_dterm(a); }
+__device__ __forceinline__ float4 vphase_dterm(float4 a) { return KGE_F4(phase_dterm(a.x), phase_dterm(a.y), phase_dterm(a.z), phase_dterm(a.w)); }
 __device__ __forceinline__ float shx(float v, int off) { return __shfl_xor(v, off, 64); }
 __device__ __forceinline__ float4 shx(float4 v, int off) {
   return KGE_F4(__shfl_xor(v.x, off, 64), __shfl_xor(v.y, off, 64), __shfl_xor(v.z, off, 64), __shfl_xor(v.w, off, 64));
@@ -71,7 +75,7 @@ template <int MODEL, int NORM, int LOSS, int G, int VEC, bool DROP>
 __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                    const int32_t* __restrict__ pos, int64_t m_pos,
                                                    const int32_t* __restrict__ neg, int64_t m_neg, int N, int R, int d_e,
-                                                   int nchunk, float gamma, float margin, float* __restrict__ coef,
+                                                   int nchunk, float gamma, float modulus, float margin, float* __restrict__ coef,
                                                    float* __restrict__ scores, float* __restrict__ loss_partials,
                                                    uint32_t* __restrict__ err, uint64_t seed, uint32_t thr, float dscale) {
   using C = V<VEC>;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, c
           auto sv = C::ld(es + c * VEC), pv = C::ld(rp + c * VEC), ov = C::ld(eo + c * VEC);
           if (DROP) { sv = sv * D::mul(ks, c, thr, dscale); pv = pv * D::mul(kp, c, thr, dscale); ov = ov * D::mul(ko, c, thr, dscale); }
           if (MODEL == KGE_DISTMULT) acc += hsum(sv * pv * ov);
-          else { auto x = sv + pv - ov; acc += NORM == 1 ? hsum(vabs(x)) : hsum(x * x); }
+          else { auto x = sv + pv - ov; acc += NORM == 1 ? hsum(vabs(x)) : (NORM == 3 ? hsum(vphase_abs(x)) : hsum(x * x)); }
         }
       }
     }
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, c
       float score = acc, dist = acc;
       if (MODEL == KGE_TRANSE) {
         if (NORM == 2) dist = sqrtf(acc);
+        if (NORM == 3) dist = modulus * acc;
         score = gamma > 0.f ? gamma - dist : dist;
       }
       if (!ok) { score = __builtin_nanf(""); atomicOr(err, 1u); }
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, c
         if (MODEL == KGE_TRANSE) {
           g = gamma > 0.f ? -g : g;                            // d score / d dist
           if (NORM == 2) g = dist > 0.f ? g / dist : 0.f;      // d dist / d x = x / dist (0 at the origin; TF: NaN)
+          if (NORM == 3) g *= 0.5f * modulus;                  // d dist / d x = modulus/2 * phase_dterm(x)
         }
         coef[t] = g;
       }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ E, c
 
 // dL/dscore (pairwise path) -> list coefficient, in place
 template <int MODEL, int NORM>
-__global__ void coef_from_g_kernel(const float* __restrict__ scores, float* __restrict__ g, int64_t n, float gamma) {
+__global__ void coef_from_g_kernel(const float* __restrict__ scores, float* __restrict__ g, int64_t n, float gamma, float modulus) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   float c = g[t];
@@ -161,6 +167,7 @@ __global__ void coef_from_g_kernel(const float* __restrict__ scores, float* __re
       const float dist = gamma > 0.f ? gamma - sc : sc;
       c = dist > 0.f ? c / dist : 0.f;
     }
+    if (NORM == 3) c *= 0.5f * modulus;
   }
   g[t] = c;
 }
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
           if (is_rel) x = a + m - b;              // dest p: a = s, b = o
           else if (!kind1) x = m + a - b;         // dest s: a = p, b = o
           else { x = b + a - m; sg = -cf; }        // dest o: a = p, b = s ; d/do = -d/dx
-          T term = sg * (NORM == 1 ? vsgn(x) : x);
+          T term = sg * (NORM == 1 ? vsgn(x) : (NORM == 3 ? vphase_dterm(x) : x));
           if (DROP) term = term * md1;
           acc[j] = acc[j] + term;
         } else {  // ComplEx: halves [real | imag]
@@ -498,7 +505,7 @@ static void launch_fwd(int G, int grid, hipStream_t st, const float* E, const fl
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
 #define KGE_FWD(GW, DR) hipLaunchKernelGGL((fwd_kernel<MODEL, NORM, LOSS, GW, VEC, DR>), dim3(grid), dim3(256), 0, st, E, Rel, pos, m_pos, neg, m_neg, \
-                                           md->num_entities, md->num_relations, md->d_e, nchunk, md->gamma, margin, coef, scores, partials, err, seed, thr, dscale)
+                                           md->num_entities, md->num_relations, md->d_e, nchunk, md->gamma, md->modulus, margin, coef, scores, partials, err, seed, thr, dscale)
 #define KGE_FWD2(GW) do { if (drop) KGE_FWD(GW, true); else KGE_FWD(GW, false); } while (0)
   switch (G) {
     case 4: KGE_FWD2(4); break;
@@ -587,6 +594,7 @@ int pull_forward(const kge_model_desc* md, int loss, float margin, const float* 
   if (md->model == KGE_DISTMULT) KGE_GO(KGE_DISTMULT, 1);
   else if (md->model == KGE_COMPLEX) KGE_GO(KGE_COMPLEX, 1);
   else if (md->norm == 1) KGE_GO(KGE_TRANSE, 1);
+  else if (md->norm == 3) KGE_GO(KGE_TRANSE, 3);
   else KGE_GO(KGE_TRANSE, 2);
 #undef KGE_GO
   KGE_HIP_TRY(hipGetLastError());
@@ -602,10 +610,11 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
   const int tgrid = (int)cdiv(n, 256);
   if (g_is_dscore) {
     if (md->model == KGE_TRANSE) {
-      if (md->norm == 1) hipLaunchKernelGGL((coef_from_g_kernel<KGE_TRANSE, 1>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma);
-      else hipLaunchKernelGGL((coef_from_g_kernel<KGE_TRANSE, 2>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma);
+      if (md->norm == 1) hipLaunchKernelGGL((coef_from_g_kernel<KGE_TRANSE, 1>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma, md->modulus);
+      else if (md->norm == 3) hipLaunchKernelGGL((coef_from_g_kernel<KGE_TRANSE, 3>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma, md->modulus);
+      else hipLaunchKernelGGL((coef_from_g_kernel<KGE_TRANSE, 2>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma, md->modulus);
     } else {
-      hipLaunchKernelGGL((coef_from_g_kernel<KGE_DISTMULT, 1>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma);
+      hipLaunchKernelGGL((coef_from_g_kernel<KGE_DISTMULT, 1>), dim3(tgrid), dim3(256), 0, st, scores, p.coef, n, md->gamma, md->modulus);
     }
   }
   hipLaunchKernelGGL(fill_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, p.coef, p.off, p.ranks, p.entries);
@@ -623,6 +632,7 @@ int pull_backward(const kge_model_desc* md, const float* E, const float* Rel, fl
     if (md->model == KGE_DISTMULT) KGE_GO(KGE_DISTMULT, 1);
     else if (md->model == KGE_COMPLEX) KGE_GO(KGE_COMPLEX, 1);
     else if (md->norm == 1) KGE_GO(KGE_TRANSE, 1);
+    else if (md->norm == 3) KGE_GO(KGE_TRANSE, 3);
     else KGE_GO(KGE_TRANSE, 2);
 #undef KGE_GO
   }
@@ -664,6 +674,7 @@ int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel
     if (md->model == KGE_DISTMULT) launch_pull<KGE_DISTMULT, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
     else if (md->model == KGE_COMPLEX) launch_pull<KGE_COMPLEX, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
     else if (md->norm == 1) launch_pull<KGE_TRANSE, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
+    else if (md->norm == 3) launch_pull<KGE_TRANSE, 3, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
     else launch_pull<KGE_TRANSE, 2, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
   }
   KGE_HIP_TRY(hipGetLastError());

@@ -319,6 +319,8 @@ __device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.
 __device__ __forceinline__ float4 abs4(float4 a) { return make_float4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w)); }
 __device__ __forceinline__ float sg(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 __device__ __forceinline__ float4 sgn4(float4 a) { return make_float4(sg(a.x), sg(a.y), sg(a.z), sg(a.w)); }
+__device__ __forceinline__ float4 phase_abs4(float4 a) { return make_float4(phase_abs(a.x), phase_abs(a.y), phase_abs(a.z), phase_abs(a.w)); }
+__device__ __forceinline__ float4 phase_dterm4(float4 a) { return make_float4(phase_dterm(a.x), phase_dterm(a.y), phase_dterm(a.z), phase_dterm(a.w)); }
 __device__ __forceinline__ float4 shx4(float4 v, int off) {
   return make_float4(__shfl_xor(v.x, off, 64), __shfl_xor(v.y, off, 64), __shfl_xor(v.z, off, 64), __shfl_xor(v.w, off, 64));
 }
@@ -327,7 +329,7 @@ __device__ __forceinline__ float4 shx4(float4 v, int off) {
 // chunks l, l+16, ... (NV of them) of the row (of each half row for ComplEx).
 template <int MODEL, int NORM, int LOSS, int NV, bool DROP>
 __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ E, const float* __restrict__ Rel, int64_t m_pos,
-                                                       int64_t m_neg, int d_e, int nchunk, float gamma, float margin,
+                                                       int64_t m_neg, int d_e, int nchunk, float gamma, float modulus, float margin,
                                                        const int32_t* __restrict__ rcnt, const int32_t* __restrict__ roff,
                                                        const int32_t* __restrict__ rtotal, const int2* __restrict__ rumap,
                                                        const int4* __restrict__ rentries, float* __restrict__ coef,
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
           }
         }
         if (MODEL == KGE_DISTMULT) part += sum4(mul4(mul4(sv[j], pm[j]), ov[j]));
-        else if (MODEL == KGE_TRANSE) { const float4 x = sub4(add4(sv[j], pm[j]), ov[j]); part += NORM == 1 ? sum4(abs4(x)) : sum4(mul4(x, x)); }
+        else if (MODEL == KGE_TRANSE) { const float4 x = sub4(add4(sv[j], pm[j]), ov[j]); part += NORM == 1 ? sum4(abs4(x)) : (NORM == 3 ? sum4(phase_abs4(x)) : sum4(mul4(x, x))); }
         else {
           const float4 sr = sv[j], si = sv[NV + j], pr = pm[j], pi = pm[NV + j], orr = ov[j], oi = ov[NV + j];
           part += sum4(add4(add4(mul4(mul4(sr, pr), orr), mul4(mul4(pr, si), oi)), sub4(mul4(mul4(pi, sr), oi), mul4(mul4(pi, si), orr))));
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
       float score = part, dist = part;
       if (MODEL == KGE_TRANSE) {
         if (NORM == 2) dist = sqrtf(part);
+        if (NORM == 3) dist = modulus * part;
         score = gamma > 0.f ? gamma - dist : dist;
       }
       float g, l;
@@ -406,6 +409,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
       if (MODEL == KGE_TRANSE) {
         g = gamma > 0.f ? -g : g;
         if (NORM == 2) g = dist > 0.f ? g / dist : 0.f;
+        if (NORM == 3) g *= 0.5f * modulus;
       }
       if (lane == 0) {
         lsum += l;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ 
             acc[j] = fma4(f4(g), term, acc[j]);
           } else if (MODEL == KGE_TRANSE) {
             const float4 x = sub4(add4(sv[j], pm[j]), ov[j]);
-            float4 term = NORM == 1 ? sgn4(x) : x;
+            float4 term = NORM == 1 ? sgn4(x) : (NORM == 3 ? phase_dterm4(x) : x);
             if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
             acc[j] = fma4(f4(g), term, acc[j]);
           } else {
@@ -625,7 +629,7 @@ static void launch_fwd_rel(int nv, bool drop, int grid, hipStream_t st, const fl
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
 #define KGE_FR(NVV, DR) hipLaunchKernelGGL((fwd_rel_kernel<MODEL, NORM, LOSS, NVV, DR>), dim3(grid), dim3(256), 0, st, E, Rel, m_pos, m_neg, md->d_e, \
-                                           nchunk, md->gamma, margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, p.ent.coef, scores, p.rslab,  \
+                                           nchunk, md->gamma, md->modulus, margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, p.ent.coef, scores, p.rslab,  \
                                            partials, seed, thr, dscale)
 #define KGE_FR2(NVV) do { if (drop) KGE_FR(NVV, true); else KGE_FR(NVV, false); } while (0)
   if (nv <= 1) KGE_FR2(1);
@@ -763,6 +767,7 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     if (md->model == KGE_DISTMULT) launch_fwd_rel_loss<KGE_DISTMULT, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
     else if (md->model == KGE_COMPLEX) launch_fwd_rel_loss<KGE_COMPLEX, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
     else if (md->norm == 1) launch_fwd_rel_loss<KGE_TRANSE, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else if (md->norm == 3) launch_fwd_rel_loss<KGE_TRANSE, 3>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
     else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
   }
   if (join) KGE_HIP_TRY(hipStreamWaitEvent(st, join, 0));

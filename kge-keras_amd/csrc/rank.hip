@@ -517,36 +517,36 @@ __global__ __launch_bounds__(256) void rank_filter_kernel(const float* __restric
 template <int NORM>
 __device__ __forceinline__ float dist_step(float acc, float q, float e) {
   const float x = q - e;
-  return NORM == 1 ? acc + fabsf(x) : __fmaf_rn(x, x, acc);
+  return NORM == 1 ? acc + fabsf(x) : (NORM == 3 ? acc + phase_abs(x) : __fmaf_rn(x, x, acc));
 }
 template <int NORM>
-__device__ __forceinline__ float dist_score(float acc, float gamma) {
-  const float d = NORM == 1 ? acc : sqrtf(acc);
+__device__ __forceinline__ float dist_score(float acc, float gamma, float modulus) {
+  const float d = NORM == 1 ? acc : (NORM == 3 ? modulus * acc : sqrtf(acc));  // 3: pRotatE phase distance (models.py:479-489)
   return gamma > 0.f ? gamma - d : d;
 }
 template <int NORM>
-__device__ __forceinline__ float dist_chain(const float* __restrict__ q, const float* __restrict__ e, int K, float gamma) {
+__device__ __forceinline__ float dist_chain(const float* __restrict__ q, const float* __restrict__ e, int K, float gamma, float modulus) {
   float acc = 0.f;
   for (int k = 0; k < K; ++k) acc = dist_step<NORM>(acc, q[k], e[k]);
-  return dist_score<NORM>(acc, gamma);
+  return dist_score<NORM>(acc, gamma, modulus);
 }
 
 template <int NORM>
 __global__ __launch_bounds__(256) void rank_dist_target_kernel(const float* __restrict__ Qv, const float* __restrict__ E,
                                                                 const int32_t* __restrict__ triples, int64_t nq, int side, int N,
-                                                                int K, int Kpad, float gamma, float* __restrict__ tgt,
+                                                                int K, int Kpad, float gamma, float modulus, float* __restrict__ tgt,
                                                                 int32_t* __restrict__ counts, int zero_counts) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   const int t = triples[3 * q + (side == 0 ? 2 : 0)];
-  tgt[q] = (unsigned)t < (unsigned)N ? dist_chain<NORM>(Qv + q * Kpad, E + (int64_t)t * K, K, gamma) : __builtin_nanf("");
+  tgt[q] = (unsigned)t < (unsigned)N ? dist_chain<NORM>(Qv + q * Kpad, E + (int64_t)t * K, K, gamma, modulus) : __builtin_nanf("");
   if (zero_counts) counts[q] = 0;
 }
 
 template <int NORM>
 __global__ __launch_bounds__(256) void rank_dist_sweep_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                                int64_t nq, const float* __restrict__ Ec, int K, int Kpad,
-                                                               int cand_rows, int tiles_per_block, float gamma,
+                                                               int cand_rows, int tiles_per_block, float gamma, float modulus,
                                                                int32_t* __restrict__ counts) {
   constexpr int T = 64, BK = 32;  // 64 queries x 64 candidates per block, 32-deep k chunks
   __shared__ __attribute__((aligned(16))) float Qs[BK * T];
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void rank_dist_sweep_kernel(const float* __res
     for (int j = 0; j < 4; ++j) {
       const bool valid = c0 + tx * 4 + j < cand_rows;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) cnt[i] += (valid && dist_score<NORM>(acc[i][j], gamma) > tg[i]) ? 1 : 0;
+      for (int i = 0; i < 4; ++i) cnt[i] += (valid && dist_score<NORM>(acc[i][j], gamma, modulus) > tg[i]) ? 1 : 0;
     }
   }
   __syncthreads();
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void rank_dist_sweep_kernel(const float* __res
 template <int NORM>
 __global__ __launch_bounds__(256) void rank_dist_filter_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                                 const float* __restrict__ Ec, int cand_offset, int cand_rows,
-                                                                int K, int Kpad, float gamma, const int32_t* __restrict__ pair_q,
+                                                                int K, int Kpad, float gamma, float modulus, const int32_t* __restrict__ pair_q,
                                                                 const int32_t* __restrict__ filt_ids, int64_t npairs,
                                                                 int32_t* __restrict__ counts) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -626,16 +626,16 @@ __global__ __launch_bounds__(256) void rank_dist_filter_kernel(const float* __re
   const int q = pair_q[e];
   const int c = filt_ids[e] - cand_offset;
   if ((unsigned)c >= (unsigned)cand_rows) return;
-  if (dist_chain<NORM>(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, gamma) > tgt[q]) atomicSub(&counts[q], 1);
+  if (dist_chain<NORM>(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, gamma, modulus) > tgt[q]) atomicSub(&counts[q], 1);
 }
 
 template <int NORM>
-__global__ void rank_dist_scores_kernel(const float* __restrict__ Qv, const float* __restrict__ Ec, int K, int Kpad, float gamma,
+__global__ void rank_dist_scores_kernel(const float* __restrict__ Qv, const float* __restrict__ Ec, int K, int Kpad, float gamma, float modulus,
                                          int64_t nq, int cand_rows, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq * cand_rows) return;
   const int64_t q = i / cand_rows;
-  out[i] = dist_chain<NORM>(Qv + q * Kpad, Ec + (int64_t)(i - q * cand_rows) * K, K, gamma);
+  out[i] = dist_chain<NORM>(Qv + q * Kpad, Ec + (int64_t)(i - q * cand_rows) * K, K, gamma, modulus);
 }
 
 // Debug / test hook: the score matrix entry as the chain computes it.
@@ -716,14 +716,14 @@ static void launch_dist(const kge_model_desc* md, const float* E, const float* E
                         int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs, int32_t* counts,
                         int accumulate, const float* Qv, float* tgt, int Kpad, hipStream_t st) {
   const int K = md->d_e;
-  hipLaunchKernelGGL((rank_dist_target_kernel<NORM>), dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, md->gamma, tgt, counts, accumulate ? 0 : 1);
+  hipLaunchKernelGGL((rank_dist_target_kernel<NORM>), dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, md->gamma, md->modulus, tgt, counts, accumulate ? 0 : 1);
   const int nqt = (int)cdiv(nq, 64), nct = (int)cdiv(cand_rows, 64);
   int splits = std::max(1, std::min((int)cdiv(rank_blocks_target(), nqt), nct));
   const int tpb = (int)cdiv(nct, splits);
   splits = (int)cdiv(nct, tpb);
-  hipLaunchKernelGGL((rank_dist_sweep_kernel<NORM>), dim3(nqt, splits), dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, md->gamma, counts);
+  hipLaunchKernelGGL((rank_dist_sweep_kernel<NORM>), dim3(nqt, splits), dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, md->gamma, md->modulus, counts);
   if (npairs > 0)
-    hipLaunchKernelGGL((rank_dist_filter_kernel<NORM>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, md->gamma, pair_q, filt_ids, npairs, counts);
+    hipLaunchKernelGGL((rank_dist_filter_kernel<NORM>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, md->gamma, md->modulus, pair_q, filt_ids, npairs, counts);
 }
 
 int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* Ec, int cand_offset, int cand_rows,
@@ -739,6 +739,7 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
   launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
   if (md->model == KGE_TRANSE) {
     if (md->norm == 1) launch_dist<1>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
+    else if (md->norm == 3) launch_dist<3>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
     else launch_dist<2>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
@@ -823,8 +824,9 @@ int rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel
   launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
   const int64_t tot = nq * md->num_entities;
   if (md->model == KGE_TRANSE) {
-    if (md->norm == 1) hipLaunchKernelGGL((rank_dist_scores_kernel<1>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, nq, md->num_entities, out);
-    else hipLaunchKernelGGL((rank_dist_scores_kernel<2>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, nq, md->num_entities, out);
+    if (md->norm == 1) hipLaunchKernelGGL((rank_dist_scores_kernel<1>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, md->modulus, nq, md->num_entities, out);
+    else if (md->norm == 3) hipLaunchKernelGGL((rank_dist_scores_kernel<3>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, md->modulus, nq, md->num_entities, out);
+    else hipLaunchKernelGGL((rank_dist_scores_kernel<2>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, md->modulus, nq, md->num_entities, out);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }

@@ -34,7 +34,7 @@ __device__ __forceinline__ float dm3(float4 s, float4 p, float4 o) {
 template <int NORM>
 __device__ __forceinline__ float te1(float s, float p, float o) {
   float x = s + p - o;
-  return NORM == 1 ? fabsf(x) : x * x;
+  return NORM == 1 ? fabsf(x) : (NORM == 3 ? phase_abs(x) : x * x);
 }
 template <int NORM>
 __device__ __forceinline__ float te1(float4 s, float4 p, float4 o) {
@@ -53,7 +53,7 @@ __device__ __forceinline__ float cx1(float4 sr, float4 si, float4 pr, float4 pi,
 template <int MODEL, int NORM, int G, int VEC>
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                      const int32_t* __restrict__ triples, int64_t n, int N, int R,
-                                                     int d_e, int d_r, int nchunk, float gamma,
+                                                     int d_e, int d_r, int nchunk, float gamma, float modulus,
                                                      float* __restrict__ out, uint32_t* __restrict__ err) {
   using C = Chunk<VEC>;
   const int lane = threadIdx.x & (G - 1);
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ E,
       float sc = acc;
       if (MODEL == KGE_TRANSE) {
         if (NORM == 2) sc = sqrtf(sc);
-        sc = gamma > 0.f ? gamma - sc : sc;  // models.py:187-190
+        if (NORM == 3) sc *= modulus;
+        sc = gamma > 0.f ? gamma - sc : sc;  // models.py:187-190, 486-489
       }
       if (!ok) {
         sc = __builtin_nanf("");
@@ -107,7 +108,7 @@ static int launch_score(const kge_model_desc* md, const float* E, const float* R
   const int grid = (int)(want < (int64_t)kCUs * 16 ? want : (int64_t)kCUs * 16);
   ProfScope prof(KGE_PROF_SCORE, st);
   hipLaunchKernelGGL((score_kernel<MODEL, NORM, G, VEC>), dim3(grid), dim3(256), 0, st, E, Rel, triples, n,
-                     md->num_entities, md->num_relations, md->d_e, md->d_r, nchunk, md->gamma, out, err);
+                     md->num_entities, md->num_relations, md->d_e, md->d_r, nchunk, md->gamma, md->modulus, out, err);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
@@ -139,6 +140,7 @@ int score_dispatch(const kge_model_desc* md, const float* E, const float* Rel, c
     case KGE_DISTMULT: KGE_GO(KGE_DISTMULT, 1);
     case KGE_TRANSE:
       if (md->norm == 1) { KGE_GO(KGE_TRANSE, 1); }
+      if (md->norm == 3) { KGE_GO(KGE_TRANSE, 3); }
       KGE_GO(KGE_TRANSE, 2);
     case KGE_COMPLEX: KGE_GO(KGE_COMPLEX, 1);
     case KGE_HOLE:

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
                                                     float* __restrict__ gE, float* __restrict__ gR,
                                                     const int32_t* __restrict__ pos, int64_t m_pos,
                                                     const int32_t* __restrict__ neg, int64_t m_neg, int N, int R, int d_e,
-                                                    int d_r, float gamma, float margin, const float* __restrict__ gbuf,
+                                                    int d_r, float gamma, float modulus, float margin, const float* __restrict__ gbuf,
                                                     float* __restrict__ scores, float* __restrict__ loss_partials,
                                                     uint32_t* __restrict__ err, uint64_t seed, uint32_t thr, float dscale) {
   __shared__ float red[16];
@@ -61,13 +61,14 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
       } else {
         const float sv = es[k] * ms(k), pv = rp[k] * mp(k), ov = eo[k] * mo(k);
         if (MODEL == KGE_DISTMULT) acc += sv * pv * ov;
-        else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : x * x; }
+        else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : (NORM == 3 ? phase_abs(x) : x * x); }
       }
     }
     acc = group_sum<G>(acc);
     float score = acc, dist = acc;
     if (MODEL == KGE_TRANSE) {
       if (NORM == 2) dist = sqrtf(acc);
+      if (NORM == 3) dist = modulus * acc;
       score = gamma > 0.f ? gamma - dist : dist;
     }
     float g, l = 0.f;
@@ -87,11 +88,11 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
     if (MODEL == KGE_TRANSE) {
       // d score / d x = -d dist/dx (gamma > 0) or +d dist/dx; L2: x/dist, 0 at dist == 0 (TF yields NaN there)
       const float sgn = gamma > 0.f ? -g : g;
-      const float rn = (NORM == 2) ? (dist > 0.f ? sgn / dist : 0.f) : sgn;
+      const float rn = (NORM == 2) ? (dist > 0.f ? sgn / dist : 0.f) : (NORM == 3 ? 0.5f * modulus * sgn : sgn);
       for (int k = lane; k < width; k += G) {
         const float a = ms(k), b = mp(k), c = mo(k);
         const float x = es[k] * a + rp[k] * b - eo[k] * c;
-        const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f)) : rn * x;
+        const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f)) : (NORM == 3 ? rn * phase_dterm(x) : rn * x);
         atomicAdd(gs + k, dx * a);
         atomicAdd(gp + k, dx * b);
         atomicAdd(go + k, -dx * c);
@@ -357,7 +358,7 @@ static int launch_push(int G, const kge_model_desc* md, const kge_loss_desc* ld,
   const float dscale = 1.f / (1.f - md->dropout);
 #define KGE_PUSH(GW, DR)                                                                                                \
   hipLaunchKernelGGL((push_kernel<MODEL, NORM, LOSS, GW, DR>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, pos, m_pos, \
-                     neg, m_neg, md->num_entities, md->num_relations, md->d_e, md->d_r, md->gamma, ld->margin, gbuf,      \
+                     neg, m_neg, md->num_entities, md->num_relations, md->d_e, md->d_r, md->gamma, md->modulus, ld->margin, gbuf, \
                      scores, partials, err, seed, thr, dscale)
   if (drop) { if (G == 16) KGE_PUSH(16, true); else if (G == 32) KGE_PUSH(32, true); else KGE_PUSH(64, true); }
   else { if (G == 16) KGE_PUSH(16, false); else if (G == 32) KGE_PUSH(32, false); else KGE_PUSH(64, false); }
@@ -376,6 +377,8 @@ static int push_by_model(int G, const kge_model_desc* md, const kge_loss_desc* l
     case KGE_TRANSE:
       if (md->norm == 1)
         return launch_push<KGE_TRANSE, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
+      if (md->norm == 3)
+        return launch_push<KGE_TRANSE, 3, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
       return launch_push<KGE_TRANSE, 2, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
     case KGE_COMPLEX:
       return launch_push<KGE_COMPLEX, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);

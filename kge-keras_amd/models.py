@@ -200,7 +200,8 @@ class EmbeddingModel:
     def _model_desc(self, training=False):
         return ModelDesc(MODEL_IDS[self.MODEL], self.num_entities, self.num_relations, int(self.e_dim), int(self.r_dim),
                          int(getattr(self, "norm", 1)), float(getattr(self, "gamma", 0.0)), float(self.dp) if training else 0.0,
-                         int(getattr(self, "conv_filters", 0)), float(getattr(self, "hidden_dp", 0.0)) if training else 0.0)
+                         int(getattr(self, "conv_filters", 0)), float(getattr(self, "hidden_dp", 0.0)) if training else 0.0,
+                         float(getattr(self, "modulus", 0.0)) if self.MODEL == "TransE" else 0.0)
 
     def _loss_desc(self):
         if self.loss_function not in LOSS_IDS:
@@ -634,6 +635,27 @@ class ComplEx(EmbeddingModel):
         kwargs['e_dim'] = 2 * kwargs['e_dim']  # KeyError if absent, like models.py:208
         kwargs['r_dim'] = 2 * kwargs['r_dim']
         super().__init__(name=name, **kwargs)
+
+
+class pRotatE(EmbeddingModel):
+    """models.py:461-489: score = gamma - modulus * sum_k |sin((phase_s + phase_p - phase_o)_k / 2)| (or +... when gamma <= 0), both
+    widths doubled (:469-470), modulus = modulus * embedding_range with embedding_range = (gamma + epsilon) / e_dim / 2 taken on
+    the doubled e_dim (:475-476).  The reference wraps every row into (-pi, pi] first (atan2(sin x, cos x), :481-483); a wrap
+    moves the half-angle by a multiple of pi, which |sin| does not see, so the kernels take the rows as they are.  Structurally
+    this is TransE with the element function |sin(x/2)| in place of |x|: the TransE kernels with norm id 3 (every training path,
+    batch plans, the distance sweep of the 1-vs-all ranking)."""
+    MODEL = "TransE"
+
+    def __init__(self, gamma=12, epsilon=2, modulus=0.5, name='pRotatE', **kwargs):
+        kwargs['e_dim'] = 2 * kwargs['e_dim']  # KeyError if absent, like models.py:469
+        kwargs['r_dim'] = 2 * kwargs['r_dim']
+        super().__init__(name=name, **kwargs)
+        self.gamma = gamma
+        self.epsilon = epsilon
+        self.norm = 3
+        self.pi = np.pi
+        self.embedding_range = (self.gamma + self.epsilon) / self.e_dim / 2
+        self.modulus = modulus * self.embedding_range
 
 
 class HolE(EmbeddingModel):

@@ -29,7 +29,7 @@ def glorot_uniform(rows, cols, rs, dtype=np.float32):
 
 def table_dims(model, e_dim, r_dim):
     """ComplEx doubles both widths (models.py:208-209); everything else keeps them."""
-    if model == "ComplEx":
+    if model in ("ComplEx", "pRotatE"):  # pRotatE: models.py:469-470
         return 2 * e_dim, 2 * r_dim
     return e_dim, r_dim
 
@@ -77,7 +77,22 @@ def func_hole(s, p, o):
     return np.sum(p * ccorr(s, o), axis=-1)
 
 
+def protate_modulus(e_dim_doubled, gamma=12, epsilon=2, modulus=0.5):
+    """models.py:475-476: embedding_range = (gamma + epsilon) / e_dim / 2 on the doubled e_dim; modulus * embedding_range."""
+    return modulus * ((gamma + epsilon) / e_dim_doubled / 2)
+
+
+def func_protate(s, p, o, modulus, gamma=12):
+    """models.py:479-489.  `modulus` is the product of :476.  Phases are wrapped as the reference does (atan2(sin, cos))."""
+    ph = lambda x: np.arctan2(np.sin(x), np.cos(x))  # noqa: E731
+    r = np.sum(np.abs(np.sin((ph(s) + ph(p) - ph(o)) / 2)), axis=1) * modulus
+    return gamma - r if gamma > 0 else r
+
+
 def score_rows(model, s, p, o, norm=1, gamma=12):
+    """For model == "pRotatE" the `norm` slot carries the modulus product of models.py:476."""
+    if model == "pRotatE":
+        return func_protate(s, p, o, norm, gamma)
     if model == "DistMult":
         return func_distmult(s, p, o)
     if model == "TransE":
@@ -101,6 +116,11 @@ def call(model, E, Rel, triples, norm=1, gamma=12, dtype=np.float64):
 def score_row_grads(model, s, p, o, g, norm=1, gamma=12):
     """d(sum_i g_i * score_i)/d(s,p,o) -- what autodiff hands to the three Embedding gathers [TF]."""
     g = g[:, None]
+    if model == "pRotatE":  # autodiff through atan2(sin x, cos x) is the identity; d|u|/du = sign(u) [TF sign(0) = 0]
+        ph = lambda x: np.arctan2(np.sin(x), np.cos(x))  # noqa: E731
+        y = (ph(s) + ph(p) - ph(o)) / 2
+        dx = (-1.0 if gamma > 0 else 1.0) * g * norm * 0.5 * np.sign(np.sin(y)) * np.cos(y)
+        return dx, dx, -dx
     if model == "DistMult":
         return g * p * o, g * s * o, g * s * p
     if model == "TransE":

@@ -234,3 +234,35 @@ def test_rank_yago310_shape_row_sharded(datasets):
         ref = int(np.sum(sc[keepm] > sc[o]))
         gap = np.min(np.abs(sc[keepm] - sc[o]))
         assert full[i] == ref or gap < 1e-5 * np.abs(sc).max(), (i, full[i], ref)
+
+
+@pytest.mark.parametrize("N,d,nq,gamma", [(14, 16, 40, 12), (300, 100, 257, 12), (1000, 15, 64, 0)])
+def test_rank_parity_protate(N, d, nq, gamma):
+    """pRotatE (models.py:461-489) ranks through the distance sweep with the |sin(x/2)| element function."""
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(11)
+    E0 = rs.uniform(-2, 2, (N, 2 * d)).astype(np.float32)
+    R0 = rs.uniform(-2, 2, (7, 2 * d)).astype(np.float32)
+    mdl = M.pRotatE(e_dim=d, r_dim=d, num_entities=N, num_relations=7, dp=0.0, gamma=gamma, modulus=4.0, init_entities=E0, init_relations=R0)
+    test = list({(int(rs.randint(N)), int(rs.randint(7)), int(rs.randint(N))) for _ in range(nq)})
+    tes, filt = set(test), set()
+    for (s, p, o) in test:
+        for _ in range(int(rs.randint(0, 5))):
+            c = (s, p, int(rs.randint(N)))
+            if c not in tes:
+                filt.add(c)
+            c = (int(rs.randint(N)), p, o)
+            if c not in tes:
+                filt.add(c)
+    filt = sorted(filt)
+    fh, ft = O.build_filters(filt)
+    tails, heads = mdl.rank(test, N, ft, fh)
+    gaps = []
+    to, ho = O.ranks_closed_form("pRotatE", E0, R0, test, filt, mdl.modulus, gamma, margin_out=gaps)
+    gaps = np.asarray(gaps).reshape(-1, 2)
+    tol = 2e-6 * 2 * d * mdl.modulus + 1e-6
+    for got, ref, gap in ((tails, to, gaps[:, 0]), (heads, ho, gaps[:, 1])):
+        clear = gap > tol
+        assert clear.mean() > 0.5
+        assert np.array_equal(got[clear], ref[clear])
+        assert np.all(np.abs(got[~clear] - ref[~clear]) <= 2)

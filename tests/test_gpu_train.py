@@ -639,3 +639,68 @@ def test_hole_spectral_planned_step_and_halves():
     hd, _, _, _ = _mk("HolE", N, R, d)
     hd.dp = 0.3
     assert not hd._spectral_on() and not hd.plan_supported()
+
+
+# ---------------------------------------------------------------------------------------------- pRotatE (models.py:461-489)
+def _mk_protate(N, R, d, gamma=12, amp=0.5, **kw):
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(5)
+    E0 = rs.uniform(-amp, amp, (N, 2 * d)).astype(np.float32)
+    R0 = rs.uniform(-amp, amp, (R, 2 * d)).astype(np.float32)
+    mdl = M.pRotatE(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, gamma=gamma, init_entities=E0, init_relations=R0, **kw)
+    assert mdl.e_dim == 2 * d and mdl.modulus == pytest.approx(O.protate_modulus(2 * d, gamma if gamma else 0, 2, 0.5))
+    return mdl, E0, R0, rs
+
+
+@pytest.mark.parametrize("d,n", [(16, 1), (100, 63), (15, 5000), (3, 77)])
+@pytest.mark.parametrize("gamma,amp", [(12, 0.5), (0, 4.0)])
+def test_protate_score_parity(d, n, gamma, amp):
+    mdl, E0, R0, rs = _mk_protate(97, 11, d, gamma, amp)
+    t = _triples(rs, n, 97, 11)
+    ref = O.call("pRotatE", E0, R0, t, mdl.modulus, gamma)
+    np.testing.assert_allclose(mdl.predict(t), ref, atol=TOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+@pytest.mark.parametrize("gamma", [12, 0])
+def test_protate_train_step_parity(loss, opt, gamma):
+    N, R, d, m = 40, 6, 16, 300
+    mdl, E0, R0, rs = _mk_protate(N, R, d, gamma, 2.0, loss_function=loss, margin=0.5, modulus=3.0)
+    mdl.compile(opt)
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.make_optimizer(opt)
+    for step in range(3):
+        pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
+        sc = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        L = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+        sp, sn = O.call("pRotatE", Eo, Ro, pos, mdl.modulus, gamma), O.call("pRotatE", Eo, Ro, neg, mdl.modulus, gamma)
+        np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
+        Lo = O.train_step("pRotatE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, mdl.modulus, gamma)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
+
+
+def test_protate_large_planned_and_dropout():
+    """Rows of 400 floats (d=200), a batch large enough for the relation-grouped path with duplicate folding and a BatchPlan; then a
+    dropout step against the oracle's masks."""
+    N, R, d, m = 500, 9, 200, 8000
+    a, E0, R0, rs = _mk_protate(N, R, d, 12, 1.0)
+    b, _, _, _ = _mk_protate(N, R, d, 12, 1.0)
+    a.compile("adam"); b.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.make_optimizer("adam")
+    for step in range(2):
+        pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
+        pos[: m // 2] = pos[m // 2: 2 * (m // 2)]  # duplicates
+        La = float(a.train_step([pos, neg])["loss"].item())
+        Lo = O.train_step("pRotatE", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1, 1, a.modulus, 12)
+        assert La == pytest.approx(Lo, abs=TOL, rel=1e-5)
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+        if b.plan_supported():
+            Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
+            assert Lb == pytest.approx(La, abs=1e-5, rel=1e-5)
+            np.testing.assert_allclose(b.E.cpu().numpy(), a.E.cpu().numpy(), atol=2e-6)

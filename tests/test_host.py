@@ -32,11 +32,11 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in kge_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kge_abi_version() == 2
+    assert lib.kge_abi_version() == 3
 
 
 def test_abi_struct_layouts():
-    assert ctypes.sizeof(_lib.ModelDesc) == 40
+    assert ctypes.sizeof(_lib.ModelDesc) == 44 and _lib.ModelDesc.modulus.offset == 40
     assert ctypes.sizeof(_lib.LossDesc) == 16
     assert ctypes.sizeof(_lib.OptDesc) == 72
     assert _lib.OptDesc.step.offset == 24 and _lib.OptDesc.mE.offset == 32

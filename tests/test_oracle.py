@@ -197,17 +197,22 @@ def _torch_score(model, s, p, o, norm, gamma):
     if model == "HolE":
         x = torch.fft.ifft(torch.conj(torch.fft.fft(s)) * torch.fft.fft(o)).real
         return (p * x).sum(-1)
+    if model == "pRotatE":  # models.py:479-489 op for op; `norm` carries the modulus product of :476
+        ph = lambda x: torch.atan2(torch.sin(x), torch.cos(x))  # noqa: E731
+        r = torch.abs(torch.sin((ph(s) + ph(p) - ph(o)) / 2)).sum(1) * norm
+        return gamma - r if gamma > 0 else r
 
 
 @pytest.mark.parametrize("model,norm,gamma", [("DistMult", 1, 12), ("TransE", 1, 12), ("TransE", 2, 12), ("TransE", 2, 0),
-                                              ("ComplEx", 1, 12), ("HolE", 1, 12)])
+                                              ("ComplEx", 1, 12), ("HolE", 1, 12), ("pRotatE", 0.35, 12), ("pRotatE", 0.35, 0)])
 @pytest.mark.parametrize("loss", ["pointwize_hinge", "pointwize_logistic", "pairwize_hinge"])
 def test_dense_grads_and_adam_vs_torch(model, norm, gamma, loss):
     rs = np.random.RandomState(3)
     N, R, d, m = 11, 4, 6, 40
     de, dr = O.table_dims(model, d, d)
-    E = rs.uniform(-0.6, 0.6, (N, de))
-    Rel = rs.uniform(-0.6, 0.6, (R, dr))
+    amp = 4.0 if model == "pRotatE" else 0.6  # phases beyond (-pi, pi]: the wrap of models.py:481-483 is exercised
+    E = rs.uniform(-amp, amp, (N, de))
+    Rel = rs.uniform(-amp, amp, (R, dr))
     pos = np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)
     neg = np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)
     L, sp, sn, gE, gR = O.dense_grads(model, E, Rel, pos, neg, loss, 1.0, 1, norm, gamma, regularization=0.01)
@@ -292,3 +297,14 @@ def test_c_port_matches_numpy_oracle(model, norm, gamma, loss, opt):
         np.testing.assert_allclose(ct.E, Eo, atol=1e-4)
         np.testing.assert_allclose(ct.Rel, Ro, atol=1e-4)
     assert c_port.threads() >= 1
+
+
+def test_protate_known_answers():
+    """pRotatE (models.py:461-489): doubled widths, modulus = modulus * (gamma + epsilon) / e_dim / 2 on the doubled e_dim,
+    score = gamma - modulus * sum |sin((s + p - o) / 2)|, phases wrapped first (no effect under |sin|)."""
+    assert O.table_dims("pRotatE", 5, 7) == (10, 14)
+    assert O.protate_modulus(8, gamma=12, epsilon=2, modulus=0.5) == pytest.approx(0.5 * 14 / 8 / 2)
+    s = np.array([[np.pi, 0.0]]); p = np.array([[0.0, np.pi / 3]]); o = np.array([[0.0, 0.0]])
+    assert O.func_protate(s, p, o, 2.0, 12)[0] == pytest.approx(12 - 2.0 * (1.0 + 0.5))
+    assert O.func_protate(s, p, o, 2.0, 0)[0] == pytest.approx(2.0 * 1.5)
+    assert O.func_protate(s + 2 * np.pi, p - 4 * np.pi, o + 6 * np.pi, 2.0, 12)[0] == pytest.approx(12 - 3.0)  # wrap invariance
