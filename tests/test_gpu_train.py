@@ -648,7 +648,7 @@ def _mk_protate(N, R, d, gamma=12, amp=0.5, **kw):
     E0 = rs.uniform(-amp, amp, (N, 2 * d)).astype(np.float32)
     R0 = rs.uniform(-amp, amp, (R, 2 * d)).astype(np.float32)
     mdl = M.pRotatE(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, gamma=gamma, init_entities=E0, init_relations=R0, **kw)
-    assert mdl.e_dim == 2 * d and mdl.modulus == pytest.approx(O.protate_modulus(2 * d, gamma if gamma else 0, 2, 0.5))
+    assert mdl.e_dim == 2 * d and mdl.modulus == pytest.approx(O.protate_modulus(2 * d, gamma, 2, kw.get("modulus", 0.5)))
     return mdl, E0, R0, rs
 
 
