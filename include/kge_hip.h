@@ -138,7 +138,8 @@ int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_o
  *      sorted or not: filt_query[e] = query index, filt_ids[e] = global entity id to exclude (the reference's
  *      filter_t[(s,p)] / filter_h[(p,o)]); it must not contain the target (the reference raises ValueError).
  *      accumulate != 0 adds into counts (multi-shard loops); otherwise counts is overwritten.
- *      DistMult and ComplEx run on the fp32 matrix cores; score comparisons are made on bit-identical fmaf chains. */
+ *      DistMult, ComplEx, HolE and TransE-L2 (ordered by |e|^2 - 2<q,e>; target_scores_out must be NULL for that form, otherwise
+ *      the VALU distance sweep runs) use the fp32 matrix cores; score comparisons are made on bit-identical fmaf chains. */
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries);
 int kge_rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* E_cand, int32_t cand_offset,
                     int32_t cand_rows, const int32_t* triples, int64_t n_queries, int32_t side, const int32_t* filt_query,

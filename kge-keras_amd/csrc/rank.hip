@@ -120,11 +120,11 @@ __global__ __launch_bounds__(256) void rank_target_kernel(const float* __restric
 // rows (63-75 us).  Here the wave copies the 64 query rows and the 64 target rows chunk by chunk into LDS with coalesced 128-bit
 // loads (ten consecutive lanes read 160 contiguous bytes of one row), the next chunk in flight in registers behind the current
 // one, and every lane then runs ITS query's chain from LDS -- the same fmaf sequence in the same k order as chain_dot().
-template <int BK>
+template <int BK, bool L2 = false>
 __global__ __launch_bounds__(64) void rank_target4_kernel(const float* __restrict__ Qv, const float* __restrict__ E,
                                                            const int32_t* __restrict__ triples, int nq, int side, int N, int K,
                                                            int Kpad, float* __restrict__ tgt, int32_t* __restrict__ counts,
-                                                           int zero_counts) {
+                                                           int zero_counts, const float* __restrict__ en = nullptr) {
   constexpr int LS = BK + 4, C4 = BK / 4, PF = C4;  // 64 rows x C4 float4 per operand per chunk = C4 per lane
   __shared__ __attribute__((aligned(16))) float Aq[64 * LS];
   __shared__ __attribute__((aligned(16))) float Ae[64 * LS];
@@ -172,9 +172,47 @@ __global__ __launch_bounds__(64) void rank_target4_kernel(const float* __restric
     }
   }
   if (q < nq) {
-    tgt[q] = ok ? acc : __builtin_nanf("");
+    // L2: the TransE-L2 comparison value D = |e|^2 - 2 <q, e> (see rank_sumsq_kernel)
+    tgt[q] = ok ? (L2 ? __fmaf_rn(-2.f, acc, en[t]) : acc) : __builtin_nanf("");
     if (zero_counts) counts[q] = 0;
   }
+}
+
+// TransE with the L2 norm on the matrix cores: ||q - e||^2 = |q|^2 + |e|^2 - 2 <q, e>, and for one query the order of the
+// candidates by distance is the order by D(q, e) = |e|^2 - 2 <q, e> (|q|^2 is common to all of them, the square root is monotone).
+// D is formed with ONE fused multiply-add from the dot product -- the MFMA chain of the sweep, or chain_dot() in the target and
+// filter kernels, bit-identical as for DistMult -- and the row's squared norm en[e], which this kernel computes once per call for
+// the whole table; every comparison in the sweep, the target and the filter kernels is therefore made on bit-identical numbers.
+// gamma > 0: score = gamma - dist, so "score_c > score_t" is D_c < D_t; gamma <= 0: score = +dist, D_c > D_t.
+// One 16-lane group per row; lane l takes the float4 chunks l, l+16, ...; fixed order, so en[] is deterministic.
+__global__ __launch_bounds__(256) void rank_sumsq_kernel(const float* __restrict__ E, int N, int K, float* __restrict__ en) {
+  const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  if (g >= N) return;
+  const float4* e4 = reinterpret_cast<const float4*>(E + g * K);
+  float acc = 0.f;
+  for (int c = l; c < (K >> 2); c += 16) {
+    const float4 v = e4[c];
+    acc = __fmaf_rn(v.x, v.x, acc); acc = __fmaf_rn(v.y, v.y, acc); acc = __fmaf_rn(v.z, v.z, acc); acc = __fmaf_rn(v.w, v.w, acc);
+  }
+  acc = group_sum<16>(acc);
+  if (l == 0) en[g] = acc;
+}
+
+// Filter kernel of that path: un-counts a filtered candidate if the sweep counted it (same D, same comparison).
+template <bool LESS>
+__global__ __launch_bounds__(256) void rank_filter_l2_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
+                                                              const float* __restrict__ Ec, const float* __restrict__ en_c, int cand_offset,
+                                                              int cand_rows, int K, int Kpad, const int32_t* __restrict__ pair_q,
+                                                              const int32_t* __restrict__ filt_ids, int64_t npairs,
+                                                              int32_t* __restrict__ counts) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npairs) return;
+  const int q = pair_q[e];
+  const int c = filt_ids[e] - cand_offset;
+  if ((unsigned)c >= (unsigned)cand_rows) return;  // another shard owns this candidate
+  const float D = __fmaf_rn(-2.f, chain_dot(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, Kpad), en_c[c]);
+  if (LESS ? D < tgt[q] : D > tgt[q]) atomicSub(&counts[q], 1);
 }
 
 template <int BK, bool VEC4>
@@ -326,10 +364,12 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
 //     MFMAs between scheduling barriers; the LDS fragments of group j+1 are read while group j multiplies;
 //   * the prefetch after the very last chunk re-reads the current unit's first chunk (no branch; the values are dropped).
 // The k order of every accumulation chain is the one documented at the top of the file (same LDS image, same reads).
-template <int BK, bool TAIL>
+// EPI 0: count score_c = <q, e_c> > tgt.  EPI 1 / 2 (TransE-L2, rank_sumsq_kernel): count D_c = en[c] - 2 <q, e_c> < tgt / > tgt.
+template <int BK, bool TAIL, int EPI = 0>
 __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                            int nq, const float* __restrict__ Ec, int K, int Kpad,
-                                                           int cand_rows, int32_t* __restrict__ counts) {
+                                                           int cand_rows, int32_t* __restrict__ counts,
+                                                           const float* __restrict__ en_c = nullptr) {
   constexpr int LS = BK + 4;
   constexpr int C4 = BK / 4;
   constexpr int PF = kTile * C4 / 256;
@@ -357,7 +397,8 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
     for (int r = 0; r < 16; ++r) cnt[rt][r] = 0;
   if (tid < kTile) {
     cnt_s[tid] = 0;
-    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : __builtin_inff();  // nothing is > +inf; NaN targets count nothing either
+    // rows past nq: a value nothing compares true against (NaN targets count nothing either)
+    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : (EPI == 1 ? -__builtin_inff() : __builtin_inff());
   }
 
   // loop-invariant staging slots; named scalars (PF is 4 or 5), slot 4 is compiled out when PF == 4
@@ -449,13 +490,23 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
     }
     // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
     const int c0 = ct * kTile;
+    float en0 = 0.f, en1 = 0.f;  // squared norms of this lane's two candidate columns (EPI != 0)
+    if (EPI != 0) {
+      en0 = en_c[min(c0 + wc * 64 + l31, last_row)];
+      en1 = en_c[min(c0 + wc * 64 + 32 + l31, last_row)];
+    }
+    auto hit = [&](float dot, float en, float tgv) {
+      if (EPI == 0) return dot > tgv;
+      const float D = __fmaf_rn(-2.f, dot, en);
+      return EPI == 1 ? D < tgv : D > tgv;
+    };
     if (c0 + kTile <= cand_rows) {  // uniform: every candidate column of the tile exists
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-          cnt[rt][r] += (acc[rt][0][r] > tgv ? 1 : 0) + (acc[rt][1][r] > tgv ? 1 : 0);
+          cnt[rt][r] += (hit(acc[rt][0][r], en0, tgv) ? 1 : 0) + (hit(acc[rt][1][r], en1, tgv) ? 1 : 0);
         }
     } else {
       const bool v0 = c0 + wc * 64 + l31 < cand_rows, v1 = c0 + wc * 64 + 32 + l31 < cand_rows;
@@ -464,7 +515,7 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-          cnt[rt][r] += ((v0 && acc[rt][0][r] > tgv) ? 1 : 0) + ((v1 && acc[rt][1][r] > tgv) ? 1 : 0);
+          cnt[rt][r] += ((v0 && hit(acc[rt][0][r], en0, tgv)) ? 1 : 0) + ((v1 && hit(acc[rt][1][r], en1, tgv)) ? 1 : 0);
         }
     }
     if (!has_next || nqt_ != qt) {  // uniform: the range leaves this query tile -> flush its counters
@@ -482,7 +533,7 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
         if (has_next) {  // read again after the two barriers of the next chunk
           const int nq0_ = nqt_ * kTile;
           cnt_s[tid] = 0;
-          tg_s[tid] = nq0_ + tid < nq ? tgt[nq0_ + tid] : __builtin_inff();
+          tg_s[tid] = nq0_ + tid < nq ? tgt[nq0_ + tid] : (EPI == 1 ? -__builtin_inff() : __builtin_inff());
         }
       }
     }
@@ -673,14 +724,19 @@ static int sweep_slots() {  // workgroups of the persistent sweep: two per CU (r
 }
 
 static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float* Qv, const float* tgt, int64_t nq, const float* Ec,
-                         int K, int Kpad, int cand_rows, int tpb, int32_t* counts) {
+                         int K, int Kpad, int cand_rows, int tpb, int32_t* counts, int epi = 0, const float* en_c = nullptr) {
   if (nq <= 0 || cand_rows <= 0) return;
 #define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
   if (v4 && sweep_variant() == 0 && nq < (int64_t)1 << 30) {
     const bool tail = Kpad != K;
     const int64_t units = cdiv(nq, kTile) * cdiv(cand_rows, kTile);
     const dim3 pgrid((unsigned)std::min<int64_t>(units, sweep_slots()));
-#define KGE_SWEEP4(BKV, FLAG) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts)
+#define KGE_SWEEP4(BKV, FLAG)                                                                                                                        \
+  do {                                                                                                                                               \
+    if (epi == 1) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 1>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c);      \
+    else if (epi == 2) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 2>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c); \
+    else hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 0>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c);               \
+  } while (0)
     if (BK == 40) { if (tail) KGE_SWEEP4(40, true); else KGE_SWEEP4(40, false); }
     else { if (tail) KGE_SWEEP4(32, true); else KGE_SWEEP4(32, false); }
 #undef KGE_SWEEP4
@@ -695,7 +751,14 @@ int rank_kpad(int K) { return (int)align_up(K, pick_bk(K)); }
 static int rank_kpad_model(const kge_model_desc* md) { return md->model == KGE_TRANSE ? (int)align_up(md->d_e, 32) : rank_kpad(md->d_e); }
 
 int64_t rank_workspace_bytes(const kge_model_desc* md, int64_t nq) {
-  return (int64_t)sizeof(float) * (nq * rank_kpad_model(md) + align_up(nq, 64)) + 512;
+  // TransE-L2 on the matrix cores additionally keeps the squared norm of every table row (rank_sumsq_kernel)
+  const int64_t en = md->model == KGE_TRANSE && md->norm == 2 ? align_up(md->num_entities, 64) : 0;
+  return (int64_t)sizeof(float) * (nq * rank_kpad_model(md) + align_up(nq, 64) + en) + 512;
+}
+
+static bool rank_l2_mfma() {  // KGE_RANK_L2=0: TransE-L2 ranks through the VALU distance sweep (read per call: tests flip it)
+  const char* e = getenv("KGE_RANK_L2");
+  return !(e && atoi(e) == 0);
 }
 
 static void launch_build_q(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t nq, int side,
@@ -730,12 +793,31 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
                 const int32_t* triples, int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs,
                 int32_t* counts, int accumulate, float* tgt_out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
   if (md->model == KGE_HOLE && md->d_e > 1024) return fail(KGE_EUNSUPPORTED, "kge_rank_counts: HolE rows wider than 1024 floats are not built");
-  const int K = md->d_e, BK = pick_bk(K), Kpad = rank_kpad_model(md);
+  const int K = md->d_e, BK = pick_bk(K);
+  int Kpad = rank_kpad_model(md);
   if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_counts: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)rank_workspace_bytes(md, nq));
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
   float* Qv = reinterpret_cast<float*>(p);
   float* tgt = tgt_out ? tgt_out : Qv + nq * Kpad;
   ProfScope prof(KGE_PROF_RANK, st);
+  // TransE-L2 on the matrix cores (target scores are not produced on this path: a caller asking for them gets the distance sweep)
+  if (md->model == KGE_TRANSE && md->norm == 2 && !tgt_out && rank_l2_mfma() && (K % 4 == 0) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) &&
+      nq < (int64_t)1 << 30 && sweep_variant() == 0) {
+    float* en = tgt + align_up(nq, 64);  // behind the target values (the query block is sized for align_up(K, 32) >= rank_kpad(K) floats per row)
+    Kpad = rank_kpad(K);
+    launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
+    hipLaunchKernelGGL(rank_sumsq_kernel, dim3((int)cdiv((int64_t)md->num_entities * 16, 256)), dim3(256), 0, st, E, md->num_entities, K, en);
+    if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40, true>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1, en);
+    else hipLaunchKernelGGL((rank_target4_kernel<32, true>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1, en);
+    const bool less = md->gamma > 0.f;
+    launch_sweep(BK, true, dim3(1), st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, 1, counts, less ? 1 : 2, en + cand_offset);
+    if (npairs > 0) {
+      if (less) hipLaunchKernelGGL((rank_filter_l2_kernel<true>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
+      else hipLaunchKernelGGL((rank_filter_l2_kernel<false>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
+    }
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
+  }
   launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
   if (md->model == KGE_TRANSE) {
     if (md->norm == 1) launch_dist<1>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);

@@ -87,7 +87,13 @@ def test_rank_mfma_bit_exact_vs_chain():
             sc = out.cpu().numpy()
             tgt = sc[np.arange(nq), test[:, 2] if side == 0 else test[:, 0]]
             ref = (sc > tgt[:, None]).sum(1)
-            assert np.array_equal(cnt, ref), (model, quant, side, np.abs(cnt - ref).max())
+            if model == "TransE" and kw.get("norm") == 2:
+                # TransE-L2 ranks on the matrix cores by D = |e|^2 - 2<q,e> (csrc/rank.hip, rank_sumsq_kernel), the chain-score hook
+                # reports the distance form: the two orders agree except for candidates within rounding of the target
+                near = (np.abs(sc - tgt[:, None]) <= 2e-5 * np.maximum(1.0, np.abs(tgt[:, None]))).sum(1) - 1
+                assert np.all(np.abs(cnt - ref) <= near), (model, quant, side, np.abs(cnt - ref).max())
+            else:
+                assert np.array_equal(cnt, ref), (model, quant, side, np.abs(cnt - ref).max())
             # and the chain scores are the model's scores to fp32 accuracy
             cols = np.arange(N)
             q0 = test[0]
@@ -266,3 +272,45 @@ def test_rank_parity_protate(N, d, nq, gamma):
         assert clear.mean() > 0.5
         assert np.array_equal(got[clear], ref[clear])
         assert np.all(np.abs(got[~clear] - ref[~clear]) <= 2)
+
+
+@pytest.mark.parametrize("gamma", [12, 0])
+@pytest.mark.parametrize("N,d,nq", [(700, 200, 300), (130, 12, 50), (2000, 100, 129)])
+def test_rank_transe_l2_mfma_vs_distance_sweep(N, d, nq, gamma, monkeypatch):
+    """TransE-L2 1-vs-all on the matrix cores (order by |e|^2 - 2<q,e>) against the VALU distance sweep (KGE_RANK_L2=0) and the
+    fp64 oracle: identical ranks wherever no candidate lies within fp32 rounding of the target; filters un-count exactly."""
+    mdl, E0, R0, rs = _mk("TransE", N, 7, d, seed=13, norm=2, gamma=gamma)
+    test = list({(int(rs.randint(N)), int(rs.randint(7)), int(rs.randint(N))) for _ in range(nq)})
+    tes, filt = set(test), set()
+    for (s, p, o) in test:
+        for _ in range(int(rs.randint(0, 6))):
+            c = (s, p, int(rs.randint(N)))
+            if c not in tes:
+                filt.add(c)
+            c = (int(rs.randint(N)), p, o)
+            if c not in tes:
+                filt.add(c)
+    filt = sorted(filt)
+    fh, ft = O.build_filters(filt)
+    monkeypatch.setenv("KGE_RANK_L2", "1")
+    t1, h1 = mdl.rank(test, N, ft, fh)
+    monkeypatch.setenv("KGE_RANK_L2", "0")
+    t0, h0 = mdl.rank(test, N, ft, fh)
+    gaps = []
+    to, ho = O.ranks_closed_form("TransE", E0, R0, test, filt, 2, gamma, margin_out=gaps)
+    gaps = np.asarray(gaps).reshape(-1, 2)
+    tol = 1e-4  # distances here are ~sqrt(d); fp32 rounding of either form stays well below this
+    for got1, got0, ref, gap in ((t1, t0, to, gaps[:, 0]), (h1, h0, ho, gaps[:, 1])):
+        clear = gap > tol
+        assert clear.mean() > 0.3
+        assert np.array_equal(got1[clear], ref[clear]) and np.array_equal(got0[clear], ref[clear])
+        assert np.all(np.abs(got1[~clear] - ref[~clear]) <= 2)
+    # quantised tables: every quantity is exact in fp32 on both paths -> identical ranks, ties optimistic
+    mq, Eq, Rq, rs = _mk("TransE", 300, 5, 16, seed=4, quant=2, norm=2, gamma=gamma)
+    tq = list({(int(rs.randint(300)), int(rs.randint(5)), int(rs.randint(300))) for _ in range(120)})
+    monkeypatch.setenv("KGE_RANK_L2", "1")
+    a = mq.rank(tq, 300, {}, {})
+    monkeypatch.setenv("KGE_RANK_L2", "0")
+    b = mq.rank(tq, 300, {}, {})
+    ro = O.ranks_closed_form("TransE", Eq, Rq, tq, [], 2, gamma)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], ro[0]) and np.array_equal(a[1], ro[1])
