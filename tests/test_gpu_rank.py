@@ -147,9 +147,10 @@ def test_rank_error_behaviour():
         U.validate(mdl, [(0, 1, 2)], 14, 32)
 
 
-def test_rank_sharded_candidates_sum_to_unsharded():
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=2, gamma=12)), ("TransE", dict(norm=1, gamma=12))])
+def test_rank_sharded_candidates_sum_to_unsharded(model, kw):
     """Row-sharded sweep (SURVEY 8(e) schedule ii on one GPU): counts over candidate shards add up exactly."""
-    mdl, E0, R0, rs = _mk("DistMult", 1000, 4, 64, seed=9)
+    mdl, E0, R0, rs = _mk(model, 1000, 4, 64, seed=9, **kw)
     nq = 300
     test = np.stack([rs.randint(0, 1000, nq), rs.randint(0, 4, nq), rs.randint(0, 1000, nq)], 1).astype(np.int32)
     fq = np.repeat(np.arange(nq, dtype=np.int32), 3)
