@@ -68,7 +68,17 @@ int hole_spec_forward(const float* X, int64_t rows, int d, const float* W, float
   const int w2 = 2 * hole_spec_half(d);
   const float one = 1.f, zero = 0.f;
   KGE_BLAS_TRY(rocblas_set_stream(h, st));
-  KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, w2, (rocblas_int)rows, d, &one, W, w2, X, d, &zero, out, w2));
+  // m = 2hp is a few hundred, n = rows tens of thousands: as ONE GEMM rocBLAS tiles this NN product 256 x 256 and fills ~57 of 256
+  // CUs (78 us at FB15k-237, against 25 us for the transposed product of the adjoint).  The rows are independent, so the table is cut
+  // into 16 equal row blocks of one strided-batched GEMM (W shared: stride 0) plus a plain GEMM for the < 16 remaining rows.
+  const int64_t per = rows / 16;
+  const int64_t done = rows >= 4096 ? per * 16 : 0;
+  if (done)
+    KGE_BLAS_TRY(rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, w2, (rocblas_int)per, d, &one, W, w2, 0, X, d,
+                                               per * d, &zero, out, w2, per * w2, 16));
+  if (done < rows)
+    KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, w2, (rocblas_int)(rows - done), d, &one, W, w2, X + done * d, d,
+                               &zero, out + done * w2, w2));
   return KGE_OK;
 }
 
@@ -81,18 +91,7 @@ int hole_spec_adjoint(float* Ghat, int64_t rows, int d, const float* W, float* G
   const int w2 = 2 * hole_spec_half(d);
   const float one = 1.f;
   KGE_BLAS_TRY(rocblas_set_stream(h, st));
-  // m = d is a few hundred, n = rows tens of thousands: as ONE GEMM rocBLAS tiles it 256 x 256 and fills ~57 of 256 CUs
-  // (78 us at FB15k-237).  The rows are independent, so the table is cut into 16 row blocks of one strided-batched GEMM
-  // (W shared: stride 0) plus a plain GEMM for the remainder.
-  const int64_t per = cdiv(rows, 16);
-  const int nb = rows >= 4096 ? (int)(rows / per) : 0;
-  if (nb > 1)
-    KGE_BLAS_TRY(rocblas_sgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, d, (rocblas_int)per, w2, &one, W, w2, 0,
-                                               Ghat, w2, per * w2, &one, G, d, per * d, nb));
-  const int64_t done = nb > 1 ? (int64_t)nb * per : 0;
-  if (done < rows)
-    KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, d, (rocblas_int)(rows - done), w2, &one, W, w2,
-                               Ghat + done * w2, w2, &one, G + done * d, d));
+  KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_transpose, rocblas_operation_none, d, (rocblas_int)rows, w2, &one, W, w2, Ghat, w2, &one, G, d));
   if (zero_hat) KGE_HIP_TRY(hipMemsetAsync(Ghat, 0, sizeof(float) * (size_t)rows * w2, st));
   return KGE_OK;
 }
