@@ -54,7 +54,7 @@ def rank(model, N, R, d, nq, reps=5, **kw):
     dt = (time.perf_counter() - t0) / reps
     K = int(mdl.e_dim)
     out = {"ms_per_sweep": dt * 1e3, "ranks_per_s": nq / dt, "queries": nq, "row_floats": K}
-    if model != "TransE":
+    if model != "TransE" or kw.get("norm") == 2:  # TransE-L2 ranks on the matrix cores too (|e|^2 - 2<q,e>)
         out["mfma_tflops_algorithmic"] = 2.0 * K * N * nq / dt / 1e12
         out["mfma_frac_of_157.3"] = out["mfma_tflops_algorithmic"] / 157.3
     return out
