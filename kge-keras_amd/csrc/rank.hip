@@ -570,16 +570,56 @@ __device__ __forceinline__ float dist_step(float acc, float q, float e) {
   const float x = q - e;
   return NORM == 1 ? acc + fabsf(x) : (NORM == 3 ? acc + phase_abs(x) : __fmaf_rn(x, x, acc));
 }
+// NORM 4 = the pRotatE phase distance (NORM 3) on rows that hold (sin(x/2), cos(x/2)) PAIRS: |sin((q - e)/2)| =
+// |sin(q/2) cos(e/2) - cos(q/2) sin(e/2)|, one multiply, one fused multiply-add and one |.|-add per element instead of a sinf
+// (about 30 VALU instructions with its range reduction).  The sweep, the target and the filter kernels all take this form (the
+// tables are built once per call by rank_phase_table_kernel / rank_build_q_phase_kernel), so comparisons stay on bit-identical
+// numbers; against the direct form the element differs by a few ulp.
+__device__ __forceinline__ float phase_pair_step(float acc, float qs, float qc, float es, float ec) {
+  return acc + fabsf(__fmaf_rn(-qc, es, __fmul_rn(qs, ec)));
+}
 template <int NORM>
 __device__ __forceinline__ float dist_score(float acc, float gamma, float modulus) {
-  const float d = NORM == 1 ? acc : (NORM == 3 ? modulus * acc : sqrtf(acc));  // 3: pRotatE phase distance (models.py:479-489)
+  const float d = NORM == 1 ? acc : (NORM >= 3 ? modulus * acc : sqrtf(acc));  // 3, 4: pRotatE phase distance (models.py:479-489)
   return gamma > 0.f ? gamma - d : d;
 }
 template <int NORM>
 __device__ __forceinline__ float dist_chain(const float* __restrict__ q, const float* __restrict__ e, int K, float gamma, float modulus) {
   float acc = 0.f;
-  for (int k = 0; k < K; ++k) acc = dist_step<NORM>(acc, q[k], e[k]);
+  if (NORM == 4) {
+    for (int k = 0; k + 1 < K; k += 2) acc = phase_pair_step(acc, q[k], q[k + 1], e[k], e[k + 1]);
+  } else {
+    for (int k = 0; k < K; ++k) acc = dist_step<NORM>(acc, q[k], e[k]);
+  }
   return dist_score<NORM>(acc, gamma, modulus);
+}
+
+// Rows of (sin(x/2), cos(x/2)) pairs of a table (rows, K) -> (rows, 2K)
+__global__ __launch_bounds__(256) void rank_phase_table_kernel(const float* __restrict__ E, int64_t n, float* __restrict__ P) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sn, cs;
+  sincosf(0.5f * E[i], &sn, &cs);
+  reinterpret_cast<float2*>(P)[i] = make_float2(sn, cs);
+}
+// Query rows of the same form: q = s + p (tail side) or o - p (head side), zero padded to Kpad2 floats
+__global__ __launch_bounds__(256) void rank_build_q_phase_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
+                                                                  const int32_t* __restrict__ triples, int64_t nq, int side, int N, int R,
+                                                                  int K, int Kpad2, float* __restrict__ Qp, uint32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= nq) return;
+  const int s = triples[3 * q + 0], p = triples[3 * q + 1], o = triples[3 * q + 2];
+  const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+  if (!ok && lane == 0) atomicOr(err, 1u);
+  const float* er = E + (int64_t)(ok ? (side == 0 ? s : o) : 0) * K;
+  const float* rp = Rel + (int64_t)(ok ? p : 0) * K;
+  float* out = Qp + q * Kpad2;
+  for (int k = lane; k < Kpad2 / 2; k += 64) {
+    float sn = 0.f, cs = 0.f;
+    if (ok && k < K) sincosf(0.5f * (side == 0 ? er[k] + rp[k] : er[k] - rp[k]), &sn, &cs);
+    reinterpret_cast<float2*>(out)[k] = make_float2(sn, cs);
+  }
 }
 
 template <int NORM>
@@ -641,15 +681,29 @@ __global__ __launch_bounds__(256) void rank_dist_sweep_kernel(const float* __res
         for (int u = 0; u < 4; ++u) { Qs[(kl + u) * T + srow] = qv[u]; Es[(kl + u) * T + srow] = ev[u]; }
       }
       __syncthreads();
+      if (NORM == 4) {
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {  // rows of (sin, cos) pairs: two k-rows of the tile per element
+          const float4 qs4 = *reinterpret_cast<const float4*>(Qs + kk * T + ty * 4), qc4 = *reinterpret_cast<const float4*>(Qs + (kk + 1) * T + ty * 4);
+          const float4 es4 = *reinterpret_cast<const float4*>(Es + kk * T + tx * 4), ec4 = *reinterpret_cast<const float4*>(Es + (kk + 1) * T + tx * 4);
+          const float qs[4] = {qs4.x, qs4.y, qs4.z, qs4.w}, qc[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
+          const float es[4] = {es4.x, es4.y, es4.z, es4.w}, ec[4] = {ec4.x, ec4.y, ec4.z, ec4.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = phase_pair_step(acc[i][j], qs[i], qc[i], es[j], ec[j]);
+        }
+      } else {
 #pragma unroll 8
-      for (int kk = 0; kk < BK; ++kk) {
-        const float4 q4 = *reinterpret_cast<const float4*>(Qs + kk * T + ty * 4);
-        const float4 e4 = *reinterpret_cast<const float4*>(Es + kk * T + tx * 4);
-        const float qa[4] = {q4.x, q4.y, q4.z, q4.w}, ea[4] = {e4.x, e4.y, e4.z, e4.w};
+        for (int kk = 0; kk < BK; ++kk) {
+          const float4 q4 = *reinterpret_cast<const float4*>(Qs + kk * T + ty * 4);
+          const float4 e4 = *reinterpret_cast<const float4*>(Es + kk * T + tx * 4);
+          const float qa[4] = {q4.x, q4.y, q4.z, q4.w}, ea[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = dist_step<NORM>(acc[i][j], qa[i], ea[j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = dist_step<NORM>(acc[i][j], qa[i], ea[j]);
+        }
       }
     }
 #pragma unroll
@@ -752,10 +806,19 @@ static int rank_kpad_model(const kge_model_desc* md) { return md->model == KGE_T
 
 int64_t rank_workspace_bytes(const kge_model_desc* md, int64_t nq) {
   // TransE-L2 on the matrix cores additionally keeps the squared norm of every table row (rank_sumsq_kernel)
-  const int64_t en = md->model == KGE_TRANSE && md->norm == 2 ? align_up(md->num_entities, 64) : 0;
-  return (int64_t)sizeof(float) * (nq * rank_kpad_model(md) + align_up(nq, 64) + en) + 512;
+  int64_t en = md->model == KGE_TRANSE && md->norm == 2 ? align_up(md->num_entities, 64) : 0;
+  int64_t qrow = rank_kpad_model(md);
+  if (md->model == KGE_TRANSE && md->norm == 3) {  // pRotatE: (sin, cos) pair rows of the queries and of the whole table
+    qrow = align_up(2 * (int64_t)md->d_e, 32);
+    en = align_up(2 * (int64_t)md->d_e * md->num_entities, 64);
+  }
+  return (int64_t)sizeof(float) * (nq * qrow + align_up(nq, 64) + en) + 512;
 }
 
+static bool rank_phase_pairs() {  // KGE_RANK_PHASE=0: pRotatE ranks with one sinf per element (read per call: tests flip it)
+  const char* e = getenv("KGE_RANK_PHASE");
+  return !(e && atoi(e) == 0);
+}
 static bool rank_l2_mfma() {  // KGE_RANK_L2=0: TransE-L2 ranks through the VALU distance sweep (read per call: tests flip it)
   const char* e = getenv("KGE_RANK_L2");
   return !(e && atoi(e) == 0);
@@ -815,6 +878,22 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
       if (less) hipLaunchKernelGGL((rank_filter_l2_kernel<true>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
       else hipLaunchKernelGGL((rank_filter_l2_kernel<false>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
     }
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
+  }
+  if (md->model == KGE_TRANSE && md->norm == 3 && rank_phase_pairs()) {
+    // pRotatE on (sin, cos) pair rows (NORM 4 of the distance kernels): tables once per call, then 3 VALU operations per element
+    const int K2 = 2 * K, Kpad2 = (int)align_up(K2, 32);
+    float* tg = tgt_out ? tgt_out : Qv + nq * Kpad2;
+    float* EP = Qv + nq * Kpad2 + align_up(nq, 64);
+    const int64_t ne = (int64_t)md->num_entities * K;
+    hipLaunchKernelGGL(rank_phase_table_kernel, dim3((unsigned)cdiv(ne, 256)), dim3(256), 0, st, E, ne, EP);
+    hipLaunchKernelGGL(rank_build_q_phase_kernel, dim3((unsigned)cdiv(nq * 64, 256)), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities,
+                       md->num_relations, K, Kpad2, Qv, err);
+    kge_model_desc m2 = *md;
+    m2.d_e = m2.d_r = K2;
+    launch_dist<4>(&m2, EP, EP + (int64_t)cand_offset * K2, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tg,
+                   Kpad2, st);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }

@@ -315,3 +315,31 @@ def test_rank_transe_l2_mfma_vs_distance_sweep(N, d, nq, gamma, monkeypatch):
     b = mq.rank(tq, 300, {}, {})
     ro = O.ranks_closed_form("TransE", Eq, Rq, tq, [], 2, gamma)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], ro[0]) and np.array_equal(a[1], ro[1])
+
+
+def test_rank_protate_pair_tables_vs_direct(monkeypatch):
+    """pRotatE ranks on (sin, cos) pair tables (3 VALU operations per element) by default; KGE_RANK_PHASE=0 keeps one sinf per element.
+    Same ranks wherever no candidate lies within rounding of the target, with filters and candidate shards."""
+    from kge_keras_amd import models as M
+    N, d, nq = 900, 50, 200
+    rs = np.random.RandomState(21)
+    E0 = rs.uniform(-3, 3, (N, 2 * d)).astype(np.float32)
+    R0 = rs.uniform(-3, 3, (5, 2 * d)).astype(np.float32)
+    mdl = M.pRotatE(e_dim=d, r_dim=d, num_entities=N, num_relations=5, dp=0.0, gamma=12, modulus=2.0, init_entities=E0, init_relations=R0)
+    test = np.stack([rs.randint(0, N, nq), rs.randint(0, 5, nq), rs.randint(0, N, nq)], 1).astype(np.int32)
+    fq = np.repeat(np.arange(nq, dtype=np.int32), 2)
+    fi = rs.randint(0, N, 2 * nq).astype(np.int32)
+    keep = (fi != np.repeat(test[:, 2], 2)) & (fi != np.repeat(test[:, 0], 2))
+    fq, fi = fq[keep], fi[keep]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("KGE_RANK_PHASE", mode)
+        out[mode] = [mdl.rank_counts(test, side, fq, fi).cpu().numpy() for side in (0, 1)]
+    for side in (0, 1):
+        diff = np.abs(out["1"][side] - out["0"][side])
+        assert (diff == 0).mean() > 0.9 and diff.max() <= 2, (side, diff.max(), (diff == 0).mean())
+    monkeypatch.setenv("KGE_RANK_PHASE", "1")
+    acc = None
+    for a, b in ((0, 300), (300, 900)):
+        acc = mdl.rank_counts(test, 0, fq, fi, cand_offset=a, cand_rows=b - a, counts=acc)
+    assert np.array_equal(acc.cpu().numpy(), out["1"][0])
