@@ -327,6 +327,11 @@ class EmbeddingModel:
         md, ld = self._model_desc(True), self._loss_desc()
         return lib.kge_batch_plan_bytes(C.byref(md), C.byref(ld), 1, 1) > 0
 
+    def pipeline_supported(self):
+        """True where the whole step is ONE planned library call (what pipeline.TrainPipeline captures into its step graph); HolE's
+        frequency-domain step takes plans too but is a composite of calls and runs batch by batch."""
+        return type(self).train_step is EmbeddingModel.train_step and self.plan_supported()
+
     def plan_batch_counted(self, cand_rows, cand_counts, n_pos_cand, m_pos, m_neg, out=None, parts=7, pos_lanes=1):
         """BatchPlan of a batch given in folded form: cand_rows (rows of the batch before oversampling, positives first) with
         their multiplicities cand_counts (DeviceSampler.build_batch(..., counted=...): pos_lanes = _lib.CAND_POS_LANES striped
@@ -457,7 +462,7 @@ class EmbeddingModel:
             if shuffle:
                 random.shuffle(order)  # Keras shuffles the batch order of a Sequence with Python's `random`
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
-            if hasattr(x, "run_epoch") and self.plan_supported():
+            if hasattr(x, "run_epoch") and self.pipeline_supported():
                 # device generator + a model with batch plans: draw | plan | step pipelined on the GPU, replayed from hipGraphs
                 tot = x.run_epoch(self, order)
             else:

@@ -23,8 +23,7 @@ class TrainPipeline:
         """kg: (n,3) int32 device rows; n_rows: length of the epoch permutation; sampler: DeviceSampler whose states are loaded.
         `between`: optional callable run between the gradient half and the optimizer half of every step (the data-parallel
         all-reduce); the optimizer half then stays outside the graphs."""
-        from .models import EmbeddingModel
-        if not model.plan_supported() or type(model).train_step is not EmbeddingModel.train_step:
+        if not model.pipeline_supported():
             # (HolE's frequency-domain step takes plans too, but is a composite of library calls, not one captured step)
             raise NotImplementedError("TrainPipeline needs a model / loss with batch plans (EmbeddingModel.plan_supported)")
         self.model, self.kg, self.B, self.ns, self.num_e, self.sampler = model, kg, int(batch_size), int(ns), int(num_e), sampler

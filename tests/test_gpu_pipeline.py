@@ -242,3 +242,28 @@ def test_device_generator_end_to_end_with_validation_and_callback(datasets):
     assert len(h.history["loss"]) == 30 and len(h.history["val_loss"]) == 30
     assert h.history["loss"][-1] < h.history["loss"][0]
     assert after["mrr"] > before["mrr"] + 0.1 and after["mr"] < 4.0, (before, after)
+
+
+def test_device_generator_fit_hole_frequency_domain(datasets):
+    """HolE without dropout takes batch plans but its step is a composite of library calls: fit() over the DeviceDataGenerator runs it
+    batch by batch (no TrainPipeline) on the device-drawn batches -- same batches as the host generator, same tables as the oracle."""
+    from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
+    hp = dict(num_entities=14, num_relations=55, dim=16, embedding_model="HolE", loss_function="pointwize_hinge", margin=1, dp=0.0, seed=5)
+    np.random.seed(3)
+    random.seed(4)
+    mdl = build_model(hp)
+    assert mdl.plan_supported() and not mdl.pipeline_supported()
+    E0, R0 = mdl.E.cpu().numpy().astype(np.float64), mdl.Rel.cpu().numpy().astype(np.float64)
+    gen = DeviceDataGenerator(datasets["nations_train"], ns=10, batch_size=64)
+    h = mdl.fit(gen, epochs=1, verbose=0, shuffle=False)
+    np.random.seed(3)
+    random.seed(4)
+    hgen = DataGenerator(datasets["nations_train"], ns=10, batch_size=64)
+    oo = O.make_optimizer("adam")
+    tot = 0.0
+    for i in range(len(hgen)):
+        (pos, neg), _y = hgen[i]
+        tot += O.train_step("HolE", E0, R0, oo, pos, neg, "pointwize_hinge", 1.0, 1)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
+    np.testing.assert_allclose(h.history["loss"], [tot / len(hgen)], rtol=1e-4)
