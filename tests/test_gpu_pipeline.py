@@ -267,3 +267,28 @@ def test_device_generator_fit_hole_frequency_domain(datasets):
     np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
     np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
     np.testing.assert_allclose(h.history["loss"], [tot / len(hgen)], rtol=1e-4)
+
+
+def test_pipeline_protate(datasets):
+    """pRotatE (TransE kernels, norm id 3) through the graph-replayed pipeline: same tables as the host generator + oracle."""
+    from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
+    hp = dict(num_entities=14, num_relations=55, dim=16, embedding_model="pRotatE", loss_function="pointwize_logistic", margin=1, dp=0.0, seed=2)
+    np.random.seed(7)
+    random.seed(8)
+    mdl = build_model(hp)
+    assert mdl.pipeline_supported()
+    E0, R0 = mdl.E.cpu().numpy().astype(np.float64), mdl.Rel.cpu().numpy().astype(np.float64)
+    gen = DeviceDataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    h = mdl.fit(gen, epochs=1, verbose=0, shuffle=False)
+    assert gen._pipe.use_graphs and gen._pipe.graphs
+    np.random.seed(7)
+    random.seed(8)
+    hgen = DataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    oo = O.make_optimizer("adam")
+    tot = 0.0
+    for i in range(len(hgen)):
+        (pos, neg), _y = hgen[i]
+        tot += O.train_step("pRotatE", E0, R0, oo, pos, neg, "pointwize_logistic", 1.0, 1, mdl.modulus, 12)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
+    np.testing.assert_allclose(h.history["loss"], [tot / len(hgen)], rtol=1e-4)
