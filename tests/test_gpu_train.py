@@ -719,3 +719,21 @@ def test_hole_spectral_large_table_row_blocks():
         assert La == pytest.approx(Lb, abs=1e-5, rel=1e-5)
         np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=1e-5)
         np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=1e-5)
+
+
+def test_hole_spectral_with_l3_regulariser():
+    """The L3 regulariser (models.py:10-11,78-92) acts on the REAL entity table in the optimizer sweep while the data term comes back
+    from the frequency domain: loss value and tables against the oracle."""
+    N, R, d, m = 60, 5, 24, 500
+    mdl, E0, R0, rs = _mk("HolE", N, R, d, loss_function="pointwize_logistic", regularization=0.01)
+    assert mdl._spectral_on()
+    mdl.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.make_optimizer("adam")
+    for step in range(3):
+        pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
+        L = float(mdl.train_step([pos, neg])["loss"].item())
+        Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, 1, 12, regularization=0.01)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
