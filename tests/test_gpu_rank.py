@@ -343,3 +343,34 @@ def test_rank_protate_pair_tables_vs_direct(monkeypatch):
     for a, b in ((0, 300), (300, 900)):
         acc = mdl.rank_counts(test, 0, fq, fi, cand_offset=a, cand_rows=b - a, counts=acc)
     assert np.array_equal(acc.cpu().numpy(), out["1"][0])
+
+
+def test_rank_fuzz_shapes_vs_chain_scores():
+    """Seeded sweep of awkward shapes (tables smaller than a tile, one query, K with and without chunk padding, candidate shards that cut
+    tiles) through the persistent MFMA sweep: counts equal the counts taken on the chain scores bit for bit (DistMult / ComplEx)."""
+    from kge_keras_amd import _lib
+    rs = np.random.RandomState(77)
+    for case in range(24):
+        model = ("DistMult", "ComplEx")[case % 2]
+        N = int(rs.choice([1, 2, 127, 128, 129, 255, 257, 640, 1111]))
+        d = int(rs.choice([4, 8, 12, 36, 40, 44, 100, 132]))
+        nq = int(rs.choice([1, 2, 63, 128, 129, 300, 515]))
+        mdl, E0, R0, _ = _mk(model, N, 3, d, seed=case)
+        test = np.stack([rs.randint(0, N, nq), rs.randint(0, 3, nq), rs.randint(0, N, nq)], 1).astype(np.int32)
+        side = int(rs.randint(2))
+        empty = np.zeros(0, np.int32)
+        cnt = mdl.rank_counts(test, side, empty, empty).cpu().numpy()
+        md = mdl._model_desc(False)
+        out = torch.empty((nq, N), dtype=torch.float32, device="cuda")
+        t = torch.from_numpy(test).cuda()
+        _lib.check(_lib.lib.kge_rank_chain_scores(C.byref(md), mdl.E.data_ptr(), mdl.Rel.data_ptr(), t.data_ptr(), nq, side, out.data_ptr(),
+                                                  mdl._rank_ws.data_ptr(), mdl._rank_ws.numel(), mdl._err.data_ptr(), _lib.stream_ptr()))
+        sc = out.cpu().numpy()
+        tgt = sc[np.arange(nq), test[:, 2] if side == 0 else test[:, 0]]
+        assert np.array_equal(cnt, (sc > tgt[:, None]).sum(1)), (case, model, N, d, nq, side)
+        if N >= 3:  # candidate shards with cuts inside tiles add up exactly
+            cuts = sorted(set([0, N] + [int(x) for x in rs.randint(1, N, 2)]))
+            acc = None
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                acc = mdl.rank_counts(test, side, empty, empty, cand_offset=a, cand_rows=b - a, counts=acc)
+            assert np.array_equal(acc.cpu().numpy(), cnt), (case, "shards", cuts)
