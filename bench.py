@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: run the pipeline stages one after the other on one stream, kernel by kernel, in every phase "
                          "(what the roofline leg does), so that a rocprofv3 kernel trace of the run times every kernel alone")
+    ap.add_argument("--model", default="DistMult", choices=["DistMult", "TransE"],
+                    help="DistMult: the BASELINE configs[1] workload (the contract line).  TransE: configs[2] (L2, gamma 12) through the same "
+                         "pipeline, for comparison only (no CPU baseline; the metric string names it)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed code paths even with WORLD_SIZE=1 (rehearsal on one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
@@ -199,15 +202,16 @@ def main():
 
     from kge_keras_amd import _lib
     from kge_keras_amd import dist as D
-    from kge_keras_amd.models import DistMult
+    from kge_keras_amd import models as KM
 
     rs = np.random.RandomState(1234)
     def glorot(rows, cols):  # Keras GlorotUniform on an Embedding matrix (models.py:87-93): U(-l, l), l = sqrt(6 / (rows + cols))
         lim = np.sqrt(6.0 / (rows + cols))
         return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
     E0, R0 = glorot(CFG["N"], CFG["d"]), glorot(CFG["R"], CFG["d"])
-    model = DistMult(e_dim=CFG["d"], r_dim=CFG["d"], num_entities=CFG["N"], num_relations=CFG["R"], dp=0.0,
-                     init_entities=E0, init_relations=R0, loss_function="pointwize_hinge", margin=1)
+    mkw = dict(norm=2, gamma=12) if args.model == "TransE" else {}
+    model = getattr(KM, args.model)(e_dim=CFG["d"], r_dim=CFG["d"], num_entities=CFG["N"], num_relations=CFG["R"], dp=0.0,
+                                    init_entities=E0, init_relations=R0, loss_function="pointwize_hinge", margin=1, **mkw)
     model.compile("adam")
     n_pool = 8
     host_batches = make_batches(n_pool, rank)
@@ -399,10 +403,10 @@ def main():
         k_avg, k_bytes = kernels[dom]
         achieved = k_bytes / k_avg if k_avg else 0.0
         res = {
-            "metric": "scored triples/sec (train, 100 neg), FB15k-237 d=200", "value": value, "unit": "scored triples/s",
+            "metric": "scored triples/sec (train, 100 neg), FB15k-237 d=200" + ("" if args.model == "DistMult" else f" [{args.model}-L2]"), "value": value, "unit": "scored triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FB15k-237 DistMult d=200, B=2048, 100 negatives (409600 scored triples/step), pointwize_hinge + Adam(TF semantics)",
+            "config": {"workload": f"FB15k-237 {args.model if args.model == 'DistMult' else 'TransE-L2 (gamma 12)'} d=200, B=2048, 100 negatives (409600 scored triples/step), pointwize_hinge + Adam(TF semantics)",
                        "N": CFG["N"], "R": CFG["R"], "d": CFG["d"], "B": CFG["B"], "ns": CFG["ns"],
                        "parallelism": f"dp{world}" if dist_on else "single",
                        "sampler": ("bit-exact MT19937 HIP sampler inside the timed region (side stream, one batch ahead)" if args.sampler == "device"
@@ -433,7 +437,7 @@ def main():
                                   if plan_ahead else "built inside the step")},
         }
         res["eval_1vsall"] = ev
-        if rank == 0 and not args.no_cpu_baseline and world == 1:
+        if rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "DistMult":
             res["cpu_baseline"] = cpu_baseline(host_batches, E0, R0)
         print(json.dumps(res), flush=True)
     if dist_on:
