@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- scored triples/sec of the KGE train step (BASELINE.json metric) on N MI355X.
+"""bench.py -- scored triples/sec of the KGE train step + 1-vs-all ranks/sec (BASELINE.json metric) on N MI355X.
 
 Workload (BASELINE.json configs[1]): FB15k-237-shaped DistMult d=200, B=2048 positives, 100 negatives ->
 m = 204 800 rows per input array, 409 600 scored triples per step; N=14 541 entities, R=237 relations;
@@ -9,16 +9,23 @@ gradients + optimizer update on one batch resident in HBM.  By default (--sample
 the timed region by the bit-exact MT19937 HIP sampler (negative sampling + oversampling, the reference's exact draws) on a
 side stream, one batch ahead of training; --sampler pre uses batches built on the host before timing.
 
-N > 1: data-parallel replicas, one process per GPU (torch.distributed, backend nccl = RCCL): every rank runs the
-gradient half on its own batch, the dense gradient tables are all-reduced (mean) over xGMI, every rank applies
-the same update.  value = triples scored by all ranks / max-over-ranks wall time (weak scaling).
+--check (on by default): before the timed region the SAME code path (TrainPipeline, device sampler, counted plans, hipGraphs,
+full batch size) runs 3 steps on a fresh model and is compared with the oracle -- drawn batches bit for bit against the host
+generator, loss and both tables after every step against oracle/kge_oracle_c.c -- and the line carries "checked" / "max_abs_err".
+
+N > 1: one process per GPU (torch.distributed; backend nccl = RCCL).  `python bench.py --gpus N` starts the N ranks itself when
+it is not already running under torch.distributed.run.  Training: data-parallel replicas, the dense gradient tables are
+all-reduced (mean) between the gradient half and the optimizer half of every step; value = triples scored by all ranks /
+max-over-ranks wall time (weak scaling).  Evaluation: the YAGO3-10 shape (BASELINE configs[4]; N=123 182, d=200, 10 000
+queries) with the entity table row-sharded, in both schedules of SURVEY 8(e): (i) all-gather the table, split the queries;
+(ii) resident shards + kge_rank_counts over the rank's own rows + all-reduce of the int32 counts.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,31 +35,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG = dict(N=14541, R=237, d=200, B=2048, ns=100, n_train=272115)
+YAGO = dict(N=123182, R=37, d=200, n_test=5000)   # BASELINE configs[4]: YAGO3-10 DistMult d=200, 5000 test triples x head/tail
 A_FWD = 4 * (2 * CFG["d"] + CFG["d"]) + 12 + 4   # two entity rows, one relation row, 3 ids, 1 score
 A_BWD = 4 * (2 * CFG["d"] + CFG["d"])            # three gradient rows written once
 A_TRAIN = A_FWD + A_BWD                          # 4816 B per scored triple at d=200
+A_OPT = 32 * (CFG["N"] * CFG["d"] + CFG["R"] * CFG["d"])  # TF-Adam: read g,w,m,v; write w,m,v; re-zero g (94.6 MB per step)
 HBM_PEAK = 8.0e12                                # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK = 157.3e12                         # MI355X_MICROARCH.md: dense fp32 matrix peak
+METRIC = "scored triples/sec (train, 100 neg) + 1-vs-all ranks/sec, FB15k-237 d=200"  # BASELINE.json, verbatim
 
 
+# ----------------------------------------------------------------------------------------------------------------- profiles
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the named kernel family from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
     produced by tools/pmc.sh; FETCH_SIZE x2 + WRITE_SIZE, see that file's _source).  None when no pass exists."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
-        return None
+        return None, None
     fam = kernel_label.split()[0]
     best = None
     for name, v in d.get("kernels", {}).items():
         if v.get("family") == fam and (best is None or v["hbm_bytes_per_launch"] > best):
             best = v["hbm_bytes_per_launch"]
-    return best
+    return best, d.get("_tag")
 
 
 def rocprof_avg_ms(kernel_label):
     """Average duration of the named kernel family in the newest committed `rocprofv3 --kernel-trace --stats` summary of
-    `bench.py --serial` (profiles/*_serial_kernel_stats.csv): every kernel alone, dispatches serialised by the profiler with cold
-    caches in between -- the cold-cache counterpart of the live hipEvent duration.  None when no summary is committed."""
+    `bench.py --serial` (profiles/*_serial_kernel_stats.csv): every kernel alone, dispatches serialised by the profiler.
+    None when no summary is committed."""
     import csv
     import glob
     fam = kernel_label.split()[0]
@@ -68,20 +80,150 @@ def rocprof_avg_ms(kernel_label):
     return None
 
 
-def make_batches(n_batches, rank):
+# ----------------------------------------------------------------------------------------------------------------- workload
+def workload(model_name="DistMult", rank=0):
+    """The synthetic FB15k-237-shaped workload of one rank, as plain host arrays (shared by the timed run, --check and the
+    parity tests): Glorot tables, the rank's training triples, model kwargs."""
+    rs = np.random.RandomState(1234)
+
+    def glorot(rows, cols):  # Keras GlorotUniform on an Embedding matrix (models.py:87-93): U(-l, l), l = sqrt(6 / (rows + cols))
+        lim = np.sqrt(6.0 / (rows + cols))
+        return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
+    E0, R0 = glorot(CFG["N"], CFG["d"]), glorot(CFG["R"], CFG["d"])
+    rs_t = np.random.RandomState(1234 + 7919 * rank)
+    train = np.stack([rs_t.randint(0, CFG["N"], CFG["n_train"]), rs_t.randint(0, CFG["R"], CFG["n_train"]),
+                      rs_t.randint(0, CFG["N"], CFG["n_train"])], 1).astype(np.int32)
+    mkw = dict(norm=2, gamma=12) if model_name == "TransE" else {}
+    return dict(E0=E0, R0=R0, train=train, mkw=mkw, model=model_name)
+
+
+def make_model(w):
+    from kge_keras_amd import models as KM
+    model = getattr(KM, w["model"])(e_dim=CFG["d"], r_dim=CFG["d"], num_entities=CFG["N"], num_relations=CFG["R"], dp=0.0,
+                                    init_entities=w["E0"], init_relations=w["R0"], loss_function="pointwize_hinge", margin=1, **w["mkw"])
+    model.compile("adam")
+    return model
+
+
+def make_pipeline(torch, model, w, rank, total_steps, graphs=True, between=None):
+    """The benched object: TrainPipeline over the device sampler seeded like the host generator of make_batches()."""
+    from kge_keras_amd.pipeline import TrainPipeline
+    from kge_keras_amd.sampler import NumpyStream, PythonStream, DeviceSampler
+    nps = NumpyStream(rank)
+    perm = nps.shuffle(np.arange(CFG["n_train"], dtype=np.int64))  # epoch permutation (host, once per epoch)
+    train_dev, perm_dev = torch.from_numpy(w["train"]).cuda(), torch.from_numpy(perm).cuda()
+    dsamp = DeviceSampler(nps, PythonStream(rank))
+    pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=graphs, between=between)
+    nb_epoch = CFG["n_train"] // CFG["B"]
+    pipe.load_epoch(perm_dev, [i % nb_epoch for i in range(total_steps)])
+    return pipe, dsamp
+
+
+def host_batches(w, rank, n_batches, folded=False):
+    """The same batches from the host generator (csrc/sampler.cpp: the reference's draws bit for bit).  folded=True also
+    returns every batch before oversampling (B positives + B*ns generated negatives) and the pick counts of random.choices."""
     from kge_keras_amd.sampler import NumpyStream, PythonStream, build_batch
-    rs = np.random.RandomState(1234 + 7919 * rank)
-    train = np.stack([rs.randint(0, CFG["N"], CFG["n_train"]), rs.randint(0, CFG["R"], CFG["n_train"]),
-                      rs.randint(0, CFG["N"], CFG["n_train"])], 1).astype(np.int32)
+    B, ns, N = CFG["B"], CFG["ns"], CFG["N"]
+    m = B * ns
     nps, pys = NumpyStream(rank), PythonStream(rank)
     perm = nps.shuffle(np.arange(CFG["n_train"], dtype=np.int64))
+    nb_epoch = CFG["n_train"] // B
     out = []
-    for b in range(n_batches):
-        batch = train[perm[b * CFG["B"]:(b + 1) * CFG["B"]]]
-        out.append(build_batch(nps, pys, batch, CFG["ns"], CFG["N"]))
+    for i in range(n_batches):
+        b = i % nb_epoch
+        batch = w["train"][perm[b * B:(b + 1) * B]]
+        if folded:  # twin streams replay the draws of this batch: utils.py:118-119 (fs, then fo), :136 (positives, then negatives)
+            n2, p2 = NumpyStream(), PythonStream()
+            n2._buf[:] = nps._buf
+            p2._buf[:] = pys._buf
+            fs, fo = n2.randint(0, N, m), n2.randint(0, N, m)
+            cand = np.concatenate([batch, np.stack([fs, np.repeat(batch[:, 1], ns), fo], 1).astype(np.int32)])
+            ip, ineg = p2.choices_idx(B, m), p2.choices_idx(m, m)
+            counts = (np.bincount(ip, minlength=B), np.bincount(ineg, minlength=m))
+        pos, neg = build_batch(nps, pys, batch, ns, N)
+        if folded:
+            assert np.array_equal(pos, cand[:B][ip]) and np.array_equal(neg, cand[B:][ineg])
+            out.append((pos, neg, cand, counts))
+        else:
+            out.append((pos, neg))
     return out
 
 
+def check_benched_path(model_name="DistMult", steps=3, rank=0, fp64=False, tol=1e-4):
+    """Parity of the benched code path at the benched size: a fresh model driven by TrainPipeline (device sampler, counted
+    plans, one hipGraph per stage) for `steps` steps on the bench workload.  (a) every batch the device drew == the host
+    generator's, bit for bit (rows before oversampling and pick counts; tests.py:55-61, utils.py:114-147); (b) loss, entity
+    table and relation table after every step against the oracle's C restatement (fp32; fp64=True: also the NumPy fp64 oracle)
+    within `tol`.  The oracle is the checker only.  Returns a dict for the bench line; raises AssertionError on a mismatch."""
+    import torch
+    import oracle as O
+    from oracle import c_port
+    from kge_keras_amd import _lib
+    w = workload(model_name, rank)
+    model = make_model(w)
+    pipe, dsamp = make_pipeline(torch, model, w, rank, steps + 2)
+    hb = host_batches(w, rank, steps + 2, folded=True)
+    B, L = CFG["B"], _lib.CAND_POS_LANES
+    kw = w["mkw"]
+    ct = c_port.CTrainer(model_name, w["E0"], w["R0"], "adam", "pointwize_hinge", 1.0, kw.get("norm", 1), kw.get("gamma", 12.0))
+    if fp64:
+        Eo, Ro, oo = w["E0"].astype(np.float64), w["R0"].astype(np.float64), O.AdamTF()
+    seen = set()
+
+    def check_batch(k):
+        """slot k % 2 holds batch k in folded form"""
+        rows, cnt = (x.cpu().numpy() for x in pipe.cand[k % 2])
+        _pos, _neg, cand, (cp, cn) = hb[k]
+        assert np.array_equal(rows, cand), f"batch {k}: rows before oversampling differ from the host generator"
+        assert np.array_equal(cnt[:L * B].reshape(L, B).sum(0), cp) and np.array_equal(cnt[L * B:], cn), f"batch {k}: pick counts differ"
+        seen.add(k)
+
+    pipe.start()
+    torch.cuda.synchronize()
+    assert pipe.use_graphs and pipe.graphs and pipe.counted, "the benched path is the graph-replayed pipeline with counted plans"
+    check_batch(0)
+    check_batch(1)
+    err = dict(loss=0.0, E=0.0, Rel=0.0)
+    err64 = dict(loss=0.0, E=0.0, Rel=0.0)
+    for t in range(steps):
+        pipe.tick()
+        torch.cuda.synchronize()
+        if t + 2 < len(hb):
+            check_batch(t + 2)
+        pos, neg = hb[t][0], hb[t][1]
+        Lg = float(model._loss[0].item())
+        Eg, Rg = model.E.cpu().numpy(), model.Rel.cpu().numpy()
+        Lc = ct.step(pos, neg)
+        for k, a, b in (("loss", Lg, Lc), ("E", Eg, ct.E), ("Rel", Rg, ct.Rel)):
+            e = float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+            err[k] = max(err[k], e)
+            assert e <= tol, f"step {t}: {k} differs from the C oracle by {e:.3g} (> {tol})"
+        if fp64:
+            Lo = O.train_step(model_name, Eo, Ro, oo, pos, neg, "pointwize_hinge", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+            for k, a, b in (("loss", Lg, Lo), ("E", Eg, Eo), ("Rel", Rg, Ro)):
+                e = float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)))
+                err64[k] = max(err64[k], e)
+                assert e <= tol, f"step {t}: {k} differs from the fp64 oracle by {e:.3g} (> {tol})"
+    pipe.finish()
+    torch.cuda.synchronize()
+    model._raise_on_flag()
+    assert int(dsamp.err.item()) == 0, "device sampler: rejection margin ran short"
+    # the generator states the device left behind == the host streams after the same batches
+    from kge_keras_amd.sampler import NumpyStream, PythonStream, build_batch
+    nps, pys = NumpyStream(rank), PythonStream(rank)
+    perm = nps.shuffle(np.arange(CFG["n_train"], dtype=np.int64))
+    for i in range(steps + 2):
+        build_batch(nps, pys, w["train"][perm[i * B:(i + 1) * B]], CFG["ns"], CFG["N"])
+    dn, dp_ = dsamp.to_streams()
+    assert np.array_equal(dn._buf[:625], nps._buf[:625]) and np.array_equal(dp_._buf[:625], pys._buf[:625]), "generator states diverged"
+    res = dict(checked=True, check_steps=steps, check_batches_bit_exact=sorted(seen), max_abs_err=max(err.values()), max_abs_err_by=err,
+               check_oracle="oracle/kge_oracle_c.c (fp32 C restatement)" + (" + oracle/kge_oracle.py (NumPy fp64)" if fp64 else ""), check_tol=tol)
+    if fp64:
+        res["max_abs_err_fp64"] = max(err64.values())
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------- baselines
 def cpu_baseline(batches, E0, R0, budget_s=15.0):
     """The oracle's C restatement of the same train step (oracle/kge_oracle_c.c: gather, DistMult score, pointwize_hinge,
     duplicate-summed gradients, Keras-formula Adam; fp32, OpenMP over the host cores) on the same batches, bounded to
@@ -100,57 +242,141 @@ def cpu_baseline(batches, E0, R0, budget_s=15.0):
                 sample=f"{steps} full-size steps ({n} scored triples) of the C oracle (oracle/kge_oracle_c.c, fp32, OpenMP x{c_port.threads()}) in {dt:.1f}s")
 
 
-def eval_leg(torch, dist, model, rank, world, reps=3, dist_on=False):
-    """1-vs-all ranks/sec on the same FB15k-237-shaped tables: 40 932 queries (20 466 test triples x head/tail),
-    filters = 3 random ids per query.  N > 1: every rank holds a row shard of E, the shards are all-gathered over
-    RCCL into a full table, and the queries are split across ranks (SURVEY 8(e) schedule i)."""
-    import numpy as np
+# ----------------------------------------------------------------------------------------------------------------- evaluation legs
+def eval_leg(torch, model, reps=3):
+    """1-vs-all ranks/sec on the FB15k-237-shaped tables of the train leg, one GPU: 40 932 queries (20 466 test triples x
+    head/tail), filters = 3 random ids per query."""
     from kge_keras_amd import _lib
     rs = np.random.RandomState(99)
     nt = 20466
     test = np.stack([rs.randint(0, CFG["N"], nt), rs.randint(0, CFG["R"], nt), rs.randint(0, CFG["N"], nt)], 1).astype(np.int32)
-    mine = test[rank::world]
-    nq = len(mine)
-    fq = np.repeat(np.arange(nq, dtype=np.int32), 3)
-    fi = rs.randint(0, CFG["N"], 3 * nq).astype(np.int32)
-    keep = (fi != np.repeat(mine[:, 2], 3)) & (fi != np.repeat(mine[:, 0], 3))
+    fq = np.repeat(np.arange(nt, dtype=np.int32), 3)
+    fi = rs.randint(0, CFG["N"], 3 * nt).astype(np.int32)
+    keep = (fi != np.repeat(test[:, 2], 3)) & (fi != np.repeat(test[:, 0], 3))
     fq, fi = torch.from_numpy(fq[keep]).cuda(), torch.from_numpy(fi[keep]).cuda()  # the filter index is resident, like the tables
-    tq = torch.from_numpy(mine).cuda()
-    from kge_keras_amd import dist as D
-    lo, hi = D.shard_range(CFG["N"], rank, world)
-    shard_at_rest = model.E[lo:hi].clone()
+    tq = torch.from_numpy(test).cuda()
 
     def sweep():
-        if dist_on:  # all-gather of the row shards into the full table (kge_keras_amd.dist.allgather_rows)
-            model.E.copy_(D.allgather_rows(shard_at_rest, CFG["N"]))
-        c0 = model.rank_counts(tq, 0, fq, fi)
-        c1 = model.rank_counts(tq, 1, fq, fi)
-        return c0, c1
+        return model.rank_counts(tq, 0, fq, fi), model.rank_counts(tq, 1, fq, fi)
 
     sweep()
     torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
     _lib.lib.kge_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(reps):
         c0, c1 = sweep()
     torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
     dt = time.perf_counter() - t0
     _lib.lib.kge_prof_enable(0)
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     ms, n = _lib.prof_read("rank")
+    sw_ms, sw_n = _lib.prof_read("rank_sweep")
     total_q = 2 * nt
     flops = 2.0 * CFG["d"] * CFG["N"]  # SURVEY 8(d): 2*d_e*N per rank
     return dict(ranks_per_sec=total_q * reps / dt, queries=total_q, ms_per_sweep=dt / reps * 1e3,
-                mfma_tflops_algorithmic=total_q * reps * flops / dt / 1e12, mfma_peak_tflops=157.3,
-                mfma_frac=total_q * reps * flops / dt / 157.3e12, rank_call_avg_ms=ms / max(1, n),
+                mfma_tflops_algorithmic=total_q * reps * flops / dt / 1e12, mfma_peak_tflops=MFMA_F32_PEAK / 1e12,
+                mfma_frac=total_q * reps * flops / dt / MFMA_F32_PEAK, rank_call_avg_ms=ms / max(1, n),
+                sweep_kernel_avg_ms=sw_ms / max(1, sw_n), sweep_kernel_launches=sw_n, flop_per_launch=nt * flops,
                 mean_rank=float((1 + c0.float().mean() + 1 + c1.float().mean()).item() / 2))
+
+
+def eval_sharded_leg(torch, dist, rank, world, reps=3):
+    """The north star's multi-GPU half on the shape it is quoted for (BASELINE configs[4]: YAGO3-10 DistMult d=200): the entity
+    table row-sharded across the ranks, 10 000 filtered queries, both schedules of SURVEY 8(e).  Ranks of the two schedules
+    must be identical."""
+    from kge_keras_amd import models as KM
+    from kge_keras_amd import dist as D
+    N, R, d, nt = YAGO["N"], YAGO["R"], YAGO["d"], YAGO["n_test"]
+    rs = np.random.RandomState(4321)
+    lim = np.sqrt(6.0 / (N + d))
+    E0 = rs.uniform(-lim, lim, size=(N, d)).astype(np.float32)
+    R0 = rs.uniform(-0.4, 0.4, size=(R, d)).astype(np.float32)
+    test = np.stack([rs.randint(0, N, nt), rs.randint(0, R, nt), rs.randint(0, N, nt)], 1).astype(np.int32)
+    fq_all = np.repeat(np.arange(nt, dtype=np.int32), 3)
+    fi_all = rs.randint(0, N, 3 * nt).astype(np.int32)
+    keep = (fi_all != np.repeat(test[:, 2], 3)) & (fi_all != np.repeat(test[:, 0], 3))
+    fq_all, fi_all = fq_all[keep], fi_all[keep]
+    lo, hi = D.shard_range(N, rank, world)
+    model = KM.DistMult(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0)
+    shard = model.E[lo:hi].clone()          # what this rank holds at rest
+    model.E.zero_()                         # schedule (i) rebuilds the full table from the shards
+
+    # schedule (i): all-gather the table, split the queries, gather the ranks
+    idx = D.split_queries(nt, rank, world).numpy()
+    mine = torch.from_numpy(test[idx]).cuda()
+    sel = np.isin(fq_all, idx)
+    fq1 = torch.from_numpy(np.searchsorted(idx, fq_all[sel]).astype(np.int32)).cuda()
+    fi1 = torch.from_numpy(fi_all[sel]).cuda()
+    ag = [0.0]
+
+    def sched1():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        model.E.copy_(D.allgather_rows(shard, N))
+        e1.record()
+        t = 1 + model.rank_counts(mine, 0, fq1, fi1).long()
+        h = 1 + model.rank_counts(mine, 1, fq1, fi1).long()
+        out = D.gather_ranks(t, nt), D.gather_ranks(h, nt)
+        torch.cuda.synchronize()
+        ag[0] += e0.elapsed_time(e1)
+        return out
+
+    # schedule (ii): resident shards, referenced rows exchanged, counts all-reduced
+    fq2, fi2 = torch.from_numpy(fq_all).cuda(), torch.from_numpy(fi_all).cuda()
+
+    def sched2():
+        return D.resident_shard_eval(test, lambda ref, local, side: model.rank_counts_shard(ref, local, side, fq2, fi2, shard, lo), shard, lo)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ag[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return out, dt / reps
+
+    (t1, h1), dt1 = timed(sched1)
+    ag_ms = ag[0] / reps
+    (t2, h2), dt2 = timed(sched2)
+    same = bool(torch.equal(t1, t2) and torch.equal(h1, h2))
+    n_ref = int(len(D.referenced_rows(test)))
+    per = (N + world - 1) // world
+    return dict(workload=f"YAGO3-10 shape: DistMult d={d}, N={N}, R={R}, {2 * nt} filtered queries, entity table row-sharded over {world} rank(s)",
+                ranks_identical_between_schedules=same, mean_rank=float((t1.double().mean() + h1.double().mean()).item() / 2),
+                schedule_i=dict(what="all-gather E, split queries, all-gather ranks", ranks_per_sec=2 * nt / dt1, ms=dt1 * 1e3,
+                                allgather_ms=ag_ms, allgather_bytes_per_rank=per * d * 4, allgather_bytes_total=per * world * d * 4),
+                schedule_ii=dict(what="resident shards: exchange referenced rows, kge_rank_counts over own rows, all-reduce int32 counts",
+                                 ranks_per_sec=2 * nt / dt2, ms=dt2 * 1e3, exchanged_row_bytes=n_ref * d * 4, allreduce_count_bytes=2 * nt * 4))
+
+
+# ----------------------------------------------------------------------------------------------------------------- launcher
+def launch_children(argv, n, backend):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as child processes (this parent makes no GPU
+    call and never execs), forward their output, exit with the worst return code.  Rank 0 prints the JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -159,12 +385,14 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the parity check of the benched path against the oracle (outside the timed region)")
     ap.add_argument("--sampler", default="device", choices=["device", "pre"],
                     help="device: every step's batch is drawn by the bit-exact MT19937 HIP sampler on a side stream, one batch ahead "
                          "(inside the timed region); pre: batches pre-built on the host before timing")
     ap.add_argument("--plan", default="ahead", choices=["ahead", "step"],
                     help="ahead: batch plans (ids-only half of the step) built on their own stream ahead of the step; step: inside the step")
-    ap.add_argument("--settle", type=int, default=20000, help="upper bound of the extra untimed steps run until the step time is stable")
+    ap.add_argument("--settle", type=int, default=4000, help="upper bound of the extra untimed steps run until the step time is stable "
+                    "(the K steps right after the W warm-up steps are timed too: value_first_steps)")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "stream"],
                     help="graph / auto: the TrainPipeline object (every stage one hipGraph launch per step on one GPU; kernel-by-kernel "
                          "launches of the same stages under torch.distributed); stream: the plain double-buffered loop of this file")
@@ -173,10 +401,13 @@ def main():
                          "(what the roofline leg does), so that a rocprofv3 kernel trace of the run times every kernel alone")
     ap.add_argument("--model", default="DistMult", choices=["DistMult", "TransE"],
                     help="DistMult: the BASELINE configs[1] workload (the contract line).  TransE: configs[2] (L2, gamma 12) through the same "
-                         "pipeline, for comparison only (no CPU baseline; the metric string names it)")
+                         "pipeline, for comparison only (no CPU baseline; config.workload names it)")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed code paths even with WORLD_SIZE=1 (rehearsal on one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(sys.argv[1:], args.gpus, args.backend))
 
     import torch
     import torch.distributed as dist
@@ -187,7 +418,7 @@ def main():
     # sharded eval) with a world of one process, on a box that has a single GPU
     dist_on = world > 1 or args.force_dist
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if dist_on:
@@ -202,149 +433,149 @@ def main():
 
     from kge_keras_amd import _lib
     from kge_keras_amd import dist as D
-    from kge_keras_amd import models as KM
 
-    rs = np.random.RandomState(1234)
-    def glorot(rows, cols):  # Keras GlorotUniform on an Embedding matrix (models.py:87-93): U(-l, l), l = sqrt(6 / (rows + cols))
-        lim = np.sqrt(6.0 / (rows + cols))
-        return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
-    E0, R0 = glorot(CFG["N"], CFG["d"]), glorot(CFG["R"], CFG["d"])
-    mkw = dict(norm=2, gamma=12) if args.model == "TransE" else {}
-    model = getattr(KM, args.model)(e_dim=CFG["d"], r_dim=CFG["d"], num_entities=CFG["N"], num_relations=CFG["R"], dp=0.0,
-                                    init_entities=E0, init_relations=R0, loss_function="pointwize_hinge", margin=1, **mkw)
-    model.compile("adam")
+    checked = None
+    if not args.no_check and rank == 0:
+        checked = check_benched_path(args.model, steps=3, rank=0)
+    if dist_on:
+        dist.barrier()
+
+    w = workload(args.model, rank)
+    E0, R0 = w["E0"], w["R0"]
+    model = make_model(w)
     n_pool = 8
-    host_batches = make_batches(n_pool, rank)
-    dev = [(torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda()) for p, n in host_batches]
+    hb = host_batches(w, rank, n_pool)
+    dev = [(torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda()) for p, n in hb]
     m = CFG["B"] * CFG["ns"]
     per_step = 2 * m
 
-    # device sampler pipeline: batch i+2 is drawn on a side stream while batch i trains (double-buffered in HBM)
+    # plain double-buffered loop (--launch stream / --sampler pre / --plan step): batch i+2 is drawn on a side stream while batch i trains
     from kge_keras_amd.sampler import NumpyStream, PythonStream, DeviceSampler
-    main_stream, side = torch.cuda.current_stream(), torch.cuda.Stream()
-    rs_t = np.random.RandomState(1234 + 7919 * rank)
-    train = np.stack([rs_t.randint(0, CFG["N"], CFG["n_train"]), rs_t.randint(0, CFG["R"], CFG["n_train"]),
-                      rs_t.randint(0, CFG["N"], CFG["n_train"])], 1).astype(np.int32)
-    nps = NumpyStream(rank)
-    perm = nps.shuffle(np.arange(CFG["n_train"], dtype=np.int64))  # epoch permutation (host, once per epoch)
-    train_dev, perm_dev = torch.from_numpy(train).cuda(), torch.from_numpy(perm).cuda()
-    dsamp = DeviceSampler(nps, PythonStream(rank))
-    bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device="cuda") for _ in range(2)) for _ in range(2)]
-    ready = [torch.cuda.Event() for _ in range(2)]     # batch arrays drawn
-    freed = [torch.cuda.Event() for _ in range(2)]     # batch arrays no longer needed
-    planned = [torch.cuda.Event() for _ in range(2)]   # batch plan built
-    pfreed = [torch.cuda.Event() for _ in range(2)]    # batch plan consumed
-    nb_epoch = CFG["n_train"] // CFG["B"]
-    # --plan ahead (default): the ids-only half of the step (duplicate-row fold, gradient lists) is built on a third stream
-    # right behind the sampler, one to two batches ahead of the step that consumes it; --plan step builds it inside the step
+    main_stream = torch.cuda.current_stream()
     plan_ahead = args.plan == "ahead" and model.plan_supported()
-    pstream = torch.cuda.Stream() if plan_ahead else None
-    plans = [None, None]
-
-    def produce(i):
-        j = i % 2
-        if args.sampler == "device":
-            with torch.cuda.stream(side):
-                side.wait_event(freed[j])
-                b = i % nb_epoch
-                batch = train_dev.index_select(0, perm_dev[b * CFG["B"]:(b + 1) * CFG["B"]])
-                dsamp.build_batch(batch, CFG["ns"], CFG["N"], *bufs[j])
-                ready[j].record(side)
-        if plan_ahead:
-            with torch.cuda.stream(pstream):
-                if args.sampler == "device":
-                    pstream.wait_event(ready[j])
-                pstream.wait_event(pfreed[j])
-                plans[j] = model.plan_batch(list(bufs[j]) if args.sampler == "device" else list(dev[i % n_pool]), out=plans[j])
-                planned[j].record(pstream)
-                freed[j].record(pstream)
-
-    def step(i):  # kernel-by-kernel launches (--launch stream, --sampler pre, --plan step)
-        j = i % 2
-        if plan_ahead:
-            main_stream.wait_event(planned[j])
-            data = plans[j]
-        elif args.sampler == "device":
-            main_stream.wait_event(ready[j])
-            data = list(bufs[j])
-        else:
-            data = list(dev[i % n_pool])
-        if not dist_on:
-            model.train_step(data)
-        else:  # data-parallel: gradient half, all-reduce of the dense gradient tables over RCCL, optimizer half
-            # gradient tables and the loss word are one flat buffer: ONE all-reduce per step
-            D.dp_train_step(lambda: model.train_grads(data), model.apply_grads, [model._gall], None)
-        if plan_ahead:
-            pfreed[j].record(main_stream)
-        elif args.sampler == "device":
-            freed[j].record(main_stream)
-        if args.sampler == "device" or plan_ahead:
-            produce(i + 2)
-
-    # default: the three-stage pipeline (draw batch t+2 | plan batch t+1 | train step t) replayed from hipGraphs, one launch per step
-    pipe = None
-    # auto: the pipeline object in both cases; under torch.distributed it launches its stages kernel by kernel (the gradient
-    # all-reduce sits between the two halves of the step and stays outside any graph)
     launch = args.launch if args.launch != "auto" else "graph"
-    if args.sampler == "device" and plan_ahead and launch == "graph":
-        from kge_keras_amd.pipeline import TrainPipeline
+    use_pipe = args.sampler == "device" and plan_ahead and launch == "graph"
+    pipe = dsamp = None
+    if use_pipe:
         # gradient tables and the loss word are one flat buffer: ONE all-reduce per step (= dist.allreduce_sum_([model._gall]))
         between = (lambda: (dist.all_reduce(model._gall, op=dist.ReduceOp.SUM), 1.0 / world)[1]) if dist_on else None
-        pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=True, between=between)
-        total = args.warmup + args.settle + 2 * args.steps + 8
+        total = args.warmup + args.settle + 3 * args.steps + 8
+        pipe, dsamp = make_pipeline(torch, model, w, rank, total, graphs=True, between=between)
         if args.serial:
             pipe.use_graphs, pipe.serial = False, True
-        pipe.load_epoch(perm_dev, [i % nb_epoch for i in range(total)])
         pipe.start()
         step = lambda i: pipe.tick()  # noqa: E731
-    elif args.sampler == "device" or plan_ahead:
-        side.wait_stream(main_stream)
-        if pstream is not None:
-            pstream.wait_stream(main_stream)
-        produce(0)
-        produce(1)
+    else:
+        side = torch.cuda.Stream()
+        nps = NumpyStream(rank)
+        perm = nps.shuffle(np.arange(CFG["n_train"], dtype=np.int64))
+        train_dev, perm_dev = torch.from_numpy(w["train"]).cuda(), torch.from_numpy(perm).cuda()
+        dsamp = DeviceSampler(nps, PythonStream(rank))
+        bufs = [tuple(torch.empty((m, 3), dtype=torch.int32, device="cuda") for _ in range(2)) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]     # batch arrays drawn
+        freed = [torch.cuda.Event() for _ in range(2)]     # batch arrays no longer needed
+        planned = [torch.cuda.Event() for _ in range(2)]   # batch plan built
+        pfreed = [torch.cuda.Event() for _ in range(2)]    # batch plan consumed
+        nb_epoch = CFG["n_train"] // CFG["B"]
+        pstream = torch.cuda.Stream() if plan_ahead else None
+        plans = [None, None]
+
+        def produce(i):
+            j = i % 2
+            if args.sampler == "device":
+                with torch.cuda.stream(side):
+                    side.wait_event(freed[j])
+                    b = i % nb_epoch
+                    batch = train_dev.index_select(0, perm_dev[b * CFG["B"]:(b + 1) * CFG["B"]])
+                    dsamp.build_batch(batch, CFG["ns"], CFG["N"], *bufs[j])
+                    ready[j].record(side)
+            if plan_ahead:
+                with torch.cuda.stream(pstream):
+                    if args.sampler == "device":
+                        pstream.wait_event(ready[j])
+                    pstream.wait_event(pfreed[j])
+                    plans[j] = model.plan_batch(list(bufs[j]) if args.sampler == "device" else list(dev[i % n_pool]), out=plans[j])
+                    planned[j].record(pstream)
+                    freed[j].record(pstream)
+
+        def step(i):  # kernel-by-kernel launches
+            j = i % 2
+            if plan_ahead:
+                main_stream.wait_event(planned[j])
+                data = plans[j]
+            elif args.sampler == "device":
+                main_stream.wait_event(ready[j])
+                data = list(bufs[j])
+            else:
+                data = list(dev[i % n_pool])
+            if not dist_on:
+                model.train_step(data)
+            else:  # data-parallel: gradient half, ONE all-reduce of the flat gradient buffer over RCCL, optimizer half
+                D.dp_train_step(lambda: model.train_grads(data), model.apply_grads, [model._gall], None)
+            if plan_ahead:
+                pfreed[j].record(main_stream)
+            elif args.sampler == "device":
+                freed[j].record(main_stream)
+            if args.sampler == "device" or plan_ahead:
+                produce(i + 2)
+
+        if args.sampler == "device" or plan_ahead:
+            side.wait_stream(main_stream)
+            if pstream is not None:
+                pstream.wait_stream(main_stream)
+            produce(0)
+            produce(1)
 
     def fence():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(first, n):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        t_issue = time.perf_counter() - t0  # host time to enqueue the steps (the GPU runs behind it)
+        fence()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, t_issue
+
     for i in range(args.warmup):
         step(i)
-    fence()
-    # settle (untimed, bounded): the first process on a fresh box can run several times slower for its first tenths of a second
-    # (the image is still paging in: a cold host, not a cold GPU).  Keep stepping in blocks of 20 for at least 0.6 s and until a
-    # block is within 15 % of the best one seen, at most 3 s.  Under torch.distributed every rank runs the same fixed count.
+    # the K steps right behind the W warm-up steps, exactly as asked for (on a fresh box the host is still paging the image in)
+    dt_first, _ = timed(args.warmup, args.steps)
+    # settle (untimed, bounded): keep stepping in blocks of 20 until a block is within 15 % of the best one seen, for at most 1 s
+    # (one GPU) or a fixed count (torch.distributed: every rank runs the same number of steps)
     settle, best, t_settle = 0, None, time.perf_counter()
+    base = args.warmup + args.steps
     while settle + 20 <= args.settle:
         el = time.perf_counter() - t_settle
-        if dist_on and settle >= min(args.settle, 2000):
+        if dist_on and settle >= min(args.settle, 400):
             break
-        if not dist_on and el > 3.0:
+        if not dist_on and el > 1.0:
             break
         tb = time.perf_counter()
         for i in range(20):
-            step(args.warmup + settle + i)
+            step(base + settle + i)
         fence()
         tb = time.perf_counter() - tb
         settle += 20
-        if not dist_on and best is not None and el >= 0.6 and tb <= 1.15 * best:
+        if not dist_on and best is not None and el >= 0.2 and tb <= 1.15 * best:
             break
         best = tb if best is None else min(best, tb)
-    base = args.warmup + settle
+    base += settle
     if pipe is None:
         _lib.lib.kge_prof_enable(1)  # hipEvents around the dominant kernels, recorded on the launch stream
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(base + i)
-    t_issue = time.perf_counter() - t0  # host time to enqueue the steps (the GPU runs behind it)
-    fence()
-    dt = time.perf_counter() - t0
+    dt, t_issue = timed(base, args.steps)
     if pipe is not None:
         # kernel durations for the roofline object: the same K steps again, launched kernel by kernel on ONE stream (events cannot
         # be read back from inside a replayed graph, and kernels of concurrent stages stretch each other: the roofline is about
         # the kernel, so it is timed alone, like rocprofv3's kernel trace does), hipEvents recorded by the library on that stream
-        fence()
         pipe.use_graphs = False
         pipe.serial = True
         _lib.lib.kge_prof_enable(1)
@@ -353,12 +584,8 @@ def main():
         fence()
         pipe.finish()
     _lib.lib.kge_prof_enable(0)
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     model._raise_on_flag()
-    loss = float(model._loss.item()) / world  # summed over ranks by the flat all-reduce
+    loss = float(model._loss.item()) / (world if dist_on else 1)  # summed over ranks by the flat all-reduce
     s_ms, s_n = _lib.prof_read("sampler")
     i_ms, i_n = _lib.prof_read("index")
     assert int(dsamp.err.item()) == 0, "device sampler: rejection margin ran short"
@@ -376,20 +603,24 @@ def main():
     if pipe is not None and pipe.counted:  # rows with a pick count (the sampler's folded form of the last two batches)
         L = _lib.CAND_POS_LANES * CFG["B"]
         rows_launch = float(np.mean([int((c[:L].view(_lib.CAND_POS_LANES, CFG["B"]).sum(0) > 0).sum() + (c[L:] > 0).sum()) for _r, c in pipe.cand]))
+        folded = True
     else:
         used = list(pipe.bufs) if pipe is not None else (list(bufs) if args.sampler == "device" else dev)
         rows_launch = float(np.mean([distinct(p) + distinct(n) for p, n in used])) if folded else float(per_step)
 
-    ev = eval_leg(torch, dist, model, rank, world, dist_on=dist_on)
+    ev = eval_leg(torch, model) if rank == 0 or not dist_on else None
+    if dist_on:
+        dist.barrier()
+    ev_sh = eval_sharded_leg(torch, dist, rank, world) if dist_on else None
 
     if rank == 0:
+        ms_step = dt / args.steps * 1e3
         value = per_step * world * args.steps / dt
-        # pull path: two gather kernels (fwd_kernel: A_FWD per triple; pull_kernel: A_BWD per triple); push path: one
-        # fused kernel carrying A_TRAIN.  The roofline object is for the dominant (longest) one.
+        # pull path: two gather kernels (fwd_rel_kernel: A_FWD + the relation-gradient row per triple; pull_kernel: the two entity
+        # gradient rows per triple); push path: one fused kernel carrying A_TRAIN.
         kernels = {}
         variant = 1 if os.environ.get("KGE_PULL_VARIANT", "2") == "1" else 2
         if f_n and variant == 2:
-            # relation-grouped forward carries the relation-gradient row too; the pull is left with the two entity rows
             kernels["fwd_rel_kernel (gather+score+loss+relation gradient)"] = (f_ms / f_n * 1e-3, rows_launch * (A_FWD + 4 * CFG["d"]))
             kernels["pull_kernel (per-entity-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, rows_launch * 8 * CFG["d"])
         elif f_n:
@@ -397,14 +628,21 @@ def main():
             kernels["pull_kernel (per-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, per_step * A_BWD)
         else:
             kernels["push_kernel (gather+score+loss+atomic grad)"] = (k_ms / max(1, k_n) * 1e-3, per_step * A_TRAIN)
-        # the roofline object describes the kernel that moves the most bytes on the memory side per launch (committed PMC passes:
-        # pull_kernel 196 MB, fwd_rel_kernel 169 MB), falling back to the longest one when no PMC pass exists
-        dom = max(kernels, key=lambda k: (pmc_traffic(k) or 0.0, kernels[k][0]))
-        k_avg, k_bytes = kernels[dom]
+        # the roofline object describes the kernel that moves the most bytes on the memory side per launch (committed PMC passes),
+        # falling back to the longest one when no PMC pass exists
+        dom = max(kernels, key=lambda k: (pmc_traffic(k)[0] or 0.0, kernels[k][0]))
+        k_live, k_bytes = kernels[dom]
+        rp = rocprof_avg_ms(dom)
+        # The duration the roofline fraction is priced on: the SLOWER of (a) the live hipEvent average of this run (kernel by kernel on
+        # one stream, right behind its producer kernels: part of its rows still in L2) and (b) the committed rocprofv3 --kernel-trace
+        # average of the same command (profiles/: dispatches serialised by the profiler) -- so the headline fraction always follows
+        # from profiles/ or is lower.
+        k_avg = max(k_live, rp[0] * 1e-3) if rp is not None else k_live
         achieved = k_bytes / k_avg if k_avg else 0.0
+        traffic, traffic_tag = pmc_traffic(dom)
         res = {
-            "metric": "scored triples/sec (train, 100 neg), FB15k-237 d=200" + ("" if args.model == "DistMult" else f" [{args.model}-L2]"), "value": value, "unit": "scored triples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": dt / args.steps * 1e3,
+            "metric": METRIC, "value": value, "unit": "scored triples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"FB15k-237 {args.model if args.model == 'DistMult' else 'TransE-L2 (gamma 12)'} d=200, B=2048, 100 negatives (409600 scored triples/step), pointwize_hinge + Adam(TF semantics)",
                        "N": CFG["N"], "R": CFG["R"], "d": CFG["d"], "B": CFG["B"], "ns": CFG["ns"],
@@ -412,18 +650,25 @@ def main():
                        "sampler": ("bit-exact MT19937 HIP sampler inside the timed region (side stream, one batch ahead)" if args.sampler == "device"
                                    else "bit-exact MT19937 batches pre-built on host, resident in HBM"),
                        "final_loss": loss},
+            # value counts every row of both oversampled arrays (what the reference's step scores); the step folds duplicate rows, so
+            # the gather kernels touch rows_per_launch distinct rows: value_distinct is the rate on those
+            "value_distinct": rows_launch * world * args.steps / dt,
+            "value_ranks_per_sec": ev["ranks_per_sec"] if ev else None,
+            "value_first_steps": per_step * world * args.steps / dt_first,
+            "ms_per_step_first_steps": dt_first / args.steps * 1e3,
+            "settle_steps": settle,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(dom),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "traffic_source": (f"committed rocprofv3 --pmc passes ({traffic_tag or 'profiles/pmc_traffic.json'}; tools/pmc.sh), not this run" if traffic else None),
                          "algorithmic_bytes_per_launch": k_bytes, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
-                         "cold_cache": (lambda rp: None if rp is None else {
-                             "avg_kernel_ms": rp[0], "achieved": k_bytes / (rp[0] * 1e-3) / 1e9, "frac": k_bytes / (rp[0] * 1e-3) / HBM_PEAK,
-                             "source": f"profiles/{rp[1]} (rocprofv3 --kernel-trace --stats of bench.py --serial: the profiler serialises "
-                                       "dispatches and every kernel starts with cold caches; the live hipEvent duration above is the same "
-                                       "launch right behind its producer kernels, most of its rows still in L2)"})(rocprof_avg_ms(dom)),
+                         "avg_kernel_ms_live_hipevents": k_live * 1e3,
+                         "avg_kernel_ms_rocprofv3": rp[0] if rp else None, "rocprofv3_source": f"profiles/{rp[1]}" if rp else None,
+                         "frac_live_hipevents": k_bytes / k_live / HBM_PEAK if k_live else None,
                          "all_kernels": {k: {"avg_ms": v[0] * 1e3, "algorithmic_GBps": v[1] / v[0] / 1e9} for k, v in kernels.items()},
-                         "whole_step_algorithmic_GBps": per_step * A_TRAIN / (dt / args.steps) / 1e9,
+                         # whole step on the rows really processed: gathers + gradient rows + the dense optimizer sweep
+                         "whole_step_algorithmic_GBps": (rows_launch * A_TRAIN + A_OPT) / (dt / args.steps) / 1e9,
                          "rows_per_launch": rows_launch, "batch_rows": per_step,
-                         "duplicate_row_folding": ("on: the gather kernels run on the distinct rows of the batch (hash fold inside the step); "
+                         "duplicate_row_folding": ("on: the gather kernels run on the distinct rows of the batch; "
                                                    "bytes per launch are priced on those rows" if folded else "off"),
                          "fold_avg_ms": d_ms / max(1, d_n),
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
@@ -436,11 +681,25 @@ def main():
                          "plan": ("ids-only half of the step (fold + gradient lists) built 1-2 batches ahead on its own stream, inside the timed region"
                                   if plan_ahead else "built inside the step")},
         }
-        res["eval_1vsall"] = ev
-        if rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "DistMult":
-            res["cpu_baseline"] = cpu_baseline(host_batches, E0, R0)
+        if ev:
+            sw = ev["sweep_kernel_avg_ms"] * 1e-3
+            res["roofline_mfma"] = {"bound": "mfma", "kernel": "rank_sweep4_kernel (fp32 MFMA 1-vs-all sweep with fused count epilogue)",
+                                    "achieved": (ev["flop_per_launch"] / sw / 1e12) if sw else None, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                                    "frac": (ev["flop_per_launch"] / sw / MFMA_F32_PEAK) if sw else None, "avg_kernel_ms": ev["sweep_kernel_avg_ms"],
+                                    "launches": ev["sweep_kernel_launches"], "algorithmic_flop_per_launch": ev["flop_per_launch"],
+                                    "end_to_end_frac": ev["mfma_frac"], "traffic": pmc_traffic("rank_sweep4_kernel")[0]}
+            res["eval_1vsall"] = ev
+        if ev_sh:
+            res["eval_sharded"] = ev_sh
+        if checked is not None:
+            res.update(checked)
+        else:
+            res["checked"] = False
+        if not args.no_cpu_baseline and world == 1 and args.model == "DistMult":
+            res["cpu_baseline"] = cpu_baseline(hb, E0, R0)
         print(json.dumps(res), flush=True)
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
 
 

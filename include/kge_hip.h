@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 3
+#define KGE_ABI_VERSION 4
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -132,9 +132,11 @@ int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_o
  *      model.predict (:211,231) + rankdata(res,'max') (:212,232).  For query i (row i of `triples`; side 0 ranks
  *      the tail o against (s,p,?), side 1 ranks the head s against (?,p,o)):
  *          counts[i] (+)= #{c in [cand_offset, cand_offset+cand_rows) : c not filtered, score(i,c) > score(i,target_i)}
- *      so that real_rank = 1 + counts[i] summed over the shards that cover all entities.  E is the full table
- *      (query vectors and target scores are built from it); E_cand points at the row of global id cand_offset
- *      (E_cand = E + cand_offset*d_e for a local full table; a row shard otherwise).  The filter is a COO list
+ *      so that real_rank = 1 + counts[i] summed over the shards that cover all entities.  E is the table the ids in
+ *      `triples` index (md->num_entities rows; query vectors and target scores are built from it): the full table, or --
+ *      with the table row-sharded across GPUs and never gathered (SURVEY 8(e) schedule ii) -- just the rows the queries
+ *      reference, `triples` then holding positions in it.  E_cand points at the candidate row of GLOBAL id cand_offset
+ *      (E_cand = E + cand_offset*d_e for a local full table; a row shard otherwise; cand_rows may be 0).  The filter is a COO list
  *      sorted or not: filt_query[e] = query index, filt_ids[e] = global entity id to exclude (the reference's
  *      filter_t[(s,p)] / filter_h[(p,o)]); it must not contain the target (the reference raises ValueError).
  *      accumulate != 0 adds into counts (multi-shard loops); otherwise counts is overwritten.
@@ -265,7 +267,8 @@ int kge_set_dedup_mode(int mode);
  *      kernel with hipEvents recorded on the launch stream.  kge_prof_read synchronises those events, returns the
  *      summed duration (ms) and launch count for one label and clears that label.  Off by default. */
 typedef enum { KGE_PROF_TRAIN_GRADS = 0, KGE_PROF_OPT = 1, KGE_PROF_SCORE = 2, KGE_PROF_PAIRWISE = 3, KGE_PROF_RANK = 4,
-               KGE_PROF_SAMPLER = 5, KGE_PROF_FWD = 6, KGE_PROF_INDEX = 7, KGE_PROF_DEDUP = 8, KGE_PROF_NLABELS = 9 } kge_prof_label;
+               KGE_PROF_SAMPLER = 5, KGE_PROF_FWD = 6, KGE_PROF_INDEX = 7, KGE_PROF_DEDUP = 8,
+               KGE_PROF_RANK_SWEEP = 9 /* the MFMA sweep kernel alone, inside KGE_PROF_RANK */, KGE_PROF_NLABELS = 10 } kge_prof_label;
 int kge_prof_enable(int on);
 int kge_prof_read(int label, double* total_ms, int64_t* launches);
 

@@ -111,7 +111,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 
-PROF_LABELS = {"train_grads": 0, "opt": 1, "score": 2, "pairwise": 3, "rank": 4, "sampler": 5, "fwd": 6, "index": 7, "dedup": 8}
+PROF_LABELS = {"train_grads": 0, "opt": 1, "score": 2, "pairwise": 3, "rank": 4, "sampler": 5, "fwd": 6, "index": 7, "dedup": 8, "rank_sweep": 9}
 
 
 def prof_read(label):

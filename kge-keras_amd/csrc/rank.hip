@@ -780,6 +780,7 @@ static int sweep_slots() {  // workgroups of the persistent sweep: two per CU (r
 static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float* Qv, const float* tgt, int64_t nq, const float* Ec,
                          int K, int Kpad, int cand_rows, int tpb, int32_t* counts, int epi = 0, const float* en_c = nullptr) {
   if (nq <= 0 || cand_rows <= 0) return;
+  ProfScope prof_sweep(KGE_PROF_RANK_SWEEP, st);
 #define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
   if (v4 && sweep_variant() == 0 && nq < (int64_t)1 << 30) {
     const bool tail = Kpad != K;
@@ -864,8 +865,11 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
   float* tgt = tgt_out ? tgt_out : Qv + nq * Kpad;
   ProfScope prof(KGE_PROF_RANK, st);
   // TransE-L2 on the matrix cores (target scores are not produced on this path: a caller asking for them gets the distance sweep)
+  // (the per-row tables of the two forms below -- squared norms, (sin, cos) pairs -- are built from E and indexed by global id, so the
+  // candidates must be rows of E itself; a row shard held apart from the query table takes the direct distance sweep)
+  const bool cand_in_table = Ec == E + (int64_t)cand_offset * K && cand_offset + cand_rows <= md->num_entities;
   if (md->model == KGE_TRANSE && md->norm == 2 && !tgt_out && rank_l2_mfma() && (K % 4 == 0) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) &&
-      nq < (int64_t)1 << 30 && sweep_variant() == 0) {
+      nq < (int64_t)1 << 30 && sweep_variant() == 0 && cand_in_table) {
     float* en = tgt + align_up(nq, 64);  // behind the target values (the query block is sized for align_up(K, 32) >= rank_kpad(K) floats per row)
     Kpad = rank_kpad(K);
     launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
@@ -881,7 +885,7 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
-  if (md->model == KGE_TRANSE && md->norm == 3 && rank_phase_pairs()) {
+  if (md->model == KGE_TRANSE && md->norm == 3 && rank_phase_pairs() && cand_in_table) {
     // pRotatE on (sin, cos) pair rows (NORM 4 of the distance kernels): tables once per call, then 3 VALU operations per element
     const int K2 = 2 * K, Kpad2 = (int)align_up(K2, 32);
     float* tg = tgt_out ? tgt_out : Qv + nq * Kpad2;

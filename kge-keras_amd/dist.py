@@ -4,9 +4,13 @@
 * training  : triples are independent units -> data-parallel replicas.  The one exchange per step is the
               all-reduce of the dense gradient tables between kge_train_grads and kge_opt_apply; every rank
               then applies the identical update (tables stay bit-identical across ranks).
-* evaluation: the entity table is row-sharded at rest; for a 1-vs-all sweep the shards are all-gathered into a
-              full table on every GPU (YAGO3-10: 98.5 MB, one collective per evaluation, not per query), the
-              queries are split across ranks and the integer ranks are all-gathered back.
+* evaluation: the entity table is row-sharded at rest.  Schedule (i) (`sharded_eval`): the shards are all-gathered
+              into a full table on every GPU (YAGO3-10: 98.5 MB, one collective per evaluation, not per query), the
+              queries are split across ranks and the integer ranks are all-gathered back.  Schedule (ii)
+              (`resident_shard_eval`): the table STAYS sharded; only the rows the queries reference (query entity +
+              target, <= 2 rows per test triple) are exchanged, every rank counts `score > target` over its own rows
+              for ALL queries (kge_rank_counts with a candidate range) and the int32 counts are all-reduced -- traffic
+              independent of the table size, the schedule that scales past one GPU's memory.
 
 The functions here only move tensors; the compute is injected (the HIP-backed model methods in production, so the
 same orchestration can be exercised on CPU tensors with gloo).  The reference has no counterpart (single process).
@@ -103,3 +107,44 @@ def sharded_eval(test, side_fn, n_entities, table_shard=None, set_table=None, gr
     t = torch.as_tensor(t, dtype=torch.int64)
     h = torch.as_tensor(h, dtype=torch.int64)
     return gather_ranks(t, len(test), group), gather_ranks(h.to(t.device), len(test), group)
+
+
+def referenced_rows(test):
+    """Sorted distinct entity ids the queries of `test` (n,3) need as rows: the query entity and the target of either side."""
+    import numpy as np
+    t = np.asarray(test).reshape(-1, 3)
+    return np.unique(np.concatenate([t[:, 0], t[:, 2]])).astype(np.int64)
+
+
+def exchange_referenced_rows(shard, lo, ids, group=None):
+    """(len(ids), d) rows of the global table for the sorted global ids `ids`, on every rank, with the table row-sharded
+    (this rank holds rows [lo, lo + len(shard))): every rank fills the rows it owns, zeros elsewhere, one all-reduce(sum)
+    (x + 0 is exact in floating point)."""
+    ids_t = torch.as_tensor(ids, dtype=torch.int64, device=shard.device)
+    ref = torch.zeros((ids_t.numel(), shard.shape[1]), dtype=shard.dtype, device=shard.device)
+    own = (ids_t >= lo) & (ids_t < lo + shard.shape[0])
+    if bool(own.any()):
+        ref[own] = shard.index_select(0, ids_t[own] - lo)
+    allreduce_sum_([ref], group)
+    return ref
+
+
+def resident_shard_eval(test, count_fn, shard, lo, group=None):
+    """SURVEY 8(e) schedule (ii): filtered 1-vs-all ranks of `test` ((n,3) integer array) with the entity table row-sharded and
+    never gathered.  count_fn(ref_rows, test_local, side) -> int32 (n,) tensor of #{kept c in this rank's shard:
+    score(q, c) > score(q, target)} where ref_rows holds the referenced rows and test_local is `test` with s / o replaced by
+    their positions in ref_rows (the GPU implementation is EmbeddingModel.rank_counts_shard = kge_rank_counts with E =
+    ref_rows, E_cand = shard, cand_offset = lo).  Returns (tail_ranks, head_ranks) int64 tensors on every rank."""
+    import numpy as np
+    t = np.ascontiguousarray(np.asarray(test).reshape(-1, 3))
+    ids = referenced_rows(t)
+    ref = exchange_referenced_rows(shard, lo, ids, group)
+    local = t.copy()
+    local[:, 0] = np.searchsorted(ids, t[:, 0])
+    local[:, 2] = np.searchsorted(ids, t[:, 2])
+    out = []
+    for side in (0, 1):
+        c = count_fn(ref, local, side).to(torch.int32)
+        allreduce_sum_([c], group)
+        out.append(1 + c.to(torch.int64))
+    return out[0], out[1]

@@ -558,6 +558,31 @@ class EmbeddingModel:
                                   self._rank_ws.data_ptr(), self._rank_ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
         return counts
 
+    def rank_counts_shard(self, ref_rows, triples_local, side, filt_q, filt_ids, shard, lo, counts=None):
+        """SURVEY 8(e) schedule (ii), one rank's share: counts[i] = #{kept c in [lo, lo + len(shard)) : score(i, c) >
+        score(i, target_i)} with the entity table row-sharded.  ref_rows: the rows the queries reference (dist.
+        exchange_referenced_rows), triples_local: the queries with s / o given as positions in ref_rows; filters carry GLOBAL
+        entity ids (the kernels skip ids outside this shard).  kge_rank_counts with E = ref_rows, E_cand = shard."""
+        ref_rows = ref_rows.contiguous()
+        shard = shard.contiguous()
+        t = as_triples(triples_local, self.device, ref_rows.shape[0], self.num_relations)
+        nq = t.shape[0]
+        md = self._model_desc(False)
+        md.num_entities = int(ref_rows.shape[0])
+        need = check(lib.kge_rank_workspace_bytes(C.byref(md), nq))
+        if getattr(self, "_rank_ws", None) is None or self._rank_ws.numel() < need:
+            self._rank_ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        fq = torch.as_tensor(filt_q, dtype=torch.int32, device=self.device).contiguous()
+        fi = torch.as_tensor(filt_ids, dtype=torch.int32, device=self.device).contiguous()
+        acc = counts is not None
+        if counts is None:
+            counts = torch.empty(nq, dtype=torch.int32, device=self.device)
+        check(lib.kge_rank_counts(C.byref(md), ref_rows.data_ptr(), self.Rel.data_ptr(), shard.data_ptr(), int(lo), int(shard.shape[0]),
+                                  t.data_ptr(), nq, int(side), fq.data_ptr() if fq.numel() else None,
+                                  fi.data_ptr() if fi.numel() else None, fq.numel(), counts.data_ptr(), 1 if acc else 0, None,
+                                  self._rank_ws.data_ptr(), self._rank_ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        return counts
+
     def rank(self, test_data, num_entities, filter_t, filter_h, chunk=32768):
         """(tail_ranks, head_ranks) of `validate` (utils.py:199-264): real_rank = 1 + #{kept c: score_c > score_target}."""
         test = [tuple(int(v) for v in t) for t in test_data]

@@ -75,6 +75,59 @@ def test_sharded_eval_matches_unsharded():
     assert out[0][2] == (0, 52) and out[1][2] == (52, 103)
 
 
+def _resident_worker(rank, world):
+    """Schedule (ii): shards stay resident; referenced rows exchanged; counts over own rows; all-reduce of int32 counts."""
+    from kge_keras_amd import dist as D
+    rs = np.random.RandomState(3)
+    N, R, d = 103, 5, 8
+    E = rs.uniform(-1, 1, (N, d))
+    Rl = rs.uniform(-1, 1, (R, d))
+    test = np.stack([rs.randint(0, N, 41), rs.randint(0, R, 41), rs.randint(0, N, 41)], 1)
+    filt = [(int(rs.randint(N)), int(rs.randint(R)), int(rs.randint(N))) for _ in range(300)]
+    tset = set(map(tuple, test.tolist()))
+    filt = [t for t in filt if t not in tset]
+    fh, ft = O.build_filters(filt)
+    lo, hi = D.shard_range(N, rank, world)
+    shard = torch.from_numpy(E[lo:hi].copy())
+
+    def count_fn(ref, local, side):  # what kge_rank_counts does on the GPU, restated with NumPy on this rank's rows
+        ref = ref.numpy()
+        out = np.zeros(len(local), dtype=np.int32)
+        for i, (s, p, o) in enumerate(local.tolist()):
+            q = ref[s] * Rl[p] if side == 0 else Rl[p] * ref[o]
+            tgt = float(q @ ref[o if side == 0 else s])
+            sc = shard.numpy() @ q
+            gs, gp, go = test[i].tolist()
+            excl = ft.get((gs, gp), []) if side == 0 else fh.get((gp, go), [])
+            keep = np.ones(hi - lo, dtype=bool)
+            for x in [go if side == 0 else gs]:  # the target itself (the kernels compare bit-identical chains: never greater)
+                if lo <= x < hi:
+                    keep[x - lo] = False
+            for x in excl:
+                if lo <= x < hi:
+                    keep[x - lo] = False
+            out[i] = int(np.sum((sc > tgt) & keep))
+        return torch.from_numpy(out)
+
+    t, h = D.resident_shard_eval(test, count_fn, shard, lo)
+    return t.numpy(), h.numpy()
+
+
+def test_resident_shard_eval_matches_unsharded():
+    out = _spawn(_resident_worker)
+    rs = np.random.RandomState(3)
+    N, R, d = 103, 5, 8
+    E = rs.uniform(-1, 1, (N, d))
+    Rl = rs.uniform(-1, 1, (R, d))
+    test = np.stack([rs.randint(0, N, 41), rs.randint(0, R, 41), rs.randint(0, N, 41)], 1)
+    filt = [(int(rs.randint(N)), int(rs.randint(R)), int(rs.randint(N))) for _ in range(300)]
+    tset = set(map(tuple, test.tolist()))
+    filt = [t for t in filt if t not in tset]
+    t, h = O.ranks_closed_form("DistMult", E, Rl, [tuple(x) for x in test.tolist()], filt)
+    for r in range(2):
+        assert np.array_equal(out[r][0], t) and np.array_equal(out[r][1], h)
+
+
 def _dp_worker(rank, world):
     from kge_keras_amd import dist as D
     rs = np.random.RandomState(1)

@@ -292,3 +292,16 @@ def test_pipeline_protate(datasets):
     np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
     np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
     np.testing.assert_allclose(h.history["loss"], [tot / len(hgen)], rtol=1e-4)
+
+
+@pytest.mark.parametrize("model", ["DistMult", "TransE"])
+def test_benched_path_at_benched_size(model):
+    """The exact code path bench.py times, at its size: TrainPipeline with the device sampler, counted plans and one hipGraph per
+    stage on the BASELINE configs[1] / configs[2] workload (N=14 541, R=237, d=200, B=2048, ns=100, 272 115 synthetic triples,
+    bench.py's seeds).  Every drawn batch bit for bit against the host generator (rows before oversampling + pick counts, and the
+    generator states left behind); loss and both tables after each of 3 steps against the oracle's C restatement AND the NumPy
+    fp64 oracle at 1e-4 (tests.py:55-61,130-134)."""
+    import bench
+    res = bench.check_benched_path(model, steps=3, fp64=True, tol=TOL)
+    assert res["checked"] and res["check_batches_bit_exact"] == [0, 1, 2, 3, 4]
+    assert res["max_abs_err"] <= TOL and res["max_abs_err_fp64"] <= TOL

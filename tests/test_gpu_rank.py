@@ -374,3 +374,34 @@ def test_rank_fuzz_shapes_vs_chain_scores():
             for a, b in zip(cuts[:-1], cuts[1:]):
                 acc = mdl.rank_counts(test, side, empty, empty, cand_offset=a, cand_rows=b - a, counts=acc)
             assert np.array_equal(acc.cpu().numpy(), cnt), (case, "shards", cuts)
+
+
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("ComplEx", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12))])
+def test_resident_shard_schedule_equals_full_table(model, kw):
+    """SURVEY 8(e) schedule (ii) on one GPU: the table cut into 3 row shards (the last one short, one EMPTY shard appended) that are
+    never gathered; per shard kge_rank_counts with E = the rows the queries reference, E_cand = the shard, filters in global
+    ids; counts summed over shards == the ranks of the full-table call, exactly (bit-identical comparisons)."""
+    from kge_keras_amd import models as M
+    from kge_keras_amd import dist as D
+    N, R, d = 1000, 6, 32
+    rs = np.random.RandomState(17)
+    de, dr = O.table_dims(model, d, d)
+    E0 = (rs.randint(-8, 9, (N, de)) / 8.0).astype(np.float32)   # quantised: exact arithmetic, true ties
+    R0 = (rs.randint(-8, 9, (R, dr)) / 8.0).astype(np.float32)
+    mdl = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0, **kw)
+    test = np.stack([rs.randint(0, N, 300), rs.randint(0, R, 300), rs.randint(0, N, 300)], 1).astype(np.int32)
+    fq = np.repeat(np.arange(300, dtype=np.int32), 4)
+    fi = rs.randint(0, N, 1200).astype(np.int32)
+    for side in (0, 1):
+        keep = fi != np.repeat(test[:, 2 if side == 0 else 0], 4)
+        q, f = torch.from_numpy(fq[keep]).cuda(), torch.from_numpy(fi[keep]).cuda()
+        full = mdl.rank_counts(test, side, q, f).cpu().numpy()
+        ids = D.referenced_rows(test)
+        ref = mdl.E.index_select(0, torch.from_numpy(ids).cuda())
+        local = test.copy()
+        local[:, 0], local[:, 2] = np.searchsorted(ids, test[:, 0]), np.searchsorted(ids, test[:, 2])
+        acc = None
+        for lo, hi in ((0, 400), (400, 800), (800, 1000), (1000, 1000)):
+            acc = mdl.rank_counts_shard(ref, local, side, q, f, mdl.E[lo:hi].clone(), lo, counts=acc)
+        assert np.array_equal(acc.cpu().numpy(), full), (model, kw, side)
+    mdl._raise_on_flag()

@@ -32,7 +32,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in kge_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.kge_abi_version() == 3
+    assert lib.kge_abi_version() == int(re.search(r"#define KGE_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "kge_hip.h")).read()).group(1))
 
 
 def test_abi_struct_layouts():
