@@ -180,7 +180,7 @@ def check_benched_path(model_name="DistMult", steps=3, rank=0, fp64=False, tol=1
 
     pipe.start()
     torch.cuda.synchronize()
-    assert pipe.use_graphs and pipe.graphs and pipe.counted, "the benched path is the graph-replayed pipeline with counted plans"
+    assert pipe._native_active and pipe.counted, "the benched path is the natively driven, graph-replayed pipeline with counted plans"
     check_batch(0)
     check_batch(1)
     err = dict(loss=0.0, E=0.0, Rel=0.0)
@@ -465,6 +465,7 @@ def main():
             pipe.use_graphs, pipe.serial = False, True
         pipe.start()
         step = lambda i: pipe.tick()  # noqa: E731
+        steps_n = pipe.run            # n steps in ONE library call (kge_pipeline_run): the tick loop is native
     else:
         side = torch.cuda.Stream()
         nps = NumpyStream(rank)
@@ -526,16 +527,23 @@ def main():
             produce(0)
             produce(1)
 
+    if pipe is None:
+        nxt = [0]
+
+        def steps_n(n):
+            for _ in range(n):
+                step(nxt[0])
+                nxt[0] += 1
+
     def fence():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(first, n):
+    def timed(n):
         fence()
         t0 = time.perf_counter()
-        for i in range(n):
-            step(first + i)
+        steps_n(n)
         t_issue = time.perf_counter() - t0  # host time to enqueue the steps (the GPU runs behind it)
         fence()
         dt = time.perf_counter() - t0
@@ -545,14 +553,12 @@ def main():
             dt = float(t.item())
         return dt, t_issue
 
-    for i in range(args.warmup):
-        step(i)
+    steps_n(args.warmup)
     # the K steps right behind the W warm-up steps, exactly as asked for (on a fresh box the host is still paging the image in)
-    dt_first, _ = timed(args.warmup, args.steps)
+    dt_first, _ = timed(args.steps)
     # settle (untimed, bounded): keep stepping in blocks of 20 until a block is within 15 % of the best one seen, for at most 1 s
     # (one GPU) or a fixed count (torch.distributed: every rank runs the same number of steps)
     settle, best, t_settle = 0, None, time.perf_counter()
-    base = args.warmup + args.steps
     while settle + 20 <= args.settle:
         el = time.perf_counter() - t_settle
         if dist_on and settle >= min(args.settle, 400):
@@ -560,27 +566,28 @@ def main():
         if not dist_on and el > 1.0:
             break
         tb = time.perf_counter()
-        for i in range(20):
-            step(base + settle + i)
+        steps_n(20)
         fence()
         tb = time.perf_counter() - tb
         settle += 20
         if not dist_on and best is not None and el >= 0.2 and tb <= 1.15 * best:
             break
         best = tb if best is None else min(best, tb)
-    base += settle
     if pipe is None:
         _lib.lib.kge_prof_enable(1)  # hipEvents around the dominant kernels, recorded on the launch stream
-    dt, t_issue = timed(base, args.steps)
+    if pipe is not None:
+        pipe.host_stats(reset=True)
+    dt, t_issue = timed(args.steps)
+    host_stats = pipe.host_stats() if pipe is not None else None
     if pipe is not None:
         # kernel durations for the roofline object: the same K steps again, launched kernel by kernel on ONE stream (events cannot
         # be read back from inside a replayed graph, and kernels of concurrent stages stretch each other: the roofline is about
         # the kernel, so it is timed alone, like rocprofv3's kernel trace does), hipEvents recorded by the library on that stream
         pipe.use_graphs = False
         pipe.serial = True
+        fence()
         _lib.lib.kge_prof_enable(1)
-        for i in range(args.steps):
-            step(base + args.steps + i)
+        steps_n(args.steps)
         fence()
         pipe.finish()
     _lib.lib.kge_prof_enable(0)
@@ -673,7 +680,11 @@ def main():
                          "fold_avg_ms": d_ms / max(1, d_n),
                          "opt_kernel_avg_ms": o_ms / max(1, o_n), "index_build_avg_ms": i_ms / max(1, i_n),
                          "sampler_avg_ms": s_ms / max(1, s_n), "host_enqueue_ms_per_step": t_issue / args.steps * 1e3,
-                         "launch": (("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams)" if not dist_on else
+                         # of which: waiting for a stage graph's previous launch to finish (back-pressure from the GPU) vs inside hipGraphLaunch
+                         "host_wait_ms_per_step": host_stats["wait_prev_launch_ms"] / args.steps if host_stats else None,
+                         "host_graph_launch_ms_per_step": host_stats["graph_launch_ms"] / args.steps if host_stats else None,
+                         "host_wait_by_stage_ms_per_step": {k: v / args.steps for k, v in host_stats["wait_by_stage_ms"].items()} if host_stats else None,
+                         "launch": (("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams), issued by the library's native loop (kge_pipeline_run: one C call for the K timed steps)" if not dist_on else
                                      "draw and plan stages replayed from hipGraphs on their streams; the step (gradient half, all-reduce, optimizer half) launched kernel by kernel")
                                     + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)"
                                     if pipe is not None

@@ -215,9 +215,12 @@ int kge_rank_sweep_q(const float* Q, int64_t n_queries, int32_t K, const float* 
  *        kge_batch_plan_bytes   size for (md, ld, m_pos, m_neg); KGE_EUNSUPPORTED where no plan exists (pairwize losses, HolE,
  *                               ConvE, gradient mode 1) -- callers then use kge_train_step;
  *        kge_batch_plan_build   asynchronous on `stream` (any stream; the arrays pos / neg are not referenced once part 1 is
- *                               done).  parts: 1 = rows (duplicates folded, counters cleared), 2 = entity lists, 4 = relation
- *                               lists; 7 = everything.  2 and 4 need 1 and are independent of each other, so a caller may
- *                               run them on two streams (fork after 1, join before the step);
+ *                               done).  parts: 1 = rows (duplicates folded, counters cleared) + the histograms of both index
+ *                               halves, 2 = entity list offsets, 4 = relation list offsets and lists; 7 = everything.  2 and 4
+ *                               need 1 and are independent of each other, so a caller may run them on two streams (fork after
+ *                               1, join before the step); together they are one launch.  Adding 8 says that the plan buffer's
+ *                               counters are known to be zero -- the buffer was zero-filled when it was allocated and every
+ *                               build since has been consumed by a step (which leaves them zero) -- and saves the clearing launch;
  *        kge_train_step_planned = kge_train_step on the batch the plan was built from (same md, ld, m_pos, m_neg), without
  *                               scores_out.  CONSUMES the plan: one step per build.  The caller orders build -> step
  *                               (events or same stream).  Workspace as for kge_train_step. */
@@ -228,7 +231,8 @@ int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, cons
  * multiplicities cand_counts laid out as (pos_lanes * n_pos_cand + n_neg_cand) int32 (count of positive a = sum over lanes l of
  * cand_counts[l * n_pos_cand + a]; pos_lanes = 1 for a plain count vector, KGE_CAND_POS_LANES for the sampler's output).  Rows
  * with count 0 are skipped; the counts of the positives sum to m_pos, those of the negatives to m_neg.  No hash table is
- * needed.  Buffer size as for (m_pos, m_neg); requires n_pos_cand + n_neg_cand <= m_pos + m_neg. */
+ * needed (every candidate becomes a row of the plan, multiplicity 0 where nobody picked it: no compaction either).  Buffer size as
+ * for (m_pos, m_neg); requires n_pos_cand + n_neg_cand <= m_pos + m_neg. */
 int kge_batch_plan_build_counted(const kge_model_desc* md, const kge_loss_desc* ld, const int32_t* cand_rows, const int32_t* cand_counts,
                                  int32_t pos_lanes, int64_t n_pos_cand, int64_t n_neg_cand, int64_t m_pos, int64_t m_neg, void* plan,
                                  int64_t plan_bytes, int32_t parts, uint32_t* err_flag, kge_stream_t stream);
@@ -331,6 +335,80 @@ int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const
  * state words by raw words [J, J+624) of the stream (bits 0..30 of word 0 are not state and not guaranteed). */
 int kge_mt_jump_poly(int64_t J, uint64_t* out_host);
 int kge_mt_jump_host(void* state_host, int64_t J);
+
+/* ---- the device batch builder in streamed form: word generation AHEAD of the batches that consume it.  An MT19937 stream is one
+ *      fixed sequence of 624-word blocks; which of its words a batch consumes is data dependent (NumPy's masked rejection,
+ *      utils.py:118-119), the words themselves are not.  Each generator gets a ring of raw state blocks in HBM:
+ *        kge_sampler_stream_init     seeds both rings from the state blobs (block 0 = the state block, consumption from its position);
+ *        kge_sampler_stream_produce  one production round per generator (16 jump-started segments, as kge_build_batch_device with a
+ *                                    plan; sequential when plan_dev is NULL) -- skipped on the device while at least two batches'
+ *                                    worth of words lie ahead of the consumer.  Run it on its own stream, one batch ahead: before the
+ *                                    draw of batch k the caller must have issued rounds 0..k, round k ordered behind the draw of
+ *                                    batch k-2 at the latest and in front of the draw of batch k;
+ *        kge_sampler_stream_draw     the consumer half of kge_build_batch_device[_indexed] (same arguments, same outputs, same
+ *                                    generator states left in the blobs): select -> choices / assembly -> advance.
+ *      Bit-identical to kge_build_batch_device.  The buffer also holds the scratch of the draw (no separate workspace). */
+int64_t kge_sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e);
+int kge_sampler_stream_init(void* stream_buf, int64_t stream_bytes, const void* np_state_dev, const void* py_state_dev, int64_t B, int64_t ns,
+                            int64_t num_e, kge_stream_t stream);
+int kge_sampler_stream_produce(void* stream_buf, int64_t stream_bytes, int64_t B, int64_t ns, int64_t num_e, const void* plan_dev,
+                               kge_stream_t stream);
+int kge_sampler_stream_draw(void* stream_buf, int64_t stream_bytes, void* np_state_dev, void* py_state_dev, const int32_t* batch_dev,
+                            const int32_t* kg_dev, const int64_t* index_dev, const int64_t* starts_dev, int64_t* cursor_dev, int64_t B,
+                            int64_t ns, int64_t num_e, int32_t* pos_out_dev, int32_t* neg_out_dev, int32_t* cand_rows_dev,
+                            int32_t* cand_counts_dev, uint32_t* err_flag, kge_stream_t stream);
+
+/* ---- training pipeline: what Keras' fit() does for the reference with a prefetching Sequence (tests.py:29-61,130-134) as a native
+ *      host loop over four device streams, one to two batches apart: word generation (kge_sampler_stream_produce), draw batch k
+ *      (kge_sampler_stream_draw, folded output), plan batch k (kge_batch_plan_build_counted), train step k
+ *      (kge_train_step_planned with the device-resident optimizer step state).  Everything that changes from step to step lives on
+ *      the device (generator rings and states, batch cursor, step state): the loop only launches.  By default it launches every
+ *      stage's kernels itself (about 15 launches per step, ~0.05 ms of host time); with KGE_PIPE_GRAPHS=1 in the environment every
+ *      stage is captured once per buffer parity into a hipGraph and replayed (slower on ROCm 7.2: back-to-back graph launches on
+ *      one stream leave 20-30 us of idle time each).  The descriptor's pointers are borrowed until kge_pipeline_destroy.
+ *        kge_pipeline_start   (re)starts an epoch of n_batches batches: the caller has loaded index / starts / the generator states
+ *                             and reset *cursor on `stream`; seeds the rings, issues rounds, draws and plans of batches 0 and 1;
+ *        kge_pipeline_run     n_steps training steps on `stream` (steps t .. t+n_steps-1 of the epoch), each followed by the round,
+ *                             the draw and the plan of the batch two steps ahead; asynchronous (returns when everything is enqueued);
+ *        kge_pipeline_finish  makes `stream` wait for the producer streams.
+ *      No dropout (every oversampled row would need its own mask: no folded batches) and no hook between the halves of a step:
+ *      data-parallel training and dropout steps drive the same library calls themselves. */
+typedef struct {
+  kge_model_desc md;
+  kge_loss_desc ld;
+  kge_opt_desc od;            /* od.step_dev is required (kge_opt_state_init) */
+  float *E, *Rel, *gradE, *gradRel;
+  float* loss_out;
+  void* train_ws;             /* kge_train_step_workspace_bytes(md, ld, B*ns, B*ns) */
+  int64_t train_ws_bytes;
+  uint32_t* err_flag;
+  void *np_state, *py_state;  /* KGE_MT_STATE_BYTES each, device */
+  const int32_t* kg;          /* (n,3) training triples */
+  const int64_t* index;       /* epoch permutation */
+  const int64_t* starts;      /* batch numbers in drawing order */
+  int64_t* cursor;            /* one int64 */
+  int64_t B, ns, num_e;
+  const void* sampler_plan;   /* kge_sampler_plan_host output, uploaded (may be NULL: sequential generation) */
+  void* sampler_ws;
+  int64_t sampler_ws_bytes;
+  uint32_t* sampler_err;
+  void* sampler_stream;       /* kge_sampler_stream_bytes(B, ns, num_e), zero-filled when allocated: the generators' word rings, filled
+                               * one batch ahead on a stream of their own (NULL: every batch regenerates its words itself) */
+  int64_t sampler_stream_bytes;
+  int32_t* cand_rows[2];      /* ((B + B*ns), 3) per buffer parity */
+  int32_t* cand_counts[2];    /* KGE_CAND_POS_LANES*B + B*ns per buffer parity */
+  void* plan[2];              /* kge_batch_plan_bytes(md, ld, B*ns, B*ns) per buffer parity */
+  int64_t plan_bytes;
+} kge_pipeline_desc;
+int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void** handle);
+int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream);
+int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream);
+int kge_pipeline_finish(void* handle, kge_stream_t stream);
+/* Host-side accounting of kge_pipeline_run since the last reset: out = {ms inside run, ms inside the stage launchers, stage launches;
+ * graph mode only: ms waiting for a graph's previous launch to finish, launches that had to wait, that wait by stage} in the
+ * order {run, wait, launch, launches, waited, wait draw, wait plan, wait step}. */
+int kge_pipeline_stats(void* handle, double out[8], int32_t reset);
+int kge_pipeline_destroy(void* handle);
 
 #ifdef __cplusplus
 }

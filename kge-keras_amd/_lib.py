@@ -43,6 +43,18 @@ class OptDesc(C.Structure):
                 ("step_dev", C.c_void_p)]
 
 
+class PipelineDesc(C.Structure):
+    """kge_pipeline_desc (include/kge_hip.h): everything the native three-stage pipeline driver borrows."""
+    _fields_ = [("md", ModelDesc), ("ld", LossDesc), ("od", OptDesc),
+                ("E", C.c_void_p), ("Rel", C.c_void_p), ("gradE", C.c_void_p), ("gradRel", C.c_void_p), ("loss_out", C.c_void_p),
+                ("train_ws", C.c_void_p), ("train_ws_bytes", C.c_int64), ("err_flag", C.c_void_p),
+                ("np_state", C.c_void_p), ("py_state", C.c_void_p), ("kg", C.c_void_p), ("index", C.c_void_p), ("starts", C.c_void_p),
+                ("cursor", C.c_void_p), ("B", C.c_int64), ("ns", C.c_int64), ("num_e", C.c_int64),
+                ("sampler_plan", C.c_void_p), ("sampler_ws", C.c_void_p), ("sampler_ws_bytes", C.c_int64), ("sampler_err", C.c_void_p),
+                ("sampler_stream", C.c_void_p), ("sampler_stream_bytes", C.c_int64),
+                ("cand_rows", C.c_void_p * 2), ("cand_counts", C.c_void_p * 2), ("plan", C.c_void_p * 2), ("plan_bytes", C.c_int64)]
+
+
 _P, _I64, _I32, _U64, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float
 _MD, _LD, _OD = C.POINTER(ModelDesc), C.POINTER(LossDesc), C.POINTER(OptDesc)
 
@@ -104,6 +116,16 @@ SIGNATURES = {
     "kge_mt_jump_poly": (C.c_int, [_I64, _P]),
     "kge_mt_jump_host": (C.c_int, [_P, _I64]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "kge_sampler_stream_bytes": (_I64, [_I64, _I64, _I64]),
+    "kge_sampler_stream_init": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _I64, _P]),
+    "kge_sampler_stream_produce": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, _P]),
+    "kge_sampler_stream_draw": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "kge_pipeline_create": (C.c_int, [C.POINTER(PipelineDesc), _P, C.POINTER(C.c_void_p)]),
+    "kge_pipeline_start": (C.c_int, [_P, _I64, _P]),
+    "kge_pipeline_run": (C.c_int, [_P, _I64, _P]),
+    "kge_pipeline_finish": (C.c_int, [_P, _P]),
+    "kge_pipeline_stats": (C.c_int, [_P, _P, _I32]),
+    "kge_pipeline_destroy": (C.c_int, [_P]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync

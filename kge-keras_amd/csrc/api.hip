@@ -50,6 +50,8 @@ struct ProfState {
 ProfState g_prof;
 }  // namespace
 
+bool prof_is_on() { return g_prof.on; }
+
 void prof_begin(int label, hipStream_t st) {
   if (!g_prof.on) return;
   hipEvent_t a;
@@ -145,9 +147,9 @@ int64_t batch_plan_bytes(const kge_model_desc*, int64_t);
 int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int, int64_t, int64_t, void*,
                      int, uint32_t*, hipStream_t);
 int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, void*, int64_t, int64_t, float*,
-                          uint64_t, void*, int64_t, hipStream_t);
+                          uint64_t, void*, int64_t, hipStream_t, const kge_opt_desc* advance = nullptr);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
-              int64_t, hipStream_t);
+              int64_t, hipStream_t, bool advanced = false);
 
 int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
 int loss_pairs(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, int64_t, hipStream_t);
@@ -181,6 +183,11 @@ int64_t sampler_workspace_bytes(int64_t, int64_t, int64_t);
 int build_batch_device(void*, void*, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int64_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, int32_t*, int32_t*, const void*, void*, int64_t, uint32_t*,
                        hipStream_t);
 int sampler_plan_host(int64_t, int64_t, int64_t, uint64_t*);
+int64_t sampler_stream_bytes(int64_t, int64_t, int64_t);
+int sampler_stream_init(void*, int64_t, const void*, const void*, int64_t, int64_t, int64_t, hipStream_t);
+int sampler_stream_produce(void*, int64_t, int64_t, int64_t, int64_t, const void*, hipStream_t);
+int sampler_stream_draw(void*, int64_t, void*, void*, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int64_t*, int64_t, int64_t, int64_t,
+                        int32_t*, int32_t*, int32_t*, int32_t*, uint32_t*, hipStream_t);
 int64_t sampler_plan_bytes();
 
 }  // namespace kge
@@ -321,7 +328,7 @@ int kge_batch_plan_build(const kge_model_desc* md, const kge_loss_desc* ld, cons
   if (!pos || !neg || !plan || !err_flag) return fail(KGE_EINVAL, "kge_batch_plan_build: null pointer");
   if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
     return fail(KGE_EWORKSPACE, "kge_batch_plan_build: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
-  if (parts < 1 || parts > 7) return fail(KGE_EINVAL, "kge_batch_plan_build: parts mask %d outside 1..7", parts);
+  if (parts < 1 || parts > 15 || !(parts & 7)) return fail(KGE_EINVAL, "kge_batch_plan_build: parts mask %d outside 1..15", parts);
   return batch_plan_build(md, pos, m_pos, neg, m_neg, nullptr, nullptr, 1, 0, 0, plan, parts, err_flag, static_cast<hipStream_t>(stream));
 }
 
@@ -338,7 +345,7 @@ int kge_batch_plan_build_counted(const kge_model_desc* md, const kge_loss_desc* 
   if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
     return fail(KGE_EWORKSPACE, "kge_batch_plan_build_counted: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes,
                 (long long)batch_plan_bytes(md, m_pos + m_neg));
-  if (parts < 1 || parts > 7) return fail(KGE_EINVAL, "kge_batch_plan_build_counted: parts mask %d outside 1..7", parts);
+  if (parts < 1 || parts > 15 || !(parts & 7)) return fail(KGE_EINVAL, "kge_batch_plan_build_counted: parts mask %d outside 1..15", parts);
   return batch_plan_build(md, nullptr, m_pos, nullptr, m_neg, cand_rows, cand_counts, pos_lanes, n_pos_cand, n_neg_cand, plan, parts, err_flag,
                           static_cast<hipStream_t>(stream));
 }
@@ -358,9 +365,16 @@ int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, co
                            float* gradRel, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed,
                            void* workspace, int64_t workspace_bytes, kge_stream_t stream) {
   if (!od) return fail(KGE_EINVAL, "kge_train_step_planned: optimizer descriptor is null");
-  if (int rc = kge_train_grads_planned(md, ld, E, Rel, gradE, gradRel, plan, plan_bytes, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, stream))
+  if (int rc = check_plan("kge_train_step_planned", md, ld, m_pos, m_neg)) return rc;
+  if (!E || !Rel || !gradE || !gradRel || !plan || !loss_out) return fail(KGE_EINVAL, "kge_train_step_planned: null pointer");
+  if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
+    return fail(KGE_EWORKSPACE, "kge_train_step_planned: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
+  // device-resident step state and no L3 term: the gradient half's closing kernel advances the state, the step ends with the sweep
+  const bool fused = od->step_dev && ld->regularization == 0.f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, st, fused ? od : nullptr))
     return rc;
-  return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+  return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, st, fused);
 }
 
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries) {
@@ -436,6 +450,48 @@ int kge_build_batch_device_indexed(void* np_state_dev, void* py_state_dev, const
     return fail(KGE_EINVAL, "kge_build_batch_device_indexed: bad sizes");
   return build_batch_device(np_state_dev, py_state_dev, nullptr, kg_dev, index_dev, starts_dev, cursor_dev, B, ns, num_e, pos_out_dev, neg_out_dev,
                             cand_rows_dev, cand_counts_dev, plan_dev, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+static int check_sampler_shape(const char* who, int64_t B, int64_t ns, int64_t num_e) {
+  if (B <= 0 || ns <= 0 || num_e <= 0 || num_e > 0x7FFFFFFFll || B * ns > 0x3FFFFFFFll) return fail(KGE_EINVAL, "%s: bad sizes", who);
+  return KGE_OK;
+}
+
+int64_t kge_sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e) {
+  if (int rc = check_sampler_shape("kge_sampler_stream_bytes", B, ns, num_e)) return rc;
+  return sampler_stream_bytes(B, ns, num_e);
+}
+
+int kge_sampler_stream_init(void* stream_buf, int64_t stream_bytes, const void* np_state_dev, const void* py_state_dev, int64_t B, int64_t ns,
+                            int64_t num_e, kge_stream_t stream) {
+  clear_stale_error();
+  if (int rc = check_sampler_shape("kge_sampler_stream_init", B, ns, num_e)) return rc;
+  if (!stream_buf || !np_state_dev || !py_state_dev) return fail(KGE_EINVAL, "kge_sampler_stream_init: null pointer");
+  return sampler_stream_init(stream_buf, stream_bytes, np_state_dev, py_state_dev, B, ns, num_e, static_cast<hipStream_t>(stream));
+}
+
+int kge_sampler_stream_produce(void* stream_buf, int64_t stream_bytes, int64_t B, int64_t ns, int64_t num_e, const void* plan_dev,
+                               kge_stream_t stream) {
+  clear_stale_error();
+  if (int rc = check_sampler_shape("kge_sampler_stream_produce", B, ns, num_e)) return rc;
+  if (!stream_buf) return fail(KGE_EINVAL, "kge_sampler_stream_produce: null pointer");
+  return sampler_stream_produce(stream_buf, stream_bytes, B, ns, num_e, plan_dev, static_cast<hipStream_t>(stream));
+}
+
+int kge_sampler_stream_draw(void* stream_buf, int64_t stream_bytes, void* np_state_dev, void* py_state_dev, const int32_t* batch_dev,
+                            const int32_t* kg_dev, const int64_t* index_dev, const int64_t* starts_dev, int64_t* cursor_dev, int64_t B,
+                            int64_t ns, int64_t num_e, int32_t* pos_out_dev, int32_t* neg_out_dev, int32_t* cand_rows_dev,
+                            int32_t* cand_counts_dev, uint32_t* err_flag, kge_stream_t stream) {
+  clear_stale_error();
+  if (int rc = check_sampler_shape("kge_sampler_stream_draw", B, ns, num_e)) return rc;
+  if (!stream_buf || !np_state_dev || !py_state_dev || !err_flag) return fail(KGE_EINVAL, "kge_sampler_stream_draw: null pointer");
+  if (!batch_dev && (!kg_dev || !index_dev || !starts_dev || !cursor_dev))
+    return fail(KGE_EINVAL, "kge_sampler_stream_draw: give the batch rows, or kg / index / starts / cursor");
+  if ((cand_rows_dev == nullptr) != (cand_counts_dev == nullptr)) return fail(KGE_EINVAL, "kge_sampler_stream_draw: cand_rows and cand_counts go together");
+  if ((pos_out_dev == nullptr) != (neg_out_dev == nullptr) || (!pos_out_dev && !cand_rows_dev))
+    return fail(KGE_EINVAL, "kge_sampler_stream_draw: give pos_out and neg_out, or cand_rows and cand_counts, or both");
+  return sampler_stream_draw(stream_buf, stream_bytes, np_state_dev, py_state_dev, batch_dev, kg_dev, index_dev, starts_dev, cursor_dev, B, ns, num_e,
+                             pos_out_dev, neg_out_dev, cand_rows_dev, cand_counts_dev, err_flag, static_cast<hipStream_t>(stream));
 }
 
 int64_t kge_loss_workspace_bytes(int64_t m_true, int64_t m_false) {

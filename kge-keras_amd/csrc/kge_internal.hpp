@@ -84,6 +84,26 @@ __device__ __forceinline__ float phase_dterm(float x) {
   return r > 0.f ? c : (r < 0.f ? -c : 0.f);
 }
 
+// Device-resident optimizer step state (kge_opt_desc.step_dev, 16 bytes): {int64 t = updates done, float lr_t of update t+1,
+// float running sum of the step losses}.
+__device__ __forceinline__ float lr_of_step(int kind, float lr, float b1, float b2, int64_t t) {
+  if (kind != KGE_OPT_ADAM_TF) return lr;
+  return (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));  // Keras Adam
+}
+// A whole step in one library call (kge_train_step*, no L3 term): the kernel that closes the gradient half also advances the step
+// state -- t += 1, the learning rate of THIS update into *lr_slot (read by the optimizer sweep that follows on the stream), lr_t of
+// the next one and the loss sum into the state -- so the step ends with the optimizer sweep, without a one-thread kernel behind it.
+struct StepAdvance { int64_t* step; float* lr_slot; int kind; float lr, b1, b2; };
+__device__ __forceinline__ void step_advance(const StepAdvance& a, float loss) {
+  if (!a.step) return;
+  const int64_t t = a.step[0] + 1;
+  a.step[0] = t;
+  a.lr_slot[0] = lr_of_step(a.kind, a.lr, a.b1, a.b2, t);
+  float* f = reinterpret_cast<float*>(a.step + 1);
+  f[0] = lr_of_step(a.kind, a.lr, a.b1, a.b2, t + 1);
+  f[1] += loss;
+}
+
 // Block-wide sum of one float per thread (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
 __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats */) {
   v = group_sum<64>(v);

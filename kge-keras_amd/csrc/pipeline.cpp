@@ -1,0 +1,315 @@
+// Native driver of the training pipeline (see include/kge_hip.h, "training pipeline").  What Keras' fit() does for the reference
+// with prefetching worker threads (tests.py:130-134) is here one host loop in C over four device streams:
+//
+//   gen   G(k)  extend the two MT19937 word rings by one round if the consumers are close to their heads   (ahead of need)
+//   draw  S(k)  batch k: masked-rejection select, choices, assembly -> candidate rows + pick counts          (needs G(k))
+//   plan  P(k)  ids-only half of step k: histograms, list offsets, relation lists                            (needs S(k))
+//   step  T(k)  forward, loss, gradients, optimizer                                                          (needs P(k))
+//
+// double-buffered batches and plans; per tick the loop issues T(t) and then G, S, P of batch t+2.  By default every stage is
+// launched kernel by kernel from this loop (about 15 launches and a dozen event operations per step, ~0.05 ms of host time: the
+// device, not the host, sets the pace).  KGE_PIPE_GRAPHS=1 replays each stage from a hipGraph captured once per buffer parity
+// instead; on ROCm 7.2 consecutive graph launches on one stream cost 20-30 us of idle time each, which makes that the slower form
+// (measured: 0.162 ms per step against 0.150 ms).  Host-only translation unit.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <new>
+
+#include "kge_host.hpp"
+
+namespace kge {
+
+// sampler_dev.hip
+int sampler_stream_init(void* buf, int64_t bytes, const void* np_state, const void* py_state, int64_t B, int64_t ns, int64_t num_e, hipStream_t st);
+int sampler_stream_produce(void* buf, int64_t bytes, int64_t B, int64_t ns, int64_t num_e, const void* plan_dev, hipStream_t st);
+int sampler_stream_draw(void* buf, int64_t bytes, void* np_state, void* py_state, const int32_t* batch, const int32_t* kg, const int64_t* index,
+                        const int64_t* starts, int64_t* cursor, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out, int32_t* neg_out,
+                        int32_t* cand_rows, int32_t* cand_cnt, uint32_t* err, hipStream_t st);
+int64_t sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e);
+
+namespace {
+
+#define KGE_PIPE_TRY(expr)                                                                                  \
+  do {                                                                                                      \
+    hipError_t e__ = (expr);                                                                                \
+    if (e__ != hipSuccess) return ::kge::fail(KGE_EHIP, "%s: %s", #expr, hipGetErrorString(e__));           \
+  } while (0)
+
+constexpr int kStages = 4;
+enum { GEN = 0, DRAW = 1, PLAN = 2, STEP = 3 };
+
+struct Pipeline {
+  kge_pipeline_desc d;
+  hipStream_t s_gen = nullptr, s_draw = nullptr, s_plan = nullptr;
+  hipEvent_t gen[2] = {}, ready[2] = {}, freed[2] = {}, planned[2] = {}, pfreed[2] = {};
+  hipEvent_t fork = nullptr;
+  hipEvent_t done[kStages][2] = {};      // graphs only: behind the last launch of graph (stage, slot)
+  bool launched[kStages][2] = {};
+  hipGraphExec_t exec[kStages][2] = {};
+  bool graphs = false;             // replay the stages from hipGraphs instead of launching their kernels from the loop
+  bool ring = false;               // word generation ahead of the batches (kge_sampler_stream_*); else kge_build_batch_device_indexed
+  int64_t n_batches = 0;           // batches of the loaded epoch
+  int64_t t = 0;                   // ticks done
+  bool started = false;
+  // host-side accounting of kge_pipeline_run (kge_pipeline_stats): where the issuing thread spends its time
+  double ns_spin = 0.0, ns_launch = 0.0, ns_total = 0.0, ns_spin_stage[kStages] = {};
+  int64_t n_launch = 0, n_spun = 0;
+  int stage_mask = 15;  // experiments only (KGE_PIPE_STAGES): bit s clear = stage s is not launched (its events still are recorded)
+};
+
+inline double now_ns() { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
+  const kge_pipeline_desc& d = p->d;
+  const int64_t m = d.B * d.ns;
+  switch (stage) {
+    case GEN:
+      return p->ring ? sampler_stream_produce(d.sampler_stream, d.sampler_stream_bytes, d.B, d.ns, d.num_e, d.sampler_plan, st) : KGE_OK;
+    case DRAW:  // positives read in place, folded output only (candidate rows + pick counts); the last kernel moves the cursor
+      if (p->ring)
+        return sampler_stream_draw(d.sampler_stream, d.sampler_stream_bytes, d.np_state, d.py_state, nullptr, d.kg, d.index, d.starts, d.cursor, d.B, d.ns,
+                                   d.num_e, nullptr, nullptr, d.cand_rows[slot], d.cand_counts[slot], d.sampler_err, st);
+      return kge_build_batch_device_indexed(d.np_state, d.py_state, d.kg, d.index, d.starts, d.cursor, d.B, d.ns, d.num_e, nullptr, nullptr,
+                                            d.cand_rows[slot], d.cand_counts[slot], d.sampler_plan, d.sampler_ws, d.sampler_ws_bytes, d.sampler_err, st);
+    case PLAN:  // (8: the plan buffers' counters are zero -- zero-filled by the caller, left zero by every step)
+      return kge_batch_plan_build_counted(&d.md, &d.ld, d.cand_rows[slot], d.cand_counts[slot], KGE_CAND_POS_LANES, d.B, m, m, m, d.plan[slot],
+                                          d.plan_bytes, 7 | 8, d.err_flag, st);
+    default:
+      return kge_train_step_planned(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, d.plan[slot], d.plan_bytes, m, m, d.loss_out, 0, d.train_ws,
+                                    d.train_ws_bytes, st);
+  }
+}
+
+int capture(Pipeline* p, int stage, int slot, hipStream_t st) {
+  hipGraph_t g = nullptr;
+  KGE_PIPE_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  const int rc = stage_calls(p, stage, slot, st);
+  const hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc != KGE_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return fail(KGE_EHIP, "hipStreamEndCapture (stage %d, slot %d): %s", stage, slot, hipGetErrorString(e));
+  const hipError_t ei = hipGraphInstantiate(&p->exec[stage][slot], g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ei != hipSuccess) return fail(KGE_EHIP, "hipGraphInstantiate (stage %d, slot %d): %s", stage, slot, hipGetErrorString(ei));
+  return KGE_OK;
+}
+
+int launch(Pipeline* p, int stage, int slot, hipStream_t st) {
+  if (!((p->stage_mask >> stage) & 1)) return KGE_OK;
+  if (stage == GEN && !p->ring) return KGE_OK;
+  if (!p->graphs) {
+    const double t0 = now_ns();
+    if (int rc = stage_calls(p, stage, slot, st)) return rc;
+    p->ns_launch += now_ns() - t0;
+    p->n_launch += 1;
+    return KGE_OK;
+  }
+  // A graph exec cannot run twice at once: launching it again while its previous launch is in flight blocks inside the runtime
+  // with a sleeping wait (milliseconds on a busy host).  Spin on the event behind the previous launch instead -- bounded: a stage
+  // that never finishes (a fault on the device) becomes an error, not a hang.
+  const double ta = now_ns();
+  if (p->launched[stage][slot]) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+      const hipError_t q = hipEventQuery(p->done[stage][slot]);
+      if (q == hipSuccess) { if (spins) p->n_spun += 1; break; }
+      if (q != hipErrorNotReady) return fail(KGE_EHIP, "hipEventQuery (stage %d, slot %d): %s", stage, slot, hipGetErrorString(q));
+      if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+        return fail(KGE_EHIP, "kge_pipeline: stage %d of slot %d did not finish within 20 s", stage, slot);
+    }
+  }
+  const double tb = now_ns();
+  KGE_PIPE_TRY(hipGraphLaunch(p->exec[stage][slot], st));
+  KGE_PIPE_TRY(hipEventRecord(p->done[stage][slot], st));
+  p->launched[stage][slot] = true;
+  p->ns_spin += tb - ta;
+  p->ns_spin_stage[stage] += tb - ta;
+  p->ns_launch += now_ns() - tb;
+  p->n_launch += 1;
+  return KGE_OK;
+}
+
+// generator round, draw and plan of batch k on their streams
+int produce(Pipeline* p, int64_t k) {
+  if (k >= p->n_batches) return KGE_OK;
+  const int j = (int)(k & 1);
+  if (p->ring) {
+    // round k sees the consumer position of batch k-2 at the latest (`ready[j]` still is the record behind draw k-2): stale by one
+    // batch at most, which is what the rings' low-water mark is sized for (sampler_dev.hip)
+    KGE_PIPE_TRY(hipStreamWaitEvent(p->s_gen, p->ready[j], 0));
+    if (int rc = launch(p, GEN, j, p->s_gen)) return rc;
+    KGE_PIPE_TRY(hipEventRecord(p->gen[j], p->s_gen));
+    KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->gen[j], 0));
+  }
+  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->freed[j], 0));
+  if (int rc = launch(p, DRAW, j, p->s_draw)) return rc;
+  KGE_PIPE_TRY(hipEventRecord(p->ready[j], p->s_draw));
+  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->ready[j], 0));
+  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[j], 0));
+  if (int rc = launch(p, PLAN, j, p->s_plan)) return rc;
+  KGE_PIPE_TRY(hipEventRecord(p->planned[j], p->s_plan));
+  KGE_PIPE_TRY(hipEventRecord(p->freed[j], p->s_plan));
+  return KGE_OK;
+}
+
+void destroy(Pipeline* p) {
+  for (int s = 0; s < kStages; ++s)
+    for (int j = 0; j < 2; ++j) {
+      if (p->exec[s][j]) (void)hipGraphExecDestroy(p->exec[s][j]);
+      if (p->done[s][j]) (void)hipEventDestroy(p->done[s][j]);
+    }
+  for (int j = 0; j < 2; ++j)
+    for (hipEvent_t e : {p->gen[j], p->ready[j], p->freed[j], p->planned[j], p->pfreed[j]})
+      if (e) (void)hipEventDestroy(e);
+  if (p->fork) (void)hipEventDestroy(p->fork);
+  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan})
+    if (s) (void)hipStreamDestroy(s);
+  delete p;
+}
+
+}  // namespace
+
+}  // namespace kge
+
+using namespace kge;
+
+extern "C" {
+
+int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void** handle) {
+  (void)hipGetLastError();
+  (void)stream;
+  if (!desc || !handle) return fail(KGE_EINVAL, "kge_pipeline_create: null argument");
+  const kge_pipeline_desc& d = *desc;
+  if (!d.od.step_dev) return fail(KGE_EINVAL, "kge_pipeline_create: the optimizer needs its device-resident step state (kge_opt_desc.step_dev)");
+  if (d.md.dropout > 0.f) return fail(KGE_EUNSUPPORTED, "kge_pipeline_create: folded batches and dropout exclude each other (dropout must be 0)");
+  if (!d.E || !d.Rel || !d.gradE || !d.gradRel || !d.loss_out || !d.train_ws || !d.err_flag || !d.np_state || !d.py_state || !d.kg || !d.index ||
+      !d.starts || !d.cursor || !d.sampler_ws || !d.sampler_err || !d.cand_rows[0] || !d.cand_rows[1] || !d.cand_counts[0] || !d.cand_counts[1] ||
+      !d.plan[0] || !d.plan[1])
+    return fail(KGE_EINVAL, "kge_pipeline_create: null pointer in the descriptor");
+  if (d.B <= 0 || d.ns <= 0 || d.num_e <= 0) return fail(KGE_EINVAL, "kge_pipeline_create: bad batch shape");
+  const int64_t need = kge_batch_plan_bytes(&d.md, &d.ld, d.B * d.ns, d.B * d.ns);
+  if (need < 0) return (int)need;
+  if (d.plan_bytes < need) return fail(KGE_EWORKSPACE, "kge_pipeline_create: plan buffers have %lld bytes, need %lld", (long long)d.plan_bytes, (long long)need);
+  if (d.sampler_stream && d.sampler_stream_bytes < sampler_stream_bytes(d.B, d.ns, d.num_e))
+    return fail(KGE_EWORKSPACE, "kge_pipeline_create: sampler stream buffer has %lld bytes, needs %lld", (long long)d.sampler_stream_bytes,
+                (long long)sampler_stream_bytes(d.B, d.ns, d.num_e));
+  Pipeline* p = new (std::nothrow) Pipeline();
+  if (!p) return fail(KGE_EINVAL, "kge_pipeline_create: out of host memory");
+  p->d = d;
+  p->ring = d.sampler_stream != nullptr;
+  if (const char* e = std::getenv("KGE_PIPE_STAGES")) p->stage_mask = std::atoi(e) & 15;
+  if (const char* e = std::getenv("KGE_PIPE_GRAPHS")) p->graphs = std::atoi(e) != 0;
+  if (const char* e = std::getenv("KGE_PIPE_RING")) { if (std::atoi(e) == 0) p->ring = false; }
+  if (p->graphs && prof_is_on()) {
+    delete p;
+    return fail(KGE_EINVAL, "kge_pipeline_create: switch kernel timing off first (kge_prof_enable(0)): timing events cannot be captured");
+  }
+  auto bail = [&](int rc) { destroy(p); return rc; };
+#define KGE_CREATE_TRY(expr)                                                                                                    \
+  do {                                                                                                                          \
+    hipError_t e__ = (expr);                                                                                                    \
+    if (e__ != hipSuccess) return bail(fail(KGE_EHIP, "%s: %s", #expr, hipGetErrorString(e__)));                                \
+  } while (0)
+  KGE_CREATE_TRY(hipStreamCreateWithFlags(&p->s_gen, hipStreamNonBlocking));
+  KGE_CREATE_TRY(hipStreamCreateWithFlags(&p->s_draw, hipStreamNonBlocking));
+  KGE_CREATE_TRY(hipStreamCreateWithFlags(&p->s_plan, hipStreamNonBlocking));
+  KGE_CREATE_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+  for (int j = 0; j < 2; ++j) {
+    for (hipEvent_t* e : {&p->gen[j], &p->ready[j], &p->freed[j], &p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (int s = 0; s < kStages; ++s) KGE_CREATE_TRY(hipEventCreateWithFlags(&p->done[s][j], hipEventDisableTiming));
+  }
+#undef KGE_CREATE_TRY
+  if (p->graphs) {  // capture on streams of the library's own (the caller's may be the legacy default stream, which cannot be captured)
+    for (int j = 0; j < 2; ++j) {
+      if (p->ring) if (int rc = capture(p, GEN, j, p->s_gen)) return bail(rc);
+      if (int rc = capture(p, DRAW, j, p->s_draw)) return bail(rc);
+      if (int rc = capture(p, PLAN, j, p->s_plan)) return bail(rc);
+      if (int rc = capture(p, STEP, j, p->s_draw)) return bail(rc);
+    }
+  }
+  *handle = p;
+  return KGE_OK;
+}
+
+int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream) {
+  (void)hipGetLastError();
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p || n_batches < 0) return fail(KGE_EINVAL, "kge_pipeline_start: bad arguments");
+  hipStream_t main_st = static_cast<hipStream_t>(stream);
+  const kge_pipeline_desc& d = p->d;
+  p->n_batches = n_batches;
+  p->t = 0;
+  // the rings restart from the generator states the caller loaded (the reference's global generators at the start of an epoch)
+  if (p->ring)
+    if (int rc = sampler_stream_init(d.sampler_stream, d.sampler_stream_bytes, d.np_state, d.py_state, d.B, d.ns, d.num_e, main_st)) return rc;
+  // everything the caller enqueued so far (epoch permutation, cursor reset, generator states) precedes the first draw and plan
+  KGE_PIPE_TRY(hipEventRecord(p->fork, main_st));
+  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan}) KGE_PIPE_TRY(hipStreamWaitEvent(s, p->fork, 0));
+  p->started = true;
+  if (int rc = produce(p, 0)) return rc;
+  return produce(p, 1);
+}
+
+int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
+  (void)hipGetLastError();
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p || !p->started || n_steps < 0) return fail(KGE_EINVAL, "kge_pipeline_run: not started / bad arguments");
+  if (p->t + n_steps > p->n_batches)
+    return fail(KGE_EINVAL, "kge_pipeline_run: %lld steps asked, %lld batches left in the epoch", (long long)n_steps, (long long)(p->n_batches - p->t));
+  hipStream_t main_st = static_cast<hipStream_t>(stream);
+  const double t_in = now_ns();
+  for (int64_t i = 0; i < n_steps; ++i) {
+    const int j = (int)(p->t & 1);
+    KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->planned[j], 0));
+    if (int rc = launch(p, STEP, j, main_st)) return rc;
+    KGE_PIPE_TRY(hipEventRecord(p->pfreed[j], main_st));
+    if (int rc = produce(p, p->t + 2)) return rc;
+    p->t += 1;
+  }
+  p->ns_total += now_ns() - t_in;
+  return KGE_OK;
+}
+
+int kge_pipeline_stats(void* handle, double out[8], int32_t reset) {
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p || !out) return fail(KGE_EINVAL, "kge_pipeline_stats: null argument");
+  out[0] = p->ns_total * 1e-6;   // ms inside kge_pipeline_run
+  out[1] = p->ns_spin * 1e-6;    // graphs only: ms of it waiting for a graph's previous launch to finish
+  out[2] = p->ns_launch * 1e-6;  // ms of it inside the stage launchers (kernel launches, or hipGraphLaunch + the event record behind it)
+  out[3] = (double)p->n_launch;  // stage launches
+  out[4] = (double)p->n_spun;    // graphs only: launches that had to wait
+  out[5] = p->ns_spin_stage[DRAW] * 1e-6;
+  out[6] = p->ns_spin_stage[PLAN] * 1e-6;
+  out[7] = p->ns_spin_stage[STEP] * 1e-6;
+  if (reset) {
+    p->ns_total = p->ns_spin = p->ns_launch = 0.0;
+    p->n_launch = p->n_spun = 0;
+    for (double& x : p->ns_spin_stage) x = 0.0;
+  }
+  return KGE_OK;
+}
+
+int kge_pipeline_finish(void* handle, kge_stream_t stream) {
+  (void)hipGetLastError();
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p) return fail(KGE_EINVAL, "kge_pipeline_finish: null handle");
+  hipStream_t main_st = static_cast<hipStream_t>(stream);
+  // join: the caller's stream waits for whatever the producer streams still hold (batches drawn ahead of the last step)
+  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan}) {
+    KGE_PIPE_TRY(hipEventRecord(p->fork, s));
+    KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->fork, 0));
+  }
+  p->started = false;
+  return KGE_OK;
+}
+
+int kge_pipeline_destroy(void* handle) {
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p) return KGE_OK;
+  (void)hipDeviceSynchronize();
+  destroy(p);
+  return KGE_OK;
+}
+
+}  // extern "C"

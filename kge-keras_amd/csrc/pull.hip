@@ -239,65 +239,12 @@ __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ p
   }
 }
 
-// Tiled single-workgroup scan: 256 threads x 4 consecutive keys per tile, wave shuffles inside, carry across tiles
-// (a small workgroup is admitted quickly beside the chip-filling gather kernels).
-struct Tri { int a, b, c; };
-__device__ __forceinline__ Tri tri_add(Tri x, Tri y) { return Tri{x.a + y.a, x.b + y.b, x.c + y.c}; }
-__device__ __forceinline__ Tri tri_shfl_up(Tri x, int d) { return Tri{__shfl_up(x.a, d, 64), __shfl_up(x.b, d, 64), __shfl_up(x.c, d, 64)}; }
-
-__global__ __launch_bounds__(256) void scan_kernel(const int32_t* __restrict__ cnt, int NK, int C, int32_t* __restrict__ off,
-                                                     int32_t* __restrict__ eoff, int32_t* __restrict__ poff,
-                                                     int32_t* __restrict__ totals) {
-  __shared__ Tri wsum[4];
-  __shared__ Tri carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = Tri{0, 0, 0};
-  __syncthreads();
-  for (int base = 0; base < NK; base += 1024) {
-    const int k0 = base + tid * 4;
-    int n[4];
-    Tri v[4];
-    Tri run{0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      n[j] = k0 + j < NK ? cnt[k0 + j] : 0;
-      const int nch = (n[j] + C - 1) / C;
-      v[j] = run;  // exclusive within the thread
-      run = tri_add(run, Tri{n[j], nch > 1 ? nch - 1 : 0, nch > 1 ? nch : 0});
-    }
-    Tri inc = run;  // inclusive scan of thread totals across the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const Tri up = tri_shfl_up(inc, d);
-      if (lane >= d) inc = tri_add(inc, up);
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    Tri wpre{0, 0, 0};
-    for (int w = 0; w < wave; ++w) wpre = tri_add(wpre, wsum[w]);
-    const Tri carry = carry_s;
-    Tri pre = tri_add(tri_add(carry, wpre), Tri{inc.a - run.a, inc.b - run.b, inc.c - run.c});
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (k0 + j < NK) {
-        const Tri x = tri_add(pre, v[j]);
-        off[k0 + j] = x.a; eoff[k0 + j] = x.b; poff[k0 + j] = x.c;
-      }
-    __syncthreads();
-    if (tid == 255) carry_s = tri_add(tri_add(carry, wpre), inc);
-    __syncthreads();
-  }
-  if (tid == 0) { totals[0] = carry_s.b; totals[1] = carry_s.c; totals[2] = carry_s.a; }
-}
-
-__global__ __launch_bounds__(256) void emap_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ eoff, int NK,
-                                                    int C, int max_extra, int2* __restrict__ emap) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= NK) return;
-  const int nch = (cnt[k] + C - 1) / C;
-  const int base = eoff[k];
-  for (int j = 1; j < nch; ++j)
-    if (base + j - 1 < max_extra) emap[base + j - 1] = make_int2(k, j);
+// Offsets of the per-key lists: one workgroup per tile of 1024 keys (scan_tile_body, pull.hpp); also writes the (key, chunk) map.
+__global__ __launch_bounds__(256) void scan_mb_kernel(const int32_t* __restrict__ cnt, int NK, int C, int32_t* __restrict__ off,
+                                                       int32_t* __restrict__ eoff, int32_t* __restrict__ poff,
+                                                       int32_t* __restrict__ totals, int2* __restrict__ emap, int max_extra) {
+  __shared__ Tri red[8];
+  scan_tile_body(cnt, NK, C, blockIdx.x, off, eoff, poff, totals, emap, max_extra, red);
 }
 
 // Atomic-free list fill: position = list start of the destination + the rank handed out by hist_kernel.
@@ -569,8 +516,7 @@ int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, co
   const int igrid = (int)cdiv(n, kIdxBlockTriples);
   ProfScope prof(KGE_PROF_INDEX, st);  // index build (ids only)
   hipLaunchKernelGGL(hist_kernel, dim3(igrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, md->num_relations, p.cnt, p.ranks);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals);
-  hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(NK, 256)), dim3(256), 0, st, p.cnt, p.eoff, NK, p.chunk, p.max_extra, p.emap);
+  hipLaunchKernelGGL(scan_mb_kernel, dim3((int)cdiv(NK, kScanTile)), dim3(256), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals, p.emap, p.max_extra);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
@@ -659,8 +605,7 @@ int pull_finish_launch(const kge_model_desc* md, float* gE, float* gR, const Pul
 
 // ---- entry points for pull2.hip: the same scan / pull / finish kernels over the N entity keys only
 void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st) {
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals);
-  hipLaunchKernelGGL(emap_kernel, dim3((int)cdiv(N, 256)), dim3(256), 0, st, e.cnt, e.eoff, N, e.chunk, e.max_extra, e.emap);
+  hipLaunchKernelGGL(scan_mb_kernel, dim3((int)cdiv(N, kScanTile)), dim3(256), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals, e.emap, e.max_extra);
 }
 
 // (the finish of the entity keys is fused into pull2.hip's rel_finish_kernel)

@@ -3,11 +3,14 @@
 // relation gradient  d/dp = g * f(s, o)  is accumulated in registers from the very rows the score needed -- the
 // backward pull then only has the entity rows left (2 list entries and 2 entity-row reads per triple instead of 3 and 4).
 //
-//   main stream                                              side stream (joins before ent_fill)
-//   rel_hist_kernel   LDS histogram of p, rank per triple     ent_hist_kernel  returning int atomics on s and o
-//   rel_plan_kernel   offsets, unit map (relation, chunk)     scan_kernel / emap_kernel over the N entity keys
-//   rel_fill_kernel   relation lists {s, o, t}
-//   fwd_rel_kernel    one wave per (relation, chunk of 64): score, loss, coef[t], partial d/dp row -> slab
+//   plan (ids only; built inside the step or ahead of it on any stream)
+//   plan_hist_kernel  one pass over the rows: materialises {s, p, o, +-multiplicity}, LDS histogram of p and LDS hash of s / o per
+//                     1024 rows, one global atomic per distinct key -> rank of every row in its relation / entity lists
+//   plan_scan_kernel  list offsets of the N entity keys (one workgroup per 1024 keys) + chunk map; last workgroup: relation
+//                     offsets and the (relation, chunk) unit map
+//   rel_fill_kernel   relation lists {s, o, t, multiplicity}
+//   step (parameters)
+//   fwd_rel_kernel    one wave per (relation, chunk of 32): score, loss, coef[t], partial d/dp row -> slab
 //   ent_fill_kernel   entity lists {p | role, other entity, coef, t}
 //   pull_kernel       (pull.hip) over entity keys only
 //   rel_finish_kernel d/dp rows = sum of the relation's slab rows (chunk order); pull_finish for hub entities
@@ -33,7 +36,6 @@ constexpr int kRelChunk = 32;   // rows per forward work unit ...
 // relation of FB15k-237 carries 16 % of the triples) leaves a few hundred partial gradient rows to sum, not thousands
 __host__ __device__ __forceinline__ int rel_chunk_rows(int c) { return c > 4096 ? 4 * kRelChunk : kRelChunk; }
 __host__ __device__ __forceinline__ int rel_units(int c) { const int ch = rel_chunk_rows(c); return (c + ch - 1) / ch; }
-constexpr int kRelBlockTriples = 1024;
 
 struct Dedup {
   unsigned long long* keys;  // [cap]  0 = empty, else key + 1
@@ -66,12 +68,13 @@ struct Plan2 {
   int32_t* erank;   // [2][n]
 };
 
-// Where the step's rows come from: the caller's (pos, neg) arrays, or the folded rows {s, p, o, +-multiplicity}.
+// Where the step's rows come from: the caller's (pos, neg) arrays, or the materialised rows {s, p, o, +-multiplicity} of the plan
+// (multiplicity 0: the row takes no part -- a candidate nobody picked, or ids outside the tables).
 struct Src {
   const int32_t* pos; int64_t m_pos;
   const int32_t* neg; int64_t m_neg;
-  const int4* uniq;     // null: no folding
-  const int32_t* nu;    // device count of folded rows
+  const int4* uniq;     // null: the caller's arrays
+  const int32_t* nu;    // device count of materialised rows
 };
 __device__ __forceinline__ int64_t src_rows(const Src& x) { return x.uniq ? (int64_t)x.nu[0] : x.m_pos + x.m_neg; }
 __device__ __forceinline__ void src_load(const Src& x, int64_t t, int& s, int& p, int& o, int& w) {
@@ -171,39 +174,10 @@ __global__ __launch_bounds__(256) void dedup_scores_kernel(const int32_t* __rest
   scores[t] = sl < 0 ? __builtin_nanf("") : uscore[uid[sl]];
 }
 
-__global__ __launch_bounds__(256) void rel_hist_kernel(Src src, int N, int R, int32_t* __restrict__ rcnt, int32_t* __restrict__ rrank) {
-  __shared__ int lrel[kRelMax];
-  for (int i = threadIdx.x; i < R; i += 256) lrel[i] = 0;
-  __syncthreads();
-  const int64_t n = src_rows(src);
-  const int64_t t0 = (int64_t)blockIdx.x * kRelBlockTriples;
-  constexpr int PER = kRelBlockTriples / 256;
-  int rp[PER], pp[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int64_t t = t0 + threadIdx.x + i * 256;
-    rp[i] = pp[i] = -1;
-    if (t < n) {
-      int s, p, o, w;
-      src_load(src, t, s, p, o, w);
-      if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) { pp[i] = p; rp[i] = atomicAdd(&lrel[p], 1); }
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < R; i += 256) { const int v = lrel[i]; lrel[i] = v ? atomicAdd(&rcnt[i], v) : 0; }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int64_t t = t0 + threadIdx.x + i * 256;
-    if (t < n) rrank[t] = pp[i] < 0 ? -1 : lrel[pp[i]] + rp[i];
-  }
-}
-
 // One workgroup of 256 threads: exclusive scans over R <= 4096 relations (list offsets, unit offsets) and the unit map.
-__global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
-                                                        int32_t* __restrict__ ruoff, int32_t* __restrict__ rtotal,
-                                                        int2* __restrict__ rumap, int max_units) {
-  __shared__ int wa[4], wb[4];
+__device__ __forceinline__ void rel_plan_body(const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
+                                              int32_t* __restrict__ ruoff, int32_t* __restrict__ rtotal,
+                                              int2* __restrict__ rumap, int max_units, int* wa, int* wb) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (R + 255) / 256;  // <= 16
   const int k0 = tid * per, k1 = min(R, k0 + per);
@@ -227,12 +201,34 @@ __global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict
   if (tid == 255) rtotal[0] = rb;
 }
 
+__global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
+                                                        int32_t* __restrict__ ruoff, int32_t* __restrict__ rtotal,
+                                                        int2* __restrict__ rumap, int max_units) {
+  __shared__ int wa[4], wb[4];
+  rel_plan_body(rcnt, R, roff, ruoff, rtotal, rumap, max_units, wa, wb);
+}
+
+// Offsets of both index halves in ONE launch: workgroups [0, etiles) scan the entity keys (scan_tile_body, pull.hpp), the last
+// workgroup plans the relations.
+__global__ __launch_bounds__(256) void plan_scan_kernel(const int32_t* __restrict__ ecnt, int N, int C, int32_t* __restrict__ off,
+                                                         int32_t* __restrict__ eoff, int32_t* __restrict__ poff,
+                                                         int32_t* __restrict__ totals, int2* __restrict__ emap, int max_extra, int etiles,
+                                                         const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
+                                                         int32_t* __restrict__ ruoff, int32_t* __restrict__ rtotal,
+                                                         int2* __restrict__ rumap, int max_units) {
+  __shared__ Tri red[8];
+  __shared__ int wa[4], wb[4];
+  if ((int)blockIdx.x < etiles) scan_tile_body(ecnt, N, C, blockIdx.x, off, eoff, poff, totals, emap, max_extra, red);
+  else rel_plan_body(rcnt, R, roff, ruoff, rtotal, rumap, max_units, wa, wb);
+}
+
 __global__ __launch_bounds__(256) void rel_fill_kernel(Src src, const int32_t* __restrict__ roff, const int32_t* __restrict__ rrank,
                                                         int4* __restrict__ rentries, float* __restrict__ scores,
                                                         uint32_t* __restrict__ err) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= src_rows(src)) return;
   const int r = rrank[t];
+  if (r == -2) return;  // a candidate row nobody picked (multiplicity 0)
   if (r < 0) {  // ids outside the tables: the row takes no part in the step, scores NaN, error flag raised
     if (scores) scores[t] = __builtin_nanf("");
     atomicOr(err, 1u);
@@ -243,28 +239,64 @@ __global__ __launch_bounds__(256) void rel_fill_kernel(Src src, const int32_t* _
   rentries[roff[p] + r] = make_int4(s, o, (int)t, w);  // w: +multiplicity for a positive row, -multiplicity for a negative one
 }
 
-// Rank of every (row, role) inside its destination entity's list.  Entities of real graphs are heavy tailed: a hub would take
-// thousands of same-address returning atomics per batch, which serialise (0.48 ms measured on a Zipf batch of 409 600 rows).
-// Each workgroup therefore first aggregates its 1024 rows in an LDS hash table (key -> occurrences so far), then issues ONE
-// global returning atomic per distinct key, and adds the returned base to the local ranks.
+// The one pass of the plan over the rows of a batch (1024 rows per workgroup, 4 per thread):
+//   * where the rows come from -- MODE 0: the plan's materialised rows (the hash fold wrote them); MODE 1: the caller's arrays
+//     (copied into the plan when `uniq_out` is given: a plan built ahead must not refer to them afterwards); MODE 2: a batch in
+//     folded form, candidate rows + pick counts (the device sampler's by-product): every candidate becomes a row, multiplicity 0
+//     where nobody picked it -- no compaction, no atomics on a row counter;
+//   * rank of every row inside its relation's list: LDS histogram of the relation column, one global atomic per (workgroup,
+//     relation);
+//   * rank of every (row, role) inside its destination entity's list.  Entities of real graphs are heavy tailed: a hub would take
+//     thousands of same-address returning atomics per batch, which serialise (0.48 ms measured on a Zipf batch of 409 600 rows).
+//     Each workgroup therefore first aggregates its rows in an LDS hash table (key -> occurrences so far), then issues ONE global
+//     returning atomic per distinct key, and adds the returned base to the local ranks.
+// rrank: -1 = ids outside the tables (rel_fill_kernel raises the error flag), -2 = multiplicity 0.
 constexpr int kEntRows = 1024;   // rows per workgroup (4 per thread)
 constexpr int kEntSlots = 4096;  // LDS hash slots (2 * kEntRows keys at most -> load factor <= 0.5)
-__global__ __launch_bounds__(256) void ent_hist_kernel(Src src, int64_t n, int N, int R, int32_t* __restrict__ cnt, int32_t* __restrict__ erank) {
+struct HistSrc {
+  Src src;                      // MODE 0 / 1
+  const int32_t* cand_rows;     // MODE 2
+  const int32_t* cand_cnt;
+  int lanes;
+  int64_t n_pos_cand, n_all;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void plan_hist_kernel(HistSrc hs, int64_t n, int N, int R, int32_t* __restrict__ ecnt,
+                                                         int32_t* __restrict__ erank, int32_t* __restrict__ rcnt,
+                                                         int32_t* __restrict__ rrank, int4* __restrict__ uniq_out,
+                                                         int32_t* __restrict__ nu_out, uint32_t* __restrict__ err) {
+  __shared__ int lrel[kRelMax];
   __shared__ int hkey[kEntSlots];
   __shared__ int hcnt[kEntSlots];
+  for (int i = threadIdx.x; i < R; i += 256) lrel[i] = 0;
   for (int i = threadIdx.x; i < kEntSlots; i += 256) { hkey[i] = -1; hcnt[i] = 0; }
   __syncthreads();
-  const int64_t rows = src_rows(src);
+  const int64_t rows = MODE == 2 ? hs.n_all : src_rows(hs.src);
+  if (MODE != 0 && nu_out && blockIdx.x == 0 && threadIdx.x == 0) nu_out[0] = (int32_t)rows;
   const int64_t t0 = (int64_t)blockIdx.x * kEntRows;
-  int slot[8], lrank[8];
+  int slot[8], lrank[8], rp[4], pp[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t t = t0 + threadIdx.x + i * 256;  // n = m_pos + m_neg: stride of the two rank planes
+    const int64_t t = t0 + threadIdx.x + i * 256;  // n = m_pos + m_neg: stride of the two entity rank planes
     slot[2 * i] = slot[2 * i + 1] = -1;
+    rp[i] = -2; pp[i] = 0;
     if (t < rows) {
       int s, p, o, w;
-      src_load(src, t, s, p, o, w);
-      if ((unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N) {
+      if (MODE == 2) {
+        w = 0;
+        if (t < hs.n_pos_cand) { for (int l = 0; l < hs.lanes; ++l) w += hs.cand_cnt[l * hs.n_pos_cand + t]; }  // striped counters of the positives
+        else w = -hs.cand_cnt[(int64_t)(hs.lanes - 1) * hs.n_pos_cand + t];
+        s = hs.cand_rows[3 * t]; p = hs.cand_rows[3 * t + 1]; o = hs.cand_rows[3 * t + 2];
+      } else {
+        src_load(hs.src, t, s, p, o, w);
+      }
+      const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+      if (MODE == 2 && w != 0 && !ok) { atomicOr(err, 1u); w = 0; }  // a picked row outside the tables: flagged, takes no part
+      if (MODE != 0 && uniq_out) uniq_out[t] = make_int4(s, p, o, w);
+      if (w != 0 && !ok) rp[i] = -1;
+      if (w != 0 && ok) {
+        pp[i] = p;
+        rp[i] = atomicAdd(&lrel[p], 1);
 #pragma unroll
         for (int role = 0; role < 2; ++role) {
           const int key = role == 0 ? s : o;
@@ -283,13 +315,15 @@ __global__ __launch_bounds__(256) void ent_hist_kernel(Src src, int64_t n, int N
   __syncthreads();
   for (int i = threadIdx.x; i < kEntSlots; i += 256) {
     const int key = hkey[i];
-    if (key >= 0) hcnt[i] = atomicAdd(&cnt[key], hcnt[i]);  // base of this workgroup's occurrences in the key's list
+    if (key >= 0) hcnt[i] = atomicAdd(&ecnt[key], hcnt[i]);  // base of this workgroup's occurrences in the key's list
   }
+  for (int i = threadIdx.x; i < R; i += 256) { const int v = lrel[i]; lrel[i] = v ? atomicAdd(&rcnt[i], v) : 0; }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t t = t0 + threadIdx.x + i * 256;
     if (t < rows) {
+      rrank[t] = rp[i] < 0 ? rp[i] : lrel[pp[i]] + rp[i];
       erank[t] = slot[2 * i] >= 0 ? hcnt[slot[2 * i]] + lrank[2 * i] : -1;
       erank[n + t] = slot[2 * i + 1] >= 0 ? hcnt[slot[2 * i + 1]] + lrank[2 * i + 1] : -1;
     }
@@ -466,7 +500,7 @@ __global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR,
                                                           const float* __restrict__ loss_partials, int n_partials,
                                                           float* __restrict__ loss_out, int ent_blocks, float* __restrict__ gE, int N,
                                                           int32_t* __restrict__ ecnt, const int32_t* __restrict__ epoff,
-                                                          const float* __restrict__ eslab, int C) {
+                                                          const float* __restrict__ eslab, int C, StepAdvance adv) {
   __shared__ float red[16];
   __shared__ float part[4][512];  // relation rows of this path are at most 512 floats wide (pull2_supported)
   if ((int)blockIdx.x < ent_blocks) {
@@ -478,7 +512,7 @@ __global__ __launch_bounds__(256) void rel_finish_kernel(float* __restrict__ gR,
     float s = 0.f;
     for (int i = threadIdx.x; i < n_partials; i += 256) s += loss_partials[i];
     const float b = block_sum(s, red);
-    if (threadIdx.x == 0) loss_out[0] = b;
+    if (threadIdx.x == 0) { loss_out[0] = b; step_advance(adv, b); }
     return;
   }
   // one workgroup per relation: the four waves take every fourth slab row (eight loads in flight each) and meet in LDS,
@@ -649,58 +683,17 @@ static void launch_fwd_rel_loss(int loss, int nv, bool drop, int grid, hipStream
   else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
 }
 
-// Batch given in folded form (the sampler's candidates + pick counts): keep the rows with a count, dense ids from a ballot
-// per wave and one atomicAdd per workgroup on the row counter (zeroed with the plan's counters).
-__global__ __launch_bounds__(256) void counted_rows_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ cnt, int lanes,
-                                                            int64_t n_pos, int64_t n_all, int N, int R, int4* __restrict__ uniq, int32_t* nu,
-                                                            uint32_t* __restrict__ err) {
-  __shared__ int wbase[4];
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int s = 0, p = 0, o = 0, w = 0;
-  bool keep = false;
-  if (c < n_all) {
-    if (c < n_pos) { for (int l = 0; l < lanes; ++l) w += cnt[l * n_pos + c]; }  // striped counters of the positives
-    else w = cnt[(int64_t)(lanes - 1) * n_pos + c];
-    if (w > 0) {
-      s = rows[3 * c]; p = rows[3 * c + 1]; o = rows[3 * c + 2];
-      keep = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
-      if (!keep) atomicOr(err, 1u);
-    }
-  }
-  const unsigned long long m = __ballot(keep);
-  if (lane == 0) wbase[wave] = __popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int tot = wbase[0] + wbase[1] + wbase[2] + wbase[3];
-    const int base = tot ? atomicAdd(nu, tot) : 0;
-    int acc = base;
-    for (int i = 0; i < 4; ++i) { const int v = wbase[i]; wbase[i] = acc; acc += v; }
-  }
-  __syncthreads();
-  if (keep) uniq[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(s, p, o, c < n_pos ? w : -w);
-}
-
 __global__ __launch_bounds__(256) void zero_words_kernel(int32_t* __restrict__ p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void rows_copy_kernel(const int32_t* __restrict__ pos, int64_t m_pos, const int32_t* __restrict__ neg,
-                                                         int64_t m_neg, int4* __restrict__ rows, int32_t* __restrict__ nu) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) nu[0] = (int32_t)(m_pos + m_neg);
-  if (t >= m_pos + m_neg) return;
-  const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
-  rows[t] = make_int4(tr[0], tr[1], tr[2], t < m_pos ? 1 : -1);
-}
-
 // ---- plan: everything that depends on the ids only.  `own_rows`: the plan must not refer to the caller's arrays afterwards
-// (kge_batch_plan_build), so rows that are not folded are copied.  `side` may be null (then everything runs on `st`).
+// (kge_batch_plan_build), so rows that are not folded are copied.
 struct Counted { const int32_t* rows; const int32_t* cnt; int lanes; int64_t n_pos, n_all; };  // batch in folded form (rows == null: not given)
 
 static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const Plan2& p, bool own_rows,
-                      bool clear_counters, int parts, const Counted& cd, Src* src_out, bool* folded, float* scores, uint32_t* err, hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+                      bool clear_counters, int parts, const Counted& cd, Src* src_out, bool* folded, float* scores, uint32_t* err, hipStream_t st) {
   const int64_t n = m_pos + m_neg;
   const int N = md->num_entities, R = md->num_relations;
   const int tgrid = (int)cdiv(n, 256);
@@ -710,40 +703,42 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
   const Dedup& d = p.dd;
   if (fold || own_rows || cd.rows) { src.uniq = d.uniq; src.nu = d.nu; }
   *src_out = src;
-  if (parts & 1) {  // rows: fold duplicates (or copy), counters cleared
+  if (parts & 1) {  // rows (duplicates folded / copied / taken from the candidates) + both histograms
     // a plan buffer keeps its counters right in front of the row counter and the hash table: one memset clears what is needed
     const int64_t cbytes = clear_counters ? (char*)d.keys - (char*)p.ent.cnt : 0;
     // (small clears by kernel: two replayed hipGraphs that both hold memset nodes stall each other's launches on ROCm 7.2)
     if (!fold && clear_counters) hipLaunchKernelGGL(zero_words_kernel, dim3((int)cdiv(cbytes / 4, 256)), dim3(256), 0, st, (int32_t*)p.ent.cnt, cbytes / 4);
-    if (cd.rows) {
-      ProfScope prof(KGE_PROF_DEDUP, st);
-      hipLaunchKernelGGL(counted_rows_kernel, dim3((int)cdiv(cd.n_all, 256)), dim3(256), 0, st, cd.rows, cd.cnt, cd.lanes, cd.n_pos, cd.n_all, N, R,
-                         d.uniq, d.nu, err);
-    } else if (fold) {
+    if (fold) {
       ProfScope prof(KGE_PROF_DEDUP, st);
       KGE_HIP_TRY(hipMemsetAsync(clear_counters ? (void*)p.ent.cnt : (void*)d.keys, 0, cbytes + d.clear_bytes, st));
       hipLaunchKernelGGL(dedup_insert_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, R, d.keys, d.cnt,
                          (unsigned long long)(d.cap - 1), d.slot_of, d.frank, d.bcnt, err);
       hipLaunchKernelGGL(dedup_rows_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.bcnt, d.frank, d.slot_of, d.cnt, d.uid,
                          d.uniq, d.nu);
-    } else if (own_rows) {
-      hipLaunchKernelGGL(rows_copy_kernel, dim3(tgrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, d.uniq, d.nu);
+    }
+    ProfScope prof(KGE_PROF_INDEX, st);
+    const int hgrid = (int)cdiv(cd.rows ? cd.n_all : n, kEntRows);
+    if (cd.rows) {
+      const HistSrc hs{src, cd.rows, cd.cnt, cd.lanes, cd.n_pos, cd.n_all};
+      hipLaunchKernelGGL((plan_hist_kernel<2>), dim3(hgrid), dim3(256), 0, st, hs, n, N, R, p.ent.cnt, p.erank, p.rcnt, p.rrank, d.uniq, d.nu, err);
+    } else if (fold) {
+      const HistSrc hs{src, nullptr, nullptr, 1, 0, 0};
+      hipLaunchKernelGGL((plan_hist_kernel<0>), dim3(hgrid), dim3(256), 0, st, hs, n, N, R, p.ent.cnt, p.erank, p.rcnt, p.rrank, nullptr, nullptr, err);
+    } else {  // the caller's arrays as they are (copied into the plan when it must own its rows)
+      const HistSrc hs{Src{pos, m_pos, neg, m_neg, nullptr, nullptr}, nullptr, nullptr, 1, 0, 0};
+      hipLaunchKernelGGL((plan_hist_kernel<1>), dim3(hgrid), dim3(256), 0, st, hs, n, N, R, p.ent.cnt, p.erank, p.rcnt, p.rrank, own_rows ? d.uniq : nullptr,
+                         own_rows ? d.nu : nullptr, err);
     }
   }
-  if (parts & 2) {  // entity index (side stream when there is one)
-    hipStream_t es = side ? side : st;
-    if (side) { KGE_HIP_TRY(hipEventRecord(fork, st)); KGE_HIP_TRY(hipStreamWaitEvent(side, fork, 0)); }
-    {
-      ProfScope prof(KGE_PROF_INDEX, es);
-      hipLaunchKernelGGL(ent_hist_kernel, dim3((int)cdiv(n, kEntRows)), dim3(256), 0, es, src, n, N, R, p.ent.cnt, p.erank);
-      pull2_entity_plan(p.ent, N, es);
-    }
-    if (side) KGE_HIP_TRY(hipEventRecord(join, side));
-  }
-  if (parts & 4) {  // relation index
-    hipLaunchKernelGGL(rel_hist_kernel, dim3((int)cdiv(n, kRelBlockTriples)), dim3(256), 0, st, src, N, R, p.rcnt, p.rrank);
-    hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
-    hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
+  if (parts & 6) {
+    ProfScope prof(KGE_PROF_INDEX, st);
+    const int etiles = (int)cdiv(N, kScanTile);
+    if ((parts & 6) == 6)  // offsets of the entity lists and of the relation lists in one launch
+      hipLaunchKernelGGL(plan_scan_kernel, dim3(etiles + 1), dim3(256), 0, st, p.ent.cnt, N, p.ent.chunk, p.ent.off, p.ent.eoff, p.ent.poff, p.ent.totals,
+                         p.ent.emap, p.ent.max_extra, etiles, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
+    else if (parts & 2) pull2_entity_plan(p.ent, N, st);
+    else hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
+    if (parts & 4) hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
   }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
@@ -752,7 +747,7 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
 // ---- step: everything that depends on the parameters.  Consumes the plan (the finish kernels leave its counters zero).
 static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, int64_t m_pos,
                      int64_t m_neg, const Plan2& p, const Src& src, float* fwd_scores, float* loss_partials, int* n_partials, float* loss_out,
-                     uint64_t seed, hipStream_t st, hipEvent_t join) {
+                     uint64_t seed, hipStream_t st, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}) {
   const int64_t n = m_pos + m_neg;
   const int R = md->num_relations;
   const int tgrid = (int)cdiv(n, 256);
@@ -770,21 +765,19 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     else if (md->norm == 3) launch_fwd_rel_loss<KGE_TRANSE, 3>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
     else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
   }
-  if (join) KGE_HIP_TRY(hipStreamWaitEvent(st, join, 0));
   hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.coef, p.ent.off, p.erank, p.ent.entries);
   if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st)) return rc;
   const int eb = (int)cdiv(md->num_entities, 4);
   hipLaunchKernelGGL(rel_finish_kernel, dim3(eb + R + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
-                     *n_partials, loss_out, eb, gE, md->num_entities, p.ent.cnt, p.ent.poff, p.ent.slab, p.ent.chunk);
+                     *n_partials, loss_out, eb, gE, md->num_entities, p.ent.cnt, p.ent.poff, p.ent.slab, p.ent.chunk, adv);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
 
-// One step with the plan built on the spot (kge_train_step / kge_train_grads).  `side` may be null.
+// One step with the plan built on the spot (kge_train_step / kge_train_grads).
 int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
                       const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* scores, float* loss_partials,
-                      int* n_partials, float* loss_out, void* hdr, void* ws, uint32_t* err, uint64_t seed, hipStream_t st, hipStream_t side,
-                      hipEvent_t fork, hipEvent_t join) {
+                      int* n_partials, float* loss_out, void* hdr, void* ws, uint32_t* err, uint64_t seed, hipStream_t st) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
   carve_plan(hdr, ws, md, n, &p);
@@ -794,9 +787,8 @@ int train_grads_pull2(const kge_model_desc* md, const kge_loss_desc* ld, const f
   // folded rows: the forward writes the scores of the distinct rows, expanded to the caller's rows afterwards
   const bool fold = dedup_applies(md, n);
   float* fwd_scores = fold && scores ? p.dd.uscore : scores;
-  if (int rc = plan_build(md, pos, m_pos, neg, m_neg, p, false, false, 7, Counted{nullptr, nullptr, 1, 0, 0}, &src, &folded, fold ? nullptr : scores, err, st, side, fork, join)) return rc;
-  if (int rc = plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, fwd_scores, loss_partials, n_partials, loss_out, seed, st, side ? join : nullptr))
-    return rc;
+  if (int rc = plan_build(md, pos, m_pos, neg, m_neg, p, false, false, 7, Counted{nullptr, nullptr, 1, 0, 0}, &src, &folded, fold ? nullptr : scores, err, st)) return rc;
+  if (int rc = plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, fwd_scores, loss_partials, n_partials, loss_out, seed, st)) return rc;
   if (folded && scores) hipLaunchKernelGGL(dedup_scores_kernel, dim3((int)cdiv(n, 256)), dim3(256), 0, st, p.dd.slot_of, p.dd.uid, p.dd.uscore, n, scores);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
@@ -823,19 +815,21 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
   carve_plan_buffer(plan, md, n, &p);
   Src src;
   bool folded;
-  return plan_build(md, pos, m_pos, neg, m_neg, p, true, true, parts, Counted{cand_rows, cand_cnt, pos_lanes, n_pos_cand, n_pos_cand + n_neg_cand}, &src, &folded,
-                    nullptr, err, st, nullptr, nullptr, nullptr);
+  // parts bit 3: the caller vouches that the plan buffer's counters are all zero (zero-filled at allocation, or left so by the step
+  // that consumed the previous build): no clearing launch
+  return plan_build(md, pos, m_pos, neg, m_neg, p, true, !(parts & 8), parts & 7, Counted{cand_rows, cand_cnt, pos_lanes, n_pos_cand, n_pos_cand + n_neg_cand}, &src, &folded,
+                    nullptr, err, st);
 }
 
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
-                        hipStream_t st) {
+                        hipStream_t st, const StepAdvance& adv) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
   carve_plan_buffer(plan, md, n, &p);
   carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
   const Src src{nullptr, m_pos, nullptr, m_neg, p.dd.uniq, p.dd.nu};
-  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, nullptr);
+  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv);
 }
 
 }  // namespace kge

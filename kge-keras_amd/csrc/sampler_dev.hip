@@ -15,7 +15,9 @@
 //   mt_advance_kernel    new generator states (the block the consumption stopped in + position inside it)
 //
 // The NumPy stream consumes a data-dependent number of words; the raw buffer is sized with a margin of tens of
-// standard deviations and err_flag bit 1 is raised if it ever ran short (the host then falls back to a larger margin).
+// standard deviations and err_flag bit 1 is raised if it ever ran short (never observed).  There is no fallback: the batch
+// drawn is then NOT the reference's, and the callers (harness.DeviceDataGenerator.release_global, pipeline.TrainPipeline.finish,
+// bench.py) read the flag and raise.
 #include <cstring>
 
 #include "kge_internal.hpp"
@@ -449,6 +451,395 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
   const AdvanceArgs adv_np{rng ? nps : nullptr, p.U_np, p.K_np * 624, p.consumed, 0};
   const AdvanceArgs adv_py{pys, p.U_py, p.K_py * 624, nullptr, 4 * m};
   hipLaunchKernelGGL(mt_advance_kernel, dim3(2), dim3(256), 0, st, adv_np, adv_py, batch ? nullptr : cursor, p.epoch, err);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+
+// =================================================================================================================
+// Streamed form of the same sampler (kge_sampler_stream_*): word generation runs AHEAD of the batches that consume it.
+//
+// Drawing a batch the way above puts ~70 us of latency-bound generator kernels (sequential pre-pass, GF(2) jumps, segment
+// regeneration) in front of every select / assemble pair.  But an MT19937 stream is one fixed sequence of 624-word blocks:
+// which words a batch consumes is data dependent (NumPy's masked rejection), the words themselves are not.  Each generator
+// therefore gets a RING of raw state blocks in HBM that a producer extends round by round -- 16 segments of `segb` blocks per
+// round, started from block head-1 by the same jump polynomials -- on its own stream, one batch ahead, while the consumer side
+// of a batch shrinks to select -> assemble -> advance.  Global numbering: block 0 is the state block the ring was seeded with,
+// word w of the stream lives in block w / 624 at offset w % 624, block b is stored in slot b % RB.
+//   control word per generator: head (blocks [0, head) exist; committed lazily by the next round), wpos (next word to consume).
+//   A round runs only while fewer than LOW = 2 M words lie between wpos and the head (M = the most a batch can consume):
+//     skip:     avail_seen >= 2M, the producer may have missed at most one batch's consumption  -> >= M words for the next batch
+//     generate: the previous invariant (>= M before the last batch) + P*624 >= M new words - M   -> >= M words again
+//   (the pipeline orders round k behind the consumer of batch k-2, so wpos is stale by at most one batch; P*624 >= M by
+//   construction of segb).  Ring capacity RB >= (2M + 2 P*624) / 624 + 4 blocks: nothing still readable is overwritten, the block
+//   holding the last consumed word (the generator state handed back to NumPy / CPython) included.
+struct GenCtl {
+  int64_t head;        // blocks generated and committed
+  int64_t wpos;        // global index of the next word to consume
+  int64_t head_round;  // head when the running / last round started
+  int32_t go;          // the last round generated (its blocks are committed by the next round's first kernel)
+  int32_t pad;
+};
+struct Ring {
+  uint32_t* blocks;
+  int64_t RB;      // capacity in blocks
+  GenCtl* ctl;
+  int64_t P;       // blocks per round
+  int64_t low;     // words: generate while avail < low
+  int32_t segb;    // blocks per segment (0: the round is one sequential pass of P blocks)
+};
+__device__ __forceinline__ uint32_t* ring_block(const Ring& r, int64_t gb) { return r.blocks + (gb % r.RB) * 624; }
+__device__ __forceinline__ uint32_t ring_word(const Ring& r, int64_t w) {
+  const int64_t b = w / 624;
+  return mt_temper(r.blocks[(b % r.RB) * 624 + (w - b * 624)]);
+}
+
+// Seeds both rings from the generator state blobs: block 0 = the state block, consumption starts at its position.
+__global__ __launch_bounds__(256) void ring_init_kernel(Ring r0, const MTDev* __restrict__ st0, Ring r1, const MTDev* __restrict__ st1) {
+  const Ring& r = blockIdx.x == 0 ? r0 : r1;
+  const MTDev* st = blockIdx.x == 0 ? st0 : st1;
+  for (int i = threadIdx.x; i < 624; i += 256) r.blocks[i] = st->mt[i];
+  if (threadIdx.x == 0) { r.ctl->head = 1; r.ctl->wpos = st->pos; r.ctl->head_round = 1; r.ctl->go = 0; }
+}
+
+// Same as mt_regen_blocks, into ring slots: regenerates global blocks [g_begin, g_end) from the block held in buf[0].
+#define KGE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__device__ __forceinline__ void ring_regen_blocks(uint32_t (*buf)[624], const Ring& r, int64_t g_begin, int64_t g_end) {
+  const int tid = threadIdx.x;
+  int cur = 0;
+  for (int64_t g = g_begin; g < g_end; ++g) {
+    const uint32_t* o = buf[cur];
+    uint32_t* n = buf[cur ^ 1];
+    uint32_t* dst = ring_block(r, g);
+    if (tid < 227) {
+      const uint32_t a0 = o[tid], a1 = o[tid + 1], a397 = o[tid + 397];
+      const uint32_t b0 = o[227 + tid], b1 = o[228 + tid];
+      const uint32_t v0 = a397 ^ mt_twist(a0, a1);
+      const uint32_t v1 = v0 ^ mt_twist(b0, b1);
+      n[tid] = v0;
+      n[227 + tid] = v1;
+      dst[tid] = v0;
+      dst[227 + tid] = v1;
+      if (tid < 169) {
+        const uint32_t v2 = v1 ^ mt_twist(o[454 + tid], o[455 + tid]);
+        n[454 + tid] = v2;
+        dst[454 + tid] = v2;
+      } else if (tid == 169) {
+        const uint32_t n0 = o[397] ^ mt_twist(o[0], o[1]);
+        const uint32_t v2 = v1 ^ mt_twist(o[623], n0);
+        n[623] = v2;
+        dst[623] = v2;
+      }
+    }
+    KGE_LDS_BARRIER();
+    cur ^= 1;
+  }
+}
+#undef KGE_LDS_BARRIER
+
+// First kernel of a round (one workgroup per generator): commits the previous round, decides go / skip, and -- when going --
+// regenerates the first kJumpBlocks blocks behind the head sequentially (all P of them when the round is not segmented).
+__global__ __launch_bounds__(256) void ring_pre_kernel(Ring r0, Ring r1, uint32_t* __restrict__ Jst) {
+  __shared__ uint32_t buf[2][624];
+  __shared__ int64_t head_s;
+  __shared__ int go_s;
+  const Ring& r = blockIdx.x == 0 ? r0 : r1;
+  __builtin_amdgcn_s_setprio(3);
+  if (threadIdx.x == 0) {
+    GenCtl* c = r.ctl;
+    int64_t head = c->head;
+    if (c->go) head = c->head_round + r.P;  // the previous round's blocks are complete (same stream): commit them
+    const int64_t wpos = __hip_atomic_load(&c->wpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a consumer may be advancing it)
+    const int go = head * 624 - wpos < r.low ? 1 : 0;
+    c->head = head;
+    c->head_round = head;
+    c->go = go;
+    head_s = head;
+    go_s = go;
+  }
+  // accumulated into by ring_jump_kernel
+  if (r.segb) for (int i = threadIdx.x; i < kSeg * 624; i += 256) Jst[(int64_t)blockIdx.x * kSeg * 624 + i] = 0u;
+  __syncthreads();
+  if (!go_s) return;
+  const int64_t head = head_s;
+  const uint32_t* src = ring_block(r, head - 1);
+  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = src[i];
+  __syncthreads();
+  ring_regen_blocks(buf, r, head, head + (r.segb ? (int64_t)kJumpBlocks : r.P));
+}
+
+// Jst[z][s][j] ^= XOR_{k in this block's slice : g_s[k]} W_z[k + j], W = block head-1 followed by the blocks behind it.
+__global__ __launch_bounds__(256) void ring_jump_kernel(Ring r0, Ring r1, const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jst) {
+  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;
+  constexpr int WIN = WPS * 64 + 64;
+  __shared__ uint32_t win[WIN];
+  __shared__ uint32_t part[4][64];
+  const int z = blockIdx.z, s = blockIdx.y + 1;
+  const Ring& r = z == 0 ? r0 : r1;
+  if (r.segb == 0 || !r.ctl->go) return;
+  const int64_t base = r.ctl->head_round - 1;  // global block of W's first word
+  const uint64_t* poly = polys + ((int64_t)z * (kSeg - 1) + (s - 1)) * kPolyWords;
+  const int tile = blockIdx.x % 10, slice = blockIdx.x / 10;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = tile * 64 + lane;
+  const int lo = slice * WPS * 64 + tile * 64;
+  for (int i = threadIdx.x; i < WIN; i += 256) {
+    const int idx = lo + i;
+    const int b = idx / 624;
+    win[i] = idx < 624 * (kJumpBlocks + 1) ? ring_block(r, base + b)[idx - b * 624] : 0u;
+  }
+  __syncthreads();
+  uint32_t acc = 0;
+  for (int wi = wave; wi < WPS; wi += 4) {
+    const int w = slice * WPS + wi;
+    if (w >= kPolyWords) break;
+    const uint64_t gwv = poly[w];
+    const uint32_t g[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gwv),
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gwv >> 32))};
+    const uint32_t* src = win + wi * 64 + lane;
+#pragma unroll
+    for (int hw = 0; hw < 2; ++hw) {
+#pragma unroll 16
+      for (int bit = 0; bit < 32; ++bit) acc ^= ((g[hw] >> bit) & 1u) ? src[32 * hw + bit] : 0u;
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && j < 624) {
+    const uint32_t v = part[0][lane] ^ part[1][lane] ^ part[2][lane] ^ part[3][lane];
+    if (v) atomicXor(&Jst[((int64_t)z * kSeg + s) * 624 + j], v);
+  }
+}
+
+// grid (kSeg, 2): segment s of generator z regenerates blocks [head + s*segb, head + (s+1)*segb) of the round.
+__global__ __launch_bounds__(256) void ring_seg_kernel(Ring r0, Ring r1, const uint32_t* __restrict__ Jst) {
+  __shared__ uint32_t buf[2][624];
+  const int z = blockIdx.y, s = blockIdx.x;
+  const Ring& r = z == 0 ? r0 : r1;
+  if (r.segb == 0 || !r.ctl->go) return;
+  const int64_t head = r.ctl->head_round;
+  int64_t b0 = (int64_t)s * r.segb, b1 = min(r.P, (int64_t)(s + 1) * r.segb);
+  if (s == 0) b0 = kJumpBlocks;
+  if (b0 >= b1) return;
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t* src = s == 0 ? ring_block(r, head + kJumpBlocks - 1) : Jst + ((int64_t)z * kSeg + s) * 624;
+  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = src[i];
+  __syncthreads();
+  ring_regen_blocks(buf, r, head + b0, head + b1);
+}
+
+// np_select_kernel on ring words: tiles of 1024 words from wpos on, at most max_words of them.
+__global__ __launch_bounds__(256) void ring_select_kernel(Ring r, int64_t max_words, uint32_t rng, uint32_t mask, unsigned long long* tile_agg,
+                                                           const uint32_t* __restrict__ epoch_ptr, int64_t m, int32_t* __restrict__ fs,
+                                                           int32_t* __restrict__ fo, int64_t* __restrict__ consumed,
+                                                           int32_t* __restrict__ zero_p, int64_t zero_n) {
+  __shared__ int wsum[4];
+  __shared__ long long pre_s[4];
+  for (int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * blockDim.x) zero_p[z] = 0;
+  const unsigned long long ep = (unsigned long long)(epoch_ptr[0] + 1u);
+  const int64_t w0 = r.ctl->wpos;
+  const int64_t base = (int64_t)blockIdx.x * kTileW + threadIdx.x * 4;
+  uint32_t v[4];
+  int a[4], c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = base + j < max_words ? (ring_word(r, w0 + base + j) & mask) : 0xFFFFFFFFu;
+    a[j] = (base + j < max_words && v[j] <= rng) ? 1 : 0;
+    c += a[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = c;
+  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(tile_agg + blockIdx.x, ep << 32 | (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  long long before = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) {
+    unsigned long long s;
+    do { s = __hip_atomic_load(tile_agg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((s >> 32) != ep);
+    before += (long long)(s & 0xFFFFFFFFull);
+  }
+  for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) pre_s[wave] = before;
+  __syncthreads();
+  int64_t rk = pre_s[0] + pre_s[1] + pre_s[2] + pre_s[3] + inc - c;
+  for (int w = 0; w < wave; ++w) rk += wsum[w];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!a[j]) continue;
+    if (rk < m) fs[rk] = (int32_t)v[j];
+    else if (rk < 2 * m) fo[rk - m] = (int32_t)v[j];
+    if (rk == 2 * m - 1) { consumed[0] = base + j + 1; consumed[1] = (int64_t)ep; }
+    ++rk;
+  }
+}
+
+__device__ __forceinline__ int64_t ring_choice(const Ring& r, int64_t w0, int64_t i, double n) {
+  const uint32_t a = ring_word(r, w0 + 2 * i) >> 5, b = ring_word(r, w0 + 2 * i + 1) >> 6;
+  const double x = ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+  return (int64_t)floor(x * n);
+}
+
+// py_assemble_kernel on ring words
+__global__ __launch_bounds__(256) void ring_assemble_kernel(Ring r, BatchSrc batch, int64_t B, int64_t ns, const int32_t* __restrict__ fs,
+                                                             const int32_t* __restrict__ fo, int32_t* __restrict__ pos_out,
+                                                             int32_t* __restrict__ neg_out, int32_t* __restrict__ cand_rows,
+                                                             int32_t* __restrict__ cand_cnt) {
+  const int64_t m = B * ns;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * m) return;
+  const int64_t w0 = r.ctl->wpos;
+  if (i < m) {
+    const int64_t a = ring_choice(r, w0, i, (double)B);
+    if (pos_out) {
+      const int32_t* row = batch_row(batch, B, a);
+      pos_out[3 * i + 0] = row[0];
+      pos_out[3 * i + 1] = row[1];
+      pos_out[3 * i + 2] = row[2];
+    }
+    if (cand_rows) {
+      atomicAdd(cand_cnt + (i & (KGE_CAND_POS_LANES - 1)) * B + a, 1);
+      if (i < B) {
+        const int32_t* q = batch_row(batch, B, i);
+        cand_rows[3 * i + 0] = q[0]; cand_rows[3 * i + 1] = q[1]; cand_rows[3 * i + 2] = q[2];
+      }
+      int32_t* g = cand_rows + 3 * (B + i);
+      g[0] = fs[i]; g[1] = batch_row(batch, B, i / ns)[1]; g[2] = fo[i];
+    }
+  } else {
+    const int64_t j = ring_choice(r, w0, i, (double)m);
+    const int64_t o = i - m;
+    if (neg_out) {
+      neg_out[3 * o + 0] = fs[j];
+      neg_out[3 * o + 1] = batch_row(batch, B, j / ns)[1];
+      neg_out[3 * o + 2] = fo[j];
+    }
+    if (cand_rows) atomicAdd(cand_cnt + KGE_CAND_POS_LANES * B + j, 1);
+  }
+}
+
+// Last kernel of a batch (one workgroup per generator): wpos += words consumed; the state blob handed back to NumPy / CPython =
+// the block holding the last consumed word + the position behind it; the batch cursor and the batch epoch move on.
+__global__ __launch_bounds__(256) void ring_advance_kernel(Ring r0, MTDev* st0, int64_t max_np, const int64_t* __restrict__ consumed_ptr, Ring r1,
+                                                            MTDev* st1, int64_t consumed_py, int64_t* __restrict__ cursor,
+                                                            uint32_t* __restrict__ epoch, uint32_t* __restrict__ err) {
+  __shared__ int64_t c_s;
+  const bool np = blockIdx.x == 0;
+  const Ring& r = np ? r0 : r1;
+  MTDev* st = np ? st0 : st1;
+  if (!np && threadIdx.x == 0 && cursor) cursor[0] += 1;
+  if (threadIdx.x == 0 && st) {
+    c_s = consumed_py;
+    if (np) c_s = consumed_ptr[1] == (int64_t)(epoch[0] + 1u) ? consumed_ptr[0] : -1;  // -1: the 2m-th accepted draw was not reached
+  }
+  __syncthreads();
+  if (np && threadIdx.x == 0) epoch[0] += 1;
+  if (!st) return;
+  int64_t c = c_s;
+  if (c < 0) {
+    if (threadIdx.x == 0) atomicOr(err, 2u);
+    c = max_np;
+  }
+  const int64_t w1 = r.ctl->wpos + c;  // next word to consume
+  __syncthreads();
+  if (c > 0) {
+    const int64_t blk = (w1 - 1) / 624;  // block holding the last consumed word
+    const uint32_t* src = ring_block(r, blk);
+    for (int i = threadIdx.x; i < 624; i += 256) st->mt[i] = src[i];
+    if (threadIdx.x == 0) st->pos = (int32_t)(w1 - blk * 624);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&r.ctl->wpos, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct StreamPlan {
+  SamplerPlan sp;   // tile_agg / epoch / consumed / fs / fo / Jst of the workspace, K_* and segb_* of the batch shape
+  Ring r_np, r_py;
+  int64_t max_np;   // most words of the NumPy stream one batch may consume (the old raw buffer's size)
+  int64_t bytes;
+};
+
+static StreamPlan plan_stream(int64_t B, int64_t ns, int64_t num_e, void* buf) {
+  StreamPlan q;
+  q.sp = plan_sampler(B, ns, num_e, buf);
+  const int64_t m = B * ns;
+  char* p = buf ? reinterpret_cast<char*>(buf) + align_up(q.sp.bytes, 256) : reinterpret_cast<char*>(align_up(q.sp.bytes, 256));
+  p = reinterpret_cast<char*>(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  auto ring = [&](int64_t K, int segb, int64_t max_words) {
+    Ring r;
+    r.segb = segb;
+    r.P = segb ? (int64_t)kSeg * segb : std::max<int64_t>(K, 1);
+    const int64_t M = std::max<int64_t>(max_words, 1);
+    r.low = 2 * M;
+    r.RB = (2 * M + 2 * r.P * 624) / 624 + 8;
+    r.ctl = reinterpret_cast<GenCtl*>(p);
+    p += 256;
+    r.blocks = reinterpret_cast<uint32_t*>(p);
+    p += align_up(r.RB * 624 * 4, 256);
+    return r;
+  };
+  q.max_np = q.sp.K_np * 624;
+  q.r_np = ring(q.sp.K_np, q.sp.segb_np, q.max_np);
+  q.r_py = ring(q.sp.K_py, q.sp.segb_py, 4 * m);
+  q.bytes = (p - reinterpret_cast<char*>(buf)) + 512;
+  return q;
+}
+
+int64_t sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e) { return plan_stream(B, ns, num_e, nullptr).bytes + 512; }
+
+int sampler_stream_init(void* buf, int64_t bytes, const void* np_state, const void* py_state, int64_t B, int64_t ns, int64_t num_e, hipStream_t st) {
+  if (bytes < sampler_stream_bytes(B, ns, num_e))
+    return fail(KGE_EWORKSPACE, "kge_sampler_stream_init: buffer has %lld bytes, needs %lld", (long long)bytes, (long long)sampler_stream_bytes(B, ns, num_e));
+  const StreamPlan q = plan_stream(B, ns, num_e, buf);
+  hipLaunchKernelGGL(ring_init_kernel, dim3(2), dim3(256), 0, st, q.r_np, static_cast<const MTDev*>(np_state), q.r_py, static_cast<const MTDev*>(py_state));
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// One production round for both generators (skipped on the device while enough words lie ahead of the consumers).
+int sampler_stream_produce(void* buf, int64_t bytes, int64_t B, int64_t ns, int64_t num_e, const void* plan_dev, hipStream_t st) {
+  if (bytes < sampler_stream_bytes(B, ns, num_e)) return fail(KGE_EWORKSPACE, "kge_sampler_stream_produce: buffer too small");
+  StreamPlan q = plan_stream(B, ns, num_e, buf);
+  if (!plan_dev) {  // no jump polynomials: every round is one sequential pass
+    q.r_np.segb = 0; q.r_py.segb = 0;
+  }
+  const bool rng = num_e > 1;
+  if (!rng) { q.r_np.P = 0; q.r_np.low = 0; }  // a range of one: NumPy draws nothing
+  ProfScope prof(KGE_PROF_SAMPLER, st);
+  hipLaunchKernelGGL(ring_pre_kernel, dim3(2), dim3(256), 0, st, q.r_np, q.r_py, q.sp.Jst);
+  if (q.r_np.segb || q.r_py.segb) {
+    hipLaunchKernelGGL(ring_jump_kernel, dim3(10 * kJumpSplit, kSeg - 1, 2), dim3(256), 0, st, q.r_np, q.r_py, static_cast<const uint64_t*>(plan_dev), q.sp.Jst);
+    hipLaunchKernelGGL(ring_seg_kernel, dim3(kSeg, 2), dim3(256), 0, st, q.r_np, q.r_py, q.sp.Jst);
+  }
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// Select + assemble + advance of one batch from the rings (the consumer half of kge_build_batch_device_indexed).
+int sampler_stream_draw(void* buf, int64_t bytes, void* np_state, void* py_state, const int32_t* batch, const int32_t* kg, const int64_t* index,
+                        const int64_t* starts, int64_t* cursor, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out, int32_t* neg_out,
+                        int32_t* cand_rows, int32_t* cand_cnt, uint32_t* err, hipStream_t st) {
+  if (bytes < sampler_stream_bytes(B, ns, num_e)) return fail(KGE_EWORKSPACE, "kge_sampler_stream_draw: buffer too small");
+  const StreamPlan q = plan_stream(B, ns, num_e, buf);
+  const SamplerPlan& p = q.sp;
+  const int64_t m = B * ns;
+  const uint32_t rng = (uint32_t)(num_e - 1), mask = (uint32_t)smear64(rng);
+  ProfScope prof(KGE_PROF_SAMPLER, st);
+  const int64_t n_cnt = cand_cnt ? KGE_CAND_POS_LANES * B + m : 0;
+  if (rng) {
+    const int ntiles = (int)cdiv(q.max_np, kTileW);
+    hipLaunchKernelGGL(ring_select_kernel, dim3(ntiles), dim3(256), 0, st, q.r_np, q.max_np, rng, mask, p.tile_agg, p.epoch, m, p.fs, p.fo, p.consumed,
+                       cand_cnt, n_cnt);
+  } else {
+    if (cand_cnt) hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(n_cnt, 256)), dim3(256), 0, st, cand_cnt, n_cnt, 0);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fs, m, 0);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fo, m, 0);
+  }
+  hipLaunchKernelGGL(ring_assemble_kernel, dim3((int)cdiv(2 * m, 256)), dim3(256), 0, st, q.r_py, BatchSrc{batch, kg, index, starts, cursor}, B, ns, p.fs, p.fo,
+                     pos_out, neg_out, cand_rows, cand_cnt);
+  hipLaunchKernelGGL(ring_advance_kernel, dim3(2), dim3(256), 0, st, q.r_np, rng ? static_cast<MTDev*>(np_state) : nullptr, q.max_np, p.consumed, q.r_py,
+                     static_cast<MTDev*>(py_state), 4 * m, batch ? nullptr : cursor, p.epoch, err);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

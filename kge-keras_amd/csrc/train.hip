@@ -301,6 +301,7 @@ struct Workspace {
   float* gbuf;           // m_pos + m_neg (pairwise, push path)
   float* sbuf;           // m_pos + m_neg (pairwise, when scores_out is null)
   float* pair;           // all-pairs partial sums (null when the batch is too large for it)
+  float* lr_slot;        // learning rate of the running update when the gradient half advances the step state (StepAdvance)
   void* pull_hdr;        // pull-path counters: fixed place, zero on entry, left zero by every step
   void* pull;            // pull-path plan and lists
 };
@@ -315,7 +316,7 @@ SideStream* side_stream();  // api.hip: lazily created helper stream (nullptr wh
 constexpr int kPairChunks = 16;
 constexpr int64_t kPairMaxRows = 131072;
 static int64_t pair_floats(int64_t n) { return n <= kPairMaxRows ? 3 * kPairChunks * align_up(n, 64) : 0; }
-static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 2 * align_up(n, 64) + pair_floats(n); }
+static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 64 + 2 * align_up(n, 64) + pair_floats(n); }
 
 int64_t train_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
   return (int64_t)sizeof(float) * base_floats(m_pos + m_neg) + 512 +
@@ -333,7 +334,8 @@ static int carve(void* ws, int64_t bytes, const kge_model_desc* md, int64_t m_po
   float* f = reinterpret_cast<float*>(p);
   out->loss_partials = f;
   out->reg_partials = f + kMaxBlocks;
-  out->gbuf = f + 2 * kMaxBlocks;
+  out->lr_slot = f + 2 * kMaxBlocks;
+  out->gbuf = f + 2 * kMaxBlocks + 64;
   out->sbuf = out->gbuf + align_up(m_pos + m_neg, 64);
   out->pair = pair_floats(m_pos + m_neg) ? out->sbuf + align_up(m_pos + m_neg, 64) : nullptr;
   out->pull = f + base_floats(m_pos + m_neg);
@@ -555,9 +557,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   }
   int nb = 0;
   if (grad_mode() == 0 && pull_variant() == 2 && pull2_supported(md, ld)) {
-    SideStream* ss = side_stream();
-    return train_grads_pull2(md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, scores_out, ws.loss_partials, &nb, loss_out, ws.pull_hdr, ws.pull, err, seed,
-                             st, ss ? ss->stream : nullptr, ss ? ss->fork : nullptr, ss ? ss->join : nullptr);
+    return train_grads_pull2(md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, scores_out, ws.loss_partials, &nb, loss_out, ws.pull_hdr, ws.pull, err, seed, st);
   }
   if ((grad_mode() == 0 || md->model == KGE_HOLE) && pull_supported(md)) {
     // The index build depends on the ids only and the forward gather does not need it: fork it onto the library's side
@@ -625,10 +625,6 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
 
 // Device-resident optimizer step state (kge_opt_desc.step_dev, 16 bytes): {int64 t = updates done, float lr_t of update t+1,
 // float running sum of the step losses}.  Advanced by one tiny kernel at the end of every kge_opt_apply.
-__device__ __forceinline__ float lr_of_step(int kind, float lr, float b1, float b2, int64_t t) {
-  if (kind != KGE_OPT_ADAM_TF) return lr;
-  return (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));  // Keras Adam
-}
 __global__ void opt_state_init_kernel(int64_t* step, int64_t done, int kind, float lr, float b1, float b2) {
   step[0] = done;
   float* f = reinterpret_cast<float*>(step + 1);
@@ -651,8 +647,10 @@ int opt_state_init(const kge_opt_desc* od, hipStream_t st) {
 
 template <int KIND>
 static int launch_opt(bool reg, OptSeg a, OptSeg b, float lr_t, const kge_opt_desc* od, float gscale, float regw, float* reg_partials,
-                      hipStream_t st, int* nb) {
-  const float* lr_dev = od->step_dev ? reinterpret_cast<const float*>(od->step_dev + 1) : nullptr;
+                      hipStream_t st, int* nb, const float* lr_slot = nullptr) {
+  // device-resident step state: lr_t of this update comes from the state (prepared by the previous update's post kernel), or from
+  // the slot the gradient half just wrote (StepAdvance)
+  const float* lr_dev = lr_slot ? lr_slot : (od->step_dev ? reinterpret_cast<const float*>(od->step_dev + 1) : nullptr);
   auto blocks = [](int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(cdiv(n, 4), 256), kCUs * 8)); };
   const int ga = blocks(a.n), gb = b.n > 0 ? blocks(b.n) : 0;
   *nb = ga;
@@ -672,12 +670,17 @@ bool plan_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
   return grad_mode() == 0 && pull_variant() == 2 && pull2_supported(md, ld);
 }
 
+// advance != null (a whole step in one call, no L3 term): the closing kernel of the gradient half advances the step state of
+// that optimizer descriptor (StepAdvance); the optimizer half is then opt_apply(..., advanced = true).
 int train_grads_with_plan(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
-                          int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace, int64_t wbytes, hipStream_t st) {
+                          int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace, int64_t wbytes, hipStream_t st,
+                          const kge_opt_desc* advance) {
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   int nb = 0;
-  return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st);
+  StepAdvance adv{nullptr, nullptr, 0, 0.f, 0.f, 0.f};
+  if (advance) adv = StepAdvance{advance->step_dev, ws.lr_slot, advance->kind, advance->lr, advance->beta1, advance->beta2};
+  return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv);
 }
 
 int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float gscale, hipStream_t st) {
@@ -694,9 +697,10 @@ int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, floa
 }
 
 int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gE,
-              float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st) {
+              float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st, bool advanced) {
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, 0, 0, &ws)) return rc;
+  const float* lr_slot = advanced ? ws.lr_slot : nullptr;
   const int64_t nE = (int64_t)md->num_entities * md->d_e, nR = (int64_t)md->num_relations * md->d_r;
   const bool reg = ld->regularization != 0.f;
   int nb = 0;
@@ -706,16 +710,16 @@ int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_d
       if (!od->mE || !od->vE || !od->mRel || !od->vRel) return fail(KGE_EINVAL, "adam: moment buffers are null");
       if (!od->step_dev && od->step < 1) return fail(KGE_EINVAL, "adam: step must be >= 1");
       if (int rc = launch_opt<KGE_OPT_ADAM_TF>(reg, OptSeg{E, gE, od->mE, od->vE, nE}, OptSeg{Rel, gR, od->mRel, od->vRel, nR}, host_lr_t(od), od, gscale,
-                                               ld->regularization, ws.reg_partials, st, &nb)) return rc;
+                                               ld->regularization, ws.reg_partials, st, &nb, lr_slot)) return rc;
     } else if (od->kind == KGE_OPT_SGD) {
       if (int rc = launch_opt<KGE_OPT_SGD>(reg, OptSeg{E, gE, nullptr, nullptr, nE}, OptSeg{Rel, gR, nullptr, nullptr, nR}, od->lr, od, gscale,
-                                           ld->regularization, ws.reg_partials, st, &nb)) return rc;
+                                           ld->regularization, ws.reg_partials, st, &nb, lr_slot)) return rc;
     } else {
       return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
     }
   }
   if (reg && loss_out) hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.reg_partials, nb, ld->regularization, 1, loss_out);
-  if (od->step_dev) hipLaunchKernelGGL(opt_state_post_kernel, dim3(1), dim3(1), 0, st, od->step_dev, od->kind, od->lr, od->beta1, od->beta2, loss_out);
+  if (od->step_dev && !advanced) hipLaunchKernelGGL(opt_state_post_kernel, dim3(1), dim3(1), 0, st, od->step_dev, od->kind, od->lr, od->beta1, od->beta2, loss_out);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

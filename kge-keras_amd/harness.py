@@ -83,7 +83,12 @@ class DeviceDataGenerator:
         self.sampler.load_streams(NumpyStream().adopt_global(), PythonStream().adopt_global())
 
     def release_global(self):
-        """Write the generator states back into np.random / random (where the reference's generator would stand)."""
+        """Write the generator states back into np.random / random (where the reference's generator would stand).  Raises if
+        the device sampler flagged a short rejection buffer since the last check (its draws would not be the reference's)."""
+        err = int(self.sampler.err.item())
+        if err:
+            self.sampler.err.zero_()
+            raise RuntimeError(f"device sampler error flag {err}: the masked-rejection buffer ran short (kge_build_batch_device)")
         nps, pys = self.sampler.to_streams()
         nps.release_global()
         pys.release_global()

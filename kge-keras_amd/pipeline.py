@@ -12,6 +12,12 @@ with double-buffered batches and plans and four events per buffer pair (drawn / 
 parity into a hipGraph and a training step costs three graph launches.  (One graph holding all three stages as branches
 does not overlap them on ROCm 7.2; separate graphs on separate streams do.)  Everything that changes from step to step lives
 on the device: the generator states, the batch cursor, the optimizer step state (kge_opt_desc.step_dev).
+
+Without dropout and without a hook between the halves of a step the whole loop is native: kge_pipeline_create captures the
+stage graphs inside the library and kge_pipeline_run(n) issues n steps from C (csrc/pipeline.cpp) -- one ctypes call per
+`run`, no per-step Python.  The Python loop below remains for dropout (a per-step mask seed: kernel-by-kernel launches), for
+data-parallel training (`between`: the gradient all-reduce sits between the halves of the step, outside any graph) and for
+`serial` profiling runs.
 """
 import torch
 
@@ -45,7 +51,7 @@ class TrainPipeline:
         md, ld = model._model_desc(True), model._loss_desc()
         need = _lib.check(_lib.lib.kge_batch_plan_bytes(_lib.C.byref(md), _lib.C.byref(ld), m, m))
         from .models import BatchPlan
-        self.plans = [BatchPlan(torch.empty(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(2)]
+        self.plans = [BatchPlan(torch.zeros(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(2)]
         self.index = torch.zeros(int(n_rows), dtype=torch.int64, device=self.dev)   # epoch permutation (tests.py:50-53)
         self.starts = None                                                          # batch numbers in drawing order
         self.cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -60,6 +66,9 @@ class TrainPipeline:
         self._done = {}  # (stage, slot) -> event recorded behind the last replay of that graph
         self._sig = None
         self.serial = False  # True: every stage on the caller's stream, nothing overlaps (clean per-kernel timings)
+        self._h = None          # native driver (kge_pipeline_create) and the signature it was captured for
+        self._h_sig = None
+        self._native_active = False
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
@@ -80,7 +89,7 @@ class TrainPipeline:
         else:
             build = lambda parts: self.model.plan_batch(b, out=pl, parts=parts)  # noqa: E731
         if fork is None:
-            build(7)
+            build(7 | 8)  # (8: the plan buffers' counters are zero: zero-filled in start(), left zero by every step that consumes a plan)
             return
         build(1)
         fork.wait_stream(cur)
@@ -103,7 +112,8 @@ class TrainPipeline:
     # ------------------------------------------------------------------ graphs
     def _signature(self):
         mo, sa = self.model, self.sampler
-        t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.starts]
+        t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.starts,
+             getattr(sa, "_stream", None)]
         t += [x for c in self.cand if c is not None for x in c]
         if mo.optimizer.slots:
             t += list(mo.optimizer.slots)
@@ -143,7 +153,7 @@ class TrainPipeline:
         cur.wait_stream(self.s3)
 
     def _run(self, name, slot):
-        if self.use_graphs and (not self.graphs or self._sig != self._signature()):
+        if self.use_graphs and not self.graphs:  # (start() re-captures when a tensor the graphs hold has moved)
             self._capture()  # may switch use_graphs off (capture not possible on this runtime)
         if self.use_graphs and name in self.graph_stages:
             # A graph exec cannot run twice at once: launching it again while its previous launch is still in flight blocks
@@ -164,6 +174,80 @@ class TrainPipeline:
             self._stage_P(slot) if (self.serial or self.between is not None) else self._stage_P_forked(slot)
         else:
             self._stage_T(slot)
+
+    # ------------------------------------------------------------------ native driver (csrc/pipeline.cpp)
+    def native_ok(self):
+        return self.use_graphs and self.between is None and self.counted and not self.serial
+
+    def _ensure_native(self):
+        mo, sa, C = self.model, self.sampler, _lib.C
+        sig = self._signature()
+        if self._h is not None and self._h_sig == sig:
+            return
+        self.close()
+        o = mo.optimizer
+        sl = [x.data_ptr() for x in o.slots] if o.slots else [None] * 4
+        m = self.B * self.ns
+        d = _lib.PipelineDesc()
+        d.md, d.ld = mo._model_desc(True), mo._loss_desc()
+        d.od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, 1, *sl, self.step_dev.data_ptr())
+        d.E, d.Rel, d.gradE, d.gradRel, d.loss_out = mo.E.data_ptr(), mo.Rel.data_ptr(), mo._gE.data_ptr(), mo._gR.data_ptr(), mo._loss.data_ptr()
+        d.train_ws, d.train_ws_bytes, d.err_flag = mo._ws.data_ptr(), mo._ws.numel(), mo._err.data_ptr()
+        d.np_state, d.py_state = sa.np_state.data_ptr(), sa.py_state.data_ptr()
+        d.kg, d.index, d.starts, d.cursor = self.kg.data_ptr(), self.index.data_ptr(), self.starts.data_ptr(), self.cursor.data_ptr()
+        d.B, d.ns, d.num_e = self.B, self.ns, self.num_e
+        plan = sa._plans.get((self.B, self.ns, self.num_e)) if sa.segmented else None
+        d.sampler_plan = plan.data_ptr() if plan is not None else None
+        d.sampler_ws, d.sampler_ws_bytes, d.sampler_err = sa._ws.data_ptr(), sa._ws.numel(), sa.err.data_ptr()
+        ring = sa.stream_buffer(self.B, self.ns, self.num_e)  # word rings of the two generators, filled one batch ahead
+        d.sampler_stream, d.sampler_stream_bytes = ring.data_ptr(), ring.numel()
+        for j in (0, 1):
+            d.cand_rows[j], d.cand_counts[j] = self.cand[j][0].data_ptr(), self.cand[j][1].data_ptr()
+            d.plan[j] = self.plans[j].buf.data_ptr()
+        d.plan_bytes = min(self.plans[0].buf.numel(), self.plans[1].buf.numel())
+        h = C.c_void_p()
+        _lib.check(_lib.lib.kge_pipeline_create(C.byref(d), _lib.stream_ptr(), C.byref(h)))
+        self._h, self._h_sig = h, sig
+
+    def host_stats(self, reset=True):
+        """kge_pipeline_stats as a dict (ms): where the thread that issues the steps spends its time."""
+        if self._h is None:
+            return None
+        out = (_lib.C.c_double * 8)()
+        _lib.check(_lib.lib.kge_pipeline_stats(self._h, out, 1 if reset else 0))
+        return dict(run_ms=out[0], wait_prev_launch_ms=out[1], graph_launch_ms=out[2], graph_launches=int(out[3]), launches_that_waited=int(out[4]),
+                    wait_by_stage_ms=dict(draw=out[5], plan=out[6], step=out[7]))
+
+    def close(self):
+        """Release the native driver (graphs, streams, events); the next start() captures again."""
+        if self._h is not None:
+            _lib.lib.kge_pipeline_destroy(self._h)
+            self._h, self._h_sig, self._native_active = None, None, False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _leave_native(self):
+        """The flags changed mid-epoch (e.g. a profiling pass switches to serial launches): hand over to the Python loop.  The
+        caller's stream then waits for the producer streams; batches t and t+1 are already drawn and planned."""
+        _lib.check(_lib.lib.kge_pipeline_finish(self._h, _lib.stream_ptr()))
+        self._native_active = False
+        main = torch.cuda.current_stream()
+        for st in (self.s1, self.s2, self.s3):
+            st.wait_stream(main)
+
+    def run(self, n):
+        """n training steps (each followed by the draw and the plan of the batch two steps ahead); asynchronous."""
+        n = int(n)
+        if self._native_active and self.native_ok():
+            _lib.check(_lib.lib.kge_pipeline_run(self._h, n, _lib.stream_ptr()))
+            self.t += n
+            return
+        for _ in range(n):
+            self.tick()
 
     # ------------------------------------------------------------------ driving
     def load_epoch(self, index, order):
@@ -200,6 +284,8 @@ class TrainPipeline:
         mo = self.model
         main = torch.cuda.current_stream()
         mo._ensure_train_state(self.B * self.ns, self.B * self.ns)
+        for pl in self.plans:  # counters of a plan that was built but never consumed (an epoch cut short) would poison the next build
+            pl.buf.zero_()
         if self.between is None:
             mo._step_dev = self.step_dev
             o = mo.optimizer
@@ -207,6 +293,12 @@ class TrainPipeline:
                               self.step_dev.data_ptr())
             _lib.check(_lib.lib.kge_opt_state_init(_lib.C.byref(od), _lib.stream_ptr()))
         self.sampler.prepare(self.B, self.ns, self.num_e)  # workspace + jump polynomials: nothing is allocated inside a capture
+        if self.native_ok():
+            self._ensure_native()
+            _lib.check(_lib.lib.kge_pipeline_start(self._h, self.n, _lib.stream_ptr()))
+            self._native_active = True
+            return
+        self._native_active = False
         if self.use_graphs and (not self.graphs or self._sig != self._signature()):
             self._capture()
         for st in (self.s1, self.s2, self.s3):
@@ -216,6 +308,10 @@ class TrainPipeline:
 
     def tick(self):
         """One training step; then the draw and the plan of the batch two steps ahead are issued."""
+        if self._native_active:
+            if self.native_ok():
+                return self.run(1)
+            self._leave_native()
         main = torch.cuda.current_stream()
         j = self.t % 2
         main.wait_event(self.planned[j])
@@ -228,8 +324,16 @@ class TrainPipeline:
     def finish(self):
         mo = self.model
         main = torch.cuda.current_stream()
+        if self._native_active:
+            self._leave_native()
         for st in (self.s1, self.s2, self.s3):
             main.wait_stream(st)
+        err = int(self.sampler.err.item())  # (synchronises: the epoch is over)
+        if err:
+            self.sampler.err.zero_()
+            mo._step_dev = None
+            raise RuntimeError(f"device sampler error flag {err}: the masked-rejection buffer ran short; the batches drawn since are not the "
+                               "reference's (kge_build_batch_device: err_flag bit 1)")
         if getattr(mo, "_step_dev", None) is not None:
             mo.optimizer.iterations = int(self.step_dev[0].item())
             mo._step_dev = None
@@ -241,8 +345,7 @@ class TrainPipeline:
         self.load_epoch(index, order)
         try:
             self.start()
-            for _ in range(self.n):
-                self.tick()
+            self.run(self.n)
         except BaseException:
             self.model._step_dev = None  # never leave the model on the device step state
             raise

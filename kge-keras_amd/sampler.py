@@ -155,6 +155,55 @@ class DeviceSampler:
             self._ws.zero_()
         self._ws_shape = shape
 
+    def stream_buffer(self, B, ns, num_e):
+        """The device buffer of the streamed form (kge_sampler_stream_*): the two generators' word rings + the draw's scratch,
+        zero-filled when allocated; one per batch shape."""
+        import torch
+        key = (int(B), int(ns), int(num_e))
+        if getattr(self, "_stream_key", None) != key:
+            need = check(lib.kge_sampler_stream_bytes(*key))
+            self._stream = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+            self._stream_key = key
+        return self._stream
+
+    # ---- streamed form: word generation ahead of the batches (kge_sampler_stream_*; what pipeline.TrainPipeline drives natively)
+    def stream_init(self, B, ns, num_e):
+        """Seed the word rings from the current generator states."""
+        from . import _lib
+        buf = self.stream_buffer(B, ns, num_e)
+        check(lib.kge_sampler_stream_init(buf.data_ptr(), buf.numel(), self.np_state.data_ptr(), self.py_state.data_ptr(), int(B), int(ns), int(num_e),
+                                          _lib.stream_ptr()))
+
+    def stream_produce(self, B, ns, num_e):
+        """One production round on the current stream (skipped on the device while enough words lie ahead)."""
+        from . import _lib
+        buf = self.stream_buffer(B, ns, num_e)
+        self.prepare(B, ns, num_e)
+        plan = self._plans.get((int(B), int(ns), int(num_e))) if self.segmented else None
+        check(lib.kge_sampler_stream_produce(buf.data_ptr(), buf.numel(), int(B), int(ns), int(num_e), plan.data_ptr() if plan is not None else None,
+                                             _lib.stream_ptr()))
+
+    def stream_draw(self, batch, ns, num_e, pos_out=None, neg_out=None, indexed=None, counted=None):
+        """build_batch() from the rings: same arguments, same outputs, same generator states left behind."""
+        import torch
+        from . import _lib
+        B = batch.shape[0] if indexed is None else int(indexed[4])
+        m = B * int(ns)
+        buf = self.stream_buffer(B, ns, num_e)
+        arrays = not (counted is not None and pos_out is False)
+        if not arrays:
+            pos_out = neg_out = None
+        elif pos_out is None:
+            pos_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
+            neg_out = torch.empty((m, 3), dtype=torch.int32, device=self.device)
+        kg, index, starts, cursor = (indexed[:4] if indexed is not None else (None,) * 4)
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        check(lib.kge_sampler_stream_draw(buf.data_ptr(), buf.numel(), self.np_state.data_ptr(), self.py_state.data_ptr(), ptr(batch) if indexed is None else None,
+                                          ptr(kg), ptr(index), ptr(starts), ptr(cursor), B, int(ns), int(num_e), ptr(pos_out) if arrays else None,
+                                          ptr(neg_out) if arrays else None, counted[0].data_ptr() if counted else None,
+                                          counted[1].data_ptr() if counted else None, self.err.data_ptr(), _lib.stream_ptr()))
+        return pos_out, neg_out
+
     def prepare(self, B, ns, num_e):
         """Allocate the workspace and compute / upload the jump polynomials for this batch shape (what build_batch does lazily
         on its first call), so that later calls allocate nothing -- needed before capturing build_batch into a hipGraph."""

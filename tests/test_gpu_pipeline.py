@@ -25,7 +25,7 @@ def test_pipeline_epochs_equal_host_generator_and_oracle(datasets, opt):
     E0, R0 = mdl.E.cpu().numpy().astype(np.float64), mdl.Rel.cpu().numpy().astype(np.float64)
     gen = DeviceDataGenerator(datasets["nations_train"], ns=100, batch_size=64)
     h = mdl.fit(gen, epochs=2, verbose=0, shuffle=False)
-    assert gen._pipe.use_graphs and gen._pipe.graphs  # the stages really were graph replays
+    assert gen._pipe.use_graphs and gen._pipe._h is not None  # the stages really were graph replays, issued by the native driver
     assert mdl.optimizer.iterations == 2 * len(gen)
     after = (np.random.randint(0, 10**6, 2).tolist(), random.random())
     # reference path: host generator (global streams) + oracle steps
@@ -214,7 +214,7 @@ def test_pipeline_with_a_hook_between_the_halves(datasets):
         gen._upload_global()
         tot = pipe.run_epoch(gen.index, list(range(len(gen))))
         gen.release_global()
-        assert pipe.use_graphs and (("T", 0) in pipe.graphs) == (not hooked) and ("S", 0) in pipe.graphs
+        assert pipe.use_graphs and (pipe._h is not None) == (not hooked) and (("S", 0) in pipe.graphs) == hooked and ("T", 0) not in pipe.graphs
         assert len(calls) == (len(gen) if hooked else 0) and mdl.optimizer.iterations == len(gen)
         out.append((mdl.E.cpu().numpy(), float(tot.item())))
     np.testing.assert_allclose(out[0][0], out[1][0], atol=2e-5)
@@ -238,7 +238,7 @@ def test_device_generator_end_to_end_with_validation_and_callback(datasets):
     gen = DeviceDataGenerator(tr, ns=10, batch_size=32)
     h = mdl.fit(gen, epochs=30, verbose=0, callbacks=[cb], validation_data=DataGenerator(va, ns=10, batch_size=32))
     after = validate(mdl, te, 14, None, filtering_triples=filt)
-    assert gen._pipe.use_graphs and mdl.optimizer.iterations == 30 * len(gen) and getattr(mdl, "_step_dev", None) is None
+    assert gen._pipe.use_graphs and gen._pipe._h is not None and mdl.optimizer.iterations == 30 * len(gen) and getattr(mdl, "_step_dev", None) is None
     assert len(h.history["loss"]) == 30 and len(h.history["val_loss"]) == 30
     assert h.history["loss"][-1] < h.history["loss"][0]
     assert after["mrr"] > before["mrr"] + 0.1 and after["mr"] < 4.0, (before, after)
@@ -280,7 +280,7 @@ def test_pipeline_protate(datasets):
     E0, R0 = mdl.E.cpu().numpy().astype(np.float64), mdl.Rel.cpu().numpy().astype(np.float64)
     gen = DeviceDataGenerator(datasets["nations_train"], ns=100, batch_size=64)
     h = mdl.fit(gen, epochs=1, verbose=0, shuffle=False)
-    assert gen._pipe.use_graphs and gen._pipe.graphs
+    assert gen._pipe.use_graphs and gen._pipe._h is not None
     np.random.seed(7)
     random.seed(8)
     hgen = DataGenerator(datasets["nations_train"], ns=100, batch_size=64)
