@@ -402,6 +402,7 @@ def main():
     ap.add_argument("--model", default="DistMult", choices=["DistMult", "TransE"],
                     help="DistMult: the BASELINE configs[1] workload (the contract line).  TransE: configs[2] (L2, gamma 12) through the same "
                          "pipeline, for comparison only (no CPU baseline; config.workload names it)")
+    ap.add_argument("--probe", action="store_true", help="timing experiments with KGE_PIPE_STAGES: do not insist on clean error flags")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed code paths even with WORLD_SIZE=1 (rehearsal on one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
@@ -589,13 +590,18 @@ def main():
         _lib.lib.kge_prof_enable(1)
         steps_n(args.steps)
         fence()
-        pipe.finish()
+        try:
+            pipe.finish()
+        except RuntimeError:
+            if not args.probe:
+                raise
     _lib.lib.kge_prof_enable(0)
-    model._raise_on_flag()
+    if not args.probe:
+        model._raise_on_flag()
     loss = float(model._loss.item()) / (world if dist_on else 1)  # summed over ranks by the flat all-reduce
     s_ms, s_n = _lib.prof_read("sampler")
     i_ms, i_n = _lib.prof_read("index")
-    assert int(dsamp.err.item()) == 0, "device sampler: rejection margin ran short"
+    assert args.probe or int(dsamp.err.item()) == 0, "device sampler: rejection margin ran short"
     k_ms, k_n = _lib.prof_read("train_grads")
     f_ms, f_n = _lib.prof_read("fwd")
     o_ms, o_n = _lib.prof_read("opt")

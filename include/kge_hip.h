@@ -340,15 +340,20 @@ int kge_mt_jump_host(void* state_host, int64_t J);
  *      fixed sequence of 624-word blocks; which of its words a batch consumes is data dependent (NumPy's masked rejection,
  *      utils.py:118-119), the words themselves are not.  Each generator gets a ring of raw state blocks in HBM:
  *        kge_sampler_stream_init     seeds both rings from the state blobs (block 0 = the state block, consumption from its position);
- *        kge_sampler_stream_produce  one production round per generator (16 jump-started segments, as kge_build_batch_device with a
- *                                    plan; sequential when plan_dev is NULL) -- skipped on the device while at least two batches'
- *                                    worth of words lie ahead of the consumer.  Run it on its own stream, one batch ahead: before the
- *                                    draw of batch k the caller must have issued rounds 0..k, round k ordered behind the draw of
- *                                    batch k-2 at the latest and in front of the draw of batch k;
+ *        kge_sampler_stream_produce  one production round per generator: R = kge_sampler_stream_round() batches' worth of words from
+ *                                    16 jump-started segments (plan_dev: the polynomials of kge_sampler_stream_plan_host, uploaded;
+ *                                    kge_sampler_plan_bytes() bytes; NULL: one sequential pass) -- skipped on the device while
+ *                                    enough words lie ahead of the consumer.  Protocol: offer one round after init and one more in
+ *                                    front of the draw of every batch k = 0, R, 2R, ... (more often is harmless), each ordered
+ *                                    behind the draw of batch k-2 at the latest; the draw of batch k must be ordered behind the
+ *                                    rounds offered before the one in front of it -- so a round can run on a stream of its own
+ *                                    and has R batches' time to finish;
  *        kge_sampler_stream_draw     the consumer half of kge_build_batch_device[_indexed] (same arguments, same outputs, same
  *                                    generator states left in the blobs): select -> choices / assembly -> advance.
  *      Bit-identical to kge_build_batch_device.  The buffer also holds the scratch of the draw (no separate workspace). */
 int64_t kge_sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e);
+int32_t kge_sampler_stream_round(void);
+int kge_sampler_stream_plan_host(int64_t B, int64_t ns, int64_t num_e, void* plan_host);
 int kge_sampler_stream_init(void* stream_buf, int64_t stream_bytes, const void* np_state_dev, const void* py_state_dev, int64_t B, int64_t ns,
                             int64_t num_e, kge_stream_t stream);
 int kge_sampler_stream_produce(void* stream_buf, int64_t stream_bytes, int64_t B, int64_t ns, int64_t num_e, const void* plan_dev,
@@ -393,8 +398,9 @@ typedef struct {
   int64_t sampler_ws_bytes;
   uint32_t* sampler_err;
   void* sampler_stream;       /* kge_sampler_stream_bytes(B, ns, num_e), zero-filled when allocated: the generators' word rings, filled
-                               * one batch ahead on a stream of their own (NULL: every batch regenerates its words itself) */
+                               * ahead of need on a stream of their own (NULL: every batch regenerates its words itself) */
   int64_t sampler_stream_bytes;
+  const void* sampler_stream_plan; /* kge_sampler_stream_plan_host output, uploaded (may be NULL: sequential rounds) */
   int32_t* cand_rows[2];      /* ((B + B*ns), 3) per buffer parity */
   int32_t* cand_counts[2];    /* KGE_CAND_POS_LANES*B + B*ns per buffer parity */
   void* plan[2];              /* kge_batch_plan_bytes(md, ld, B*ns, B*ns) per buffer parity */
@@ -408,6 +414,10 @@ int kge_pipeline_finish(void* handle, kge_stream_t stream);
  * graph mode only: ms waiting for a graph's previous launch to finish, launches that had to wait, that wait by stage} in the
  * order {run, wait, launch, launches, waited, wait draw, wait plan, wait step}. */
 int kge_pipeline_stats(void* handle, double out[8], int32_t reset);
+/* Stage timeline (a diagnostic): n > 0 arms hipEvent pairs around the next n stage launches; n == 0 synchronises and reads them back:
+ * out receives up to cap records {stage (0 rounds, 1 draw, 2 plan, 3 step), batch / round number, begin ms, end ms}, relative to the
+ * first begin; returns the number of records. */
+int64_t kge_pipeline_trace(void* handle, int64_t n, double* out, int64_t cap);
 int kge_pipeline_destroy(void* handle);
 
 #ifdef __cplusplus

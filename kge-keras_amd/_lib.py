@@ -51,7 +51,7 @@ class PipelineDesc(C.Structure):
                 ("np_state", C.c_void_p), ("py_state", C.c_void_p), ("kg", C.c_void_p), ("index", C.c_void_p), ("starts", C.c_void_p),
                 ("cursor", C.c_void_p), ("B", C.c_int64), ("ns", C.c_int64), ("num_e", C.c_int64),
                 ("sampler_plan", C.c_void_p), ("sampler_ws", C.c_void_p), ("sampler_ws_bytes", C.c_int64), ("sampler_err", C.c_void_p),
-                ("sampler_stream", C.c_void_p), ("sampler_stream_bytes", C.c_int64),
+                ("sampler_stream", C.c_void_p), ("sampler_stream_bytes", C.c_int64), ("sampler_stream_plan", C.c_void_p),
                 ("cand_rows", C.c_void_p * 2), ("cand_counts", C.c_void_p * 2), ("plan", C.c_void_p * 2), ("plan_bytes", C.c_int64)]
 
 
@@ -117,6 +117,8 @@ SIGNATURES = {
     "kge_mt_jump_host": (C.c_int, [_P, _I64]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "kge_sampler_stream_bytes": (_I64, [_I64, _I64, _I64]),
+    "kge_sampler_stream_round": (_I32, []),
+    "kge_sampler_stream_plan_host": (C.c_int, [_I64, _I64, _I64, _P]),
     "kge_sampler_stream_init": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _I64, _P]),
     "kge_sampler_stream_produce": (C.c_int, [_P, _I64, _I64, _I64, _I64, _P, _P]),
     "kge_sampler_stream_draw": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
@@ -125,6 +127,7 @@ SIGNATURES = {
     "kge_pipeline_run": (C.c_int, [_P, _I64, _P]),
     "kge_pipeline_finish": (C.c_int, [_P, _P]),
     "kge_pipeline_stats": (C.c_int, [_P, _P, _I32]),
+    "kge_pipeline_trace": (_I64, [_P, _I64, _P, _I64]),
     "kge_pipeline_destroy": (C.c_int, [_P]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

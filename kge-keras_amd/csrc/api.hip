@@ -184,6 +184,8 @@ int build_batch_device(void*, void*, const int32_t*, const int32_t*, const int64
                        hipStream_t);
 int sampler_plan_host(int64_t, int64_t, int64_t, uint64_t*);
 int64_t sampler_stream_bytes(int64_t, int64_t, int64_t);
+int sampler_stream_round();
+int sampler_stream_plan_host(int64_t, int64_t, int64_t, uint64_t*);
 int sampler_stream_init(void*, int64_t, const void*, const void*, int64_t, int64_t, int64_t, hipStream_t);
 int sampler_stream_produce(void*, int64_t, int64_t, int64_t, int64_t, const void*, hipStream_t);
 int sampler_stream_draw(void*, int64_t, void*, void*, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int64_t*, int64_t, int64_t, int64_t,
@@ -460,6 +462,14 @@ static int check_sampler_shape(const char* who, int64_t B, int64_t ns, int64_t n
 int64_t kge_sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e) {
   if (int rc = check_sampler_shape("kge_sampler_stream_bytes", B, ns, num_e)) return rc;
   return sampler_stream_bytes(B, ns, num_e);
+}
+
+int32_t kge_sampler_stream_round(void) { return sampler_stream_round(); }
+
+int kge_sampler_stream_plan_host(int64_t B, int64_t ns, int64_t num_e, void* plan_host) {
+  if (int rc = check_sampler_shape("kge_sampler_stream_plan_host", B, ns, num_e)) return rc;
+  if (!plan_host) return fail(KGE_EINVAL, "kge_sampler_stream_plan_host: null output");
+  return sampler_stream_plan_host(B, ns, num_e, static_cast<uint64_t*>(plan_host));
 }
 
 int kge_sampler_stream_init(void* stream_buf, int64_t stream_bytes, const void* np_state_dev, const void* py_state_dev, int64_t B, int64_t ns,

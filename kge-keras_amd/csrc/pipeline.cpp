@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <new>
+#include <vector>
 
 #include "kge_host.hpp"
 
@@ -28,6 +29,7 @@ int sampler_stream_draw(void* buf, int64_t bytes, void* np_state, void* py_state
                         const int64_t* starts, int64_t* cursor, int64_t B, int64_t ns, int64_t num_e, int32_t* pos_out, int32_t* neg_out,
                         int32_t* cand_rows, int32_t* cand_cnt, uint32_t* err, hipStream_t st);
 int64_t sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e);
+int sampler_stream_round();
 
 namespace {
 
@@ -43,7 +45,7 @@ enum { GEN = 0, DRAW = 1, PLAN = 2, STEP = 3 };
 struct Pipeline {
   kge_pipeline_desc d;
   hipStream_t s_gen = nullptr, s_draw = nullptr, s_plan = nullptr;
-  hipEvent_t gen[2] = {}, ready[2] = {}, freed[2] = {}, planned[2] = {}, pfreed[2] = {};
+  hipEvent_t gen[2] = {}, ready[2] = {}, planned[2] = {}, pfreed[2] = {};
   hipEvent_t fork = nullptr;
   hipEvent_t done[kStages][2] = {};      // graphs only: behind the last launch of graph (stage, slot)
   bool launched[kStages][2] = {};
@@ -52,10 +54,15 @@ struct Pipeline {
   bool ring = false;               // word generation ahead of the batches (kge_sampler_stream_*); else kge_build_batch_device_indexed
   int64_t n_batches = 0;           // batches of the loaded epoch
   int64_t t = 0;                   // ticks done
+  int64_t nround = 0;              // production rounds offered in this epoch
   bool started = false;
   // host-side accounting of kge_pipeline_run (kge_pipeline_stats): where the issuing thread spends its time
   double ns_spin = 0.0, ns_launch = 0.0, ns_total = 0.0, ns_spin_stage[kStages] = {};
   int64_t n_launch = 0, n_spun = 0;
+  // stage timeline (kge_pipeline_trace): timing events around every stage launch of the next `trace_left` launches
+  struct Rec { int stage; int64_t batch; hipEvent_t a, b; };
+  std::vector<Rec> trace;
+  int64_t trace_left = 0;
   int stage_mask = 15;  // experiments only (KGE_PIPE_STAGES): bit s clear = stage s is not launched (its events still are recorded)
 };
 
@@ -66,7 +73,7 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
   const int64_t m = d.B * d.ns;
   switch (stage) {
     case GEN:
-      return p->ring ? sampler_stream_produce(d.sampler_stream, d.sampler_stream_bytes, d.B, d.ns, d.num_e, d.sampler_plan, st) : KGE_OK;
+      return p->ring ? sampler_stream_produce(d.sampler_stream, d.sampler_stream_bytes, d.B, d.ns, d.num_e, d.sampler_stream_plan, st) : KGE_OK;
     case DRAW:  // positives read in place, folded output only (candidate rows + pick counts); the last kernel moves the cursor
       if (p->ring)
         return sampler_stream_draw(d.sampler_stream, d.sampler_stream_bytes, d.np_state, d.py_state, nullptr, d.kg, d.index, d.starts, d.cursor, d.B, d.ns,
@@ -95,14 +102,18 @@ int capture(Pipeline* p, int stage, int slot, hipStream_t st) {
   return KGE_OK;
 }
 
-int launch(Pipeline* p, int stage, int slot, hipStream_t st) {
+int launch(Pipeline* p, int stage, int slot, hipStream_t st, int64_t batch = -1) {
   if (!((p->stage_mask >> stage) & 1)) return KGE_OK;
   if (stage == GEN && !p->ring) return KGE_OK;
   if (!p->graphs) {
+    Pipeline::Rec rec{stage, batch, nullptr, nullptr};
+    const bool tr = p->trace_left > 0 && hipEventCreate(&rec.a) == hipSuccess && hipEventCreate(&rec.b) == hipSuccess;
+    if (tr) (void)hipEventRecord(rec.a, st);
     const double t0 = now_ns();
     if (int rc = stage_calls(p, stage, slot, st)) return rc;
     p->ns_launch += now_ns() - t0;
     p->n_launch += 1;
+    if (tr) { (void)hipEventRecord(rec.b, st); p->trace.push_back(rec); p->trace_left -= 1; }
     return KGE_OK;
   }
   // A graph exec cannot run twice at once: launching it again while its previous launch is in flight blocks inside the runtime
@@ -130,26 +141,34 @@ int launch(Pipeline* p, int stage, int slot, hipStream_t st) {
   return KGE_OK;
 }
 
+// One production round of the word rings (R batches' worth of words) on the generator stream.
+int offer_round(Pipeline* p, int after_ready) {
+  if (after_ready >= 0) KGE_PIPE_TRY(hipStreamWaitEvent(p->s_gen, p->ready[after_ready], 0));
+  if (int rc = launch(p, GEN, 0, p->s_gen, p->nround)) return rc;
+  KGE_PIPE_TRY(hipEventRecord(p->gen[p->nround & 1], p->s_gen));
+  p->nround += 1;
+  return KGE_OK;
+}
+
 // generator round, draw and plan of batch k on their streams
 int produce(Pipeline* p, int64_t k) {
   if (k >= p->n_batches) return KGE_OK;
   const int j = (int)(k & 1);
-  if (p->ring) {
-    // round k sees the consumer position of batch k-2 at the latest (`ready[j]` still is the record behind draw k-2): stale by one
-    // batch at most, which is what the rings' low-water mark is sized for (sampler_dev.hip)
-    KGE_PIPE_TRY(hipStreamWaitEvent(p->s_gen, p->ready[j], 0));
-    if (int rc = launch(p, GEN, j, p->s_gen)) return rc;
-    KGE_PIPE_TRY(hipEventRecord(p->gen[j], p->s_gen));
-    KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->gen[j], 0));
+  if (p->ring && k % sampler_stream_round() == 0) {
+    // The draws of batches k .. k+R-1 need the rounds offered so far -- the last of them one period ago (at the start for k = 0) --
+    // and the round offered now has until batch k+R to finish: generation never sits on a batch's critical path.  The new round
+    // sees the consumer position of batch k-2 at the latest (`ready[j]` still is the record behind draw k-2): stale by one batch at
+    // most, which is what the rings' low-water mark is sized for (sampler_dev.hip).
+    KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->gen[(p->nround - 1) & 1], 0));
+    if (int rc = offer_round(p, j)) return rc;
   }
-  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->freed[j], 0));
-  if (int rc = launch(p, DRAW, j, p->s_draw)) return rc;
+  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->planned[j], 0));  // (still the record behind plan k-2: its candidate buffers are free)
+  if (int rc = launch(p, DRAW, j, p->s_draw, k)) return rc;
   KGE_PIPE_TRY(hipEventRecord(p->ready[j], p->s_draw));
   KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->ready[j], 0));
   KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[j], 0));
-  if (int rc = launch(p, PLAN, j, p->s_plan)) return rc;
+  if (int rc = launch(p, PLAN, j, p->s_plan, k)) return rc;
   KGE_PIPE_TRY(hipEventRecord(p->planned[j], p->s_plan));
-  KGE_PIPE_TRY(hipEventRecord(p->freed[j], p->s_plan));
   return KGE_OK;
 }
 
@@ -160,7 +179,7 @@ void destroy(Pipeline* p) {
       if (p->done[s][j]) (void)hipEventDestroy(p->done[s][j]);
     }
   for (int j = 0; j < 2; ++j)
-    for (hipEvent_t e : {p->gen[j], p->ready[j], p->freed[j], p->planned[j], p->pfreed[j]})
+    for (hipEvent_t e : {p->gen[j], p->ready[j], p->planned[j], p->pfreed[j]})
       if (e) (void)hipEventDestroy(e);
   if (p->fork) (void)hipEventDestroy(p->fork);
   for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan})
@@ -216,7 +235,7 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   KGE_CREATE_TRY(hipStreamCreateWithFlags(&p->s_plan, hipStreamNonBlocking));
   KGE_CREATE_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
   for (int j = 0; j < 2; ++j) {
-    for (hipEvent_t* e : {&p->gen[j], &p->ready[j], &p->freed[j], &p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&p->gen[j], &p->ready[j], &p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int s = 0; s < kStages; ++s) KGE_CREATE_TRY(hipEventCreateWithFlags(&p->done[s][j], hipEventDisableTiming));
   }
 #undef KGE_CREATE_TRY
@@ -247,6 +266,8 @@ int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream) {
   KGE_PIPE_TRY(hipEventRecord(p->fork, main_st));
   for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan}) KGE_PIPE_TRY(hipStreamWaitEvent(s, p->fork, 0));
   p->started = true;
+  p->nround = 0;
+  if (p->ring) if (int rc = offer_round(p, -1)) return rc;  // the words of batches 0 .. R-1
   if (int rc = produce(p, 0)) return rc;
   return produce(p, 1);
 }
@@ -262,7 +283,7 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
   for (int64_t i = 0; i < n_steps; ++i) {
     const int j = (int)(p->t & 1);
     KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->planned[j], 0));
-    if (int rc = launch(p, STEP, j, main_st)) return rc;
+    if (int rc = launch(p, STEP, j, main_st, p->t)) return rc;
     KGE_PIPE_TRY(hipEventRecord(p->pfreed[j], main_st));
     if (int rc = produce(p, p->t + 2)) return rc;
     p->t += 1;
@@ -288,6 +309,29 @@ int kge_pipeline_stats(void* handle, double out[8], int32_t reset) {
     for (double& x : p->ns_spin_stage) x = 0.0;
   }
   return KGE_OK;
+}
+
+// Stage timeline: n > 0 arms timing events around the next n stage launches; n == 0 reads them back (synchronises): out receives up
+// to cap records of {stage (0 rounds, 1 draw, 2 plan, 3 step), batch / round number, begin ms, end ms} relative to the first begin.
+int64_t kge_pipeline_trace(void* handle, int64_t n, double* out, int64_t cap) {
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p) return fail(KGE_EINVAL, "kge_pipeline_trace: null handle");
+  if (n > 0) { p->trace_left = n; return 0; }
+  p->trace_left = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(KGE_EHIP, "kge_pipeline_trace: hipDeviceSynchronize failed");
+  int64_t k = 0;
+  for (const auto& r : p->trace) {
+    if (out && k < cap && !p->trace.empty()) {
+      float a = 0.f, b = 0.f;
+      (void)hipEventElapsedTime(&a, p->trace[0].a, r.a);
+      (void)hipEventElapsedTime(&b, p->trace[0].a, r.b);
+      out[4 * k] = r.stage; out[4 * k + 1] = (double)r.batch; out[4 * k + 2] = a; out[4 * k + 3] = b;
+      ++k;
+    }
+  }
+  for (auto& r : p->trace) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  p->trace.clear();
+  return k;
 }
 
 int kge_pipeline_finish(void* handle, kge_stream_t stream) {

@@ -313,11 +313,26 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(HistSrc hs, int64_t n, i
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kEntSlots; i += 256) {
-    const int key = hkey[i];
-    if (key >= 0) hcnt[i] = atomicAdd(&ecnt[key], hcnt[i]);  // base of this workgroup's occurrences in the key's list
+  {  // one returning global atomic per distinct key: base of this workgroup's occurrences in the key's list.  All of a thread's
+     // atomics are issued before the first result is used (a loop of issue -> wait -> store pays the round trip 16 times in a row).
+    constexpr int SW = kEntSlots / 256;
+    int keys[SW], vals[SW];
+#pragma unroll
+    for (int u = 0; u < SW; ++u) { const int i = threadIdx.x + u * 256; keys[u] = hkey[i]; vals[u] = hcnt[i]; }
+#pragma unroll
+    for (int u = 0; u < SW; ++u) if (keys[u] >= 0) vals[u] = atomicAdd(&ecnt[keys[u]], vals[u]);
+#pragma unroll
+    for (int u = 0; u < SW; ++u) if (keys[u] >= 0) hcnt[threadIdx.x + u * 256] = vals[u];
   }
-  for (int i = threadIdx.x; i < R; i += 256) { const int v = lrel[i]; lrel[i] = v ? atomicAdd(&rcnt[i], v) : 0; }
+  for (int i0 = 0; i0 < R; i0 += 4 * 256) {
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + threadIdx.x + u * 256; v[u] = i < R ? lrel[i] : 0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (v[u]) v[u] = atomicAdd(&rcnt[i0 + threadIdx.x + u * 256], v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + threadIdx.x + u * 256; if (i < R) lrel[i] = v[u]; }
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restric
   const MTDev* st = blockIdx.x == 0 ? st_np : st_py;
   __builtin_amdgcn_s_setprio(3);  // a latency chain of a few workgroups beside chip-filling gather kernels: win the issue arbitration
   for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = st->mt[i];
-  if (Jst_zero) for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * kSeg * 624; i += 512) Jst_zero[i] = 0u;  // accumulated into by mt_jump_kernel
+  (void)Jst_zero;
   __syncthreads();
   mt_regen_blocks(buf, blockIdx.x == 0 ? U_np : U_py, 0, blockIdx.x == 0 ? K0 : K1);
 }
@@ -103,54 +103,87 @@ __global__ __launch_bounds__(256) void mt_generate_kernel(const MTDev* __restric
 constexpr int kJumpBlocks = 33;   // 624 * 33 >= 19937 + 623 raw words after the state block
 constexpr int kPolyWords = 312;   // uint64 words of one jump polynomial
 
-// Jst[z][s][j] ^= XOR_{k in this block's slice : g_{z,s}[k]} W_z[k + j]  (W = state block followed by U; Jst pre-zeroed).
-// grid (10 j-tiles x kJumpSplit k-slices, kSeg-1, 2).  Loads are unconditional (select on the coefficient bit) so that
-// many are in flight; a block's footprint (its k slice + 64 words) stays L1-resident.
-constexpr int kJumpSplit = 16;
-__global__ __launch_bounds__(256) void mt_jump_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
-                                                       const uint32_t* __restrict__ U_np, const uint32_t* __restrict__ U_py,
-                                                       const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jst, int seg_np,
-                                                       int seg_py) {
-  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;  // polynomial words per slice (20)
+// Jump-ahead as a window XOR: state_J[j] = XOR_{k : g_J[k]} W[k + j], W = the state block followed by the raw blocks behind it.
+// All kSeg-1 jumps of one generator read the SAME window, so one workgroup takes a tile of 64 output words j and a slice of the
+// coefficient range k for ALL of them: every LDS word is read once and applied to 15 accumulators (the polynomial words sit in
+// scalar registers, a coefficient test is a scalar bit compare).  One kernel per (tile, slice, polynomial) re-read the window 15
+// times and spent its time on per-workgroup overhead (4800 workgroups of a few hundred LDS reads each: 28.6 us; now ~640).
+// Partial results go to Jpart[z][s][slice][j] (no atomics, nothing to zero); the segment kernel XORs the slices when it loads its
+// start state.
+constexpr int kJumpSplit = 32;
+constexpr int kJRow = 640;  // 624 padded
+template <typename LoadW>
+__device__ __forceinline__ void jump_core(LoadW loadw, const uint64_t* __restrict__ polys_z, uint32_t* __restrict__ Jpart_z) {
+  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;  // polynomial words per slice (10)
   constexpr int WIN = WPS * 64 + 64;                               // raw words this block touches
+  constexpr int NP = kSeg - 1;
   __shared__ uint32_t win[WIN];
-  __shared__ uint32_t part[4][64];
-  const int z = blockIdx.z, s = blockIdx.y + 1;
-  if ((z == 0 ? seg_np : seg_py) == 0) return;  // this stream is generated sequentially
-  const MTDev* st = z == 0 ? st_np : st_py;
-  const uint32_t* U = z == 0 ? U_np : U_py;
-  const uint64_t* poly = polys + ((int64_t)z * (kSeg - 1) + (s - 1)) * kPolyWords;
+  __shared__ uint32_t part[4][NP][64];
   const int tile = blockIdx.x % 10, slice = blockIdx.x / 10;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = tile * 64 + lane;
   const int lo = slice * WPS * 64 + tile * 64;  // first raw word of the window
   for (int i = threadIdx.x; i < WIN; i += 256) {
     const int idx = lo + i;
-    win[i] = idx < 624 ? st->mt[idx] : (idx < 624 * (kJumpBlocks + 1) ? U[idx - 624] : 0u);
+    win[i] = idx < 624 * (kJumpBlocks + 1) ? loadw(idx) : 0u;
   }
   __syncthreads();
-  uint32_t acc = 0;
+  uint32_t acc[NP];
+#pragma unroll
+  for (int s = 0; s < NP; ++s) acc[s] = 0u;
   for (int wi = wave; wi < WPS; wi += 4) {
     const int w = slice * WPS + wi;
     if (w >= kPolyWords) break;
-    // the polynomial word is the same for the whole wave: keep it in scalar registers, so that a coefficient test is one scalar
-    // bit compare (as a vector value it costs a 64-bit vector shift, a compare and an exec-mask dance per bit: 4x slower)
-    const uint64_t gwv = poly[w];
-    const uint32_t g[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gwv),
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gwv >> 32))};
-    const uint32_t* src = win + wi * 64 + lane;  // conflict-free: consecutive lanes, consecutive words
+    // lane s holds the word of polynomial s; readlane moves it into scalar registers
+    const uint64_t gv = lane < NP ? polys_z[(int64_t)lane * kPolyWords + w] : 0ull;
+    const uint32_t glo = (uint32_t)gv, ghi = (uint32_t)(gv >> 32);
+    uint32_t g0[NP], g1[NP];
 #pragma unroll
-    for (int hw = 0; hw < 2; ++hw) {
-#pragma unroll 16
-      for (int bit = 0; bit < 32; ++bit) acc ^= ((g[hw] >> bit) & 1u) ? src[32 * hw + bit] : 0u;
+    for (int s = 0; s < NP; ++s) {
+      g0[s] = (uint32_t)__builtin_amdgcn_readlane((int)glo, s);
+      g1[s] = (uint32_t)__builtin_amdgcn_readlane((int)ghi, s);
+    }
+    const uint32_t* src = win + wi * 64 + lane;  // conflict-free: consecutive lanes, consecutive words
+#pragma unroll 8
+    for (int bit = 0; bit < 32; ++bit) {
+      const uint32_t x0 = src[bit], x1 = src[32 + bit];
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        acc[s] ^= ((g0[s] >> bit) & 1u) ? x0 : 0u;
+        acc[s] ^= ((g1[s] >> bit) & 1u) ? x1 : 0u;
+      }
     }
   }
-  part[wave][lane] = acc;
+#pragma unroll
+  for (int s = 0; s < NP; ++s) part[wave][s][lane] = acc[s];
   __syncthreads();
-  if (wave == 0 && j < 624) {
-    const uint32_t v = part[0][lane] ^ part[1][lane] ^ part[2][lane] ^ part[3][lane];
-    if (v) atomicXor(&Jst[((int64_t)z * kSeg + s) * 624 + j], v);
+  for (int i = threadIdx.x; i < NP * 64; i += 256) {
+    const int s = i >> 6, l = i & 63;
+    if (tile * 64 + l < 624)
+      Jpart_z[((int64_t)(s + 1) * kJumpSplit + slice) * kJRow + tile * 64 + l] = part[0][s][l] ^ part[1][s][l] ^ part[2][s][l] ^ part[3][s][l];
   }
+  (void)j;
+}
+// start state of segment s (>= 1) of generator z: XOR of the slices' partial results
+__device__ __forceinline__ uint32_t jump_state_word(const uint32_t* __restrict__ Jpart, int z, int s, int i) {
+  const uint32_t* p = Jpart + (((int64_t)z * kSeg + s) * kJumpSplit) * kJRow + i;
+  uint32_t v = 0u;
+#pragma unroll 8
+  for (int sl = 0; sl < kJumpSplit; ++sl) v ^= p[(int64_t)sl * kJRow];
+  return v;
+}
+
+// grid (10 j-tiles x kJumpSplit k-slices, 1, 2 generators)
+__global__ __launch_bounds__(256) void mt_jump_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
+                                                       const uint32_t* __restrict__ U_np, const uint32_t* __restrict__ U_py,
+                                                       const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jpart, int seg_np,
+                                                       int seg_py) {
+  const int z = blockIdx.z;
+  if ((z == 0 ? seg_np : seg_py) == 0) return;  // this stream is generated sequentially
+  const MTDev* st = z == 0 ? st_np : st_py;
+  const uint32_t* U = z == 0 ? U_np : U_py;
+  jump_core([&](int idx) { return idx < 624 ? st->mt[idx] : U[idx - 624]; }, polys + (int64_t)z * (kSeg - 1) * kPolyWords,
+            Jpart + (int64_t)z * kSeg * kJumpSplit * kJRow);
 }
 
 // grid (kSeg, 2): segment s of stream z regenerates blocks [s*segb, (s+1)*segb) (segment 0 starts after the 33 blocks
@@ -167,8 +200,7 @@ __global__ __launch_bounds__(256) void mt_generate_seg_kernel(uint32_t* __restri
   if (s == 0) b0 = kJumpBlocks;
   if (b0 >= b1) return;
   __builtin_amdgcn_s_setprio(3);
-  const uint32_t* src = s == 0 ? U + (int64_t)(kJumpBlocks - 1) * 624 : Jst + ((int64_t)z * kSeg + s) * 624;
-  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = src[i];
+  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = s == 0 ? U[(int64_t)(kJumpBlocks - 1) * 624 + i] : jump_state_word(Jst, z, s, i);
   __syncthreads();
   mt_regen_blocks(buf, U, b0, b1);
 }
@@ -362,7 +394,7 @@ struct SamplerPlan {
   int64_t* consumed;
   int32_t* fs;
   int32_t* fo;
-  uint32_t* Jst;      // [2][kSeg][624] jumped segment-start states
+  uint32_t* Jst;      // [2][kSeg][kJumpSplit][kJRow] partial results of the jumps (XOR over the slices = segment-start state)
   int segb_np, segb_py;  // blocks per segment (0 = the stream is generated sequentially)
   int64_t bytes;
 };
@@ -390,7 +422,7 @@ static SamplerPlan plan_sampler(int64_t B, int64_t ns, int64_t num_e, void* ws) 
   p.consumed = (int64_t*)take(256);
   p.fs = (int32_t*)take(m * 4);
   p.fo = (int32_t*)take(m * 4);
-  p.Jst = (uint32_t*)take(2 * kSeg * 624 * 4);
+  p.Jst = (uint32_t*)take((int64_t)2 * kSeg * kJumpSplit * kJRow * 4);  // partial jump results [2][kSeg][kJumpSplit][kJRow]
   auto segb = [](int64_t K) { const int64_t sb = cdiv(K, kSeg); return (int)(sb > kJumpBlocks ? sb : 0); };
   p.segb_np = segb(p.K_np);
   p.segb_py = segb(p.K_py);
@@ -434,7 +466,7 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
   hipLaunchKernelGGL(mt_generate_kernel, dim3(2), dim3(256), 0, st, nps, pys, p.U_np, sb_np ? kJumpBlocks : (int)p.K_np, p.U_py,
                      sb_py ? kJumpBlocks : (int)p.K_py, (sb_np || sb_py) ? p.Jst : nullptr);
   if (sb_np || sb_py) {
-    hipLaunchKernelGGL(mt_jump_kernel, dim3(10 * kJumpSplit, kSeg - 1, 2), dim3(256), 0, st, nps, pys, p.U_np, p.U_py, static_cast<const uint64_t*>(plan_dev),
+    hipLaunchKernelGGL(mt_jump_kernel, dim3(10 * kJumpSplit, 1, 2), dim3(256), 0, st, nps, pys, p.U_np, p.U_py, static_cast<const uint64_t*>(plan_dev),
                        p.Jst, sb_np, sb_py);
     hipLaunchKernelGGL(mt_generate_seg_kernel, dim3(kSeg, 2), dim3(256), 0, st, p.U_np, (int)p.K_np, sb_np, p.U_py, (int)p.K_py, sb_py, p.Jst);
   }
@@ -467,31 +499,38 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
 // of a batch shrinks to select -> assemble -> advance.  Global numbering: block 0 is the state block the ring was seeded with,
 // word w of the stream lives in block w / 624 at offset w % 624, block b is stored in slot b % RB.
 //   control word per generator: head (blocks [0, head) exist; committed lazily by the next round), wpos (next word to consume).
-//   A round runs only while fewer than LOW = 2 M words lie between wpos and the head (M = the most a batch can consume):
-//     skip:     avail_seen >= 2M, the producer may have missed at most one batch's consumption  -> >= M words for the next batch
-//     generate: the previous invariant (>= M before the last batch) + P*624 >= M new words - M   -> >= M words again
-//   (the pipeline orders round k behind the consumer of batch k-2, so wpos is stale by at most one batch; P*624 >= M by
-//   construction of segb).  Ring capacity RB >= (2M + 2 P*624) / 624 + 4 blocks: nothing still readable is overwritten, the block
-//   holding the last consumed word (the generator state handed back to NumPy / CPython) included.
+//   A round covers R = kStreamRound batches (one set of jumps per R batches).  Rounds are offered one at the start and then one
+//   in front of every batch k = 0, R, 2R, ...; the draw of batch k waits only for the rounds offered BEFORE the one in front of
+//   it, so a round has R batches' time to finish -- it never sits on a batch's critical path.  A round generates only while fewer
+//   than LOW = (2R+1) M words lie between wpos and the head (M = the most a batch can consume; P*624 >= R M words per round):
+//     invariant   when batch k = 0 mod R starts, the completed rounds hold >= R M words ahead of wpos (batches k .. k+R-1)
+//     skip        avail_seen >= (2R+1) M; until batch k+R starts at most R+1 batches are consumed (R + one the producer may not
+//                 have seen yet)                                                                   -> >= R M words then
+//     generate    >= R M (invariant) - R M consumed + P*624 >= R M new                              -> >= R M words then
+//   (the caller orders the round in front of batch k behind the consumer of batch k-2, so wpos is stale by at most one batch).
+//   Ring capacity RB >= (LOW + 2 P*624) / 624 + 8 blocks, rounded up to a power of two: nothing still readable is overwritten,
+//   the block holding the last consumed word (the generator state handed back to NumPy / CPython) included.
 struct GenCtl {
   int64_t head;        // blocks generated and committed
   int64_t wpos;        // global index of the next word to consume
   int64_t head_round;  // head when the running / last round started
   int32_t go;          // the last round generated (its blocks are committed by the next round's first kernel)
   int32_t pad;
+  int64_t wsnap;       // wpos as the running batch found it (the advance of a batch shares a launch with its assembly)
+  int64_t csnap;       // the batch cursor likewise (kept in the Python generator's control block)
 };
 struct Ring {
   uint32_t* blocks;
-  int64_t RB;      // capacity in blocks
+  int64_t RB;      // capacity in blocks (a power of two)
   GenCtl* ctl;
   int64_t P;       // blocks per round
   int64_t low;     // words: generate while avail < low
   int32_t segb;    // blocks per segment (0: the round is one sequential pass of P blocks)
 };
-__device__ __forceinline__ uint32_t* ring_block(const Ring& r, int64_t gb) { return r.blocks + (gb % r.RB) * 624; }
+__device__ __forceinline__ uint32_t* ring_block(const Ring& r, int64_t gb) { return r.blocks + (gb & (r.RB - 1)) * 624; }  // RB is a power of two
 __device__ __forceinline__ uint32_t ring_word(const Ring& r, int64_t w) {
   const int64_t b = w / 624;
-  return mt_temper(r.blocks[(b % r.RB) * 624 + (w - b * 624)]);
+  return mt_temper(r.blocks[(b & (r.RB - 1)) * 624 + (w - b * 624)]);
 }
 
 // Seeds both rings from the generator state blobs: block 0 = the state block, consumption starts at its position.
@@ -499,7 +538,7 @@ __global__ __launch_bounds__(256) void ring_init_kernel(Ring r0, const MTDev* __
   const Ring& r = blockIdx.x == 0 ? r0 : r1;
   const MTDev* st = blockIdx.x == 0 ? st0 : st1;
   for (int i = threadIdx.x; i < 624; i += 256) r.blocks[i] = st->mt[i];
-  if (threadIdx.x == 0) { r.ctl->head = 1; r.ctl->wpos = st->pos; r.ctl->head_round = 1; r.ctl->go = 0; }
+  if (threadIdx.x == 0) { r.ctl->head = 1; r.ctl->wpos = st->pos; r.ctl->head_round = 1; r.ctl->go = 0; r.ctl->wsnap = st->pos; r.ctl->csnap = 0; }
 }
 
 // Same as mt_regen_blocks, into ring slots: regenerates global blocks [g_begin, g_end) from the block held in buf[0].
@@ -557,8 +596,7 @@ __global__ __launch_bounds__(256) void ring_pre_kernel(Ring r0, Ring r1, uint32_
     head_s = head;
     go_s = go;
   }
-  // accumulated into by ring_jump_kernel
-  if (r.segb) for (int i = threadIdx.x; i < kSeg * 624; i += 256) Jst[(int64_t)blockIdx.x * kSeg * 624 + i] = 0u;
+  (void)Jst;
   __syncthreads();
   if (!go_s) return;
   const int64_t head = head_s;
@@ -568,47 +606,14 @@ __global__ __launch_bounds__(256) void ring_pre_kernel(Ring r0, Ring r1, uint32_
   ring_regen_blocks(buf, r, head, head + (r.segb ? (int64_t)kJumpBlocks : r.P));
 }
 
-// Jst[z][s][j] ^= XOR_{k in this block's slice : g_s[k]} W_z[k + j], W = block head-1 followed by the blocks behind it.
-__global__ __launch_bounds__(256) void ring_jump_kernel(Ring r0, Ring r1, const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jst) {
-  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;
-  constexpr int WIN = WPS * 64 + 64;
-  __shared__ uint32_t win[WIN];
-  __shared__ uint32_t part[4][64];
-  const int z = blockIdx.z, s = blockIdx.y + 1;
+// The jumps of a round: W = block head-1 followed by the blocks behind it (jump_core).  grid (10 * kJumpSplit, 1, 2).
+__global__ __launch_bounds__(256) void ring_jump_kernel(Ring r0, Ring r1, const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jpart) {
+  const int z = blockIdx.z;
   const Ring& r = z == 0 ? r0 : r1;
   if (r.segb == 0 || !r.ctl->go) return;
   const int64_t base = r.ctl->head_round - 1;  // global block of W's first word
-  const uint64_t* poly = polys + ((int64_t)z * (kSeg - 1) + (s - 1)) * kPolyWords;
-  const int tile = blockIdx.x % 10, slice = blockIdx.x / 10;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = tile * 64 + lane;
-  const int lo = slice * WPS * 64 + tile * 64;
-  for (int i = threadIdx.x; i < WIN; i += 256) {
-    const int idx = lo + i;
-    const int b = idx / 624;
-    win[i] = idx < 624 * (kJumpBlocks + 1) ? ring_block(r, base + b)[idx - b * 624] : 0u;
-  }
-  __syncthreads();
-  uint32_t acc = 0;
-  for (int wi = wave; wi < WPS; wi += 4) {
-    const int w = slice * WPS + wi;
-    if (w >= kPolyWords) break;
-    const uint64_t gwv = poly[w];
-    const uint32_t g[2] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gwv),
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gwv >> 32))};
-    const uint32_t* src = win + wi * 64 + lane;
-#pragma unroll
-    for (int hw = 0; hw < 2; ++hw) {
-#pragma unroll 16
-      for (int bit = 0; bit < 32; ++bit) acc ^= ((g[hw] >> bit) & 1u) ? src[32 * hw + bit] : 0u;
-    }
-  }
-  part[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && j < 624) {
-    const uint32_t v = part[0][lane] ^ part[1][lane] ^ part[2][lane] ^ part[3][lane];
-    if (v) atomicXor(&Jst[((int64_t)z * kSeg + s) * 624 + j], v);
-  }
+  jump_core([&](int idx) { const int b = idx / 624; return ring_block(r, base + b)[idx - b * 624]; }, polys + (int64_t)z * (kSeg - 1) * kPolyWords,
+            Jpart + (int64_t)z * kSeg * kJumpSplit * kJRow);
 }
 
 // grid (kSeg, 2): segment s of generator z regenerates blocks [head + s*segb, head + (s+1)*segb) of the round.
@@ -622,19 +627,28 @@ __global__ __launch_bounds__(256) void ring_seg_kernel(Ring r0, Ring r1, const u
   if (s == 0) b0 = kJumpBlocks;
   if (b0 >= b1) return;
   __builtin_amdgcn_s_setprio(3);
-  const uint32_t* src = s == 0 ? ring_block(r, head + kJumpBlocks - 1) : Jst + ((int64_t)z * kSeg + s) * 624;
-  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = src[i];
+  const uint32_t* last = ring_block(r, head + kJumpBlocks - 1);
+  for (int i = threadIdx.x; i < 624; i += 256) buf[0][i] = s == 0 ? last[i] : jump_state_word(Jst, z, s, i);
   __syncthreads();
   ring_regen_blocks(buf, r, head + b0, head + b1);
 }
 
 // np_select_kernel on ring words: tiles of 1024 words from wpos on, at most max_words of them.
+__device__ __forceinline__ void ring_snapshot(GenCtl* c_np, GenCtl* c_py, const int64_t* cursor) {
+  if (c_np) c_np->wsnap = c_np->wpos;
+  c_py->wsnap = c_py->wpos;
+  c_py->csnap = cursor ? cursor[0] : 0;
+}
+__global__ void ring_snapshot_kernel(GenCtl* c_py, const int64_t* cursor) { ring_snapshot(nullptr, c_py, cursor); }
+
 __global__ __launch_bounds__(256) void ring_select_kernel(Ring r, int64_t max_words, uint32_t rng, uint32_t mask, unsigned long long* tile_agg,
                                                            const uint32_t* __restrict__ epoch_ptr, int64_t m, int32_t* __restrict__ fs,
                                                            int32_t* __restrict__ fo, int64_t* __restrict__ consumed,
-                                                           int32_t* __restrict__ zero_p, int64_t zero_n) {
+                                                           int32_t* __restrict__ zero_p, int64_t zero_n, GenCtl* c_py,
+                                                           const int64_t* __restrict__ cursor) {
   __shared__ int wsum[4];
   __shared__ long long pre_s[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ring_snapshot(r.ctl, c_py, cursor);  // what the assembly launch reads while its last blocks advance
   for (int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; z < zero_n; z += (int64_t)gridDim.x * blockDim.x) zero_p[z] = 0;
   const unsigned long long ep = (unsigned long long)(epoch_ptr[0] + 1u);
   const int64_t w0 = r.ctl->wpos;
@@ -682,15 +696,50 @@ __device__ __forceinline__ int64_t ring_choice(const Ring& r, int64_t w0, int64_
   return (int64_t)floor(x * n);
 }
 
-// py_assemble_kernel on ring words
+// New generator state after a batch (one workgroup): wpos += words consumed; the state blob handed back to NumPy / CPython = the
+// block holding the last consumed word + the position behind it.
+__device__ __forceinline__ void ring_advance(const Ring& r, MTDev* st, int64_t c) {
+  const int64_t w1 = r.ctl->wsnap + c;  // next word to consume
+  if (c > 0) {
+    const int64_t blk = (w1 - 1) / 624;  // block holding the last consumed word
+    const uint32_t* src = ring_block(r, blk);
+    for (int i = threadIdx.x; i < 624; i += 256) st->mt[i] = src[i];
+    if (threadIdx.x == 0) st->pos = (int32_t)(w1 - blk * 624);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&r.ctl->wpos, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// py_assemble_kernel on ring words; the two workgroups behind the assembly grid advance the generators (they depend on the select
+// kernel only, like the assembly itself): the batch cursor and the batch epoch move on there.  Everything the assembly reads that
+// the advance writes (wpos, cursor) is read from the snapshot the select kernel took.
+struct AdvArgs {
+  Ring r_np; MTDev* st_np; int64_t max_np; const int64_t* consumed;  // st_np null: a range of one, NumPy draws nothing
+  MTDev* st_py; int64_t consumed_py; int64_t* cursor; uint32_t* epoch; uint32_t* err;
+};
 __global__ __launch_bounds__(256) void ring_assemble_kernel(Ring r, BatchSrc batch, int64_t B, int64_t ns, const int32_t* __restrict__ fs,
                                                              const int32_t* __restrict__ fo, int32_t* __restrict__ pos_out,
                                                              int32_t* __restrict__ neg_out, int32_t* __restrict__ cand_rows,
-                                                             int32_t* __restrict__ cand_cnt) {
+                                                             int32_t* __restrict__ cand_cnt, int nblk, AdvArgs adv) {
+  __shared__ int64_t c_s;
+  if ((int)blockIdx.x >= nblk) {
+    if ((int)blockIdx.x == nblk) {  // NumPy generator
+      if (threadIdx.x == 0) {
+        c_s = adv.st_np ? (adv.consumed[1] == (int64_t)(adv.epoch[0] + 1u) ? adv.consumed[0] : -1) : 0;  // -1: the 2m-th accepted draw was not reached
+        if (adv.st_np && c_s < 0) { atomicOr(adv.err, 2u); c_s = adv.max_np; }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) adv.epoch[0] += 1;  // this batch is done (the select kernel is the only reader)
+      if (adv.st_np) ring_advance(adv.r_np, adv.st_np, c_s);
+    } else {                        // Python generator + batch cursor
+      if (threadIdx.x == 0 && adv.cursor) adv.cursor[0] += 1;
+      ring_advance(r, adv.st_py, adv.consumed_py);
+    }
+    return;
+  }
   const int64_t m = B * ns;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * m) return;
-  const int64_t w0 = r.ctl->wpos;
+  const int64_t w0 = r.ctl->wsnap;
   if (i < m) {
     const int64_t a = ring_choice(r, w0, i, (double)B);
     if (pos_out) {
@@ -720,39 +769,6 @@ __global__ __launch_bounds__(256) void ring_assemble_kernel(Ring r, BatchSrc bat
   }
 }
 
-// Last kernel of a batch (one workgroup per generator): wpos += words consumed; the state blob handed back to NumPy / CPython =
-// the block holding the last consumed word + the position behind it; the batch cursor and the batch epoch move on.
-__global__ __launch_bounds__(256) void ring_advance_kernel(Ring r0, MTDev* st0, int64_t max_np, const int64_t* __restrict__ consumed_ptr, Ring r1,
-                                                            MTDev* st1, int64_t consumed_py, int64_t* __restrict__ cursor,
-                                                            uint32_t* __restrict__ epoch, uint32_t* __restrict__ err) {
-  __shared__ int64_t c_s;
-  const bool np = blockIdx.x == 0;
-  const Ring& r = np ? r0 : r1;
-  MTDev* st = np ? st0 : st1;
-  if (!np && threadIdx.x == 0 && cursor) cursor[0] += 1;
-  if (threadIdx.x == 0 && st) {
-    c_s = consumed_py;
-    if (np) c_s = consumed_ptr[1] == (int64_t)(epoch[0] + 1u) ? consumed_ptr[0] : -1;  // -1: the 2m-th accepted draw was not reached
-  }
-  __syncthreads();
-  if (np && threadIdx.x == 0) epoch[0] += 1;
-  if (!st) return;
-  int64_t c = c_s;
-  if (c < 0) {
-    if (threadIdx.x == 0) atomicOr(err, 2u);
-    c = max_np;
-  }
-  const int64_t w1 = r.ctl->wpos + c;  // next word to consume
-  __syncthreads();
-  if (c > 0) {
-    const int64_t blk = (w1 - 1) / 624;  // block holding the last consumed word
-    const uint32_t* src = ring_block(r, blk);
-    for (int i = threadIdx.x; i < 624; i += 256) st->mt[i] = src[i];
-    if (threadIdx.x == 0) st->pos = (int32_t)(w1 - blk * 624);
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(&r.ctl->wpos, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 struct StreamPlan {
   SamplerPlan sp;   // tile_agg / epoch / consumed / fs / fo / Jst of the workspace, K_* and segb_* of the batch shape
   Ring r_np, r_py;
@@ -760,19 +776,24 @@ struct StreamPlan {
   int64_t bytes;
 };
 
+constexpr int kStreamRound = 4;  // batches per production round
+
 static StreamPlan plan_stream(int64_t B, int64_t ns, int64_t num_e, void* buf) {
   StreamPlan q;
   q.sp = plan_sampler(B, ns, num_e, buf);
   const int64_t m = B * ns;
-  char* p = buf ? reinterpret_cast<char*>(buf) + align_up(q.sp.bytes, 256) : reinterpret_cast<char*>(align_up(q.sp.bytes, 256));
-  p = reinterpret_cast<char*>(((uintptr_t)p + 255) & ~(uintptr_t)255);
-  auto ring = [&](int64_t K, int segb, int64_t max_words) {
+  char* p = reinterpret_cast<char*>(((uintptr_t)(buf ? reinterpret_cast<char*>(buf) : (char*)nullptr) + (uintptr_t)align_up(q.sp.bytes, 256) + 255) & ~(uintptr_t)255);
+  auto ring = [&](int64_t K, int64_t max_words) {
     Ring r;
-    r.segb = segb;
-    r.P = segb ? (int64_t)kSeg * segb : std::max<int64_t>(K, 1);
+    const int64_t Kr = std::max<int64_t>(K, 1) * kStreamRound;  // blocks one round must cover
+    const int64_t sb = cdiv(Kr, kSeg);
+    r.segb = sb > kJumpBlocks ? (int32_t)sb : 0;
+    r.P = r.segb ? (int64_t)kSeg * r.segb : Kr;
     const int64_t M = std::max<int64_t>(max_words, 1);
-    r.low = 2 * M;
-    r.RB = (2 * M + 2 * r.P * 624) / 624 + 8;
+    r.low = (2 * kStreamRound + 1) * M;
+    int64_t rb = (r.low + 2 * r.P * 624) / 624 + 8, pow2 = 64;
+    while (pow2 < rb) pow2 <<= 1;
+    r.RB = pow2;
     r.ctl = reinterpret_cast<GenCtl*>(p);
     p += 256;
     r.blocks = reinterpret_cast<uint32_t*>(p);
@@ -780,13 +801,29 @@ static StreamPlan plan_stream(int64_t B, int64_t ns, int64_t num_e, void* buf) {
     return r;
   };
   q.max_np = q.sp.K_np * 624;
-  q.r_np = ring(q.sp.K_np, q.sp.segb_np, q.max_np);
-  q.r_py = ring(q.sp.K_py, q.sp.segb_py, 4 * m);
-  q.bytes = (p - reinterpret_cast<char*>(buf)) + 512;
+  q.r_np = ring(q.sp.K_np, q.max_np);
+  q.r_py = ring(q.sp.K_py, 4 * m);
+  q.bytes = (p - (buf ? reinterpret_cast<char*>(buf) : (char*)nullptr)) + 512;
   return q;
 }
 
 int64_t sampler_stream_bytes(int64_t B, int64_t ns, int64_t num_e) { return plan_stream(B, ns, num_e, nullptr).bytes + 512; }
+int sampler_stream_round() { return kStreamRound; }
+
+// Jump polynomials of the streamed form's rounds: polys_host[2][kSeg-1][312] (uint64), all zero for a generator whose rounds are
+// one sequential pass.
+int sampler_stream_plan_host(int64_t B, int64_t ns, int64_t num_e, uint64_t* polys_host) {
+  const StreamPlan q = plan_stream(B, ns, num_e, nullptr);
+  for (int z = 0; z < 2; ++z) {
+    const int segb = z == 0 ? q.r_np.segb : q.r_py.segb;
+    for (int s = 1; s < kSeg; ++s) {
+      uint64_t* out = polys_host + ((int64_t)z * (kSeg - 1) + (s - 1)) * kPolyWords;
+      if (segb == 0) { std::memset(out, 0, kPolyWords * 8); continue; }
+      if (int rc = kge_mt_jump_poly((int64_t)624 * s * segb, out)) return rc;
+    }
+  }
+  return KGE_OK;
+}
 
 int sampler_stream_init(void* buf, int64_t bytes, const void* np_state, const void* py_state, int64_t B, int64_t ns, int64_t num_e, hipStream_t st) {
   if (bytes < sampler_stream_bytes(B, ns, num_e))
@@ -809,7 +846,7 @@ int sampler_stream_produce(void* buf, int64_t bytes, int64_t B, int64_t ns, int6
   ProfScope prof(KGE_PROF_SAMPLER, st);
   hipLaunchKernelGGL(ring_pre_kernel, dim3(2), dim3(256), 0, st, q.r_np, q.r_py, q.sp.Jst);
   if (q.r_np.segb || q.r_py.segb) {
-    hipLaunchKernelGGL(ring_jump_kernel, dim3(10 * kJumpSplit, kSeg - 1, 2), dim3(256), 0, st, q.r_np, q.r_py, static_cast<const uint64_t*>(plan_dev), q.sp.Jst);
+    hipLaunchKernelGGL(ring_jump_kernel, dim3(10 * kJumpSplit, 1, 2), dim3(256), 0, st, q.r_np, q.r_py, static_cast<const uint64_t*>(plan_dev), q.sp.Jst);
     hipLaunchKernelGGL(ring_seg_kernel, dim3(kSeg, 2), dim3(256), 0, st, q.r_np, q.r_py, q.sp.Jst);
   }
   KGE_HIP_TRY(hipGetLastError());
@@ -827,19 +864,23 @@ int sampler_stream_draw(void* buf, int64_t bytes, void* np_state, void* py_state
   const uint32_t rng = (uint32_t)(num_e - 1), mask = (uint32_t)smear64(rng);
   ProfScope prof(KGE_PROF_SAMPLER, st);
   const int64_t n_cnt = cand_cnt ? KGE_CAND_POS_LANES * B + m : 0;
+  const int64_t* cur = batch ? nullptr : cursor;
   if (rng) {
     const int ntiles = (int)cdiv(q.max_np, kTileW);
     hipLaunchKernelGGL(ring_select_kernel, dim3(ntiles), dim3(256), 0, st, q.r_np, q.max_np, rng, mask, p.tile_agg, p.epoch, m, p.fs, p.fo, p.consumed,
-                       cand_cnt, n_cnt);
+                       cand_cnt, n_cnt, q.r_py.ctl, cur);
   } else {
+    hipLaunchKernelGGL(ring_snapshot_kernel, dim3(1), dim3(1), 0, st, q.r_py.ctl, cur);
     if (cand_cnt) hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(n_cnt, 256)), dim3(256), 0, st, cand_cnt, n_cnt, 0);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fs, m, 0);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((int)cdiv(m, 256)), dim3(256), 0, st, p.fo, m, 0);
   }
-  hipLaunchKernelGGL(ring_assemble_kernel, dim3((int)cdiv(2 * m, 256)), dim3(256), 0, st, q.r_py, BatchSrc{batch, kg, index, starts, cursor}, B, ns, p.fs, p.fo,
-                     pos_out, neg_out, cand_rows, cand_cnt);
-  hipLaunchKernelGGL(ring_advance_kernel, dim3(2), dim3(256), 0, st, q.r_np, rng ? static_cast<MTDev*>(np_state) : nullptr, q.max_np, p.consumed, q.r_py,
-                     static_cast<MTDev*>(py_state), 4 * m, batch ? nullptr : cursor, p.epoch, err);
+  const int nblk = (int)cdiv(2 * m, 256);
+  const AdvArgs adv{q.r_np, rng ? static_cast<MTDev*>(np_state) : nullptr, q.max_np, p.consumed, static_cast<MTDev*>(py_state), 4 * m,
+                    batch ? nullptr : cursor, p.epoch, err};
+  // (the assembly reads the cursor from the snapshot: its last workgroup moves the real one on)
+  hipLaunchKernelGGL(ring_assemble_kernel, dim3(nblk + 2), dim3(256), 0, st, q.r_py, BatchSrc{batch, kg, index, starts, batch ? nullptr : &q.r_py.ctl->csnap}, B, ns,
+                     p.fs, p.fo, pos_out, neg_out, cand_rows, cand_cnt, nblk, adv);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

@@ -201,6 +201,8 @@ class TrainPipeline:
         d.sampler_ws, d.sampler_ws_bytes, d.sampler_err = sa._ws.data_ptr(), sa._ws.numel(), sa.err.data_ptr()
         ring = sa.stream_buffer(self.B, self.ns, self.num_e)  # word rings of the two generators, filled one batch ahead
         d.sampler_stream, d.sampler_stream_bytes = ring.data_ptr(), ring.numel()
+        splan = sa.stream_plan(self.B, self.ns, self.num_e)
+        d.sampler_stream_plan = splan.data_ptr() if splan is not None else None
         for j in (0, 1):
             d.cand_rows[j], d.cand_counts[j] = self.cand[j][0].data_ptr(), self.cand[j][1].data_ptr()
             d.plan[j] = self.plans[j].buf.data_ptr()
@@ -217,6 +219,20 @@ class TrainPipeline:
         _lib.check(_lib.lib.kge_pipeline_stats(self._h, out, 1 if reset else 0))
         return dict(run_ms=out[0], wait_prev_launch_ms=out[1], graph_launch_ms=out[2], graph_launches=int(out[3]), launches_that_waited=int(out[4]),
                     wait_by_stage_ms=dict(draw=out[5], plan=out[6], step=out[7]))
+
+    def trace(self, n=0):
+        """Stage timeline of the native driver (kge_pipeline_trace): trace(n) arms timing events around the next n stage launches,
+        trace() reads them back as rows (stage name, batch, begin us, end us)."""
+        if self._h is None:
+            return []
+        if n > 0:
+            _lib.check(_lib.lib.kge_pipeline_trace(self._h, int(n), None, 0))
+            return []
+        cap = 4096
+        out = (_lib.C.c_double * (4 * cap))()
+        k = int(_lib.check(_lib.lib.kge_pipeline_trace(self._h, 0, out, cap)))
+        names = ("rounds", "draw", "plan", "step")
+        return [(names[int(out[4 * i])], int(out[4 * i + 1]), out[4 * i + 2] * 1e3, out[4 * i + 3] * 1e3) for i in range(k)]
 
     def close(self):
         """Release the native driver (graphs, streams, events); the next start() captures again."""

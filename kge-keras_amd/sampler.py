@@ -174,12 +174,24 @@ class DeviceSampler:
         check(lib.kge_sampler_stream_init(buf.data_ptr(), buf.numel(), self.np_state.data_ptr(), self.py_state.data_ptr(), int(B), int(ns), int(num_e),
                                           _lib.stream_ptr()))
 
+    def stream_plan(self, B, ns, num_e):
+        """Jump polynomials of the streamed form's production rounds for this batch shape, on the device (None: sequential rounds)."""
+        import torch
+        if not self.segmented:
+            return None
+        key = ("stream", int(B), int(ns), int(num_e))
+        if key not in self._plans:
+            buf = np.empty(int(lib.kge_sampler_plan_bytes()) // 8, dtype=np.uint64)
+            check(lib.kge_sampler_stream_plan_host(int(B), int(ns), int(num_e), buf.ctypes.data))
+            self._plans[key] = torch.from_numpy(buf.view(np.int64)).to(self.device)
+        return self._plans[key]
+
     def stream_produce(self, B, ns, num_e):
-        """One production round on the current stream (skipped on the device while enough words lie ahead)."""
+        """One production round on the current stream (kge_sampler_stream_round() batches' worth of words; skipped on the device
+        while enough words lie ahead)."""
         from . import _lib
         buf = self.stream_buffer(B, ns, num_e)
-        self.prepare(B, ns, num_e)
-        plan = self._plans.get((int(B), int(ns), int(num_e))) if self.segmented else None
+        plan = self.stream_plan(B, ns, num_e)
         check(lib.kge_sampler_stream_produce(buf.data_ptr(), buf.numel(), int(B), int(ns), int(num_e), plan.data_ptr() if plan is not None else None,
                                              _lib.stream_ptr()))
 
