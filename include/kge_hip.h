@@ -39,7 +39,11 @@ typedef enum {
 } kge_status;
 
 /* KGEkeras.models.* classes on the path (models.py:164-237). */
-typedef enum { KGE_DISTMULT = 0, KGE_TRANSE = 1, KGE_COMPLEX = 2, KGE_HOLE = 3, KGE_CONVE = 4 } kge_model;
+typedef enum { KGE_DISTMULT = 0, KGE_TRANSE = 1, KGE_COMPLEX = 2, KGE_HOLE = 3, KGE_CONVE = 4,
+               KGE_ROTATE = 5 /* models.py:421-459 exactly as written: entity rows [re | im] of 2d floats, relation rows d phases;
+                               * score = gamma - S if gamma > 0 else S, S = sum_k (re_s cos p - im_s sin p - re_o) + (re_s sin p + im_s cos p - im_o)
+                               * (the signed sum: `norm` is never applied there).  d_e == 2 * d_r.  Training runs on the push path. */
+} kge_model;
 
 /* KGEkeras.utils.loss_function_lookup names (utils.py:321-330). */
 typedef enum {

@@ -18,7 +18,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 KGE_OK, KGE_EINVAL, KGE_ESHAPE, KGE_EHIP, KGE_EWORKSPACE, KGE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4}
+MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4, "RotatE": 5}
 LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, "pairwize_logistic": 3,
             "pointwize_square_loss": 4, "pairwize_square_loss": 5, "pointwize_cross_entropy": 6}
 OPT_IDS = {"sgd": 0, "adam": 1}

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "kge_internal.hpp"
+#include "pull.hpp"
 
 namespace kge {
 
@@ -28,11 +29,13 @@ static inline void clear_stale_error() { (void)hipGetLastError(); }
 int check_model(const kge_model_desc* md, const char* who) {
   clear_stale_error();
   if (!md) return fail(KGE_EINVAL, "%s: model descriptor is null", who);
-  if (md->model < KGE_DISTMULT || md->model > KGE_CONVE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
+  if (md->model < KGE_DISTMULT || md->model > KGE_ROTATE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
   if (md->num_entities <= 0 || md->num_relations <= 0 || md->d_e <= 0 || md->d_r <= 0)
     return fail(KGE_EINVAL, "%s: non-positive table shape (%d,%d) (%d,%d)", who, md->num_entities, md->d_e, md->num_relations, md->d_r);
   // s*p*o, s+p-o and the ComplEx products broadcast row-against-row: TensorFlow rejects unequal widths
-  if (md->d_e != md->d_r) return fail(KGE_ESHAPE, "%s: e_dim %d and r_dim %d do not broadcast", who, md->d_e, md->d_r);
+  if (md->model == KGE_ROTATE) {  // rotation phases: one per complex component (models.py:428-429: e_dim doubled, r_dim not)
+    if (md->d_e != 2 * md->d_r) return fail(KGE_ESHAPE, "%s: RotatE needs e_dim %d == 2 * r_dim %d (tf.split halves against the phase row)", who, md->d_e, md->d_r);
+  } else if (md->d_e != md->d_r) return fail(KGE_ESHAPE, "%s: e_dim %d and r_dim %d do not broadcast", who, md->d_e, md->d_r);
   if (md->model == KGE_COMPLEX && (md->d_e & 1)) return fail(KGE_ESHAPE, "%s: ComplEx rows must split in two halves (tf.split), width %d", who, md->d_e);
   if (md->model == KGE_TRANSE && md->norm != 1 && md->norm != 2 && md->norm != 3)
     return fail(KGE_EUNSUPPORTED, "%s: TransE norm %d (1, 2 and the pRotatE phase distance 3 are built)", who, md->norm);
@@ -147,9 +150,9 @@ int64_t batch_plan_bytes(const kge_model_desc*, int64_t);
 int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int, int64_t, int64_t, void*,
                      int, uint32_t*, hipStream_t);
 int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, void*, int64_t, int64_t, float*,
-                          uint64_t, void*, int64_t, hipStream_t, const kge_opt_desc* advance = nullptr);
+                          uint64_t, void*, int64_t, hipStream_t, const kge_opt_desc* advance = nullptr, OptFinish* finish = nullptr);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
-              int64_t, hipStream_t, bool advanced = false);
+              int64_t, hipStream_t, bool advanced = false, const OptFinish* finish = nullptr);
 
 int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
 int loss_pairs(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, int64_t, hipStream_t);
@@ -374,9 +377,11 @@ int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, co
   // device-resident step state and no L3 term: the gradient half's closing kernel advances the state, the step ends with the sweep
   const bool fused = od->step_dev && ld->regularization == 0.f;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (int rc = train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, st, fused ? od : nullptr))
+  // and the optimizer sweep closes the gradient half itself (OptFinish): no finish kernel between the pull and the sweep
+  OptFinish fin;
+  if (int rc = train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, st, fused ? od : nullptr, &fin))
     return rc;
-  return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, st, fused);
+  return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, st, fused, &fin);
 }
 
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries) {

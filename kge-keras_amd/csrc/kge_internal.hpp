@@ -104,6 +104,10 @@ __device__ __forceinline__ void step_advance(const StepAdvance& a, float loss) {
   f[1] += loss;
 }
 
+// One extra workgroup of the pull launch reduces the forward's loss partials (fixed order) and advances the step state, when the
+// step has no finish kernel to do it (OptFinish, pull.hpp).
+struct LossFinish { const float* partials; int n; float* loss_out; StepAdvance adv; };
+
 // Block-wide sum of one float per thread (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
 __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats */) {
   v = group_sum<64>(v);

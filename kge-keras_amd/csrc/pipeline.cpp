@@ -230,9 +230,17 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
     hipError_t e__ = (expr);                                                                                                    \
     if (e__ != hipSuccess) return bail(fail(KGE_EHIP, "%s: %s", #expr, hipGetErrorString(e__)));                                \
   } while (0)
-  KGE_CREATE_TRY(hipStreamCreateWithFlags(&p->s_gen, hipStreamNonBlocking));
-  KGE_CREATE_TRY(hipStreamCreateWithFlags(&p->s_draw, hipStreamNonBlocking));
-  KGE_CREATE_TRY(hipStreamCreateWithFlags(&p->s_plan, hipStreamNonBlocking));
+  {
+    // the producer stages run below the training stream's priority: the step is the critical chain, everything else has a batch
+    // or more of slack (KGE_PIPE_PRIO=0: all streams at the default priority)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
+    const char* e = std::getenv("KGE_PIPE_PRIO");
+    const int prio = (e && std::atoi(e) == 0) ? 0 : lo;
+    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_gen, hipStreamNonBlocking, prio));
+    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_draw, hipStreamNonBlocking, prio));
+    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_plan, hipStreamNonBlocking, prio));
+  }
   KGE_CREATE_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
   for (int j = 0; j < 2; ++j) {
     for (hipEvent_t* e : {&p->gen[j], &p->ready[j], &p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));

@@ -276,7 +276,15 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
                                                     const int32_t* __restrict__ eoff, const int32_t* __restrict__ poff,
                                                     const int32_t* __restrict__ totals, const int2* __restrict__ emap,
                                                     const int4* __restrict__ entries, float* __restrict__ slab, int C,
-                                                    uint64_t seed, uint32_t thr, float dscale) {
+                                                    uint64_t seed, uint32_t thr, float dscale, const float* __restrict__ coef_of_row, LossFinish lf) {
+  if (lf.partials && blockIdx.x == gridDim.x - 1) {  // (launched with one workgroup more than the units need)
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < lf.n; i += 256) s += lf.partials[i];
+    const float b = block_sum(s, red);
+    if (threadIdx.x == 0) { lf.loss_out[0] = b; step_advance(lf.adv, b); }
+    return;
+  }
   using T = typename V<VEC>::T;
   using L = V<VEC>;
   using D = DM<VEC>;
@@ -315,7 +323,8 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
 #pragma unroll 2
   for (int i = sub; i < len; i += NSUB) {
     const int4 e = entries[start + i];
-    const float cf = __int_as_float(e.z);
+    // the coefficient rides in the entry (lists filled after the forward), or is looked up by row number (lists built ahead, ids only)
+    const float cf = coef_of_row ? coef_of_row[e.w] : __int_as_float(e.z);
     if (cf == 0.f) continue;  // inactive hinge rows carry no gradient
     const int kind1 = is_rel ? 0 : ((unsigned)e.x >> 31);
     const float* ra = is_rel ? E + (int64_t)e.x * d_e : Rel + (int64_t)(e.x & 0x7fffffff) * d_e;
@@ -480,13 +489,16 @@ static void launch_fwd_loss(int loss, int G, int grid, hipStream_t st, const flo
 
 template <int MODEL, int NORM, int VEC>
 static void launch_pull(int nchunk, int grid, hipStream_t st, const float* E, const float* Rel, float* gE, float* gR,
-                        const kge_model_desc* md, const PullPlan& p, uint64_t seed, int nk_override = -1) {
+                        const kge_model_desc* md, const PullPlan& p, uint64_t seed, int nk_override = -1, const float* coef_of_row = nullptr,
+                        const LossFinish* lfp = nullptr) {
+  const LossFinish lf = lfp ? *lfp : LossFinish{nullptr, 0, nullptr, StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}};
+  if (lfp) grid += 1;
   const int N = md->num_entities, NK = nk_override >= 0 ? nk_override : N + md->num_relations;
   const bool drop = md->dropout > 0.f;
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
 #define KGE_PULL1(GW, NVV, DR) hipLaunchKernelGGL((pull_kernel<MODEL, NORM, GW, NVV, VEC, DR>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, N, NK, md->d_e, \
-                                                  nchunk, p.cnt, p.off, p.eoff, p.poff, p.totals, p.emap, p.entries, p.slab, p.chunk, seed, thr, dscale)
+                                                  nchunk, p.cnt, p.off, p.eoff, p.poff, p.totals, p.emap, p.entries, p.slab, p.chunk, seed, thr, dscale, coef_of_row, lf)
 #define KGE_PULL(GW, NVV) do { if (drop) KGE_PULL1(GW, NVV, true); else KGE_PULL1(GW, NVV, false); } while (0)
   // 16-lane sub-groups: four list entries of a row in flight per wave (measured at d=200: 114.6 us vs 149.7 us with one
   // 64-lane group on lists of ~56 entries, 49.0 vs 53.7 us on lists of ~18)
@@ -610,17 +622,17 @@ void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st) {
 
 // (the finish of the entity keys is fused into pull2.hip's rel_finish_kernel)
 int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const PullPlan& e, uint64_t seed,
-                      hipStream_t st) {
+                      hipStream_t st, const LossFinish* lf) {
   const int N = md->num_entities;
   const Shape sh = shape_of(md, E, Rel, gE, gR);
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
     const int pgrid = (int)cdiv(N + e.max_extra, 4);
-    if (md->model == KGE_DISTMULT) launch_pull<KGE_DISTMULT, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
-    else if (md->model == KGE_COMPLEX) launch_pull<KGE_COMPLEX, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
-    else if (md->norm == 1) launch_pull<KGE_TRANSE, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
-    else if (md->norm == 3) launch_pull<KGE_TRANSE, 3, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
-    else launch_pull<KGE_TRANSE, 2, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N);
+    if (md->model == KGE_DISTMULT) launch_pull<KGE_DISTMULT, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N, e.coef, lf);
+    else if (md->model == KGE_COMPLEX) launch_pull<KGE_COMPLEX, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N, e.coef, lf);
+    else if (md->norm == 1) launch_pull<KGE_TRANSE, 1, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N, e.coef, lf);
+    else if (md->norm == 3) launch_pull<KGE_TRANSE, 3, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N, e.coef, lf);
+    else launch_pull<KGE_TRANSE, 2, 4>(sh.nchunk, pgrid, st, E, Rel, gE, gR, md, e, seed, N, e.coef, lf);
   }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;

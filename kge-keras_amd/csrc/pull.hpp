@@ -8,6 +8,32 @@
 
 namespace kge {
 
+// rows per forward work unit of the relation-grouped path (pull2.hip): 32, or 128 for a relation with more than 4096 rows in the batch,
+// so that a dominant relation (real graphs: the top relation of FB15k-237 carries 16 % of the triples) leaves a few hundred partial
+// gradient rows to sum, not thousands
+constexpr int kRelChunk = 32;
+__host__ __device__ __forceinline__ int rel_chunk_rows(int c) { return c > 4096 ? 4 * kRelChunk : kRelChunk; }
+__host__ __device__ __forceinline__ int rel_units(int c) { const int ch = rel_chunk_rows(c); return (c + ch - 1) / ch; }
+
+// A whole step in one library call on the relation-grouped path: the optimizer sweep closes the gradient half itself instead of
+// reading finished gradient tables -- a hub entity row (more than C list entries) is the sum of its slab rows, every relation row
+// the sum of its units' partial rows -- and leaves the plan's counters zero; the loss partials are reduced (and the step state
+// advanced) by one extra workgroup of the pull launch.  That takes the finish kernel (10 us + a launch) off the step's chain.
+struct OptFinish {
+  const int32_t* eoff;     // [N] starts of the entity lists (length of row r: eoff[r+1] - eoff[r]; last row: etotals[2] - eoff[N-1])
+  const int32_t* etotals;
+  const int32_t* epoff;    // [N] first slab slot of a hub row
+  const float* eslab;
+  int32_t* ecnt;           // [N] zeroed here
+  int C, N;
+  const int32_t* roff;     // [R] starts of the relation lists (last row: rtotal[1] - roff[R-1])
+  const int32_t* rtotal;
+  const int32_t* ruoff;    // [R] first unit of the relation
+  const float* rslab;
+  int32_t* rcnt;           // [R] zeroed here
+  int R;
+};
+
 struct PullPlan {
   int32_t* cnt;     // [NK]   contributions per key (key = entity id, or N + relation id)
   int32_t* off;     // [NK]   list start
@@ -140,7 +166,7 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
 struct StepAdvance;  // kge_internal.hpp
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
-                        hipStream_t st, const StepAdvance& adv);
+                        hipStream_t st, const StepAdvance& adv, OptFinish* finish);
 
 // HolE (hole.hip)
 int hole_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,

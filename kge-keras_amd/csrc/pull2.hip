@@ -31,11 +31,6 @@
 namespace kge {
 
 constexpr int kRelMax = 4096;   // relations handled by the LDS histogram / single-workgroup plan
-constexpr int kRelChunk = 32;   // rows per forward work unit ...
-// ... of a relation with up to 4096 rows in the batch; 128 above that, so that a dominant relation (real graphs: the top
-// relation of FB15k-237 carries 16 % of the triples) leaves a few hundred partial gradient rows to sum, not thousands
-__host__ __device__ __forceinline__ int rel_chunk_rows(int c) { return c > 4096 ? 4 * kRelChunk : kRelChunk; }
-__host__ __device__ __forceinline__ int rel_units(int c) { const int ch = rel_chunk_rows(c); return (c + ch - 1) / ch; }
 
 struct Dedup {
   unsigned long long* keys;  // [cap]  0 = empty, else key + 1
@@ -198,7 +193,7 @@ __device__ __forceinline__ void rel_plan_body(const int32_t* __restrict__ rcnt, 
     for (int j = 0; j < nch; ++j) if (rb + j < max_units) rumap[rb + j] = make_int2(k, j);
     ra += c; rb += nch;
   }
-  if (tid == 255) rtotal[0] = rb;
+  if (tid == 255) { rtotal[0] = rb; rtotal[1] = ra; }  // units, list entries
 }
 
 __global__ __launch_bounds__(256) void rel_plan_kernel(const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
@@ -345,7 +340,9 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(HistSrc hs, int64_t n, i
   }
 }
 
-__global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const float* __restrict__ coef, const int32_t* __restrict__ off,
+// Entity lists: entry {relation | role bit, other entity, 0, row} at off[destination] + rank.  Ids only -- part of the plan; the
+// coefficient of a row (dL/dscore, known after the forward) is looked up by pull_kernel through the row number.
+__global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const int32_t* __restrict__ off,
                                                         const int32_t* __restrict__ erank, int4* __restrict__ entries) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= src_rows(src)) return;
@@ -353,7 +350,7 @@ __global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const
   if (r0 < 0) return;
   int s, p, o, w;
   src_load(src, t, s, p, o, w);
-  const int cb = __float_as_int(coef[t]);
+  const int cb = 0;
   entries[off[s] + r0] = make_int4(p, o, cb, (int)t);
   entries[off[o] + erank[n + t]] = make_int4(p | (int)0x80000000, s, cb, (int)t);
 }
@@ -606,11 +603,11 @@ static Sizes sizes_of(const kge_model_desc* md, int64_t n) {
 static int64_t counters_bytes(const Sizes& z) { return b256(z.N * 4) + b256(z.R * 4); }
 static int64_t plan_bytes(const Sizes& z) {
   return b256(z.R * 4) * 2 + 256 + b256(z.max_units * 8) + b256(z.n * 4) + b256(z.n * 16) +                 // relation side
-         b256(z.N * 4) * 3 + 256 + b256(z.max_extra * 8) + b256(2 * z.n * 4) +                               // entity side
+         b256(z.N * 4) * 3 + 256 + b256(z.max_extra * 8) + b256(2 * z.n * 4) + b256(2 * z.n * 16) +          // entity side (incl. list entries)
          b256(z.cap * 8) + b256(z.cap * 4) + 256 + b256(z.cap * 4) + b256(z.n * 4) * 2 + b256((z.n / 256 + 1) * 4) + b256(z.n * 16) + 512;
 }
 static int64_t scratch_bytes(const Sizes& z, int d_e) {
-  return b256(z.max_units * d_e * 4) + b256(2 * z.n * 16) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + 512;
+  return b256(z.max_units * d_e * 4) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + 512;
 }
 
 int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n) {
@@ -650,6 +647,7 @@ static void carve_plan(void* counters, void* region, const kge_model_desc* md, i
   p->ent.totals = (int32_t*)take(16);
   p->ent.emap = (int2*)take(z.max_extra * 8);
   p->erank = (int32_t*)take(2 * n * 4);
+  p->ent.entries = (int4*)take(2 * n * 16);
   p->ent.ranks = p->erank;
   p->ent.max_extra = (int)z.max_extra;
   p->ent.chunk = z.C;
@@ -660,7 +658,6 @@ static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Pla
   char* q = reinterpret_cast<char*>(((uintptr_t)region + 255) & ~(uintptr_t)255);
   auto take = [&](int64_t bytes) { char* r = q; q += b256(bytes); return r; };
   p->rslab = (float*)take(z.max_units * md->d_e * 4);
-  p->ent.entries = (int4*)take(2 * n * 16);
   p->ent.coef = (float*)take(n * 4);
   p->ent.slab = (float*)take(2 * z.max_extra * md->d_e * 4);
   p->dd.uscore = (float*)take(n * 4);
@@ -669,7 +666,7 @@ static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Pla
 // kernels of pull.hip reused on the entity keys
 void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st);
 int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const PullPlan& e, uint64_t seed,
-                      hipStream_t st);
+                      hipStream_t st, const LossFinish* lf);
 
 template <int MODEL, int NORM, int LOSS>
 static void launch_fwd_rel(int nv, bool drop, int grid, hipStream_t st, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
@@ -754,6 +751,7 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
     else if (parts & 2) pull2_entity_plan(p.ent, N, st);
     else hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
     if (parts & 4) hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
+    if (parts & 2) hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.off, p.erank, p.ent.entries);
   }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
@@ -762,10 +760,8 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
 // ---- step: everything that depends on the parameters.  Consumes the plan (the finish kernels leave its counters zero).
 static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, int64_t m_pos,
                      int64_t m_neg, const Plan2& p, const Src& src, float* fwd_scores, float* loss_partials, int* n_partials, float* loss_out,
-                     uint64_t seed, hipStream_t st, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}) {
-  const int64_t n = m_pos + m_neg;
+                     uint64_t seed, hipStream_t st, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}, OptFinish* finish = nullptr) {
   const int R = md->num_relations;
-  const int tgrid = (int)cdiv(n, 256);
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const int nchunk = width / 4;
   const bool drop = md->dropout > 0.f;
@@ -780,8 +776,17 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     else if (md->norm == 3) launch_fwd_rel_loss<KGE_TRANSE, 3>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
     else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
   }
-  hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.coef, p.ent.off, p.erank, p.ent.entries);
-  if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st)) return rc;
+  if (finish) {
+    // a whole step in one call: no finish kernel.  The pull launch carries one extra workgroup for the loss (and the step state);
+    // the optimizer sweep that follows sums the slab rows and leaves the counters zero (OptFinish, pull.hpp).
+    const LossFinish lf{loss_partials, *n_partials, loss_out, adv};
+    if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st, &lf)) return rc;
+    *finish = OptFinish{p.ent.off, p.ent.totals, p.ent.poff, p.ent.slab, p.ent.cnt, p.ent.chunk, md->num_entities,
+                        p.roff, p.rtotal, p.ruoff, p.rslab, p.rcnt, R};
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
+  }
+  if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st, nullptr)) return rc;
   const int eb = (int)cdiv(md->num_entities, 4);
   hipLaunchKernelGGL(rel_finish_kernel, dim3(eb + R + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
                      *n_partials, loss_out, eb, gE, md->num_entities, p.ent.cnt, p.ent.poff, p.ent.slab, p.ent.chunk, adv);
@@ -838,13 +843,13 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
 
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
-                        hipStream_t st, const StepAdvance& adv) {
+                        hipStream_t st, const StepAdvance& adv, OptFinish* finish) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
   carve_plan_buffer(plan, md, n, &p);
   carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
   const Src src{nullptr, m_pos, nullptr, m_neg, p.dd.uniq, p.dd.nu};
-  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv);
+  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv, finish);
 }
 
 }  // namespace kge

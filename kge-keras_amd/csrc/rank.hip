@@ -67,11 +67,14 @@ __device__ __forceinline__ float chain_dot(const float* __restrict__ q, const fl
 }
 
 // side 0 = tail queries (s,p,?) ; side 1 = head queries (?,p,o)
+// RotatE (models.py:439-459) is linear in s and in o, so a 1-vs-all query is a dot product too: the order of the candidates by
+// score is their order by <q, e_c>, with  tails: q = +-1 (score = const + sum of the candidate's row; the reference's score ranks all
+// tails of every query by their row sums),  heads: q = -+[cos p + sin p | cos p - sin p]; sign by gamma (gamma - S / S).
 template <int MODEL>
 __global__ __launch_bounds__(256) void rank_build_q_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                             const int32_t* __restrict__ triples, int64_t nq, int side, int N,
                                                             int R, int d_e, int Kpad, float* __restrict__ Qv,
-                                                            uint32_t* __restrict__ err) {
+                                                            uint32_t* __restrict__ err, float gamma = 0.f) {
   constexpr int G = 64;
   const int lane = threadIdx.x & (G - 1);
   const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -80,10 +83,25 @@ __global__ __launch_bounds__(256) void rank_build_q_kernel(const float* __restri
   const int ent = side == 0 ? s : o;
   const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
   const float* er = E + (int64_t)(ok ? ent : 0) * d_e;
-  const float* rp = Rel + (int64_t)(ok ? p : 0) * d_e;
+  const float* rp = Rel + (int64_t)(ok ? p : 0) * (MODEL == KGE_ROTATE ? d_e >> 1 : d_e);
   float* out = Qv + q * Kpad;
   if (!ok && lane == 0) atomicOr(err, 1u);
-  if (MODEL == KGE_DISTMULT) {
+  if (MODEL == KGE_ROTATE) {
+    const int h = d_e >> 1;
+    const float sg = gamma > 0.f ? 1.f : -1.f;
+    for (int k = lane; k < Kpad; k += G) {
+      float v = 0.f;
+      if (ok && k < d_e) {
+        if (side == 0) v = sg;
+        else {
+          float sn, c;
+          sincosf(rp[k < h ? k : k - h], &sn, &c);
+          v = -sg * (k < h ? c + sn : c - sn);
+        }
+      }
+      out[k] = v;
+    }
+  } else if (MODEL == KGE_DISTMULT) {
     for (int k = lane; k < Kpad; k += G) out[k] = (ok && k < d_e) ? er[k] * rp[k] : 0.f;
   } else if (MODEL == KGE_TRANSE) {
     // ||s+p-o||: tail candidates o against q = s+p ; head candidates s against q = o-p  (|q-e| = |e-q|)
@@ -831,11 +849,13 @@ static void launch_build_q(const kge_model_desc* md, const float* E, const float
   const int grid = (int)cdiv(nq * 64, 256);
   const int K = md->d_e;
   if (md->model == KGE_DISTMULT)
-    hipLaunchKernelGGL((rank_build_q_kernel<KGE_DISTMULT>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_DISTMULT>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err, 0.f);
   else if (md->model == KGE_TRANSE)
-    hipLaunchKernelGGL((rank_build_q_kernel<KGE_TRANSE>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_TRANSE>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err, 0.f);
+  else if (md->model == KGE_ROTATE)
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_ROTATE>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err, md->gamma);
   else
-    hipLaunchKernelGGL((rank_build_q_kernel<KGE_COMPLEX>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err);
+    hipLaunchKernelGGL((rank_build_q_kernel<KGE_COMPLEX>), dim3(grid), dim3(256), 0, st, E, Rel, triples, nq, side, md->num_entities, md->num_relations, K, Kpad, Qv, err, 0.f);
 }
 
 template <int NORM>

@@ -49,7 +49,18 @@ __device__ __forceinline__ float cx1(float4 sr, float4 si, float4 pr, float4 pi,
          cx1(sr.z, si.z, pr.z, pi.z, orr.z, oi.z) + cx1(sr.w, si.w, pr.w, pi.w, orr.w, oi.w);
 }
 
-// nchunk: chunks (of VEC floats) per row for DistMult/TransE, per HALF row for ComplEx.
+// RotatE as written (models.py:439-459): (re_s cos p - im_s sin p - re_o) + (re_s sin p + im_s cos p - im_o), summed with its signs.
+// The reference wraps the phase first (atan2(sin p, cos p)); cos / sin of the wrapped phase are cos p / sin p.
+__device__ __forceinline__ float rt1(float sr, float si, float ph, float orr, float oi) {
+  float sn, c;
+  sincosf(ph, &sn, &c);
+  return (sr * c - si * sn - orr) + (sr * sn + si * c - oi);
+}
+__device__ __forceinline__ float rt1(float4 sr, float4 si, float4 ph, float4 orr, float4 oi) {
+  return rt1(sr.x, si.x, ph.x, orr.x, oi.x) + rt1(sr.y, si.y, ph.y, orr.y, oi.y) + rt1(sr.z, si.z, ph.z, orr.z, oi.z) + rt1(sr.w, si.w, ph.w, orr.w, oi.w);
+}
+
+// nchunk: chunks (of VEC floats) per row for DistMult/TransE, per HALF row for ComplEx and RotatE.
 template <int MODEL, int NORM, int G, int VEC>
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                      const int32_t* __restrict__ triples, int64_t n, int N, int R,
@@ -76,6 +87,11 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ E,
           auto orr = C::ld(eo + c * VEC), oi = C::ld(eo + h + c * VEC);
           acc += cx1(sr, si, pr, pi, orr, oi);
         }
+      } else if (MODEL == KGE_ROTATE) {
+        const int h = d_e >> 1;
+#pragma unroll 2
+        for (int c = lane; c < nchunk; c += G)
+          acc += rt1(C::ld(es + c * VEC), C::ld(es + h + c * VEC), C::ld(rp + c * VEC), C::ld(eo + c * VEC), C::ld(eo + h + c * VEC));
       } else {
 #pragma unroll 4
         for (int c = lane; c < nchunk; c += G) {
@@ -92,6 +108,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ E,
         if (NORM == 3) sc *= modulus;
         sc = gamma > 0.f ? gamma - sc : sc;  // models.py:187-190, 486-489
       }
+      if (MODEL == KGE_ROTATE) sc = gamma > 0.f ? gamma - sc : sc;  // models.py:455-458
       if (!ok) {
         sc = __builtin_nanf("");
         atomicOr(err, 1u);
@@ -129,7 +146,7 @@ int score_group_width(int nchunk);  // tuning.cpp
 
 int score_dispatch(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n,
                    float* out, uint32_t* err, hipStream_t st) {
-  const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
+  const int width = (md->model == KGE_COMPLEX || md->model == KGE_ROTATE) ? md->d_e / 2 : md->d_e;
   const bool v4 = (width % 4 == 0) && (md->d_e % 4 == 0) && (((uintptr_t)E | (uintptr_t)Rel) % 16 == 0);
   const int nchunk = v4 ? width / 4 : width;
   const int G = score_group_width(nchunk);
@@ -143,6 +160,7 @@ int score_dispatch(const kge_model_desc* md, const float* E, const float* Rel, c
       if (md->norm == 3) { KGE_GO(KGE_TRANSE, 3); }
       KGE_GO(KGE_TRANSE, 2);
     case KGE_COMPLEX: KGE_GO(KGE_COMPLEX, 1);
+    case KGE_ROTATE: KGE_GO(KGE_ROTATE, 1);
     case KGE_HOLE:
       return hole_forward(md, -1, 0.f, E, Rel, triples, n, nullptr, 0, nullptr, out, nullptr, nullptr, err, 0, false, st);
     default: return fail(KGE_EUNSUPPORTED, "kge_score: model %d has no HIP scoring kernel yet", md->model);

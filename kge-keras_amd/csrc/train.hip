@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
   const int64_t group = (int64_t)(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
   const int64_t ngroups = (int64_t)gridDim.x * blockDim.x / G;
   const int64_t n = m_pos + m_neg;
-  const int h = d_e >> 1;                               // ComplEx half width
-  const int width = MODEL == KGE_COMPLEX ? h : d_e;     // elements each lane strides over
+  const int h = d_e >> 1;                               // ComplEx / RotatE half width
+  const int width = (MODEL == KGE_COMPLEX || MODEL == KGE_ROTATE) ? h : d_e;  // elements each lane strides over
   const float inv_pos = 1.f / (float)m_pos, inv_neg = 1.f / (float)m_neg;
   float lsum = 0.f;
   for (int64_t t = group; t < n; t += ngroups) {
@@ -58,6 +58,11 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
         const float sr = es[k] * ms(k), si = es[h + k] * ms(h + k), pr = rp[k] * mp(k), pi = rp[h + k] * mp(h + k),
                     orr = eo[k] * mo(k), oi = eo[h + k] * mo(h + k);
         acc += sr * pr * orr + pr * si * oi + pi * sr * oi - pi * si * orr;
+      } else if (MODEL == KGE_ROTATE) {  // models.py:439-453
+        const float sr = es[k] * ms(k), si = es[h + k] * ms(h + k), orr = eo[k] * mo(k), oi = eo[h + k] * mo(h + k);
+        float sn, c;
+        sincosf(rp[k] * mp(k), &sn, &c);
+        acc += (sr * c - si * sn - orr) + (sr * sn + si * c - oi);
       } else {
         const float sv = es[k] * ms(k), pv = rp[k] * mp(k), ov = eo[k] * mo(k);
         if (MODEL == KGE_DISTMULT) acc += sv * pv * ov;
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
       if (NORM == 3) dist = modulus * acc;
       score = gamma > 0.f ? gamma - dist : dist;
     }
+    if (MODEL == KGE_ROTATE) score = gamma > 0.f ? gamma - acc : acc;
     float g, l = 0.f;
     if (LOSS >= 0) pointwise_term<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
     else g = gbuf[t];
@@ -96,6 +102,20 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
         atomicAdd(gs + k, dx * a);
         atomicAdd(gp + k, dx * b);
         atomicAdd(go + k, -dx * c);
+      }
+    } else if (MODEL == KGE_ROTATE) {
+      // linear in s and o: d/ds = [cos + sin | cos - sin], d/do = -1, d/dp = re_s (cos - sin) - im_s (cos + sin)  (d atan2(sin p, cos p)/dp = 1)
+      const float gg = gamma > 0.f ? -g : g;
+      for (int k = lane; k < width; k += G) {
+        const float asr = ms(k), asi = ms(h + k), ap = mp(k), aor = mo(k), aoi = mo(h + k);
+        const float sr = es[k] * asr, si = es[h + k] * asi;
+        float sn, c;
+        sincosf(rp[k] * ap, &sn, &c);
+        atomicAdd(gs + k, gg * (c + sn) * asr);
+        atomicAdd(gs + h + k, gg * (c - sn) * asi);
+        atomicAdd(gp + k, gg * (sr * (c - sn) - si * (c + sn)) * ap);
+        atomicAdd(go + k, -gg * aor);
+        atomicAdd(go + h + k, -gg * aoi);
       }
     } else if (MODEL == KGE_DISTMULT) {
       for (int k = lane; k < width; k += G) {
@@ -217,10 +237,39 @@ __global__ __launch_bounds__(256) void pairwise_finish_kernel(const float* __res
 // ---- optimizer sweeps (dense over the whole table, as Keras does for IndexedSlices + 'adam'; for 'sgd' the dense
 // sweep equals the sparse scatter because untouched rows have g == 0 exactly).  Also re-zeroes the accumulator and,
 // when the L3 regulariser is on (models.py:10-11), adds 3w*x*|x| to the gradient and reduces sum|x|^3 for the loss.
-template <int KIND, bool REG>
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// The rest of the gradient of float4 element i of a table whose rows are d4 float4s wide, for a step whose finish kernel was left
+// out (OptFinish, pull.hpp): SEG 0 = entity table (hub rows: sum of the slab rows), SEG 1 = relation table (sum of the units' partial
+// rows); the thread that owns the first element of a row leaves that row's counter zero.
+template <int SEG>
+__device__ __forceinline__ float4 finish_grad(const OptFinish& f, int64_t i, int d4, float4 gv) {
+  const int row = (int)(i / d4), k4 = (int)(i - (int64_t)row * d4);
+  if (SEG == 0) {
+    if (k4 == 0) f.ecnt[row] = 0;
+    const int c = (row + 1 < f.N ? f.eoff[row + 1] : f.etotals[2]) - f.eoff[row];
+    if (c <= f.C) return gv;
+    const int nch = (c + f.C - 1) / f.C;
+    const float4* src = reinterpret_cast<const float4*>(f.eslab) + (int64_t)f.epoff[row] * d4 + k4;
+    for (int j = 0; j < nch; ++j) gv = f4add(gv, src[(int64_t)j * d4]);
+    return gv;
+  }
+  if (k4 == 0) f.rcnt[row] = 0;
+  const int c = (row + 1 < f.R ? f.roff[row + 1] : f.rtotal[1]) - f.roff[row];
+  const int nch = rel_units(c);
+  const float4* src = reinterpret_cast<const float4*>(f.rslab) + (int64_t)f.ruoff[row] * d4 + k4;
+  int j = 0;
+  for (; j + 4 <= nch; j += 4) {  // four loads in flight, summed in unit order
+    const float4 a = src[(int64_t)j * d4], b = src[(int64_t)(j + 1) * d4], c2 = src[(int64_t)(j + 2) * d4], d = src[(int64_t)(j + 3) * d4];
+    gv = f4add(f4add(f4add(f4add(gv, a), b), c2), d);
+  }
+  for (; j < nch; ++j) gv = f4add(gv, src[(int64_t)j * d4]);
+  return gv;
+}
+
+template <int KIND, bool REG, int SEG = -1>
 __device__ __forceinline__ void opt_sweep(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                           int64_t n, int block, int nblocks, float lr_t, float b1, float b2, float eps, float gscale,
-                                          float regw, float* __restrict__ reg_partials, float* red) {
+                                          float regw, float* __restrict__ reg_partials, float* red, const OptFinish* fin = nullptr, int d4 = 1) {
   float rsum = 0.f;
   const int64_t stride = (int64_t)nblocks * blockDim.x;
   const int64_t n4 = n >> 2;
@@ -246,6 +295,7 @@ __device__ __forceinline__ void opt_sweep(float* __restrict__ w, float* __restri
   for (int64_t i = (int64_t)block * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 wv = w4[i], gv = g4[i], mv, vv;
     if (KIND == KGE_OPT_ADAM_TF) { mv = m4[i]; vv = v4[i]; }
+    if (SEG >= 0) gv = finish_grad<SEG>(*fin, i, d4, gv);
     upd(wv.x, gv.x, mv.x, vv.x);
     upd(wv.y, gv.y, mv.y, vv.y);
     upd(wv.z, gv.z, mv.z, vv.z);
@@ -278,6 +328,16 @@ __global__ __launch_bounds__(256) void opt_kernel(OptSeg a, OptSeg b, int grid_a
   if (lr_dev) lr_t = lr_dev[0];  // device-resident step counter (graph replay): lr_t of this step
   if ((int)blockIdx.x < grid_a) opt_sweep<KIND, REG>(a.w, a.g, a.m, a.v, a.n, blockIdx.x, grid_a, lr_t, b1, b2, eps, gscale, regw, reg_partials, red);
   else opt_sweep<KIND, false>(b.w, b.g, b.m, b.v, b.n, blockIdx.x - grid_a, gridDim.x - grid_a, lr_t, b1, b2, eps, gscale, 0.f, nullptr, red);
+}
+// The same sweep closing the gradient half of a relation-grouped step itself (OptFinish; rows of d4 float4s in both tables).
+template <int KIND, bool REG>
+__global__ __launch_bounds__(256) void opt_finish_kernel(OptSeg a, OptSeg b, int grid_a, float lr_t, float b1, float b2, float eps, float gscale,
+                                                          float regw, float* __restrict__ reg_partials, const float* __restrict__ lr_dev,
+                                                          OptFinish fin, int d4) {
+  __shared__ float red[16];
+  if (lr_dev) lr_t = lr_dev[0];
+  if ((int)blockIdx.x < grid_a) opt_sweep<KIND, REG, 0>(a.w, a.g, a.m, a.v, a.n, blockIdx.x, grid_a, lr_t, b1, b2, eps, gscale, regw, reg_partials, red, &fin, d4);
+  else opt_sweep<KIND, false, 1>(b.w, b.g, b.m, b.v, b.n, blockIdx.x - grid_a, gridDim.x - grid_a, lr_t, b1, b2, eps, gscale, 0.f, nullptr, red, &fin, d4);
 }
 
 // loss_out = (accumulate ? loss_out : 0) + scale * sum(partials[0..n)), fixed order -> run-to-run deterministic
@@ -384,6 +444,8 @@ static int push_by_model(int G, const kge_model_desc* md, const kge_loss_desc* l
       return launch_push<KGE_TRANSE, 2, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
     case KGE_COMPLEX:
       return launch_push<KGE_COMPLEX, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
+    case KGE_ROTATE:
+      return launch_push<KGE_ROTATE, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
     default:
       return fail(KGE_EUNSUPPORTED, "kge_train_step: model %d has no HIP training kernel yet", md->model);
   }
@@ -585,7 +647,7 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   }
   if (pairwise && md->dropout > 0.f)
     return fail(KGE_EUNSUPPORTED, "pairwize loss with dropout needs the pull gradient path (kge_set_grad_mode(0))");
-  const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
+  const int width = (md->model == KGE_COMPLEX || md->model == KGE_ROTATE) ? md->d_e / 2 : md->d_e;
   const int G = push_group_width(width);
   switch (ld->loss) {
     case KGE_POINTWIZE_HINGE:
@@ -647,13 +709,19 @@ int opt_state_init(const kge_opt_desc* od, hipStream_t st) {
 
 template <int KIND>
 static int launch_opt(bool reg, OptSeg a, OptSeg b, float lr_t, const kge_opt_desc* od, float gscale, float regw, float* reg_partials,
-                      hipStream_t st, int* nb, const float* lr_slot = nullptr) {
+                      hipStream_t st, int* nb, const float* lr_slot = nullptr, const OptFinish* fin = nullptr, int d4 = 1) {
   // device-resident step state: lr_t of this update comes from the state (prepared by the previous update's post kernel), or from
   // the slot the gradient half just wrote (StepAdvance)
   const float* lr_dev = lr_slot ? lr_slot : (od->step_dev ? reinterpret_cast<const float*>(od->step_dev + 1) : nullptr);
   auto blocks = [](int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(cdiv(n, 4), 256), kCUs * 8)); };
   const int ga = blocks(a.n), gb = b.n > 0 ? blocks(b.n) : 0;
   *nb = ga;
+  if (fin) {
+    if (reg) hipLaunchKernelGGL((opt_finish_kernel<KIND, true>), dim3(ga + gb), dim3(256), 0, st, a, b, ga, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials, lr_dev, *fin, d4);
+    else hipLaunchKernelGGL((opt_finish_kernel<KIND, false>), dim3(ga + gb), dim3(256), 0, st, a, b, ga, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials, lr_dev, *fin, d4);
+    KGE_HIP_TRY(hipGetLastError());
+    return KGE_OK;
+  }
   if (reg) hipLaunchKernelGGL((opt_kernel<KIND, true>), dim3(ga + gb), dim3(256), 0, st, a, b, ga, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials, lr_dev);
   else hipLaunchKernelGGL((opt_kernel<KIND, false>), dim3(ga + gb), dim3(256), 0, st, a, b, ga, lr_t, od->beta1, od->beta2, od->eps, gscale, regw, reg_partials, lr_dev);
   KGE_HIP_TRY(hipGetLastError());
@@ -672,15 +740,17 @@ bool plan_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
 
 // advance != null (a whole step in one call, no L3 term): the closing kernel of the gradient half advances the step state of
 // that optimizer descriptor (StepAdvance); the optimizer half is then opt_apply(..., advanced = true).
+// finish != null (a whole step in one call): the finish kernel is left out and *finish says what the optimizer sweep has to do in
+// its place (OptFinish); the optimizer half is then opt_apply(..., finish).
 int train_grads_with_plan(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                           int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace, int64_t wbytes, hipStream_t st,
-                          const kge_opt_desc* advance) {
+                          const kge_opt_desc* advance, OptFinish* finish) {
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   int nb = 0;
   StepAdvance adv{nullptr, nullptr, 0, 0.f, 0.f, 0.f};
   if (advance) adv = StepAdvance{advance->step_dev, ws.lr_slot, advance->kind, advance->lr, advance->beta1, advance->beta2};
-  return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv);
+  return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv, finish);
 }
 
 int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float gscale, hipStream_t st) {
@@ -697,10 +767,11 @@ int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, floa
 }
 
 int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gE,
-              float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st, bool advanced) {
+              float* gR, float gscale, float* loss_out, void* workspace, int64_t wbytes, hipStream_t st, bool advanced, const OptFinish* finish) {
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, 0, 0, &ws)) return rc;
   const float* lr_slot = advanced ? ws.lr_slot : nullptr;
+  const int d4 = md->d_e / 4;
   const int64_t nE = (int64_t)md->num_entities * md->d_e, nR = (int64_t)md->num_relations * md->d_r;
   const bool reg = ld->regularization != 0.f;
   int nb = 0;
@@ -710,10 +781,10 @@ int opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_d
       if (!od->mE || !od->vE || !od->mRel || !od->vRel) return fail(KGE_EINVAL, "adam: moment buffers are null");
       if (!od->step_dev && od->step < 1) return fail(KGE_EINVAL, "adam: step must be >= 1");
       if (int rc = launch_opt<KGE_OPT_ADAM_TF>(reg, OptSeg{E, gE, od->mE, od->vE, nE}, OptSeg{Rel, gR, od->mRel, od->vRel, nR}, host_lr_t(od), od, gscale,
-                                               ld->regularization, ws.reg_partials, st, &nb, lr_slot)) return rc;
+                                               ld->regularization, ws.reg_partials, st, &nb, lr_slot, finish, d4)) return rc;
     } else if (od->kind == KGE_OPT_SGD) {
       if (int rc = launch_opt<KGE_OPT_SGD>(reg, OptSeg{E, gE, nullptr, nullptr, nE}, OptSeg{Rel, gR, nullptr, nullptr, nR}, od->lr, od, gscale,
-                                           ld->regularization, ws.reg_partials, st, &nb, lr_slot)) return rc;
+                                           ld->regularization, ws.reg_partials, st, &nb, lr_slot, finish, d4)) return rc;
     } else {
       return fail(KGE_EINVAL, "unknown optimizer %d", od->kind);
     }

@@ -180,7 +180,7 @@ class EmbeddingModel:
         self._seed = int(seed) if seed is not None else 0
         self._lit = None
         if literal_activation:  # models.py:114-120: frozen literal table + Dense(e_dim, activation) on [embedding ; literal]
-            if self.MODEL not in ("DistMult", "TransE", "ComplEx"):
+            if self.MODEL not in ("DistMult", "TransE", "ComplEx") or type(self).__name__ == "RotatE":
                 raise NotImplementedError(f"the literal input path is built for DistMult, TransE and ComplEx, not {self.MODEL}")
             act = literal_activation if isinstance(literal_activation, str) else getattr(literal_activation, "__name__", None)
             if act not in ACT_IDS:
@@ -686,6 +686,31 @@ class pRotatE(EmbeddingModel):
         self.pi = np.pi
         self.embedding_range = (self.gamma + self.epsilon) / self.e_dim / 2
         self.modulus = modulus * self.embedding_range
+
+
+class RotatE(EmbeddingModel):
+    """models.py:421-459, exactly as written: e_dim doubled, r_dim NOT (:428-429: the relation rows are rotation phases, one per
+    complex component); phase = atan2(sin p, cos p) (:443); the rotated subject minus the object is summed WITH its signs (:446-453;
+    the constructor's `norm` is never applied), so the score is linear in s and in o -- gamma - sum if gamma > 0 else the sum
+    (:455-458).  Own model id in the library (KGE_ROTATE): scoring kernel, push-path training (forward + loss + atomic gradient
+    rows; no batch plans, so fit() steps batch by batch), and the 1-vs-all ranking as a dot-product sweep on the matrix cores (a
+    linear score orders the candidates by <q, e_c>)."""
+    MODEL = "RotatE"
+
+    def __init__(self, gamma=12, norm=2, epsilon=2, name='RotatE', **kwargs):
+        kwargs['e_dim'] = 2 * kwargs['e_dim']  # KeyError if absent, like models.py:428
+        kwargs['r_dim'] = kwargs['r_dim']
+        super().__init__(name=name, **kwargs)
+        self.gamma = gamma
+        self.epsilon = epsilon
+        self.norm = norm
+        self.pi = np.pi
+        self.embedding_range = (self.gamma + self.epsilon) / self.e_dim / 2
+
+    def _model_desc(self, training=False):
+        md = super()._model_desc(training)
+        md.norm = 1  # the constructor's `norm` takes no part in the score (models.py:446-459)
+        return md
 
 
 class HolE(EmbeddingModel):

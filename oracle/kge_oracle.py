@@ -31,6 +31,8 @@ def table_dims(model, e_dim, r_dim):
     """ComplEx doubles both widths (models.py:208-209); everything else keeps them."""
     if model in ("ComplEx", "pRotatE"):  # pRotatE: models.py:469-470
         return 2 * e_dim, 2 * r_dim
+    if model == "RotatE":  # models.py:428-429: the entity rows are doubled, the relation rows (phases) are not
+        return 2 * e_dim, r_dim
     return e_dim, r_dim
 
 
@@ -89,10 +91,27 @@ def func_protate(s, p, o, modulus, gamma=12):
     return gamma - r if gamma > 0 else r
 
 
+def func_rotate(s, p, o, gamma=12):
+    """models.py:439-459, exactly as written: the relation row is a phase vector (half as wide as the entity rows), wrapped by
+    atan2(sin, cos); the rotated subject minus the object is SUMMED with its signs (the constructor's `norm` is never applied),
+    so the score is linear in s and in o; gamma - sum if gamma > 0 else the sum."""
+    h = s.shape[-1] // 2
+    re_s, im_s = s[..., :h], s[..., h:]
+    re_o, im_o = o[..., :h], o[..., h:]
+    phase = np.arctan2(np.sin(p), np.cos(p))
+    re_r, im_r = np.cos(phase), np.sin(phase)
+    re = re_s * re_r - im_s * im_r - re_o
+    im = re_s * im_r + im_s * re_r - im_o
+    sc = np.sum(np.concatenate([re, im], axis=-1), axis=-1)
+    return gamma - sc if gamma > 0 else sc
+
+
 def score_rows(model, s, p, o, norm=1, gamma=12):
     """For model == "pRotatE" the `norm` slot carries the modulus product of models.py:476."""
     if model == "pRotatE":
         return func_protate(s, p, o, norm, gamma)
+    if model == "RotatE":
+        return func_rotate(s, p, o, gamma)
     if model == "DistMult":
         return func_distmult(s, p, o)
     if model == "TransE":
@@ -121,6 +140,15 @@ def score_row_grads(model, s, p, o, g, norm=1, gamma=12):
         y = (ph(s) + ph(p) - ph(o)) / 2
         dx = (-1.0 if gamma > 0 else 1.0) * g * norm * 0.5 * np.sign(np.sin(y)) * np.cos(y)
         return dx, dx, -dx
+    if model == "RotatE":  # linear in s and o; d atan2(sin p, cos p)/dp = 1
+        h = s.shape[-1] // 2
+        re_s, im_s = s[:, :h], s[:, h:]
+        c, sn = np.cos(p), np.sin(p)
+        gg = (-1.0 if gamma > 0 else 1.0) * g
+        ds = np.concatenate([gg * (c + sn), gg * (c - sn)], 1)
+        dp = gg * (re_s * (c - sn) - im_s * (c + sn))
+        do = -gg * np.ones_like(o)
+        return ds, dp, do
     if model == "DistMult":
         return g * p * o, g * s * o, g * s * p
     if model == "TransE":
@@ -347,7 +375,7 @@ def dense_grads(model, E, Rel, pos, neg, loss, margin=1, negative_samples=1, nor
     for t, off in ((pos, 0), (neg, len(pos))):
         s_, p_, o_ = E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]]
         if dropout:  # batch row index = position in [pos ; neg]
-            ms = [dropout_multipliers(seed, len(t), r, E.shape[1], dropout, off).astype(dt) for r in range(3)]
+            ms = [dropout_multipliers(seed, len(t), r, (Rel if r == 1 else E).shape[1], dropout, off).astype(dt) for r in range(3)]
             s_, p_, o_ = s_ * ms[0], p_ * ms[1], o_ * ms[2]
             masks.append(ms)
         rows.append((s_, p_, o_))
@@ -656,7 +684,7 @@ def conve_train_step(P, E, Rel, opt, pos, neg, loss="pointwize_hinge", margin=1,
         s_, p_, o_ = E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]]
         ms = [np.ones_like(s_)] * 3
         if dropout:
-            ms = [dropout_multipliers(seed, len(t), r, E.shape[1], dropout, off).astype(dt) for r in range(3)]
+            ms = [dropout_multipliers(seed, len(t), r, (Rel if r == 1 else E).shape[1], dropout, off).astype(dt) for r in range(3)]
             s_, p_, o_ = s_ * ms[0], p_ * ms[1], o_ * ms[2]
         c = {}
         _, sc = conve_forward(P, s_, p_, o_, True, hidden_dp, seed, off, c)

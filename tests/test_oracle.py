@@ -201,16 +201,26 @@ def _torch_score(model, s, p, o, norm, gamma):
         ph = lambda x: torch.atan2(torch.sin(x), torch.cos(x))  # noqa: E731
         r = torch.abs(torch.sin((ph(s) + ph(p) - ph(o)) / 2)).sum(1) * norm
         return gamma - r if gamma > 0 else r
+    if model == "RotatE":  # models.py:439-459 op for op
+        h = s.shape[1] // 2
+        re_s, im_s, re_o, im_o = s[:, :h], s[:, h:], o[:, :h], o[:, h:]
+        phase = torch.atan2(torch.sin(p), torch.cos(p))
+        re_r, im_r = torch.cos(phase), torch.sin(phase)
+        re = re_s * re_r - im_s * im_r - re_o
+        im = re_s * im_r + im_s * re_r - im_o
+        sc = torch.cat([re, im], 1).sum(1)
+        return gamma - sc if gamma > 0 else sc
 
 
 @pytest.mark.parametrize("model,norm,gamma", [("DistMult", 1, 12), ("TransE", 1, 12), ("TransE", 2, 12), ("TransE", 2, 0),
-                                              ("ComplEx", 1, 12), ("HolE", 1, 12), ("pRotatE", 0.35, 12), ("pRotatE", 0.35, 0)])
+                                              ("ComplEx", 1, 12), ("HolE", 1, 12), ("pRotatE", 0.35, 12), ("pRotatE", 0.35, 0),
+                                              ("RotatE", 2, 12), ("RotatE", 2, 0)])
 @pytest.mark.parametrize("loss", ["pointwize_hinge", "pointwize_logistic", "pairwize_hinge"])
 def test_dense_grads_and_adam_vs_torch(model, norm, gamma, loss):
     rs = np.random.RandomState(3)
     N, R, d, m = 11, 4, 6, 40
     de, dr = O.table_dims(model, d, d)
-    amp = 4.0 if model == "pRotatE" else 0.6  # phases beyond (-pi, pi]: the wrap of models.py:481-483 is exercised
+    amp = 4.0 if model in ("pRotatE", "RotatE") else 0.6  # phases beyond (-pi, pi]: the wrap of models.py:481-483 / :443 is exercised
     E = rs.uniform(-amp, amp, (N, de))
     Rel = rs.uniform(-amp, amp, (R, dr))
     pos = np.stack([rs.randint(0, N, m), rs.randint(0, R, m), rs.randint(0, N, m)], 1)
