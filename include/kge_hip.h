@@ -302,6 +302,22 @@ int kge_build_batch_host(void* np_state_host, void* py_state_host, const int32_t
 int kge_filter_coo_host(const int32_t* test_host, int64_t n_queries, int32_t side, const int32_t* filt_host, int64_t n_filt,
                         int64_t num_entities, int32_t* out_q_host, int32_t* out_id_host, int64_t* n_out);
 
+/* ---- dataset front-end (host): `load_kg` (utils.py:106-112: every line stripped and split on whitespace, Python's str.split()
+ *      separators) for all splits of a dataset at once, and the id mapping of the reference's script (tests.py:102-117) made
+ *      deterministic: there the ids come from enumerating Python sets of strings (they change with PYTHONHASHSEED); here an id is
+ *      the rank of the name among the sorted distinct names of all splits (entities: subjects and objects, relations: predicates;
+ *      code-point order = byte order of the UTF-8 files).  KGE_EINVAL for a missing file and for a line that does not hold exactly
+ *      three tokens (the script's `for a, b, c in train` raises ValueError there).
+ *        kge_kg_open     reads the files, builds the maps, returns a handle;
+ *        kge_kg_sizes    number of entities / relations, rows of every split;
+ *        kge_kg_triples  the (rows, 3) int32 id triples of one split;
+ *        kge_kg_names    the names in id order, concatenated, with offsets[n + 1] (buf_host NULL: offsets only -> offsets[n] bytes). */
+int kge_kg_open(const char* const* paths_host, int32_t n_splits, void** handle);
+int kge_kg_sizes(void* handle, int64_t* n_entities, int64_t* n_relations, int64_t* rows_per_split_host);
+int kge_kg_triples(void* handle, int32_t split, int32_t* out_host);
+int kge_kg_names(void* handle, int32_t which, char* buf_host, int64_t buf_bytes, int64_t* offsets_host);
+int kge_kg_close(void* handle);
+
 /* The same batch builder on the GPU: states are the same 2504-byte blobs resident in device memory, batch (B,3) int32 on
  * the device, pos_out / neg_out (B*ns,3) int32 on the device.  Bit-identical to kge_build_batch_host, including the
  * generator states left behind.  err_flag bit 1 is set if the rejection-sampling margin of the raw buffer ever ran

@@ -122,16 +122,16 @@ int grad_mode() {
 
 struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
 SideStream* side_stream() {
+  // created once, by whichever thread comes first (a function-local static is initialised exactly once); nullptr when disabled or
+  // when creation failed.  The stream and its fork / join events are shared by every caller: the library is thread-compatible,
+  // not thread-safe (kge_hip.h) -- two host threads must not run training steps through it at the same time.
   static SideStream ss;
-  static int state = 0;  // 0 = not tried, 1 = ready, -1 = disabled / failed
-  if (state == 0) {
-    state = -1;
-    if (!env_int("KGE_NO_SIDE_STREAM", 0) && hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
-        hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
-      state = 1;
-  }
-  return state == 1 ? &ss : nullptr;
+  static const bool ok = [] {
+    return !env_int("KGE_NO_SIDE_STREAM", 0) && hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+  }();
+  return ok ? &ss : nullptr;
 }
 
 int push_group_width(int width) {

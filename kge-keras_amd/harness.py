@@ -196,9 +196,11 @@ def main(train, valid, test, dim=100, bs=2048, epochs=100, verbose=2, device_gen
     Dense, DistMult, pairwize_hinge, Adam, `fit` over the generator with the validation split.  train / valid / test: paths
     (utils.load_kg) or lists of (s, p, o) string triples.  Keyword arguments override the script's hyper-parameters;
     device_generator=True draws the batches on the GPU (same draws).  Returns (model, history)."""
-    from .utils import load_kg, index_kg
-    splits = [load_kg(x) if isinstance(x, str) else list(x) for x in (train, valid, test)]
-    ents, rels, (train, valid, test) = index_kg(*splits)
+    from .utils import index_kg, load_indexed, load_kg
+    if all(isinstance(x, str) for x in (train, valid, test)):  # three files: read and indexed by the native front-end
+        ents, rels, (train, valid, test) = load_indexed(train, valid, test)
+    else:
+        ents, rels, (train, valid, test) = index_kg(*[load_kg(x) if isinstance(x, str) else list(x) for x in (train, valid, test)])
     literals = np.random.rand(len(ents), 5)  # tests.py:113
     params = {'num_entities': len(ents), 'num_relations': len(rels), 'dim': dim, 'embedding_model': 'DistMult', 'literals': literals,
               'literal_activation': 'tanh', 'loss_function': 'pairwize_hinge', 'margin': 1}

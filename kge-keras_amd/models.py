@@ -499,19 +499,37 @@ class EmbeddingModel:
         return tot / max(1, n)
 
     def batch_loss(self, data):
-        """Loss of one [pos, neg] batch, no update: gradients are accumulated and discarded by a zero-lr SGD apply."""
+        """Loss of one [pos, neg] batch in inference mode (no dropout), no update: what Keras reports as val_loss (the added loss
+        + the regularisation term).  The gradient half of a step runs -- through the literal transform when the model has one --
+        and its gradients are discarded by clearing the accumulators; no optimizer is involved."""
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
         if self.optimizer is None:
             self.compile('sgd')
         md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
         md.dropout = 0.0
-        od = OptDesc(OPT_IDS["sgd"], 0.0, 0.0, 0.0, 0.0, 1, None, None, None, None)
-        check(lib.kge_train_step(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(),
-                                 self._gE.data_ptr(), self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(),
-                                 neg.shape[0], self._loss.data_ptr(), None, 0, self._ws.data_ptr(), self._ws.numel(),
-                                 self._err.data_ptr(), _lib.stream_ptr()))
-        return self._loss[0].clone()
+        md.hidden_dropout = 0.0
+        lt = self._lit
+        if lt is not None:  # models.py:152-158: the score is taken on act(Dense([E ; literals])) rows
+            need = check(lib.kge_lit_workspace_bytes(C.byref(md), lt["L"], pos.shape[0], neg.shape[0]))
+            if lt["ws"] is None or lt["ws"].numel() < need:
+                lt["ws"] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+            check(lib.kge_lit_train_grads(C.byref(md), C.byref(ld), lt["act"], self.E.data_ptr(), self.Rel.data_ptr(), lt["table"].data_ptr(),
+                                          lt["L"], lt["table"].shape[0], lt["theta"].data_ptr(), self._gE.data_ptr(), self._gR.data_ptr(),
+                                          lt["gtheta"].data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0],
+                                          self._loss.data_ptr(), None, 0, lt["ws"].data_ptr(), lt["ws"].numel(), self._err.data_ptr(),
+                                          _lib.stream_ptr()))
+            lt["gtheta"].zero_()
+        else:
+            check(lib.kge_train_grads(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                      self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0],
+                                      self._loss.data_ptr(), None, 0, self._ws.data_ptr(), self._ws.numel(), self._err.data_ptr(),
+                                      _lib.stream_ptr()))
+        loss = self._loss[0].clone()
+        self._gall.zero_()  # gradient accumulators (and the loss word inside the same buffer) back to zero
+        if self.regularization:  # l3_reg on the whole entity table (models.py:10-11,78-92), part of every Keras loss value
+            loss = loss + float(self.regularization) * self.E.abs().pow(3).sum()
+        return loss
 
     # ------------------------------------------------------------------ filtered 1-vs-all ranking (utils.py:165-264)
     @staticmethod
@@ -615,15 +633,46 @@ class EmbeddingModel:
         return out[0], out[1]
 
     # ------------------------------------------------------------------ weights I/O (checkpointing)
+    def _extra_state(self):
+        """Every trainable or stateful tensor besides the two tables, by name (subclasses add theirs)."""
+        st = {}
+        if self._lit is not None:
+            st["lit_theta"] = self._lit["theta"]
+            if self._lit["slots"] is not None:
+                st["lit_slot_m"], st["lit_slot_v"] = self._lit["slots"]
+        return st
+
+    def _set_extra_state(self, st):
+        if self._lit is not None:
+            self._lit["theta"].copy_(st["lit_theta"])
+            if "lit_slot_m" in st:
+                self._lit["slots"] = (st["lit_slot_m"].to(self.device).clone(), st["lit_slot_v"].to(self.device).clone())
+
     def get_weights(self):
-        return self.entity_embedding.get_weights() + self.relational_embedding.get_weights()
+        out = self.entity_embedding.get_weights() + self.relational_embedding.get_weights()
+        if self._lit is not None:
+            out += list(self.get_literal_dense())
+        return out
 
     def set_weights(self, ws):
+        want = 2 + (2 if self._lit is not None else 0)
+        if len(ws) != want:
+            raise ValueError(f"You called `set_weights(weights)` on {self.name} with a weight list of length {len(ws)}, but it expects {want} weights")
         self.entity_embedding.set_weights([ws[0]])
         self.relational_embedding.set_weights([ws[1]])
+        if self._lit is not None:
+            W, b = np.asarray(ws[2], dtype=np.float32), np.asarray(ws[3], dtype=np.float32)
+            K1, d = int(self.e_dim) + self._lit["L"], int(self.e_dim)
+            if W.shape != (K1, d) or b.shape != (d,):
+                raise ValueError(f"literal Dense weights of shapes {W.shape}, {b.shape}; expected {(K1, d)}, {(d,)}")
+            self.set_literal_dense(W, b)
 
     def save_weights(self, path):
-        st = {"E": self.E.cpu(), "Rel": self.Rel.cpu(), "model": self.MODEL}
+        """Everything a resumed run needs: both tables, every other trainable / stateful tensor (literal Dense, ConvE head and its
+        batch-norm statistics), the optimizer's kind, step count and all its slots, the dropout step seed."""
+        st = {"format": 2, "model": type(self).__name__, "shapes": {"E": tuple(self.E.shape), "Rel": tuple(self.Rel.shape)},
+              "E": self.E.cpu(), "Rel": self.Rel.cpu(), "seed": self._seed,
+              "extra": {k: v.cpu() for k, v in self._extra_state().items()}}
         if self.optimizer is not None:
             st["opt"] = dict(kind=self.optimizer.kind, iterations=self.optimizer.iterations,
                              slots=[s.cpu() for s in self.optimizer.slots] if self.optimizer.slots else None)
@@ -631,12 +680,33 @@ class EmbeddingModel:
 
     def load_weights(self, path):
         st = torch.load(path, map_location="cpu")
+        if st.get("format") != 2:
+            raise ValueError(f"{path}: not a checkpoint of this package (format {st.get('format')!r})")
+        if st["model"] != type(self).__name__:
+            raise ValueError(f"{path} holds a {st['model']} model, this is a {type(self).__name__}")
+        for k, t in (("E", self.E), ("Rel", self.Rel)):
+            if tuple(st[k].shape) != tuple(t.shape):
+                raise ValueError(f"{path}: table {k} has shape {tuple(st[k].shape)}, the model expects {tuple(t.shape)}")
+        mine = self._extra_state()
+        for k, v in st["extra"].items():
+            if k in mine and tuple(v.shape) != tuple(mine[k].shape):
+                raise ValueError(f"{path}: tensor {k} has shape {tuple(v.shape)}, the model expects {tuple(mine[k].shape)}")
+        missing = [k for k in mine if k not in st["extra"] and not k.endswith(("_m", "_v"))]
+        if missing:
+            raise ValueError(f"{path} lacks {missing}")
         self.E.copy_(st["E"])
         self.Rel.copy_(st["Rel"])
-        if "opt" in st and self.optimizer is not None and st["opt"]["kind"] == self.optimizer.kind:
-            self.optimizer.iterations = st["opt"]["iterations"]
+        self._seed = int(st.get("seed", self._seed))
+        self._set_extra_state(st["extra"])
+        if "opt" in st and self.optimizer is not None:
+            if st["opt"]["kind"] != self.optimizer.kind:
+                raise ValueError(f"{path} was written with optimizer {st['opt']['kind']!r}, the model is compiled with {self.optimizer.kind!r}")
+            self.optimizer.iterations = int(st["opt"]["iterations"])
             if st["opt"]["slots"] is not None:
-                self.optimizer.slots = tuple(s.to(self.device) for s in st["opt"]["slots"])
+                shapes = [tuple(x.shape) for x in (self.E, self.E, self.Rel, self.Rel)]
+                if [tuple(s.shape) for s in st["opt"]["slots"]] != shapes:
+                    raise ValueError(f"{path}: optimizer slots do not match the tables' shapes")
+                self.optimizer.slots = tuple(s.to(self.device).clone() for s in st["opt"]["slots"])
 
 
 class DistMult(EmbeddingModel):
@@ -986,5 +1056,29 @@ class ConvE(EmbeddingModel):
         return self.rank_triples(np.asarray([tuple(int(v) for v in t) for t in test_data], dtype=np.int32), num_entities,
                                  np.asarray(filt, dtype=np.int32).reshape(-1, 3))
 
+    def _extra_state(self):
+        st = super()._extra_state()
+        st["theta"], st["bn_stats"] = self.theta, self.bn_stats
+        if self._tslots is not None:
+            st["theta_slot_m"], st["theta_slot_v"] = self._tslots
+        return st
+
+    def _set_extra_state(self, st):
+        super()._set_extra_state(st)
+        self.theta.copy_(st["theta"])
+        self.bn_stats.copy_(st["bn_stats"])
+        if "theta_slot_m" in st:
+            self._tslots = (st["theta_slot_m"].to(self.device).clone(), st["theta_slot_v"].to(self.device).clone())
+
     def get_weights(self):
         return super().get_weights() + [self.theta.cpu().numpy(), self.bn_stats.cpu().numpy()]
+
+    def set_weights(self, ws):
+        if len(ws) != 4:
+            raise ValueError(f"You called `set_weights(weights)` on {self.name} with a weight list of length {len(ws)}, but it expects 4 weights")
+        th, bn = np.asarray(ws[2], dtype=np.float32).reshape(-1), np.asarray(ws[3], dtype=np.float32).reshape(-1)
+        if th.shape[0] != self.theta.numel() or bn.shape[0] != self.bn_stats.numel():
+            raise ValueError(f"ConvE head weights of sizes {th.shape[0]}, {bn.shape[0]}; expected {self.theta.numel()}, {self.bn_stats.numel()}")
+        EmbeddingModel.set_weights(self, ws[:2])
+        self.theta.copy_(torch.from_numpy(th))
+        self.bn_stats.copy_(torch.from_numpy(bn))

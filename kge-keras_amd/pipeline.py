@@ -19,6 +19,8 @@ stage graphs inside the library and kge_pipeline_run(n) issues n steps from C (c
 data-parallel training (`between`: the gradient all-reduce sits between the halves of the step, outside any graph) and for
 `serial` profiling runs.
 """
+import time
+
 import torch
 
 from . import _lib
@@ -145,8 +147,13 @@ class TrainPipeline:
         self._sig = self._signature()
 
     def _stage_P_forked(self, slot):
-        """Stage P with its two list builds side by side (kernel-by-kernel launches only: replaying a stage graph that holds
-        this fork from another stream crashes the ROCm 7.2 runtime, and the stage is not the longest of the three anyway)."""
+        """Stage P with its two list builds side by side on a forked stream -- kernel-by-kernel launches only, never inside a
+        capture.  (Round 1 saw the ROCm 7.2 runtime crash once with this fork inside a captured stage; the failing call and its
+        error were not kept, and the two notes written then disagree on whether it died at hipStreamEndCapture or at the first
+        replay, so the cause is NOT established.  What is established: every capture this package makes is flat -- one stream, no
+        fork -- and this method refuses to run under capture.)"""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("TrainPipeline._stage_P_forked must not be captured into a hipGraph (see its docstring)")
         cur = torch.cuda.current_stream()
         self.s3.wait_stream(cur)
         self._stage_P(slot, fork=self.s3)
@@ -160,8 +167,12 @@ class TrainPipeline:
             # inside the runtime, and that wait sleeps (milliseconds on a busy host).  Spin on an event instead.
             ev = self._done.get((name, slot))
             if ev is not None:
-                while not ev.query():
-                    pass
+                t0 = None
+                while not ev.query():  # bounded: a stage that never finishes (a fault on the device) becomes an error, not a hang
+                    if t0 is None:
+                        t0 = time.monotonic()
+                    elif time.monotonic() - t0 > 20.0:
+                        raise RuntimeError(f"TrainPipeline: stage {name} of slot {slot} did not finish within 20 s")
             else:
                 ev = self._done[name, slot] = torch.cuda.Event()
             self.graphs[name, slot].replay()

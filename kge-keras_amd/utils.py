@@ -35,6 +35,40 @@ def index_kg(*splits):
     return emap, rmap, arrs
 
 
+def load_indexed(*paths):
+    """The data front-end in one native call (csrc/frontend.cpp: kge_kg_open): reads the split files like load_kg and maps the names
+    to ids like index_kg -- same maps, same arrays.  Returns (entity_map, relation_map, [int32 (n,3) array per split]).
+    FileNotFoundError / ValueError where the reference's script would raise them (open(); `for a, b, c in train`)."""
+    import ctypes as C
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+    h = C.c_void_p()
+    rc = _lib.lib.kge_kg_open(arr, n, C.byref(h))
+    if rc < 0:
+        msg = _lib.lib.kge_last_error().decode("utf-8", "replace")
+        raise (FileNotFoundError if msg.startswith("[Errno 2]") else ValueError)(msg)
+    try:
+        ne, nr = C.c_int64(0), C.c_int64(0)
+        rows = (C.c_int64 * n)()
+        _lib.check(_lib.lib.kge_kg_sizes(h, C.byref(ne), C.byref(nr), rows))
+        arrs = []
+        for i in range(n):
+            a = np.empty((int(rows[i]), 3), dtype=np.int32)
+            _lib.check(_lib.lib.kge_kg_triples(h, i, a.ctypes.data))
+            arrs.append(a)
+        maps = []
+        for which, cnt in ((0, ne.value), (1, nr.value)):
+            offs = np.zeros(cnt + 1, dtype=np.int64)
+            _lib.check(_lib.lib.kge_kg_names(h, which, None, 0, offs.ctypes.data))
+            buf = C.create_string_buffer(int(offs[-1]) + 1)
+            _lib.check(_lib.lib.kge_kg_names(h, which, buf, int(offs[-1]), offs.ctypes.data))
+            raw = buf.raw
+            maps.append({raw[offs[i]:offs[i + 1]].decode("utf-8"): i for i in range(cnt)})
+        return maps[0], maps[1], arrs
+    finally:
+        _lib.lib.kge_kg_close(h)
+
+
 def generate_negative(kg, N, negative=2, check_kg=False, corrupt_head=True, corrupt_tail=True):
     """utils.py:114-121.  Consumes NumPy's *global* legacy stream exactly like the reference
     (all `negative*len(kg)` heads, then all tails) and returns the same (negative*len(kg), 3, 1) int64 array."""

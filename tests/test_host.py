@@ -324,3 +324,32 @@ def test_graft_entry_build_contract():
     """__graft_entry__.build() is the driver's "does it build" check: run it here (incremental make, import, ABI version)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_native_loader_matches_load_kg_and_index_kg(golden, datasets, tmp_path):
+    """kge_kg_open (csrc/frontend.cpp) == load_kg (utils.py:106-112) + the sorted-string id maps, on files with tabs, runs of blanks,
+    CRLF and bare-CR line ends, non-ASCII names, Unicode whitespace and a missing final newline; the golden rows of the reference's
+    own loader; and the reference script's errors (a short row, a missing file)."""
+    from kge_keras_amd import utils as U
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    a.write_bytes("x\tr1\ty\n  z   r2 \t x  \r\nÅse r1 zebra \nété r3　x\rq r1 q".encode("utf-8"))
+    b.write_bytes(b"y r2 Z\nZ r0 x\n")
+    em, rm, (ta, tb) = U.load_indexed(str(a), str(b))
+    pa, pb = U.load_kg(str(a)), U.load_kg(str(b))
+    assert pa == [["x", "r1", "y"], ["z", "r2", "x"], ["Åse", "r1", "zebra"], ["été", "r3", "x"], ["q", "r1", "q"]]
+    em2, rm2, (ta2, tb2) = U.index_kg(pa, pb)
+    assert em == em2 and rm == rm2 and np.array_equal(ta, ta2) and np.array_equal(tb, tb2)
+    assert list(em) == sorted(em) and list(rm) == ["r0", "r1", "r2", "r3"] and ta.dtype == np.int32
+    # the reference loader's golden rows
+    rows = golden("misc")["misc"]["load_kg_first"]
+    p = tmp_path / "g.txt"
+    p.write_text("\n".join("\t".join(t) for t in rows) + "\n")
+    em3, rm3, (tg,) = U.load_indexed(str(p))
+    e4, r4, (tg4,) = U.index_kg(rows)
+    assert em3 == e4 and rm3 == r4 and np.array_equal(tg, tg4)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("a r b\nc d\n")
+    with pytest.raises(ValueError, match="line 2: not enough values to unpack"):
+        U.load_indexed(str(bad))
+    with pytest.raises(FileNotFoundError):
+        U.load_indexed(str(tmp_path / "nope.txt"))
