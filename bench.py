@@ -391,8 +391,8 @@ def main():
                          "(inside the timed region); pre: batches pre-built on the host before timing")
     ap.add_argument("--plan", default="ahead", choices=["ahead", "step"],
                     help="ahead: batch plans (ids-only half of the step) built on their own stream ahead of the step; step: inside the step")
-    ap.add_argument("--settle", type=int, default=4000, help="upper bound of the extra untimed steps run until the step time is stable "
-                    "(the K steps right after the W warm-up steps are timed too: value_first_steps)")
+    ap.add_argument("--settle", type=int, default=0, help="0 (default): the K timed steps follow the W warm-up steps directly.  > 0: upper bound of extra "
+                    "untimed steps run until the step time is stable, then K steps are timed again (the first K are kept as value_first_steps)")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "stream"],
                     help="graph / auto: the TrainPipeline object (every stage one hipGraph launch per step on one GPU; kernel-by-kernel "
                          "launches of the same stages under torch.distributed); stream: the plain double-buffered loop of this file")
@@ -556,9 +556,13 @@ def main():
 
     steps_n(args.warmup)
     # the K steps right behind the W warm-up steps, exactly as asked for (on a fresh box the host is still paging the image in)
-    dt_first, _ = timed(args.steps)
-    # settle (untimed, bounded): keep stepping in blocks of 20 until a block is within 15 % of the best one seen, for at most 1 s
-    # (one GPU) or a fixed count (torch.distributed: every rank runs the same number of steps)
+    if pipe is not None:
+        pipe.host_stats(reset=True)
+    elif args.settle == 0:
+        _lib.lib.kge_prof_enable(1)  # hipEvents around the dominant kernels, recorded on the launch stream
+    dt_first, t_issue_first = timed(args.steps)
+    # optional settle phase (--settle N > 0; off by default: with the native step loop the first K steps run at the steady rate): keep
+    # stepping in blocks of 20 until a block is within 15 % of the best one seen, for at most 1 s (one GPU) or a fixed count
     settle, best, t_settle = 0, None, time.perf_counter()
     while settle + 20 <= args.settle:
         el = time.perf_counter() - t_settle
@@ -574,11 +578,14 @@ def main():
         if not dist_on and best is not None and el >= 0.2 and tb <= 1.15 * best:
             break
         best = tb if best is None else min(best, tb)
-    if pipe is None:
-        _lib.lib.kge_prof_enable(1)  # hipEvents around the dominant kernels, recorded on the launch stream
-    if pipe is not None:
-        pipe.host_stats(reset=True)
-    dt, t_issue = timed(args.steps)
+    if pipe is None and settle > 0:
+        _lib.lib.kge_prof_enable(1)
+    if settle > 0:
+        if pipe is not None:
+            pipe.host_stats(reset=True)
+        dt, t_issue = timed(args.steps)
+    else:
+        dt, t_issue = dt_first, t_issue_first
     host_stats = pipe.host_stats() if pipe is not None else None
     if pipe is not None:
         # kernel durations for the roofline object: the same K steps again, launched kernel by kernel on ONE stream (events cannot

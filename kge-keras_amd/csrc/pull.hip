@@ -320,11 +320,16 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
     for (int i = 0; i < NV; ++i) { const int ch = lane + i * G; me[i] = ch < nchunk ? L::ld(self + ch * VEC) : L::zero(); }
   }
 
-#pragma unroll 2
+  // The coefficient rides in the entry (lists filled after the forward), or is looked up by row number (lists built ahead, ids
+  // only).  Entry and coefficient of the NEXT round are fetched while this round's rows are gathered and multiplied: the lookup is
+  // a dependent load (entry -> coefficient -> rows) that would otherwise sit in front of every round.
+  int4 e_nx = make_int4(0, 0, 0, 0);
+  float cf_nx = 0.f;
+  if (sub < len) { e_nx = entries[start + sub]; cf_nx = coef_of_row ? coef_of_row[e_nx.w] : __int_as_float(e_nx.z); }
   for (int i = sub; i < len; i += NSUB) {
-    const int4 e = entries[start + i];
-    // the coefficient rides in the entry (lists filled after the forward), or is looked up by row number (lists built ahead, ids only)
-    const float cf = coef_of_row ? coef_of_row[e.w] : __int_as_float(e.z);
+    const int4 e = e_nx;
+    const float cf = cf_nx;
+    if (i + NSUB < len) { e_nx = entries[start + i + NSUB]; cf_nx = coef_of_row ? coef_of_row[e_nx.w] : __int_as_float(e_nx.z); }
     if (cf == 0.f) continue;  // inactive hinge rows carry no gradient
     const int kind1 = is_rel ? 0 : ((unsigned)e.x >> 31);
     const float* ra = is_rel ? E + (int64_t)e.x * d_e : Rel + (int64_t)(e.x & 0x7fffffff) * d_e;

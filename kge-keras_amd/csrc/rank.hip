@@ -387,7 +387,7 @@ template <int BK, bool TAIL, int EPI = 0>
 __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                            int nq, const float* __restrict__ Ec, int K, int Kpad,
                                                            int cand_rows, int32_t* __restrict__ counts,
-                                                           const float* __restrict__ en_c = nullptr) {
+                                                           const float* __restrict__ en_c = nullptr, int parts = 0) {
   constexpr int LS = BK + 4;
   constexpr int C4 = BK / 4;
   constexpr int PF = kTile * C4 / 256;
@@ -402,8 +402,21 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
   const int nqt = (nq + kTile - 1) / kTile, nct = (cand_rows + kTile - 1) / kTile;
   const int64_t total = (int64_t)nqt * nct;
   const int nb = gridDim.x;
+  // workgroups are dealt round-robin to the 8 XCDs: logical block lb makes the 64 workgroups of an XCD neighbours in the unit order,
+  // i.e. one XCD works on one block of consecutive query tiles (its Q block stays in that XCD's L2)
   const int lb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int64_t u_begin = total * lb / nb, u_end = total * (lb + 1) / nb;
+  // parts > 0 (nb == nqt * parts): every workgroup sweeps 1/parts of ONE query tile's candidate tiles, so all workgroups start at
+  // one of `parts` candidate phases and walk in step -- the workgroups of an XCD read the same few E tiles at the same time (one
+  // fabric read, the rest L2 hits).  parts == 0: equal contiguous cuts of the unit list (phases spread over all candidate tiles).
+  int64_t u_begin, u_end;
+  if (parts > 0) {
+    const int q_ = lb / parts, p_ = lb - q_ * parts;
+    u_begin = (int64_t)q_ * nct + (int64_t)nct * p_ / parts;
+    u_end = (int64_t)q_ * nct + (int64_t)nct * (p_ + 1) / parts;
+  } else {
+    u_begin = total * lb / nb;
+    u_end = total * (lb + 1) / nb;
+  }
   if (u_begin >= u_end) return;
   int qt = (int)(u_begin / nct), ct = (int)(u_begin - (int64_t)qt * nct);
   int q0 = qt * kTile;
@@ -802,13 +815,25 @@ static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float
 #define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
   if (v4 && sweep_variant() == 0 && nq < (int64_t)1 << 30) {
     const bool tail = Kpad != K;
-    const int64_t units = cdiv(nq, kTile) * cdiv(cand_rows, kTile);
-    const dim3 pgrid((unsigned)std::min<int64_t>(units, sweep_slots()));
+    const int64_t nqt = cdiv(nq, kTile), nct = cdiv(cand_rows, kTile);
+    const int64_t units = nqt * nct;
+    const int slots = sweep_slots();
+    // phase-aligned cut (KGE_RANK_ALIGN=0: equal cuts): `parts` workgroups per query tile with nqt * parts close to, and not above,
+    // the residency slots -- worth it when that leaves at most ~12 % of the slots empty
+    int parts = 0;
+    {
+      static const bool align = [] { const char* e = getenv("KGE_RANK_ALIGN"); return !(e && atoi(e) == 0); }();
+      if (align && nqt <= slots && units > slots) {
+        const int64_t g = std::min<int64_t>(slots / nqt, nct);
+        if (g >= 1 && nqt * g * 8 >= (int64_t)slots * 7) parts = (int)g;
+      }
+    }
+    const dim3 pgrid((unsigned)(parts ? nqt * parts : std::min<int64_t>(units, slots)));
 #define KGE_SWEEP4(BKV, FLAG)                                                                                                                        \
   do {                                                                                                                                               \
-    if (epi == 1) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 1>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c);      \
-    else if (epi == 2) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 2>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c); \
-    else hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 0>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c);               \
+    if (epi == 1) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 1>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);      \
+    else if (epi == 2) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 2>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts); \
+    else hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 0>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);               \
   } while (0)
     if (BK == 40) { if (tail) KGE_SWEEP4(40, true); else KGE_SWEEP4(40, false); }
     else { if (tail) KGE_SWEEP4(32, true); else KGE_SWEEP4(32, false); }

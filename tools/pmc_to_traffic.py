@@ -6,8 +6,8 @@ import sys
 
 tag, label = sys.argv[1], sys.argv[2]
 src = json.load(open(f"gpurun_out/pmc_{tag}.json"))
-out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, tools/pmc.sh) of "
-                  f"`python3 bench.py --steps 5 --warmup 2 --settle 0 --no-cpu-baseline`, build {label} (folded batches: the gather "
+out = {"_tag": f"profiles/pmc_traffic.json from gpurun_out/pmc_{tag}.json, build {label}", "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, tools/pmc.sh) of "
+                  f"`python3 bench.py --steps 5 --warmup 2 --settle 0 --no-cpu-baseline --no-check`, build {label} (folded batches: the gather "
                   "kernels run on ~131.5 k distinct rows per batch); corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                   "MI355X_MICROARCH.md (gfx950 FETCH_SIZE reads 1/2 of wide coalesced reads; Infinity-Cache hits are counted).  "
                   "Note: the profiler serialises dispatches and the caches start cold for every kernel, so these are upper bounds "
