@@ -65,12 +65,14 @@ typedef struct {
   int32_t num_relations; /* rows of Rel */
   int32_t d_e, d_r;      /* row widths in floats (ComplEx: 2*e_dim, models.py:208-209) */
   int32_t norm;          /* TransE: 1 or 2 (models.py:178,188); 3 = the phase distance of pRotatE (models.py:479-489):
-                          * dist = modulus * sum_k |sin((s_k + p_k - o_k) / 2)|, same gamma convention (models.py:486-489) */
+                          * dist = modulus * sum_k |sin((s_k + p_k - o_k) / 2)|, same gamma convention (models.py:486-489);
+                          * 5 = tf.norm(x, ord=p) for any other positive real p (models.py:188 `ord=self.norm`): dist = (sum_k |x_k|^p)^(1/p)
+                          * with p in `modulus`; scoring, push-path training and the VALU distance sweep of the ranking */
   float gamma;           /* TransE (models.py:179,187-190): score = gamma - dist if gamma > 0 else +dist */
   float dropout;         /* Dropout(dp) on the three gathered rows, training only (models.py:122,144-148) */
   int32_t conv_filters;  /* ConvE: Conv2D filters (models.py:242; 8 is built) */
   float hidden_dropout;  /* ConvE: Dropout(hidden_dp) after each batch norm (models.py:241,257,262) */
-  float modulus;         /* norm 3 only (models.py:476: modulus * embedding_range) */
+  float modulus;         /* norm 3: models.py:476 modulus * embedding_range; norm 5: the exponent p */
 } kge_model_desc;
 
 /* loss_function(true, false, margin, negative_samples) as called at tests.py:80-81. */

@@ -37,8 +37,10 @@ int check_model(const kge_model_desc* md, const char* who) {
     if (md->d_e != 2 * md->d_r) return fail(KGE_ESHAPE, "%s: RotatE needs e_dim %d == 2 * r_dim %d (tf.split halves against the phase row)", who, md->d_e, md->d_r);
   } else if (md->d_e != md->d_r) return fail(KGE_ESHAPE, "%s: e_dim %d and r_dim %d do not broadcast", who, md->d_e, md->d_r);
   if (md->model == KGE_COMPLEX && (md->d_e & 1)) return fail(KGE_ESHAPE, "%s: ComplEx rows must split in two halves (tf.split), width %d", who, md->d_e);
-  if (md->model == KGE_TRANSE && md->norm != 1 && md->norm != 2 && md->norm != 3)
-    return fail(KGE_EUNSUPPORTED, "%s: TransE norm %d (1, 2 and the pRotatE phase distance 3 are built)", who, md->norm);
+  if (md->model == KGE_TRANSE && md->norm != 1 && md->norm != 2 && md->norm != 3 && md->norm != 5)
+    return fail(KGE_EUNSUPPORTED, "%s: TransE norm id %d (1, 2, the pRotatE phase distance 3 and the general p-norm 5 are built)", who, md->norm);
+  if (md->model == KGE_TRANSE && md->norm == 5 && !(md->modulus > 0.f))
+    return fail(KGE_EINVAL, "%s: the general p-norm (norm id 5) takes its exponent p > 0 in kge_model_desc.modulus (got %f)", who, md->modulus);
   if (!(md->dropout >= 0.f && md->dropout < 1.f)) return fail(KGE_EINVAL, "%s: dropout rate %f outside [0,1)", who, md->dropout);
   return KGE_OK;
 }

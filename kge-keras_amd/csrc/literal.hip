@@ -208,7 +208,8 @@ static int64_t l256(int64_t x) { return align_up(x, 256); }
 static int lit_check(const kge_model_desc* md, int L, int act) {
   if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX)
     return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE and ComplEx are built)", md->model);
-  if (md->model == KGE_TRANSE && md->norm == 3) return fail(KGE_EUNSUPPORTED, "literal path: the pRotatE phase distance (norm 3) is not built here");
+  if (md->model == KGE_TRANSE && (md->norm == 3 || md->norm == 5))
+    return fail(KGE_EUNSUPPORTED, "literal path: the pRotatE phase distance (norm 3) and the general p-norm (norm 5) are not built here");
   if (L <= 0) return fail(KGE_EINVAL, "literal path: literal width %d", L);
   if (act < 0 || act > 8) return fail(KGE_EUNSUPPORTED, "literal path: activation id %d (softmax and custom callables are not built)", act);
   return KGE_OK;

@@ -452,6 +452,7 @@ static void carve_pull(void* hdr, void* ws, const kge_model_desc* md, int64_t n,
 bool pull_supported(const kge_model_desc* md) {
   if (md->model == KGE_HOLE) return md->d_e <= 1024;
   if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX) return false;
+  if (md->model == KGE_TRANSE && md->norm == 5) return false;  // the general p-norm trains on the push path
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const bool v4 = width % 4 == 0 && md->d_e % 4 == 0;
   const int nchunk = v4 ? width / 4 : width;

@@ -579,6 +579,7 @@ static bool dedup_applies(const kge_model_desc* md, int64_t n) {
 
 bool pull2_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
   if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX) return false;
+  if (md->model == KGE_TRANSE && md->norm == 5) return false;  // the general p-norm trains on the push path
   if (ld->loss != KGE_POINTWIZE_HINGE && ld->loss != KGE_POINTWIZE_LOGISTIC && ld->loss != KGE_POINTWIZE_SQUARE &&
       ld->loss != KGE_POINTWIZE_CROSS_ENTROPY)
     return false;

@@ -597,9 +597,9 @@ __global__ __launch_bounds__(256) void rank_filter_kernel(const float* __restric
 // per (query, candidate, k).  Target and filtered-candidate scores come from dist_chain(), the same operation
 // sequence in the same ascending-k order, so the strict comparisons are made on bit-identical numbers.
 template <int NORM>
-__device__ __forceinline__ float dist_step(float acc, float q, float e) {
+__device__ __forceinline__ float dist_step(float acc, float q, float e, float pw = 2.f) {
   const float x = q - e;
-  return NORM == 1 ? acc + fabsf(x) : (NORM == 3 ? acc + phase_abs(x) : __fmaf_rn(x, x, acc));
+  return NORM == 1 ? acc + fabsf(x) : (NORM == 3 ? acc + phase_abs(x) : (NORM == 5 ? acc + powf(fabsf(x), pw) : __fmaf_rn(x, x, acc)));  // 5: general p-norm
 }
 // NORM 4 = the pRotatE phase distance (NORM 3) on rows that hold (sin(x/2), cos(x/2)) PAIRS: |sin((q - e)/2)| =
 // |sin(q/2) cos(e/2) - cos(q/2) sin(e/2)|, one multiply, one fused multiply-add and one |.|-add per element instead of a sinf
@@ -611,7 +611,7 @@ __device__ __forceinline__ float phase_pair_step(float acc, float qs, float qc, 
 }
 template <int NORM>
 __device__ __forceinline__ float dist_score(float acc, float gamma, float modulus) {
-  const float d = NORM == 1 ? acc : (NORM >= 3 ? modulus * acc : sqrtf(acc));  // 3, 4: pRotatE phase distance (models.py:479-489)
+  const float d = NORM == 1 ? acc : (NORM == 5 ? powf(acc, 1.f / modulus) : (NORM >= 3 ? modulus * acc : sqrtf(acc)));  // 3, 4: pRotatE phase distance (models.py:479-489); 5: (sum |x|^p)^(1/p), p = modulus
   return gamma > 0.f ? gamma - d : d;
 }
 template <int NORM>
@@ -620,7 +620,7 @@ __device__ __forceinline__ float dist_chain(const float* __restrict__ q, const f
   if (NORM == 4) {
     for (int k = 0; k + 1 < K; k += 2) acc = phase_pair_step(acc, q[k], q[k + 1], e[k], e[k + 1]);
   } else {
-    for (int k = 0; k < K; ++k) acc = dist_step<NORM>(acc, q[k], e[k]);
+    for (int k = 0; k < K; ++k) acc = dist_step<NORM>(acc, q[k], e[k], modulus);
   }
   return dist_score<NORM>(acc, gamma, modulus);
 }
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void rank_dist_sweep_kernel(const float* __res
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = dist_step<NORM>(acc[i][j], qa[i], ea[j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = dist_step<NORM>(acc[i][j], qa[i], ea[j], modulus);
         }
       }
     }
@@ -950,6 +950,7 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
   if (md->model == KGE_TRANSE) {
     if (md->norm == 1) launch_dist<1>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
     else if (md->norm == 3) launch_dist<3>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
+    else if (md->norm == 5) launch_dist<5>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
     else launch_dist<2>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
@@ -1036,6 +1037,7 @@ int rank_chain_scores(const kge_model_desc* md, const float* E, const float* Rel
   if (md->model == KGE_TRANSE) {
     if (md->norm == 1) hipLaunchKernelGGL((rank_dist_scores_kernel<1>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, md->modulus, nq, md->num_entities, out);
     else if (md->norm == 3) hipLaunchKernelGGL((rank_dist_scores_kernel<3>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, md->modulus, nq, md->num_entities, out);
+    else if (md->norm == 5) hipLaunchKernelGGL((rank_dist_scores_kernel<5>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, md->modulus, nq, md->num_entities, out);
     else hipLaunchKernelGGL((rank_dist_scores_kernel<2>), dim3((int)cdiv(tot, 256)), dim3(256), 0, st, Qv, E, K, Kpad, md->gamma, md->modulus, nq, md->num_entities, out);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;

@@ -104,65 +104,59 @@ constexpr int kJumpBlocks = 33;   // 624 * 33 >= 19937 + 623 raw words after the
 constexpr int kPolyWords = 312;   // uint64 words of one jump polynomial
 
 // Jump-ahead as a window XOR: state_J[j] = XOR_{k : g_J[k]} W[k + j], W = the state block followed by the raw blocks behind it.
-// All kSeg-1 jumps of one generator read the SAME window, so one workgroup takes a tile of 64 output words j and a slice of the
-// coefficient range k for ALL of them: every LDS word is read once and applied to 15 accumulators (the polynomial words sit in
-// scalar registers, a coefficient test is a scalar bit compare).  One kernel per (tile, slice, polynomial) re-read the window 15
-// times and spent its time on per-workgroup overhead (4800 workgroups of a few hundred LDS reads each: 28.6 us; now ~640).
-// Partial results go to Jpart[z][s][slice][j] (no atomics, nothing to zero); the segment kernel XORs the slices when it loads its
-// start state.
-constexpr int kJumpSplit = 32;
-constexpr int kJRow = 640;  // 624 padded
+// Lane l of a wave stands for COEFFICIENT k0 + l of the current polynomial word, not for an output word: the 64 coefficient bits of
+// the word become the execution mask of the wave (`if (on)`), under which each of the wave's 16 output words j takes one
+// conflict-free LDS read W[k0 + l + j] and one XOR -- no per-bit scalar test at all (a lane per output word with the bit tested in
+// scalar registers costs two scalar instructions per LDS read, and the one scalar unit of a CU serves four SIMDs: 28.6 us for the 30
+// jumps of a batch).  The 64 lanes' partial words meet in an XOR butterfly at the end.  Work unit of a workgroup: (polynomial,
+// 64 output words, one of kJumpSplit coefficient slices); partial results go to Jpart[z][s][slice][j] (no atomics, nothing to zero) and
+// the segment kernel XORs the slices when it loads its start state.
+constexpr int kJumpSplit = 4;
+constexpr int kJRow = 640;   // 624 padded
+constexpr int kJTile = 16;   // output words per wave
 template <typename LoadW>
 __device__ __forceinline__ void jump_core(LoadW loadw, const uint64_t* __restrict__ polys_z, uint32_t* __restrict__ Jpart_z) {
-  constexpr int WPS = (kPolyWords + kJumpSplit - 1) / kJumpSplit;  // polynomial words per slice (10)
-  constexpr int WIN = WPS * 64 + 64;                               // raw words this block touches
-  constexpr int NP = kSeg - 1;
+  constexpr int WPS = kPolyWords / kJumpSplit;                     // polynomial words per slice (78)
+  static_assert(kPolyWords % kJumpSplit == 0, "slices must divide the polynomial");
+  constexpr int WIN = WPS * 64 + 4 * kJTile + 64;                  // raw words this workgroup touches
   __shared__ uint32_t win[WIN];
-  __shared__ uint32_t part[4][NP][64];
-  const int tile = blockIdx.x % 10, slice = blockIdx.x / 10;
+  __shared__ uint64_t pw[WPS];                                     // this slice's polynomial words (read back as LDS broadcasts)
+  const int jt = blockIdx.x % 10, slice = blockIdx.x / 10, s = blockIdx.y;  // s: polynomial 0 .. kSeg-2 (segment s + 1)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = tile * 64 + lane;
-  const int lo = slice * WPS * 64 + tile * 64;  // first raw word of the window
+  const int j0 = jt * 64 + wave * kJTile;                          // first output word of this wave
+  const int lo = slice * WPS * 64 + jt * 64;                       // first raw word of the window
   for (int i = threadIdx.x; i < WIN; i += 256) {
     const int idx = lo + i;
     win[i] = idx < 624 * (kJumpBlocks + 1) ? loadw(idx) : 0u;
   }
+  if (threadIdx.x < WPS) pw[threadIdx.x] = polys_z[(int64_t)s * kPolyWords + slice * WPS + threadIdx.x];
   __syncthreads();
-  uint32_t acc[NP];
+  uint32_t acc[kJTile];
 #pragma unroll
-  for (int s = 0; s < NP; ++s) acc[s] = 0u;
-  for (int wi = wave; wi < WPS; wi += 4) {
-    const int w = slice * WPS + wi;
-    if (w >= kPolyWords) break;
-    // lane s holds the word of polynomial s; readlane moves it into scalar registers
-    const uint64_t gv = lane < NP ? polys_z[(int64_t)lane * kPolyWords + w] : 0ull;
-    const uint32_t glo = (uint32_t)gv, ghi = (uint32_t)(gv >> 32);
-    uint32_t g0[NP], g1[NP];
+  for (int u = 0; u < kJTile; ++u) acc[u] = 0u;
+  const uint32_t* src = win + wave * kJTile + lane;
+#pragma unroll 2
+  for (int w = 0; w < WPS; ++w) {
+    const uint64_t g = pw[w];                                      // wave-uniform
+    const bool on = (g >> lane) & 1ull;
+    if (on) {
 #pragma unroll
-    for (int s = 0; s < NP; ++s) {
-      g0[s] = (uint32_t)__builtin_amdgcn_readlane((int)glo, s);
-      g1[s] = (uint32_t)__builtin_amdgcn_readlane((int)ghi, s);
-    }
-    const uint32_t* src = win + wi * 64 + lane;  // conflict-free: consecutive lanes, consecutive words
-#pragma unroll 8
-    for (int bit = 0; bit < 32; ++bit) {
-      const uint32_t x0 = src[bit], x1 = src[32 + bit];
-#pragma unroll
-      for (int s = 0; s < NP; ++s) {
-        acc[s] ^= ((g0[s] >> bit) & 1u) ? x0 : 0u;
-        acc[s] ^= ((g1[s] >> bit) & 1u) ? x1 : 0u;
-      }
+      for (int u = 0; u < kJTile; ++u) acc[u] ^= src[w * 64 + u];
     }
   }
 #pragma unroll
-  for (int s = 0; s < NP; ++s) part[wave][s][lane] = acc[s];
-  __syncthreads();
-  for (int i = threadIdx.x; i < NP * 64; i += 256) {
-    const int s = i >> 6, l = i & 63;
-    if (tile * 64 + l < 624)
-      Jpart_z[((int64_t)(s + 1) * kJumpSplit + slice) * kJRow + tile * 64 + l] = part[0][s][l] ^ part[1][s][l] ^ part[2][s][l] ^ part[3][s][l];
+  for (int u = 0; u < kJTile; ++u) {
+    uint32_t v = acc[u];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v ^= (uint32_t)__shfl_xor((int)v, d, 64);
+    acc[u] = v;
   }
-  (void)j;
+  if (lane < kJTile && j0 + lane < 624) {
+    uint32_t v = 0u;
+#pragma unroll
+    for (int u = 0; u < kJTile; ++u) v = lane == u ? acc[u] : v;
+    Jpart_z[((int64_t)(s + 1) * kJumpSplit + slice) * kJRow + j0 + lane] = v;
+  }
 }
 // start state of segment s (>= 1) of generator z: XOR of the slices' partial results
 __device__ __forceinline__ uint32_t jump_state_word(const uint32_t* __restrict__ Jpart, int z, int s, int i) {
@@ -173,7 +167,7 @@ __device__ __forceinline__ uint32_t jump_state_word(const uint32_t* __restrict__
   return v;
 }
 
-// grid (10 j-tiles x kJumpSplit k-slices, 1, 2 generators)
+// grid (10 j-tiles x kJumpSplit k-slices, kSeg-1 polynomials, 2 generators)
 __global__ __launch_bounds__(256) void mt_jump_kernel(const MTDev* __restrict__ st_np, const MTDev* __restrict__ st_py,
                                                        const uint32_t* __restrict__ U_np, const uint32_t* __restrict__ U_py,
                                                        const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jpart, int seg_np,
@@ -466,7 +460,7 @@ int build_batch_device(void* np_state, void* py_state, const int32_t* batch, con
   hipLaunchKernelGGL(mt_generate_kernel, dim3(2), dim3(256), 0, st, nps, pys, p.U_np, sb_np ? kJumpBlocks : (int)p.K_np, p.U_py,
                      sb_py ? kJumpBlocks : (int)p.K_py, (sb_np || sb_py) ? p.Jst : nullptr);
   if (sb_np || sb_py) {
-    hipLaunchKernelGGL(mt_jump_kernel, dim3(10 * kJumpSplit, 1, 2), dim3(256), 0, st, nps, pys, p.U_np, p.U_py, static_cast<const uint64_t*>(plan_dev),
+    hipLaunchKernelGGL(mt_jump_kernel, dim3(10 * kJumpSplit, kSeg - 1, 2), dim3(256), 0, st, nps, pys, p.U_np, p.U_py, static_cast<const uint64_t*>(plan_dev),
                        p.Jst, sb_np, sb_py);
     hipLaunchKernelGGL(mt_generate_seg_kernel, dim3(kSeg, 2), dim3(256), 0, st, p.U_np, (int)p.K_np, sb_np, p.U_py, (int)p.K_py, sb_py, p.Jst);
   }
@@ -606,7 +600,7 @@ __global__ __launch_bounds__(256) void ring_pre_kernel(Ring r0, Ring r1, uint32_
   ring_regen_blocks(buf, r, head, head + (r.segb ? (int64_t)kJumpBlocks : r.P));
 }
 
-// The jumps of a round: W = block head-1 followed by the blocks behind it (jump_core).  grid (10 * kJumpSplit, 1, 2).
+// The jumps of a round: W = block head-1 followed by the blocks behind it (jump_core).  grid (10 * kJumpSplit, kSeg - 1, 2).
 __global__ __launch_bounds__(256) void ring_jump_kernel(Ring r0, Ring r1, const uint64_t* __restrict__ polys, uint32_t* __restrict__ Jpart) {
   const int z = blockIdx.z;
   const Ring& r = z == 0 ? r0 : r1;
@@ -846,7 +840,7 @@ int sampler_stream_produce(void* buf, int64_t bytes, int64_t B, int64_t ns, int6
   ProfScope prof(KGE_PROF_SAMPLER, st);
   hipLaunchKernelGGL(ring_pre_kernel, dim3(2), dim3(256), 0, st, q.r_np, q.r_py, q.sp.Jst);
   if (q.r_np.segb || q.r_py.segb) {
-    hipLaunchKernelGGL(ring_jump_kernel, dim3(10 * kJumpSplit, 1, 2), dim3(256), 0, st, q.r_np, q.r_py, static_cast<const uint64_t*>(plan_dev), q.sp.Jst);
+    hipLaunchKernelGGL(ring_jump_kernel, dim3(10 * kJumpSplit, kSeg - 1, 2), dim3(256), 0, st, q.r_np, q.r_py, static_cast<const uint64_t*>(plan_dev), q.sp.Jst);
     hipLaunchKernelGGL(ring_seg_kernel, dim3(kSeg, 2), dim3(256), 0, st, q.r_np, q.r_py, q.sp.Jst);
   }
   KGE_HIP_TRY(hipGetLastError());

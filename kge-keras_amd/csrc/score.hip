@@ -32,13 +32,13 @@ __device__ __forceinline__ float dm3(float4 s, float4 p, float4 o) {
   return s.x * p.x * o.x + s.y * p.y * o.y + s.z * p.z * o.z + s.w * p.w * o.w;
 }
 template <int NORM>
-__device__ __forceinline__ float te1(float s, float p, float o) {
+__device__ __forceinline__ float te1(float s, float p, float o, float pw) {
   float x = s + p - o;
-  return NORM == 1 ? fabsf(x) : (NORM == 3 ? phase_abs(x) : x * x);
+  return NORM == 1 ? fabsf(x) : (NORM == 3 ? phase_abs(x) : (NORM == 5 ? powf(fabsf(x), pw) : x * x));  // 5: general p-norm, exponent pw
 }
 template <int NORM>
-__device__ __forceinline__ float te1(float4 s, float4 p, float4 o) {
-  return te1<NORM>(s.x, p.x, o.x) + te1<NORM>(s.y, p.y, o.y) + te1<NORM>(s.z, p.z, o.z) + te1<NORM>(s.w, p.w, o.w);
+__device__ __forceinline__ float te1(float4 s, float4 p, float4 o, float pw) {
+  return te1<NORM>(s.x, p.x, o.x, pw) + te1<NORM>(s.y, p.y, o.y, pw) + te1<NORM>(s.z, p.z, o.z, pw) + te1<NORM>(s.w, p.w, o.w, pw);
 }
 __device__ __forceinline__ float cx1(float sr, float si, float pr, float pi, float orr, float oi) {
   // models.py:218-222  s1+s2+s3-s4
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ E,
 #pragma unroll 4
         for (int c = lane; c < nchunk; c += G) {
           auto sv = C::ld(es + c * VEC), pv = C::ld(rp + c * VEC), ov = C::ld(eo + c * VEC);
-          acc += (MODEL == KGE_DISTMULT) ? dm3(sv, pv, ov) : te1<NORM>(sv, pv, ov);
+          acc += (MODEL == KGE_DISTMULT) ? dm3(sv, pv, ov) : te1<NORM>(sv, pv, ov, modulus);
         }
       }
     }
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ E,
       if (MODEL == KGE_TRANSE) {
         if (NORM == 2) sc = sqrtf(sc);
         if (NORM == 3) sc *= modulus;
+        if (NORM == 5) sc = powf(sc, 1.f / modulus);
         sc = gamma > 0.f ? gamma - sc : sc;  // models.py:187-190, 486-489
       }
       if (MODEL == KGE_ROTATE) sc = gamma > 0.f ? gamma - sc : sc;  // models.py:455-458
@@ -158,6 +159,7 @@ int score_dispatch(const kge_model_desc* md, const float* E, const float* Rel, c
     case KGE_TRANSE:
       if (md->norm == 1) { KGE_GO(KGE_TRANSE, 1); }
       if (md->norm == 3) { KGE_GO(KGE_TRANSE, 3); }
+      if (md->norm == 5) { KGE_GO(KGE_TRANSE, 5); }
       KGE_GO(KGE_TRANSE, 2);
     case KGE_COMPLEX: KGE_GO(KGE_COMPLEX, 1);
     case KGE_ROTATE: KGE_GO(KGE_ROTATE, 1);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
       } else {
         const float sv = es[k] * ms(k), pv = rp[k] * mp(k), ov = eo[k] * mo(k);
         if (MODEL == KGE_DISTMULT) acc += sv * pv * ov;
-        else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : (NORM == 3 ? phase_abs(x) : x * x); }
+        else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : (NORM == 3 ? phase_abs(x) : (NORM == 5 ? powf(fabsf(x), modulus) : x * x)); }
       }
     }
     acc = group_sum<G>(acc);
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
     if (MODEL == KGE_TRANSE) {
       if (NORM == 2) dist = sqrtf(acc);
       if (NORM == 3) dist = modulus * acc;
+      if (NORM == 5) dist = powf(acc, 1.f / modulus);
       score = gamma > 0.f ? gamma - dist : dist;
     }
     if (MODEL == KGE_ROTATE) score = gamma > 0.f ? gamma - acc : acc;
@@ -94,11 +95,13 @@ __global__ __launch_bounds__(256) void push_kernel(const float* __restrict__ E, 
     if (MODEL == KGE_TRANSE) {
       // d score / d x = -d dist/dx (gamma > 0) or +d dist/dx; L2: x/dist, 0 at dist == 0 (TF yields NaN there)
       const float sgn = gamma > 0.f ? -g : g;
-      const float rn = (NORM == 2) ? (dist > 0.f ? sgn / dist : 0.f) : (NORM == 3 ? 0.5f * modulus * sgn : sgn);
+      // general p: d dist / d x_k = |x_k|^(p-1) sign(x_k) dist^(1-p)
+      const float rn = (NORM == 2) ? (dist > 0.f ? sgn / dist : 0.f) : (NORM == 3 ? 0.5f * modulus * sgn : (NORM == 5 ? (dist > 0.f ? sgn * powf(dist, 1.f - modulus) : 0.f) : sgn));
       for (int k = lane; k < width; k += G) {
         const float a = ms(k), b = mp(k), c = mo(k);
         const float x = es[k] * a + rp[k] * b - eo[k] * c;
-        const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f)) : (NORM == 3 ? rn * phase_dterm(x) : rn * x);
+        const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f))
+                                   : (NORM == 3 ? rn * phase_dterm(x) : (NORM == 5 ? (x == 0.f ? 0.f : rn * copysignf(powf(fabsf(x), modulus - 1.f), x)) : rn * x));
         atomicAdd(gs + k, dx * a);
         atomicAdd(gp + k, dx * b);
         atomicAdd(go + k, -dx * c);
@@ -441,6 +444,8 @@ static int push_by_model(int G, const kge_model_desc* md, const kge_loss_desc* l
         return launch_push<KGE_TRANSE, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
       if (md->norm == 3)
         return launch_push<KGE_TRANSE, 3, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
+      if (md->norm == 5)
+        return launch_push<KGE_TRANSE, 5, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
       return launch_push<KGE_TRANSE, 2, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);
     case KGE_COMPLEX:
       return launch_push<KGE_COMPLEX, 1, LOSS>(G, md, ld, E, Rel, gE, gR, pos, m_pos, neg, m_neg, gbuf, scores, partials, err, st, nb, seed);

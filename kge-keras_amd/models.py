@@ -726,6 +726,20 @@ class TransE(EmbeddingModel):
         self.gamma = gamma
         self.norm = norm
 
+    def _model_desc(self, training=False):
+        """tf.norm(x, ord=self.norm, axis=1) (models.py:188): ord 1 and 2 have their own kernels (library norm ids 1, 2); any other
+        positive real p is the general p-norm (id 5, exponent in the descriptor's `modulus` field).  'euclidean' = 2.  ord = inf
+        (max |x|) and the matrix norms tf.norm also accepts are not built."""
+        md = super()._model_desc(training)
+        n = 2 if self.norm == 'euclidean' else self.norm
+        if isinstance(n, bool) or not isinstance(n, (int, float, np.integer, np.floating)) or not np.isfinite(n) or n <= 0:
+            raise NotImplementedError(f"TransE norm {self.norm!r}: positive real orders (and 'euclidean') are built")
+        if n in (1, 2):
+            md.norm = int(n)
+        else:
+            md.norm, md.modulus = 5, float(n)
+        return md
+
 
 class ComplEx(EmbeddingModel):
     """models.py:203-222: both widths are doubled (so e_dim and r_dim must be passed as kwargs, as in the reference)."""

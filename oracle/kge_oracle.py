@@ -156,10 +156,14 @@ def score_row_grads(model, s, p, o, g, norm=1, gamma=12):
         sgn = -1.0 if gamma > 0 else 1.0
         if norm == 1:
             dx = np.sign(x)  # [TF] sign(0) = 0
-        else:
+        elif norm == 2:
             n = np.sqrt(np.sum(x * x, axis=1, keepdims=True))
             with np.errstate(invalid="ignore", divide="ignore"):
                 dx = x / n  # [TF] NaN at x == 0
+        else:  # general p: d (sum |x|^p)^(1/p) / dx_k = |x_k|^(p-1) sign(x_k) n^(1-p)
+            n = np.sum(np.abs(x) ** norm, axis=1, keepdims=True) ** (1.0 / norm)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                dx = np.sign(x) * np.abs(x) ** (norm - 1) * n ** (1 - norm)
         dx = sgn * g * dx
         return dx, dx, -dx
     if model == "ComplEx":

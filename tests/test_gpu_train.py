@@ -737,3 +737,38 @@ def test_hole_spectral_with_l3_regulariser():
         assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
         np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
         np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+
+
+@pytest.mark.parametrize("norm,gamma", [(3, 12), (1.5, 12), (4, 0)])
+def test_transe_general_p_norm(norm, gamma):
+    """tf.norm(x, ord=p) for any positive real p (models.py:188 `ord=self.norm`): scores, train steps on every loss family (push path),
+    filtered ranks."""
+    N, R, d, m = 60, 6, 24, 300
+    for loss, opt in (("pointwize_hinge", "adam"), ("pointwize_logistic", "sgd"), ("pairwize_hinge", "adam")):
+        mdl, E0, R0, rs = _mk("TransE", N, R, d, norm=norm, gamma=gamma, loss_function=loss, margin=0.5)
+        t = _triples(rs, 500, N, R)
+        np.testing.assert_allclose(mdl.predict(t), O.call("TransE", E0, R0, t, norm, gamma), atol=TOL, rtol=1e-5)
+        assert not mdl.plan_supported()
+        mdl.compile(opt)
+        Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+        oo = O.make_optimizer(opt)
+        for step in range(2):
+            pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
+            L = float(mdl.train_step([pos, neg])["loss"].item())
+            Lo = O.train_step("TransE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, norm, gamma)
+            assert L == pytest.approx(Lo, abs=TOL, rel=1e-4), (loss, step)
+            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    test = list(dict.fromkeys(tuple(int(v) for v in x) for x in _triples(rs, 40, N, R)))
+    filt = [tuple(int(v) for v in x) for x in _triples(rs, 200, N, R)]
+    filt = [x for x in filt if x not in set(test)]
+    fh, ft = O.build_filters(filt)
+    tails, heads = mdl.rank(test, N, {k: sorted(v) for k, v in ft.items()}, {k: sorted(v) for k, v in fh.items()})
+    margins = []
+    to, ho = O.ranks_closed_form("TransE", mdl.E.cpu().numpy(), mdl.Rel.cpu().numpy(), test, filt, norm, gamma, margin_out=margins)
+    mm = np.asarray(margins).reshape(-1, 2)
+    st, sh = mm[:, 0] > 1e-4, mm[:, 1] > 1e-4
+    assert np.array_equal(tails[st], to[st]) and np.array_equal(heads[sh], ho[sh]) and st.mean() > 0.8
+    from kge_keras_amd import models as M
+    with pytest.raises(NotImplementedError):
+        M.TransE(e_dim=8, r_dim=8, num_entities=5, num_relations=2, norm=np.inf).predict(np.array([[0, 0, 1]]))

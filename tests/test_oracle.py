@@ -212,7 +212,7 @@ def _torch_score(model, s, p, o, norm, gamma):
         return gamma - sc if gamma > 0 else sc
 
 
-@pytest.mark.parametrize("model,norm,gamma", [("DistMult", 1, 12), ("TransE", 1, 12), ("TransE", 2, 12), ("TransE", 2, 0),
+@pytest.mark.parametrize("model,norm,gamma", [("DistMult", 1, 12), ("TransE", 1, 12), ("TransE", 2, 12), ("TransE", 2, 0), ("TransE", 3, 12), ("TransE", 1.5, 0),
                                               ("ComplEx", 1, 12), ("HolE", 1, 12), ("pRotatE", 0.35, 12), ("pRotatE", 0.35, 0),
                                               ("RotatE", 2, 12), ("RotatE", 2, 0)])
 @pytest.mark.parametrize("loss", ["pointwize_hinge", "pointwize_logistic", "pairwize_hinge"])
