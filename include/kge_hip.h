@@ -385,6 +385,18 @@ int kge_sampler_stream_draw(void* stream_buf, int64_t stream_bytes, void* np_sta
                             int64_t ns, int64_t num_e, int32_t* pos_out_dev, int32_t* neg_out_dev, int32_t* cand_rows_dev,
                             int32_t* cand_counts_dev, uint32_t* err_flag, kge_stream_t stream);
 
+/* ---- RCCL collectives of the multi-GPU halves of the path (the reference is single-process and has no counterpart), on
+ *      a communicator the CALLER made (ncclComm_t passed as void*), enqueued on `stream`.  RCCL is resolved at run time (from the
+ *      process, else librccl.so.1); KGE_EUNSUPPORTED when it is not there.
+ *        kge_allgather_rows    schedule (i) of the sharded evaluation: every rank contributes its (rows_per_rank, d) shard (padded to
+ *                              equal size), `full` receives the (n_ranks * rows_per_rank, d) table;
+ *        kge_allreduce_counts  schedule (ii): sum over ranks of the per-query int32 counts of kge_rank_counts over resident shards;
+ *        kge_allreduce_f32     data-parallel training: sum over ranks of the flat gradient buffer (both tables + the loss word)
+ *                              between kge_train_grads[_planned] and kge_opt_apply(grad_scale = 1 / ranks). */
+int kge_allgather_rows(void* comm, const float* shard, int64_t rows_per_rank, int32_t d, float* full, kge_stream_t stream);
+int kge_allreduce_counts(void* comm, int32_t* counts, int64_t n, kge_stream_t stream);
+int kge_allreduce_f32(void* comm, float* buf, int64_t n, kge_stream_t stream);
+
 /* ---- training pipeline: what Keras' fit() does for the reference with a prefetching Sequence (tests.py:29-61,130-134) as a native
  *      host loop over four device streams, one to two batches apart: word generation (kge_sampler_stream_produce), draw batch k
  *      (kge_sampler_stream_draw, folded output), plan batch k (kge_batch_plan_build_counted), train step k

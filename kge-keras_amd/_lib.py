@@ -116,6 +116,9 @@ SIGNATURES = {
     "kge_mt_jump_poly": (C.c_int, [_I64, _P]),
     "kge_mt_jump_host": (C.c_int, [_P, _I64]),
     "kge_build_batch_host": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "kge_allgather_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "kge_allreduce_counts": (C.c_int, [_P, _P, _I64, _P]),
+    "kge_allreduce_f32": (C.c_int, [_P, _P, _I64, _P]),
     "kge_kg_open": (C.c_int, [C.POINTER(C.c_char_p), _I32, C.POINTER(C.c_void_p)]),
     "kge_kg_sizes": (C.c_int, [_P, C.POINTER(_I64), C.POINTER(_I64), _P]),
     "kge_kg_triples": (C.c_int, [_P, _I32, _P]),

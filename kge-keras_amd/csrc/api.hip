@@ -1,4 +1,6 @@
 // extern "C" surface of libkge_hip.so: argument validation, error text, dispatch.  See include/kge_hip.h.
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -665,6 +667,63 @@ int kge_lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32
   if (!Lit || !theta_l || !gtheta_l || !workspace) return fail(KGE_EINVAL, "kge_lit_train_grads: null pointer");
   return lit_train_grads(md, ld, act, E, Rel, Lit, L, lit_rows, theta_l, gradE, gradRel, gtheta_l, pos, m_pos, neg, m_neg, loss_out, scores_out, seed,
                          workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+// ---- RCCL collectives of the sharded evaluation and of data-parallel training, on a communicator the caller made (ncclComm_t passed
+// as void*).  RCCL is resolved at run time from the process (PyTorch-ROCm brings its own librccl) or from librccl.so.1: the library
+// has no link-time dependency on it and single-GPU users never load it.
+namespace {
+typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_t)(int);
+struct Rccl { nccl_allgather_t allgather = nullptr; nccl_allreduce_t allreduce = nullptr; nccl_errstr_t errstr = nullptr; };
+const Rccl* rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    void* h = RTLD_DEFAULT;
+    if (!dlsym(h, "ncclAllReduce")) {
+      h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) return x;
+    }
+    x.allgather = reinterpret_cast<nccl_allgather_t>(dlsym(h, "ncclAllGather"));
+    x.allreduce = reinterpret_cast<nccl_allreduce_t>(dlsym(h, "ncclAllReduce"));
+    x.errstr = reinterpret_cast<nccl_errstr_t>(dlsym(h, "ncclGetErrorString"));
+    return x;
+  }();
+  return (r.allgather && r.allreduce) ? &r : nullptr;
+}
+constexpr int kNcclInt32 = 2, kNcclFloat32 = 7, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values (nccl.h)
+int rccl_fail(const Rccl* r, const char* who, int rc) {
+  return fail(KGE_EHIP, "%s: RCCL error %d (%s)", who, rc, r->errstr ? r->errstr(rc) : "?");
+}
+}  // namespace
+
+int kge_allgather_rows(void* comm, const float* shard, int64_t rows_per_rank, int32_t d, float* full, kge_stream_t stream) {
+  clear_stale_error();
+  if (!comm || !shard || !full || rows_per_rank < 0 || d <= 0) return fail(KGE_EINVAL, "kge_allgather_rows: bad arguments");
+  const Rccl* r = rccl();
+  if (!r) return fail(KGE_EUNSUPPORTED, "kge_allgather_rows: RCCL (librccl.so.1) is not available in this process");
+  const int rc = r->allgather(shard, full, (size_t)rows_per_rank * (size_t)d, kNcclFloat32, comm, static_cast<hipStream_t>(stream));
+  return rc == 0 ? KGE_OK : rccl_fail(r, "kge_allgather_rows", rc);
+}
+
+int kge_allreduce_counts(void* comm, int32_t* counts, int64_t n, kge_stream_t stream) {
+  clear_stale_error();
+  if (!comm || !counts || n < 0) return fail(KGE_EINVAL, "kge_allreduce_counts: bad arguments");
+  const Rccl* r = rccl();
+  if (!r) return fail(KGE_EUNSUPPORTED, "kge_allreduce_counts: RCCL (librccl.so.1) is not available in this process");
+  const int rc = r->allreduce(counts, counts, (size_t)n, kNcclInt32, kNcclSum, comm, static_cast<hipStream_t>(stream));
+  return rc == 0 ? KGE_OK : rccl_fail(r, "kge_allreduce_counts", rc);
+}
+
+int kge_allreduce_f32(void* comm, float* buf, int64_t n, kge_stream_t stream) {
+  clear_stale_error();
+  if (!comm || !buf || n < 0) return fail(KGE_EINVAL, "kge_allreduce_f32: bad arguments");
+  const Rccl* r = rccl();
+  if (!r) return fail(KGE_EUNSUPPORTED, "kge_allreduce_f32: RCCL (librccl.so.1) is not available in this process");
+  const int rc = r->allreduce(buf, buf, (size_t)n, kNcclFloat32, kNcclSum, comm, static_cast<hipStream_t>(stream));
+  return rc == 0 ? KGE_OK : rccl_fail(r, "kge_allreduce_f32", rc);
 }
 
 }  // extern "C"

@@ -198,8 +198,10 @@ class EmbeddingModel:
 
     # ------------------------------------------------------------------ descriptors
     def _model_desc(self, training=False):
+        n = getattr(self, "norm", 1)  # (TransE maps its `norm` argument onto the library's norm ids itself)
+        nid = int(n) if isinstance(n, (int, np.integer)) and not isinstance(n, bool) else 1
         return ModelDesc(MODEL_IDS[self.MODEL], self.num_entities, self.num_relations, int(self.e_dim), int(self.r_dim),
-                         int(getattr(self, "norm", 1)), float(getattr(self, "gamma", 0.0)), float(self.dp) if training else 0.0,
+                         nid, float(getattr(self, "gamma", 0.0)), float(self.dp) if training else 0.0,
                          int(getattr(self, "conv_filters", 0)), float(getattr(self, "hidden_dp", 0.0)) if training else 0.0,
                          float(getattr(self, "modulus", 0.0)) if self.MODEL == "TransE" else 0.0)
 

@@ -405,3 +405,36 @@ def test_resident_shard_schedule_equals_full_table(model, kw):
             acc = mdl.rank_counts_shard(ref, local, side, q, f, mdl.E[lo:hi].clone(), lo, counts=acc)
         assert np.array_equal(acc.cpu().numpy(), full), (model, kw, side)
     mdl._raise_on_flag()
+
+
+def test_rccl_wrappers_one_rank_communicator():
+    """kge_allgather_rows / kge_allreduce_counts / kge_allreduce_f32 on a communicator the caller made: a one-rank RCCL communicator
+    (all a one-GPU box allows), created through RCCL's own C API.  With one rank every collective is the identity -- what is under
+    test is symbol resolution, argument marshalling, datatype codes and stream ordering."""
+    import ctypes as C
+    from kge_keras_amd import _lib
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("librccl.so")
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char * 128, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        st = _lib.stream_ptr()
+        shard = torch.arange(35 * 8, dtype=torch.float32, device="cuda").reshape(35, 8)
+        full = torch.zeros_like(shard)
+        _lib.check(_lib.lib.kge_allgather_rows(comm, shard.data_ptr(), 35, 8, full.data_ptr(), st))
+        cnt = torch.arange(1000, dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib.kge_allreduce_counts(comm, cnt.data_ptr(), cnt.numel(), st))
+        g = torch.linspace(-1, 1, 4099, device="cuda")
+        g0 = g.clone()
+        _lib.check(_lib.lib.kge_allreduce_f32(comm, g.data_ptr(), g.numel(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(full, shard) and torch.equal(cnt, torch.arange(1000, dtype=torch.int32, device="cuda")) and torch.equal(g, g0)
+        assert _lib.lib.kge_allreduce_counts(None, cnt.data_ptr(), 4, st) == _lib.KGE_EINVAL
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
