@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
   int4 e_nx = make_int4(0, 0, 0, 0);
   float cf_nx = 0.f;
   if (sub < len) { e_nx = entries[start + sub]; cf_nx = coef_of_row ? coef_of_row[e_nx.w] : __int_as_float(e_nx.z); }
+#pragma unroll 2
   for (int i = sub; i < len; i += NSUB) {
     const int4 e = e_nx;
     const float cf = cf_nx;
