@@ -95,7 +95,17 @@ __device__ __forceinline__ void scan_tile_body(const int32_t* __restrict__ cnt, 
   const int base = tile * kScanTile;
   // (1) everything in front of the tile
   Tri pre{0, 0, 0};
-  for (int k = tid; k < base; k += 256) pre = tri_add(pre, tri_of(cnt[k], C));
+  {
+    int k = tid;
+    for (; k + 7 * 256 < base; k += 8 * 256) {  // eight independent loads in flight
+      int c8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c8[u] = cnt[k + u * 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pre = tri_add(pre, tri_of(c8[u], C));
+    }
+    for (; k < base; k += 256) pre = tri_add(pre, tri_of(cnt[k], C));
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) pre = tri_add(pre, Tri{__shfl_xor(pre.a, d, 64), __shfl_xor(pre.b, d, 64), __shfl_xor(pre.c, d, 64)});
   if (lane == 0) red[wave] = pre;

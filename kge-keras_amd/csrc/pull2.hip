@@ -246,8 +246,9 @@ __global__ __launch_bounds__(256) void rel_fill_kernel(Src src, const int32_t* _
 //     Each workgroup therefore first aggregates its rows in an LDS hash table (key -> occurrences so far), then issues ONE global
 //     returning atomic per distinct key, and adds the returned base to the local ranks.
 // rrank: -1 = ids outside the tables (rel_fill_kernel raises the error flag), -2 = multiplicity 0.
-constexpr int kEntRows = 1024;   // rows per workgroup (4 per thread)
-constexpr int kEntSlots = 4096;  // LDS hash slots (2 * kEntRows keys at most -> load factor <= 0.5)
+constexpr int kEntRows = 512;    // rows per workgroup (kEntPer per thread): 400 workgroups per 204 800-row batch, so that the bursts of
+constexpr int kEntPer = kEntRows / 256;  // returning atomics of one workgroup hide behind the LDS phase of another on the same CU
+constexpr int kEntSlots = 2048;  // LDS hash slots (2 * kEntRows keys at most -> load factor <= 0.5)
 struct HistSrc {
   Src src;                      // MODE 0 / 1
   const int32_t* cand_rows;     // MODE 2
@@ -269,9 +270,9 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(HistSrc hs, int64_t n, i
   const int64_t rows = MODE == 2 ? hs.n_all : src_rows(hs.src);
   if (MODE != 0 && nu_out && blockIdx.x == 0 && threadIdx.x == 0) nu_out[0] = (int32_t)rows;
   const int64_t t0 = (int64_t)blockIdx.x * kEntRows;
-  int slot[8], lrank[8], rp[4], pp[4];
+  int slot[2 * kEntPer], lrank[2 * kEntPer], rp[kEntPer], pp[kEntPer];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kEntPer; ++i) {
     const int64_t t = t0 + threadIdx.x + i * 256;  // n = m_pos + m_neg: stride of the two entity rank planes
     slot[2 * i] = slot[2 * i + 1] = -1;
     rp[i] = -2; pp[i] = 0;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(HistSrc hs, int64_t n, i
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < kEntPer; ++i) {
     const int64_t t = t0 + threadIdx.x + i * 256;
     if (t < rows) {
       rrank[t] = rp[i] < 0 ? rp[i] : lrel[pp[i]] + rp[i];
