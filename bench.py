@@ -674,9 +674,8 @@ def main():
             # the gather kernels touch rows_per_launch distinct rows: value_distinct is the rate on those
             "value_distinct": rows_launch * world * args.steps / dt,
             "value_ranks_per_sec": ev["ranks_per_sec"] if ev else None,
-            "value_first_steps": per_step * world * args.steps / dt_first,
-            "ms_per_step_first_steps": dt_first / args.steps * 1e3,
-            "settle_steps": settle,
+            "settle_steps": settle,  # 0: the K timed steps follow the W warm-up steps directly
+            **({"value_first_steps": per_step * world * args.steps / dt_first, "ms_per_step_first_steps": dt_first / args.steps * 1e3} if settle > 0 else {}),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_source": (f"committed rocprofv3 --pmc passes ({traffic_tag or 'profiles/pmc_traffic.json'}; tools/pmc.sh), not this run" if traffic else None),
