@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 4
+#define KGE_ABI_VERSION 5
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -248,6 +248,25 @@ int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, c
 int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,
                            float* gradRel, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed,
                            void* workspace, int64_t workspace_bytes, kge_stream_t stream);
+/* kge_train_step_planned between twin tables: the step reads the parameters from (E_in, Rel_in) and writes the updated tables to
+ * (E_out, Rel_out) -- distinct buffers of the same shapes; the input tables are left as they were; the moments of `od` advance in
+ * place.  Because no reader of this step can meet an updated row, the wave that has summed the gradient of a row applies the
+ * optimizer to it on the spot: no gradient tables, no optimizer sweep (tests.py:63-89 + optimizer 'adam' / 'sgd', Keras semantics:
+ * every row of both tables is updated).  The step has two independent halves (parts mask):
+ *   1  entity half   one launch: per entity row gather, own scores, dL/dscore, gradient row, optimizer -> E_out; the plan's entity
+ *                    counters are left zero;
+ *   2  relation half relation-grouped forward (loss, partial relation rows), then relation rows + optimizer -> Rel_out, *loss_out,
+ *                    the plan's relation counters left zero, the step state od->step_dev moved on (t += 1, loss sum);
+ *   3  both, on `stream`.
+ * A caller may issue the halves of one step on two streams (both read (E_in, Rel_in) and the plan; they share nothing they write);
+ * the next step needs both.  od->step = the number of this update (1-based): lr_t travels by value.  The caller alternates the two
+ * table pairs from step to step.  Needs od->step_dev (kge_opt_state_init), no L3 term, no dropout, rows of at most 256 floats (per
+ * half row for ComplEx); kge_train_step_swap_supported says so ahead of time (1 / 0; a negative status for an invalid descriptor),
+ * the step itself returns KGE_EUNSUPPORTED otherwise.  Same results as kge_train_step_planned up to fp32 summation order. */
+int kge_train_step_swap_supported(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od);
+int kge_train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in,
+                        float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
+                        uint64_t seed, void* workspace, int64_t workspace_bytes, int32_t parts, kge_stream_t stream);
 
 /* ---- the reference's loss functions as callables on two score vectors (utils.py:288-319, reduce_mean=True):
  *      *loss_out = loss(true, false, margin, negative_samples); d_true / d_false (optional, may be NULL) receive the
@@ -439,6 +458,10 @@ typedef struct {
   int32_t* cand_counts[2];    /* KGE_CAND_POS_LANES*B + B*ns per buffer parity */
   void* plan[2];              /* kge_batch_plan_bytes(md, ld, B*ns, B*ns) per buffer parity */
   int64_t plan_bytes;
+  float *E_twin, *Rel_twin;   /* optional (both or neither): second buffers of the two tables' shapes.  With them, and where
+                               * kge_train_step_swap_supported, the steps alternate between (E, Rel) and the twins
+                               * (kge_train_step_swap: two launches per step instead of three); every kge_pipeline_run leaves the
+                               * current tables in (E, Rel) -- one device copy behind its last step when it issued an odd number */
 } kge_pipeline_desc;
 int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void** handle);
 int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream);

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkge_hip.so")
+LIB_PATH = os.environ.get("KGE_HIP_LIB") or os.path.join(_HERE, "csrc", "libkge_hip.so")  # (KGE_HIP_LIB: another build of the same library, for A/B timing)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -52,7 +52,8 @@ class PipelineDesc(C.Structure):
                 ("cursor", C.c_void_p), ("B", C.c_int64), ("ns", C.c_int64), ("num_e", C.c_int64),
                 ("sampler_plan", C.c_void_p), ("sampler_ws", C.c_void_p), ("sampler_ws_bytes", C.c_int64), ("sampler_err", C.c_void_p),
                 ("sampler_stream", C.c_void_p), ("sampler_stream_bytes", C.c_int64), ("sampler_stream_plan", C.c_void_p),
-                ("cand_rows", C.c_void_p * 2), ("cand_counts", C.c_void_p * 2), ("plan", C.c_void_p * 2), ("plan_bytes", C.c_int64)]
+                ("cand_rows", C.c_void_p * 2), ("cand_counts", C.c_void_p * 2), ("plan", C.c_void_p * 2), ("plan_bytes", C.c_int64),
+                ("E_twin", C.c_void_p), ("Rel_twin", C.c_void_p)]
 
 
 _P, _I64, _I32, _U64, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float
@@ -91,6 +92,8 @@ SIGNATURES = {
     "kge_batch_plan_build_counted": (C.c_int, [_MD, _LD, _P, _P, _I32, _I64, _I64, _I64, _I64, _P, _I64, _I32, _P, _P]),
     "kge_train_grads_planned": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_train_step_planned": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
+    "kge_train_step_swap_supported": (C.c_int, [_MD, _LD, _OD]),
+    "kge_train_step_swap": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_set_dedup_mode": (C.c_int, [C.c_int]),

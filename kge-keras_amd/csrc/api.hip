@@ -158,6 +158,10 @@ int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const flo
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
               int64_t, hipStream_t, bool advanced = false, const OptFinish* finish = nullptr);
 
+bool step_swap_supported(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*);
+int train_step_swap(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, const float*, const float*, float*, float*, void*, int64_t,
+                    int64_t, float*, uint64_t, void*, int64_t, int, hipStream_t);
+
 int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
 int loss_pairs(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, int64_t, hipStream_t);
 int64_t rank_workspace_bytes(const kge_model_desc*, int64_t);
@@ -386,6 +390,29 @@ int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, co
   if (int rc = train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, st, fused ? od : nullptr, &fin))
     return rc;
   return opt_apply(md, ld, od, E, Rel, gradE, gradRel, 1.f, loss_out, workspace, workspace_bytes, st, fused, &fin);
+}
+
+int kge_train_step_swap_supported(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od) {
+  if (!od) return fail(KGE_EINVAL, "kge_train_step_swap_supported: optimizer descriptor is null");
+  if (int rc = check_model(md, "kge_train_step_swap_supported")) return rc;
+  if (!ld) return fail(KGE_EINVAL, "kge_train_step_swap_supported: loss descriptor is null");
+  return step_swap_supported(md, ld, od) ? 1 : 0;
+}
+
+int kge_train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in,
+                        float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
+                        uint64_t seed, void* workspace, int64_t workspace_bytes, int32_t parts, kge_stream_t stream) {
+  if (!od) return fail(KGE_EINVAL, "kge_train_step_swap: optimizer descriptor is null");
+  if (parts < 1 || parts > 3) return fail(KGE_EINVAL, "kge_train_step_swap: parts mask %d outside 1..3", parts);
+  if (int rc = check_plan("kge_train_step_swap", md, ld, m_pos, m_neg)) return rc;
+  if (!E_in || !Rel_in || !E_out || !Rel_out || !plan || !loss_out) return fail(KGE_EINVAL, "kge_train_step_swap: null pointer");
+  if (E_in == E_out || Rel_in == Rel_out) return fail(KGE_EINVAL, "kge_train_step_swap: input and output tables must be distinct buffers");
+  if (!step_swap_supported(md, ld, od))
+    return fail(KGE_EUNSUPPORTED, "kge_train_step_swap: needs the device-resident step state, no L3 term, no dropout, rows of at most 1024 floats");
+  if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
+    return fail(KGE_EWORKSPACE, "kge_train_step_swap: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
+  return train_step_swap(md, ld, od, E_in, Rel_in, E_out, Rel_out, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, parts,
+                         static_cast<hipStream_t>(stream));
 }
 
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries) {

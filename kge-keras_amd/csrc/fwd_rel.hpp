@@ -1,0 +1,186 @@
+// The relation-grouped forward of the training step (fwd_rel_kernel), shared by pull2.hip (its own launch) and step1.hip (the
+// relation role of the one-launch step).  Reference: EmbeddingModel.call x2 + loss (KGEkeras/models.py:134-222; utils.py:288-298).
+#pragma once
+#include "dropout.hpp"
+#include "kge_internal.hpp"
+#include "pull.hpp"
+
+namespace kge {
+
+__device__ __forceinline__ float4 f4(float x) { return make_float4(x, x, x, x); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) { return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)); }
+__device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float4 abs4(float4 a) { return make_float4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w)); }
+__device__ __forceinline__ float sg(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float4 sgn4(float4 a) { return make_float4(sg(a.x), sg(a.y), sg(a.z), sg(a.w)); }
+__device__ __forceinline__ float4 phase_abs4(float4 a) { return make_float4(phase_abs(a.x), phase_abs(a.y), phase_abs(a.z), phase_abs(a.w)); }
+__device__ __forceinline__ float4 phase_dterm4(float4 a) { return make_float4(phase_dterm(a.x), phase_dterm(a.y), phase_dterm(a.z), phase_dterm(a.w)); }
+__device__ __forceinline__ float4 shx4(float4 v, int off) {
+  return make_float4(__shfl_xor(v.x, off, 64), __shfl_xor(v.y, off, 64), __shfl_xor(v.z, off, 64), __shfl_xor(v.w, off, 64));
+}
+
+struct FwdRelArgs {
+  const float* E; const float* Rel;
+  int64_t m_pos, m_neg;
+  int d_e, nchunk;
+  float gamma, modulus, margin;
+  const int32_t* rcnt; const int32_t* roff; const int32_t* rtotal; const int2* rumap; const int4* rentries;
+  float* coef; float* scores; float* rslab;
+  uint64_t seed; uint32_t thr; float dscale;
+};
+
+// One wave per (relation, chunk).  4 sub-groups of 16 lanes take different triples; lane l of a sub-group owns float4
+// chunks l, l+16, ... (NV of them) of the row (of each half row for ComplEx).  Adds the unit's loss terms to lsum (lane 0 of every
+// sub-group), writes the unit's partial relation-gradient row to rslab[unit]; FROM_OFFSETS: the relation's row count comes from
+// the list starts (its counter is being counted down by the units of a one-launch step).  Returns the relation; *len_out = rows.
+template <int MODEL, int NORM, int LOSS, int NV, bool DROP, bool FROM_OFFSETS = false>
+__device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R, float& lsum, int* len_out, int* c_out) {
+  constexpr int G = 16;
+  constexpr int NA = MODEL == KGE_COMPLEX ? 2 * NV : NV;
+  const float* __restrict__ E = a.E;
+  const float* __restrict__ Rel = a.Rel;
+  const int d_e = a.d_e, nchunk = a.nchunk;
+  const float gamma = a.gamma, modulus = a.modulus, margin = a.margin, dscale = a.dscale;
+  const uint64_t seed = a.seed;
+  const uint32_t thr = a.thr;
+  const int2* __restrict__ rumap = a.rumap;
+  const int32_t* __restrict__ roff = a.roff;
+  const int4* __restrict__ rentries = a.rentries;
+  float* __restrict__ coef = a.coef;
+  float* __restrict__ scores = a.scores;
+  float* __restrict__ rslab = a.rslab;
+  const int lane64 = threadIdx.x & 63, lane = lane64 & (G - 1), sub = lane64 / G;
+  const int h = d_e >> 1, hc = h / 4;
+  const float inv_pos = 1.f / (float)a.m_pos, inv_neg = 1.f / (float)a.m_neg;
+  (void)hc; (void)seed; (void)thr; (void)dscale;
+  const int2 pc = rumap[unit];
+  const int p = pc.x;
+  const int c = FROM_OFFSETS ? (p + 1 < R ? roff[p + 1] : a.rtotal[1]) - roff[p] : a.rcnt[p];
+  const int chunk = rel_chunk_rows(c);
+  const int start = roff[p] + pc.y * chunk;
+  const int len = min(chunk, c - pc.y * chunk);
+  const float* rp = Rel + (int64_t)p * d_e;
+  float4 pv[NA], acc[NA];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int ch = lane + j * G;
+    pv[j] = ch < nchunk ? *reinterpret_cast<const float4*>(rp + ch * 4) : f4(0.f);
+    acc[j] = f4(0.f);
+    if (MODEL == KGE_COMPLEX) { pv[NV + j] = ch < nchunk ? *reinterpret_cast<const float4*>(rp + h + ch * 4) : f4(0.f); acc[NV + j] = f4(0.f); }
+  }
+  for (int i = sub; i < len; i += 4) {
+    const int4 e = rentries[start + i];
+    const int64_t t = e.z;
+    const bool is_pos = e.w > 0;
+    const float mult = fabsf((float)e.w);  // how many input rows this one stands for
+    const float* es = E + (int64_t)e.x * d_e;
+    const float* eo = E + (int64_t)e.y * d_e;
+    DropKey ks{0, 0}, kp{0, 0}, ko{0, 0};
+    if (DROP) { ks = drop_key(seed, t, 0); kp = drop_key(seed, t, 1); ko = drop_key(seed, t, 2); }
+    float4 sv[NA], ov[NA], pm[NA];
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int ch = lane + j * G;
+      const bool in = ch < nchunk;
+      sv[j] = in ? *reinterpret_cast<const float4*>(es + ch * 4) : f4(0.f);
+      ov[j] = in ? *reinterpret_cast<const float4*>(eo + ch * 4) : f4(0.f);
+      pm[j] = pv[j];
+      if (MODEL == KGE_COMPLEX) {
+        sv[NV + j] = in ? *reinterpret_cast<const float4*>(es + h + ch * 4) : f4(0.f);
+        ov[NV + j] = in ? *reinterpret_cast<const float4*>(eo + h + ch * 4) : f4(0.f);
+        pm[NV + j] = pv[NV + j];
+      }
+      if (DROP) {
+        sv[j] = mul4(sv[j], drop_mul4(ks, ch, thr, dscale)); ov[j] = mul4(ov[j], drop_mul4(ko, ch, thr, dscale));
+        pm[j] = mul4(pm[j], drop_mul4(kp, ch, thr, dscale));
+        if (MODEL == KGE_COMPLEX) {
+          sv[NV + j] = mul4(sv[NV + j], drop_mul4(ks, hc + ch, thr, dscale)); ov[NV + j] = mul4(ov[NV + j], drop_mul4(ko, hc + ch, thr, dscale));
+          pm[NV + j] = mul4(pm[NV + j], drop_mul4(kp, hc + ch, thr, dscale));
+        }
+      }
+      if (MODEL == KGE_DISTMULT) part += sum4(mul4(mul4(sv[j], pm[j]), ov[j]));
+      else if (MODEL == KGE_TRANSE) { const float4 x = sub4(add4(sv[j], pm[j]), ov[j]); part += NORM == 1 ? sum4(abs4(x)) : (NORM == 3 ? sum4(phase_abs4(x)) : sum4(mul4(x, x))); }
+      else {
+        const float4 sr = sv[j], si = sv[NV + j], pr = pm[j], pi = pm[NV + j], orr = ov[j], oi = ov[NV + j];
+        part += sum4(add4(add4(mul4(mul4(sr, pr), orr), mul4(mul4(pr, si), oi)), sub4(mul4(mul4(pi, sr), oi), mul4(mul4(pi, si), orr))));
+      }
+    }
+    part = group_sum<G>(part);
+    float score = part, dist = part;
+    if (MODEL == KGE_TRANSE) {
+      if (NORM == 2) dist = sqrtf(part);
+      if (NORM == 3) dist = modulus * part;
+      score = gamma > 0.f ? gamma - dist : dist;
+    }
+    float g, l;
+    pointwise_term<LOSS>(score, is_pos, margin, (is_pos ? inv_pos : inv_neg) * mult, g, l);
+    if (MODEL == KGE_TRANSE) {
+      g = gamma > 0.f ? -g : g;
+      if (NORM == 2) g = dist > 0.f ? g / dist : 0.f;
+      if (NORM == 3) g *= 0.5f * modulus;
+    }
+    if (lane == 0) {
+      lsum += l;
+      if (coef) coef[t] = g;
+      if (scores) scores[t] = score;
+    }
+    if (g != 0.f) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if (MODEL == KGE_DISTMULT) {
+          float4 term = mul4(sv[j], ov[j]);
+          if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
+          acc[j] = fma4(f4(g), term, acc[j]);
+        } else if (MODEL == KGE_TRANSE) {
+          const float4 x = sub4(add4(sv[j], pm[j]), ov[j]);
+          float4 term = NORM == 1 ? sgn4(x) : (NORM == 3 ? phase_dterm4(x) : x);
+          if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
+          acc[j] = fma4(f4(g), term, acc[j]);
+        } else {
+          const float4 sr = sv[j], si = sv[NV + j], orr = ov[j], oi = ov[NV + j];
+          float4 gr = add4(mul4(sr, orr), mul4(si, oi)), gi = sub4(mul4(sr, oi), mul4(si, orr));
+          if (DROP) { gr = mul4(gr, drop_mul4(kp, lane + j * G, thr, dscale)); gi = mul4(gi, drop_mul4(kp, hc + lane + j * G, thr, dscale)); }
+          acc[j] = fma4(f4(g), gr, acc[j]);
+          acc[NV + j] = fma4(f4(g), gi, acc[NV + j]);
+        }
+      }
+    }
+  }
+  // meet the 4 sub-groups, one slab row per unit
+#pragma unroll
+  for (int i = 0; i < NA; ++i) { acc[i] = add4(acc[i], shx4(acc[i], 16)); acc[i] = add4(acc[i], shx4(acc[i], 32)); }
+  if (sub == 0) {
+    float* dst = rslab + (int64_t)unit * d_e;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int ch = lane + j * G;
+      if (ch < nchunk) {
+        *reinterpret_cast<float4*>(dst + ch * 4) = acc[j];
+        if (MODEL == KGE_COMPLEX) *reinterpret_cast<float4*>(dst + h + ch * 4) = acc[NV + j];
+      }
+    }
+  }
+  *len_out = len;
+  *c_out = c;
+  return p;
+}
+
+template <int MODEL, int NORM, int LOSS, int NV, bool DROP>
+__global__ __launch_bounds__(256) void fwd_rel_kernel(FwdRelArgs a, float* __restrict__ loss_partials, StepAdvance adv) {
+  __shared__ float red[16];
+  // a step closed by its pull launch (pullstep.hip): the step state moves on here, where nothing reads it -- the learning rate of
+  // THIS update goes to adv.lr_slot for the waves of the next launch
+  if (adv.step && blockIdx.x == 0 && threadIdx.x == 0) step_advance(adv, 0.f);
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float lsum = 0.f;
+  int len, c;
+  if (unit < a.rtotal[0]) fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP>(a, unit, 0, lsum, &len, &c);
+  const float b = block_sum(lsum, red);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
+}
+
+}  // namespace kge

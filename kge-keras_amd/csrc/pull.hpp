@@ -34,6 +34,30 @@ struct OptFinish {
   int R;
 };
 
+// The whole step closed by the pull launch itself (kge_train_step_swap): the wave that has a destination row's gradient in registers
+// applies the optimizer to that row -- parameters read from the step's input tables, written to the twin tables (every other wave
+// still gathers the OLD rows), moments in place -- so neither a gradient table nor an optimizer sweep exists.  Workgroups [0, R) of
+// the launch close the relation rows (sum of the forward's partial rows, fixed order) the same way.  lr: device slot holding lr_t of
+// this update (written by the forward launch, StepAdvance).
+struct StepTail {
+  int kind;                    // KGE_OPT_SGD | KGE_OPT_ADAM_TF
+  float *E_out, *mE, *vE;      // entity side (E_in is the kernel's E)
+  float *Rel_out, *mR, *vR;    // relation side (Rel_in is the kernel's Rel)
+  const float* lr;             // device slot with lr_t of this update, or null: lr_t below
+  float lr_t;
+  float b1, b2, eps;
+  const int32_t* roff;         // [R] starts of the relation lists (last row: rtotal[1] - roff[R-1])
+  const int32_t* rtotal;
+  const int32_t* ruoff;        // [R] first unit of the relation
+  const float* rslab;
+  int32_t* rcnt;               // [R] zeroed here
+  int R, d_r;
+  float* loss_acc;             // running sum of the step losses in the step state (may be null)
+  int self;                    // 1: the entity half forms its own scores (pullself.hip) and runs beside the relation half
+  int* ticket;                 // self, parts 3: a zero word of the workspace for the one-launch step's loss ticket (step1.hip)
+  int parts;                   // self: 1 = entity half, 2 = relation half (forward + relation rows + loss + step state), 3 = both
+};
+
 struct PullPlan {
   int32_t* cnt;     // [NK]   contributions per key (key = entity id, or N + relation id)
   int32_t* off;     // [NK]   list start
@@ -176,7 +200,9 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
 struct StepAdvance;  // kge_internal.hpp
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
-                        hipStream_t st, const StepAdvance& adv, OptFinish* finish);
+                        hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail = nullptr);
+// pullself.hip / pullstep.hip: the step between twin tables
+bool pull_step_supported(const kge_model_desc* md);
 
 // HolE (hole.hip)
 int hole_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,

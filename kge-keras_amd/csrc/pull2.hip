@@ -27,6 +27,7 @@
 #include "dropout.hpp"
 #include "kge_internal.hpp"
 #include "pull.hpp"
+#include "fwd_rel.hpp"  // fwd_rel_kernel (shared with step1.hip)
 
 namespace kge {
 
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void plan_hist_kernel(HistSrc hs, int64_t n, i
   }
 }
 
-// Entity lists: entry {relation | role bit, other entity, 0, row} at off[destination] + rank.  Ids only -- part of the plan; the
+// Entity lists: entry {relation | role bit, other entity, signed multiplicity, row} at off[destination] + rank.  Ids only -- part of the plan; the
 // coefficient of a row (dL/dscore, known after the forward) is looked up by pull_kernel through the row number.
 __global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const int32_t* __restrict__ off,
                                                         const int32_t* __restrict__ erank, int4* __restrict__ entries) {
@@ -351,158 +352,12 @@ __global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const
   if (r0 < 0) return;
   int s, p, o, w;
   src_load(src, t, s, p, o, w);
-  const int cb = 0;
+  const int cb = w;  // signed multiplicity (+ positive row, - negative row): what the self-contained entity half needs of the row
   entries[off[s] + r0] = make_int4(p, o, cb, (int)t);
   entries[off[o] + erank[n + t]] = make_int4(p | (int)0x80000000, s, cb, (int)t);
 }
 
 
-__device__ __forceinline__ float4 f4(float x) { return make_float4(x, x, x, x); }
-__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) { return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)); }
-__device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
-__device__ __forceinline__ float4 abs4(float4 a) { return make_float4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w)); }
-__device__ __forceinline__ float sg(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
-__device__ __forceinline__ float4 sgn4(float4 a) { return make_float4(sg(a.x), sg(a.y), sg(a.z), sg(a.w)); }
-__device__ __forceinline__ float4 phase_abs4(float4 a) { return make_float4(phase_abs(a.x), phase_abs(a.y), phase_abs(a.z), phase_abs(a.w)); }
-__device__ __forceinline__ float4 phase_dterm4(float4 a) { return make_float4(phase_dterm(a.x), phase_dterm(a.y), phase_dterm(a.z), phase_dterm(a.w)); }
-__device__ __forceinline__ float4 shx4(float4 v, int off) {
-  return make_float4(__shfl_xor(v.x, off, 64), __shfl_xor(v.y, off, 64), __shfl_xor(v.z, off, 64), __shfl_xor(v.w, off, 64));
-}
-
-// One wave per (relation, chunk).  4 sub-groups of 16 lanes take different triples; lane l of a sub-group owns float4
-// chunks l, l+16, ... (NV of them) of the row (of each half row for ComplEx).
-template <int MODEL, int NORM, int LOSS, int NV, bool DROP>
-__global__ __launch_bounds__(256) void fwd_rel_kernel(const float* __restrict__ E, const float* __restrict__ Rel, int64_t m_pos,
-                                                       int64_t m_neg, int d_e, int nchunk, float gamma, float modulus, float margin,
-                                                       const int32_t* __restrict__ rcnt, const int32_t* __restrict__ roff,
-                                                       const int32_t* __restrict__ rtotal, const int2* __restrict__ rumap,
-                                                       const int4* __restrict__ rentries, float* __restrict__ coef,
-                                                       float* __restrict__ scores, float* __restrict__ rslab,
-                                                       float* __restrict__ loss_partials, uint64_t seed, uint32_t thr, float dscale) {
-  __shared__ float red[16];
-  constexpr int G = 16;
-  constexpr int NA = MODEL == KGE_COMPLEX ? 2 * NV : NV;
-  const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63, lane = lane64 & (G - 1), sub = lane64 / G;
-  const int unit = blockIdx.x * 4 + wave;
-  const int h = d_e >> 1, hc = h / 4;
-  const float inv_pos = 1.f / (float)m_pos, inv_neg = 1.f / (float)m_neg;
-  float lsum = 0.f;
-  if (unit < rtotal[0]) {
-    const int2 pc = rumap[unit];
-    const int p = pc.x;
-    const int c = rcnt[p];
-    const int chunk = rel_chunk_rows(c);
-    const int start = roff[p] + pc.y * chunk;
-    const int len = min(chunk, c - pc.y * chunk);
-    const float* rp = Rel + (int64_t)p * d_e;
-    float4 pv[NA], acc[NA];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int ch = lane + j * G;
-      pv[j] = ch < nchunk ? *reinterpret_cast<const float4*>(rp + ch * 4) : f4(0.f);
-      acc[j] = f4(0.f);
-      if (MODEL == KGE_COMPLEX) { pv[NV + j] = ch < nchunk ? *reinterpret_cast<const float4*>(rp + h + ch * 4) : f4(0.f); acc[NV + j] = f4(0.f); }
-    }
-    for (int i = sub; i < len; i += 4) {
-      const int4 e = rentries[start + i];
-      const int64_t t = e.z;
-      const bool is_pos = e.w > 0;
-      const float mult = fabsf((float)e.w);  // how many input rows this one stands for
-      const float* es = E + (int64_t)e.x * d_e;
-      const float* eo = E + (int64_t)e.y * d_e;
-      DropKey ks{0, 0}, kp{0, 0}, ko{0, 0};
-      if (DROP) { ks = drop_key(seed, t, 0); kp = drop_key(seed, t, 1); ko = drop_key(seed, t, 2); }
-      float4 sv[NA], ov[NA], pm[NA];
-      float part = 0.f;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int ch = lane + j * G;
-        const bool in = ch < nchunk;
-        sv[j] = in ? *reinterpret_cast<const float4*>(es + ch * 4) : f4(0.f);
-        ov[j] = in ? *reinterpret_cast<const float4*>(eo + ch * 4) : f4(0.f);
-        pm[j] = pv[j];
-        if (MODEL == KGE_COMPLEX) {
-          sv[NV + j] = in ? *reinterpret_cast<const float4*>(es + h + ch * 4) : f4(0.f);
-          ov[NV + j] = in ? *reinterpret_cast<const float4*>(eo + h + ch * 4) : f4(0.f);
-          pm[NV + j] = pv[NV + j];
-        }
-        if (DROP) {
-          sv[j] = mul4(sv[j], drop_mul4(ks, ch, thr, dscale)); ov[j] = mul4(ov[j], drop_mul4(ko, ch, thr, dscale));
-          pm[j] = mul4(pm[j], drop_mul4(kp, ch, thr, dscale));
-          if (MODEL == KGE_COMPLEX) {
-            sv[NV + j] = mul4(sv[NV + j], drop_mul4(ks, hc + ch, thr, dscale)); ov[NV + j] = mul4(ov[NV + j], drop_mul4(ko, hc + ch, thr, dscale));
-            pm[NV + j] = mul4(pm[NV + j], drop_mul4(kp, hc + ch, thr, dscale));
-          }
-        }
-        if (MODEL == KGE_DISTMULT) part += sum4(mul4(mul4(sv[j], pm[j]), ov[j]));
-        else if (MODEL == KGE_TRANSE) { const float4 x = sub4(add4(sv[j], pm[j]), ov[j]); part += NORM == 1 ? sum4(abs4(x)) : (NORM == 3 ? sum4(phase_abs4(x)) : sum4(mul4(x, x))); }
-        else {
-          const float4 sr = sv[j], si = sv[NV + j], pr = pm[j], pi = pm[NV + j], orr = ov[j], oi = ov[NV + j];
-          part += sum4(add4(add4(mul4(mul4(sr, pr), orr), mul4(mul4(pr, si), oi)), sub4(mul4(mul4(pi, sr), oi), mul4(mul4(pi, si), orr))));
-        }
-      }
-      part = group_sum<G>(part);
-      float score = part, dist = part;
-      if (MODEL == KGE_TRANSE) {
-        if (NORM == 2) dist = sqrtf(part);
-        if (NORM == 3) dist = modulus * part;
-        score = gamma > 0.f ? gamma - dist : dist;
-      }
-      float g, l;
-      pointwise_term<LOSS>(score, is_pos, margin, (is_pos ? inv_pos : inv_neg) * mult, g, l);
-      if (MODEL == KGE_TRANSE) {
-        g = gamma > 0.f ? -g : g;
-        if (NORM == 2) g = dist > 0.f ? g / dist : 0.f;
-        if (NORM == 3) g *= 0.5f * modulus;
-      }
-      if (lane == 0) {
-        lsum += l;
-        coef[t] = g;
-        if (scores) scores[t] = score;
-      }
-      if (g != 0.f) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          if (MODEL == KGE_DISTMULT) {
-            float4 term = mul4(sv[j], ov[j]);
-            if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
-            acc[j] = fma4(f4(g), term, acc[j]);
-          } else if (MODEL == KGE_TRANSE) {
-            const float4 x = sub4(add4(sv[j], pm[j]), ov[j]);
-            float4 term = NORM == 1 ? sgn4(x) : (NORM == 3 ? phase_dterm4(x) : x);
-            if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
-            acc[j] = fma4(f4(g), term, acc[j]);
-          } else {
-            const float4 sr = sv[j], si = sv[NV + j], orr = ov[j], oi = ov[NV + j];
-            float4 gr = add4(mul4(sr, orr), mul4(si, oi)), gi = sub4(mul4(sr, oi), mul4(si, orr));
-            if (DROP) { gr = mul4(gr, drop_mul4(kp, lane + j * G, thr, dscale)); gi = mul4(gi, drop_mul4(kp, hc + lane + j * G, thr, dscale)); }
-            acc[j] = fma4(f4(g), gr, acc[j]);
-            acc[NV + j] = fma4(f4(g), gi, acc[NV + j]);
-          }
-        }
-      }
-    }
-    // meet the 4 sub-groups, one slab row per unit
-#pragma unroll
-    for (int i = 0; i < NA; ++i) { acc[i] = add4(acc[i], shx4(acc[i], 16)); acc[i] = add4(acc[i], shx4(acc[i], 32)); }
-    if (sub == 0) {
-      float* dst = rslab + (int64_t)unit * d_e;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int ch = lane + j * G;
-        if (ch < nchunk) {
-          *reinterpret_cast<float4*>(dst + ch * 4) = acc[j];
-          if (MODEL == KGE_COMPLEX) *reinterpret_cast<float4*>(dst + h + ch * 4) = acc[NV + j];
-        }
-      }
-    }
-  }
-  const float b = block_sum(lsum, red);
-  if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
-}
 
 // gR[p] += sum of the relation's slab rows (one workgroup per relation)
 // Also: leaves rcnt all-zero for the next step (the workspace is self-cleaning; it is zeroed once at allocation), and the
@@ -669,16 +524,26 @@ static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Pla
 void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st);
 int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel, float* gE, float* gR, const PullPlan& e, uint64_t seed,
                       hipStream_t st, const LossFinish* lf);
+// pullself.hip
+int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
+                           const PullPlan& e, const StepTail& tail, float lr_t, hipStream_t st);
+int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st);
+// step1.hip
+int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRelArgs& fa, int rel_blocks, const PullPlan& e, const StepTail& tail,
+                 float* loss_partials, float* loss_out, const StepAdvance& adv, int* ticket, hipStream_t st);
+// pullstep.hip
+int pull2_entity_step(const kge_model_desc* md, const float* E, const float* Rel, const PullPlan& e, uint64_t seed, hipStream_t st,
+                      const LossFinish* lf, const StepTail* tail);
 
 template <int MODEL, int NORM, int LOSS>
 static void launch_fwd_rel(int nv, bool drop, int grid, hipStream_t st, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
                            const kge_model_desc* md, int nchunk, float margin, const Plan2& p, float* scores, float* partials,
-                           uint64_t seed) {
+                           uint64_t seed, const StepAdvance& adv) {
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
-#define KGE_FR(NVV, DR) hipLaunchKernelGGL((fwd_rel_kernel<MODEL, NORM, LOSS, NVV, DR>), dim3(grid), dim3(256), 0, st, E, Rel, m_pos, m_neg, md->d_e, \
-                                           nchunk, md->gamma, md->modulus, margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, p.ent.coef, scores, p.rslab,  \
-                                           partials, seed, thr, dscale)
+  const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, p.ent.coef,
+                      scores, p.rslab, seed, thr, dscale};
+#define KGE_FR(NVV, DR) hipLaunchKernelGGL((fwd_rel_kernel<MODEL, NORM, LOSS, NVV, DR>), dim3(grid), dim3(256), 0, st, fa, partials, adv)
 #define KGE_FR2(NVV) do { if (drop) KGE_FR(NVV, true); else KGE_FR(NVV, false); } while (0)
   if (nv <= 1) KGE_FR2(1);
   else if (nv <= 2) KGE_FR2(2);
@@ -690,11 +555,11 @@ static void launch_fwd_rel(int nv, bool drop, int grid, hipStream_t st, const fl
 template <int MODEL, int NORM>
 static void launch_fwd_rel_loss(int loss, int nv, bool drop, int grid, hipStream_t st, const float* E, const float* Rel, int64_t m_pos,
                                 int64_t m_neg, const kge_model_desc* md, int nchunk, float margin, const Plan2& p, float* scores,
-                                float* partials, uint64_t seed) {
-  if (loss == KGE_POINTWIZE_HINGE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
-  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
-  else if (loss == KGE_POINTWIZE_SQUARE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
-  else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
+                                float* partials, uint64_t seed, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}) {
+  if (loss == KGE_POINTWIZE_HINGE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
+  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
+  else if (loss == KGE_POINTWIZE_SQUARE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
+  else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
 }
 
 __global__ __launch_bounds__(256) void zero_words_kernel(int32_t* __restrict__ p, int64_t n) {
@@ -762,21 +627,52 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
 // ---- step: everything that depends on the parameters.  Consumes the plan (the finish kernels leave its counters zero).
 static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, int64_t m_pos,
                      int64_t m_neg, const Plan2& p, const Src& src, float* fwd_scores, float* loss_partials, int* n_partials, float* loss_out,
-                     uint64_t seed, hipStream_t st, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}, OptFinish* finish = nullptr) {
+                     uint64_t seed, hipStream_t st, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}, OptFinish* finish = nullptr,
+                     const StepTail* tail = nullptr) {
   const int R = md->num_relations;
+  const StepAdvance none{nullptr, nullptr, 0, 0.f, 0.f, 0.f};
+  const StepAdvance& fadv = tail ? adv : none;  // closed by the pull launch: the forward moves the step state on
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const int nchunk = width / 4;
   const bool drop = md->dropout > 0.f;
   const int fgrid = (int)cdiv(p.max_units, 4);
   *n_partials = fgrid;
-  {
+  const bool self = tail && tail->self;
+  // both halves in one call: ONE launch (step1.hip; KGE_STEP1=0: the halves launch by launch, for A/B timing)
+  static const bool one_launch = [] { const char* v = getenv("KGE_STEP1"); return !v || atoi(v) != 0; }();
+  if (self && tail->parts == 3 && one_launch) {
+    StepTail t = *tail;
+    t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
+    const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
+                        nullptr, p.rslab, seed, 0u, 1.f};
+    return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, tail->ticket, st);
+  }
+  if (!self || (tail->parts & 2)) {
     ProfScope prof(KGE_PROF_FWD, st);
     const int nv = (int)cdiv(nchunk, 16);
-    if (md->model == KGE_DISTMULT) launch_fwd_rel_loss<KGE_DISTMULT, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
-    else if (md->model == KGE_COMPLEX) launch_fwd_rel_loss<KGE_COMPLEX, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
-    else if (md->norm == 1) launch_fwd_rel_loss<KGE_TRANSE, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
-    else if (md->norm == 3) launch_fwd_rel_loss<KGE_TRANSE, 3>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
-    else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    const StepAdvance& fa = self ? none : fadv;
+    if (md->model == KGE_DISTMULT) launch_fwd_rel_loss<KGE_DISTMULT, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
+    else if (md->model == KGE_COMPLEX) launch_fwd_rel_loss<KGE_COMPLEX, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
+    else if (md->norm == 1) launch_fwd_rel_loss<KGE_TRANSE, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
+    else if (md->norm == 3) launch_fwd_rel_loss<KGE_TRANSE, 3>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
+    else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
+  }
+  if (self) {
+    StepTail t = *tail;
+    t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
+    if (t.parts & 2) {  // relation rows, loss, step state: behind the forward
+      const LossFinish lf{loss_partials, *n_partials, loss_out, adv};
+      if (int rc = rel_tail_launch(t, Rel, lf, st)) return rc;
+    }
+    if (t.parts & 1)
+      if (int rc = pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, p.ent, t, t.lr_t, st)) return rc;
+    return KGE_OK;
+  }
+  if (tail) {
+    StepTail t = *tail;
+    t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
+    const LossFinish lf{loss_partials, *n_partials, loss_out, none};
+    return pull2_entity_step(md, E, Rel, p.ent, seed, st, &lf, &t);
   }
   if (finish) {
     // a whole step in one call: no finish kernel.  The pull launch carries one extra workgroup for the loss (and the step state);
@@ -845,13 +741,13 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
 
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
-                        hipStream_t st, const StepAdvance& adv, OptFinish* finish) {
+                        hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
   carve_plan_buffer(plan, md, n, &p);
   carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
   const Src src{nullptr, m_pos, nullptr, m_neg, p.dd.uniq, p.dd.nu};
-  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv, finish);
+  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv, finish, tail);
 }
 
 }  // namespace kge

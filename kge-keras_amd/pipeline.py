@@ -19,6 +19,7 @@ stage graphs inside the library and kge_pipeline_run(n) issues n steps from C (c
 data-parallel training (`between`: the gradient all-reduce sits between the halves of the step, outside any graph) and for
 `serial` profiling runs.
 """
+import os
 import time
 
 import torch
@@ -71,6 +72,7 @@ class TrainPipeline:
         self._h = None          # native driver (kge_pipeline_create) and the signature it was captured for
         self._h_sig = None
         self._native_active = False
+        self._twins = None
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
@@ -117,6 +119,8 @@ class TrainPipeline:
         t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.starts,
              getattr(sa, "_stream", None)]
         t += [x for c in self.cand if c is not None for x in c]
+        if self._twins is not None:
+            t += list(self._twins)
         if mo.optimizer.slots:
             t += list(mo.optimizer.slots)
         return tuple(x.data_ptr() for x in t if x is not None) + (mo.optimizer.kind, mo.optimizer.lr, mo.loss_function, float(mo.margin or 1))
@@ -218,6 +222,9 @@ class TrainPipeline:
             d.cand_rows[j], d.cand_counts[j] = self.cand[j][0].data_ptr(), self.cand[j][1].data_ptr()
             d.plan[j] = self.plans[j].buf.data_ptr()
         d.plan_bytes = min(self.plans[0].buf.numel(), self.plans[1].buf.numel())
+        # twin tables: steps alternate between (E, Rel) and these (kge_train_step_swap); run() leaves the current ones in (E, Rel)
+        if self._twins is not None:
+            d.E_twin, d.Rel_twin = self._twins[0].data_ptr(), self._twins[1].data_ptr()
         h = C.c_void_p()
         _lib.check(_lib.lib.kge_pipeline_create(C.byref(d), _lib.stream_ptr(), C.byref(h)))
         self._h, self._h_sig = h, sig
@@ -242,7 +249,7 @@ class TrainPipeline:
         cap = 4096
         out = (_lib.C.c_double * (4 * cap))()
         k = int(_lib.check(_lib.lib.kge_pipeline_trace(self._h, 0, out, cap)))
-        names = ("rounds", "draw", "plan", "step")
+        names = ("rounds", "draw", "plan", "step", "rel")
         return [(names[int(out[4 * i])], int(out[4 * i + 1]), out[4 * i + 2] * 1e3, out[4 * i + 3] * 1e3) for i in range(k)]
 
     def close(self):
@@ -315,6 +322,10 @@ class TrainPipeline:
             pl.buf.zero_()
         if self.between is None:
             mo._step_dev = self.step_dev
+            if os.environ.get("KGE_PIPE_SWAP", "1") != "0":
+                if self._twins is None or self._twins[0].shape != mo.E.shape or self._twins[1].shape != mo.Rel.shape:
+                    self._twins = (torch.empty_like(mo.E), torch.empty_like(mo.Rel))
+                mo._step_twins = self._twins
             o = mo.optimizer
             od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, int(o.iterations) + 1, None, None, None, None,
                               self.step_dev.data_ptr())
@@ -358,12 +369,12 @@ class TrainPipeline:
         err = int(self.sampler.err.item())  # (synchronises: the epoch is over)
         if err:
             self.sampler.err.zero_()
-            mo._step_dev = None
+            mo._step_dev = mo._step_twins = None
             raise RuntimeError(f"device sampler error flag {err}: the masked-rejection buffer ran short; the batches drawn since are not the "
                                "reference's (kge_build_batch_device: err_flag bit 1)")
         if getattr(mo, "_step_dev", None) is not None:
             mo.optimizer.iterations = int(self.step_dev[0].item())
-            mo._step_dev = None
+            mo._step_dev = mo._step_twins = None
             return self.step_dev.view(torch.float32)[3].double()  # running sum kept by the library (kge_opt_desc.step_dev)
         return self.loss_sum
 
@@ -374,6 +385,6 @@ class TrainPipeline:
             self.start()
             self.run(self.n)
         except BaseException:
-            self.model._step_dev = None  # never leave the model on the device step state
+            self.model._step_dev = self.model._step_twins = None  # never leave the model on the device step state
             raise
         return self.finish()

@@ -1,0 +1,110 @@
+"""GPU tests of kge_train_step_swap: the planned step closed by its pull launch (optimizer applied by the wave that summed a row's
+gradient, tables written to twin buffers) against kge_train_step_planned and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = [("DistMult", {}, 200), ("DistMult", {}, 24), ("TransE", dict(norm=1, gamma=12), 40), ("TransE", dict(norm=2, gamma=12), 200),
+         ("ComplEx", {}, 100), ("ComplEx", {}, 8), ("DistMult", {}, 256)]
+
+
+def _state(mdl):
+    from kge_keras_amd import _lib
+    sd = torch.zeros(2, dtype=torch.int64, device=mdl.device)
+    o = mdl.optimizer
+    od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, int(o.iterations) + 1, None, None, None, None, sd.data_ptr())
+    _lib.check(_lib.lib.kge_opt_state_init(_lib.C.byref(od), _lib.stream_ptr()))
+    mdl._step_dev = sd
+    return sd
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+@pytest.mark.parametrize("model,kw,d", CASES)
+def test_swap_step_equals_planned_step_and_oracle(model, kw, d, opt):
+    """Three steps on batches with a hub entity (a list of more than 128 entries: chunk waves + ticket), entities that no row touches
+    (Adam still moves them: dense update, Keras semantics) and a dominant relation (many partial rows).  Twin step == three-launch
+    planned step to fp32 rounding, both == oracle within 1e-4; the input tables of a twin step are left as they were; the step state
+    (count, loss sum) advances the same way."""
+    from kge_keras_amd import models as M
+    N, R = 300, 6
+    rs = np.random.RandomState(3)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    a, b = (getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0,
+                              loss_function="pointwize_hinge", margin=2.0, **kw) for _ in range(2))
+    for m in (a, b):
+        m.compile(opt)
+        m._ensure_train_state(64, 1500)
+    sa, sb = _state(a), _state(b)
+    a._step_twins = (torch.empty_like(a.E), torch.empty_like(a.Rel))
+    from kge_keras_amd import _lib
+    md, ld, od = a._model_desc(True), a._loss_desc(), a._opt_desc()
+    assert _lib.lib.kge_train_step_swap_supported(_lib.C.byref(md), _lib.C.byref(ld), _lib.C.byref(od)) == 1
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.make_optimizer(opt)
+    tot = 0.0
+    for step in range(3):
+        n_pos, n_neg = 64, 1500
+        ent = lambda n: np.where(rs.rand(n) < 0.3, 7, rs.randint(0, N - 40, n))  # hub: entity 7; entities N-40.. never touched
+        rel = lambda n: np.where(rs.rand(n) < 0.6, 2, rs.randint(0, R, n))
+        pos = np.stack([ent(n_pos), rel(n_pos), ent(n_pos)], 1).astype(np.int32)
+        neg = np.stack([ent(n_neg), rel(n_neg), ent(n_neg)], 1).astype(np.int32)
+        La = float(a.train_step(a.plan_batch([pos, neg]))["loss"].item())
+        Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_hinge", 2.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+        tot += La
+        assert La == pytest.approx(Lb, rel=1e-6, abs=1e-7) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), step
+        np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+    assert int(sa[0].item()) == int(sb[0].item()) == 3
+    fa, fb = sa.view(torch.float32).cpu().numpy(), sb.view(torch.float32).cpu().numpy()
+    assert fa[2] == fb[2]                                  # learning rate of the next update
+    assert fa[3] == pytest.approx(tot, rel=1e-6) and fb[3] == pytest.approx(tot, rel=1e-5)
+    a._raise_on_flag()
+    # the plans' counters are left zero: a fourth build with "counters known to be zero" (parts | 8) still trains right
+    pos = np.stack([rs.randint(0, N, 32), rs.randint(0, R, 32), rs.randint(0, N, 32)], 1).astype(np.int32)
+    neg = np.stack([rs.randint(0, N, 1500), rs.randint(0, R, 1500), rs.randint(0, N, 1500)], 1).astype(np.int32)
+    pa = a.plan_batch([pos, neg])
+    a.train_step(pa)
+    a.train_step(a.plan_batch([pos, neg], out=pa, parts=7 | 8))
+    for _ in range(2):
+        b.train_step(b.plan_batch([pos, neg]))
+    np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=4e-6)
+
+
+def test_swap_leaves_input_tables_and_rejects_aliases():
+    from kge_keras_amd import _lib, models as M
+    C = _lib.C
+    N, R, d = 50, 3, 16
+    rs = np.random.RandomState(1)
+    m = M.DistMult(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, loss_function="pointwize_logistic")
+    m.compile("adam")
+    pos = np.stack([rs.randint(0, N, 8), rs.randint(0, R, 8), rs.randint(0, N, 8)], 1).astype(np.int32)
+    neg = np.stack([rs.randint(0, N, 80), rs.randint(0, R, 80), rs.randint(0, N, 80)], 1).astype(np.int32)
+    m._ensure_train_state(8, 80)
+    _state(m)
+    E_before, R_before = m.E.clone(), m.Rel.clone()
+    Et, Rt = torch.zeros_like(m.E), torch.zeros_like(m.Rel)
+    plan = m.plan_batch([pos, neg])
+    md, ld, od = m._model_desc(True), m._loss_desc(), m._opt_desc()
+    args = lambda eo, ro: (C.byref(md), C.byref(ld), C.byref(od), m.E.data_ptr(), m.Rel.data_ptr(), eo, ro, plan.buf.data_ptr(), plan.buf.numel(), 8, 80,
+                           m._loss.data_ptr(), 0, m._ws.data_ptr(), m._ws.numel(), 3, _lib.stream_ptr())
+    assert _lib.lib.kge_train_step_swap(*args(m.E.data_ptr(), Rt.data_ptr())) == -1      # aliased tables: invalid argument
+    _lib.check(_lib.lib.kge_train_step_swap(*args(Et.data_ptr(), Rt.data_ptr())))
+    torch.cuda.synchronize()
+    assert torch.equal(m.E, E_before) and torch.equal(m.Rel, R_before)
+    assert not torch.equal(Et, E_before) and float((Et - E_before).abs().max()) < 0.01
+    # without the device step state, with dropout or an L3 term the twin step is not offered
+    od2 = _lib.OptDesc(od.kind, od.lr, od.beta1, od.beta2, od.eps, 1, od.mE, od.vE, od.mRel, od.vRel, None)
+    assert _lib.lib.kge_train_step_swap_supported(C.byref(md), C.byref(ld), C.byref(od2)) == 0
+    md2 = m._model_desc(True)
+    md2.dropout = 0.2
+    assert _lib.lib.kge_train_step_swap_supported(C.byref(md2), C.byref(ld), C.byref(od)) == 0
