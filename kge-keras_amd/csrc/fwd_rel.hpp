@@ -34,9 +34,8 @@ struct FwdRelArgs {
 
 // One wave per (relation, chunk).  4 sub-groups of 16 lanes take different triples; lane l of a sub-group owns float4
 // chunks l, l+16, ... (NV of them) of the row (of each half row for ComplEx).  Adds the unit's loss terms to lsum (lane 0 of every
-// sub-group), writes the unit's partial relation-gradient row to rslab[unit]; FROM_OFFSETS: the relation's row count comes from
-// the list starts (its counter is being counted down by the units of a one-launch step).  Returns the relation; *len_out = rows.
-template <int MODEL, int NORM, int LOSS, int NV, bool DROP, bool FROM_OFFSETS = false>
+// sub-group), writes the unit's partial relation-gradient row to rslab[unit].  Returns the relation; *len_out = rows of the unit, *c_out = rows of the relation.
+template <int MODEL, int NORM, int LOSS, int NV, bool DROP>
 __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R, float& lsum, int* len_out, int* c_out) {
   constexpr int G = 16;
   constexpr int NA = MODEL == KGE_COMPLEX ? 2 * NV : NV;
@@ -58,7 +57,7 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
   (void)hc; (void)seed; (void)thr; (void)dscale;
   const int2 pc = rumap[unit];
   const int p = pc.x;
-  const int c = FROM_OFFSETS ? (p + 1 < R ? roff[p + 1] : a.rtotal[1]) - roff[p] : a.rcnt[p];
+  const int c = a.rcnt[p];
   const int chunk = rel_chunk_rows(c);
   const int start = roff[p] + pc.y * chunk;
   const int len = min(chunk, c - pc.y * chunk);
@@ -170,11 +169,8 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
 }
 
 template <int MODEL, int NORM, int LOSS, int NV, bool DROP>
-__global__ __launch_bounds__(256) void fwd_rel_kernel(FwdRelArgs a, float* __restrict__ loss_partials, StepAdvance adv) {
+__global__ __launch_bounds__(256) void fwd_rel_kernel(FwdRelArgs a, float* __restrict__ loss_partials) {
   __shared__ float red[16];
-  // a step closed by its pull launch (pullstep.hip): the step state moves on here, where nothing reads it -- the learning rate of
-  // THIS update goes to adv.lr_slot for the waves of the next launch
-  if (adv.step && blockIdx.x == 0 && threadIdx.x == 0) step_advance(adv, 0.f);
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
   float lsum = 0.f;
   int len, c;

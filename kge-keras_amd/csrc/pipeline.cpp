@@ -39,15 +39,13 @@ namespace {
     if (e__ != hipSuccess) return ::kge::fail(KGE_EHIP, "%s: %s", #expr, hipGetErrorString(e__));           \
   } while (0)
 
-constexpr int kStages = 5;
-enum { GEN = 0, DRAW = 1, PLAN = 2, STEP = 3, REL = 4 };  // REL: the relation half of a step between twin tables, on its own stream
+constexpr int kStages = 4;
+enum { GEN = 0, DRAW = 1, PLAN = 2, STEP = 3 };
 
 struct Pipeline {
   kge_pipeline_desc d;
-  hipStream_t s_gen = nullptr, s_draw = nullptr, s_plan = nullptr, s_rel = nullptr;
+  hipStream_t s_gen = nullptr, s_draw = nullptr, s_plan = nullptr;
   hipEvent_t gen[2] = {}, ready[2] = {}, planned[2] = {}, pfreed[2] = {};
-  hipEvent_t ent_done[2] = {}, rel_done[2] = {};  // split steps: behind the entity / relation half of step k (index k & 1)
-  bool split = false;              // swap: the two halves of a step on two streams (kge_train_step_swap parts 1 | 2)
   int64_t updates = 0;             // swap: optimizer updates done (read back from the step state at kge_pipeline_start)
   hipEvent_t fork = nullptr;
   hipEvent_t done[kStages][2] = {};      // graphs only: behind the last launch of graph (stage, slot)
@@ -68,7 +66,7 @@ struct Pipeline {
   int64_t trace_left = 0;
   bool swap = false;               // steps alternate between the caller's tables and their twins (kge_train_step_swap)
   int parity = 0;                  // swap: 1 = the current tables are the twins
-  int stage_mask = 31;  // experiments only (KGE_PIPE_STAGES): bit s clear = stage s is not launched (its events still are recorded)
+  int stage_mask = 15;  // experiments only (KGE_PIPE_STAGES): bit s clear = stage s is not launched (its events still are recorded)
 };
 
 inline double now_ns() { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -89,11 +87,11 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
       return kge_batch_plan_build_counted(&d.md, &d.ld, d.cand_rows[slot], d.cand_counts[slot], KGE_CAND_POS_LANES, d.B, m, m, m, d.plan[slot],
                                           d.plan_bytes, 7 | 8, d.err_flag, st);
     default:
-      if (p->swap) {  // STEP: the entity half (split) or the whole step; REL: the relation half.  The caller moves parity / updates on.
+      if (p->swap) {  // (the caller moves parity / updates on)
         const int q = p->parity;
         kge_opt_desc od = d.od;
         od.step = p->updates + 1;
-        const int parts = !p->split ? 3 : (stage == REL ? 2 : 1);
+        const int parts = 3;
         return kge_train_step_swap(&d.md, &d.ld, &od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, d.plan[slot],
                                    d.plan_bytes, m, m, d.loss_out, 0, d.train_ws, d.train_ws_bytes, parts, st);
       }
@@ -116,7 +114,7 @@ int capture(Pipeline* p, int stage, int slot, hipStream_t st) {
 }
 
 int launch(Pipeline* p, int stage, int slot, hipStream_t st, int64_t batch = -1) {
-  if (!((p->stage_mask >> (stage == REL ? STEP : stage)) & 1)) return KGE_OK;
+  if (!((p->stage_mask >> stage) & 1)) return KGE_OK;
   if (stage == GEN && !p->ring) return KGE_OK;
   if (!p->graphs) {
     Pipeline::Rec rec{stage, batch, nullptr, nullptr};
@@ -180,7 +178,6 @@ int produce(Pipeline* p, int64_t k) {
   KGE_PIPE_TRY(hipEventRecord(p->ready[j], p->s_draw));
   KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->ready[j], 0));
   KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[j], 0));
-  if (p->split) KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->rel_done[j], 0));  // (still the record behind the relation half of step k-2)
   if (int rc = launch(p, PLAN, j, p->s_plan, k)) return rc;
   KGE_PIPE_TRY(hipEventRecord(p->planned[j], p->s_plan));
   return KGE_OK;
@@ -193,10 +190,10 @@ void destroy(Pipeline* p) {
       if (p->done[s][j]) (void)hipEventDestroy(p->done[s][j]);
     }
   for (int j = 0; j < 2; ++j)
-    for (hipEvent_t e : {p->gen[j], p->ready[j], p->planned[j], p->pfreed[j], p->ent_done[j], p->rel_done[j]})
+    for (hipEvent_t e : {p->gen[j], p->ready[j], p->planned[j], p->pfreed[j]})
       if (e) (void)hipEventDestroy(e);
   if (p->fork) (void)hipEventDestroy(p->fork);
-  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan, p->s_rel})
+  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan})
     if (s) (void)hipStreamDestroy(s);
   delete p;
 }
@@ -238,10 +235,6 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   if ((d.E_twin != nullptr) != (d.Rel_twin != nullptr)) { delete p; return fail(KGE_EINVAL, "kge_pipeline_create: E_twin and Rel_twin go together"); }
   p->swap = d.E_twin && !p->graphs && kge_train_step_swap_supported(&d.md, &d.ld, &d.od) == 1;
   if (const char* e = std::getenv("KGE_PIPE_SWAP")) { if (std::atoi(e) == 0) p->swap = false; }
-  // ... and its two halves side by side: the entity half on the caller's stream, the relation half on a stream of the library's
-  p->split = p->swap;
-  if (const char* e = std::getenv("KGE_SWAP_SELF")) { if (std::atoi(e) == 0) p->split = false; }
-  if (const char* e = std::getenv("KGE_PIPE_SPLIT")) { if (std::atoi(e) == 0) p->split = false; }
   if (p->graphs && prof_is_on()) {
     delete p;
     return fail(KGE_EINVAL, "kge_pipeline_create: switch kernel timing off first (kge_prof_enable(0)): timing events cannot be captured");
@@ -262,14 +255,10 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
     KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_gen, hipStreamNonBlocking, prio));
     KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_draw, hipStreamNonBlocking, prio));
     KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_plan, hipStreamNonBlocking, prio));
-    const char* er = std::getenv("KGE_PIPE_RELPRIO");  // experiments: -1 lowest, 0 default, 1 highest [default]
-    const int rp = er ? std::atoi(er) : 1;
-    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_rel, hipStreamNonBlocking, rp > 0 ? hi : (rp < 0 ? lo : 0)));  // part of the step
   }
   KGE_CREATE_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
   for (int j = 0; j < 2; ++j) {
-    for (hipEvent_t* e : {&p->gen[j], &p->ready[j], &p->planned[j], &p->pfreed[j], &p->ent_done[j], &p->rel_done[j]})
-      KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&p->gen[j], &p->ready[j], &p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int s = 0; s < kStages; ++s) KGE_CREATE_TRY(hipEventCreateWithFlags(&p->done[s][j], hipEventDisableTiming));
   }
 #undef KGE_CREATE_TRY
@@ -304,9 +293,7 @@ int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream) {
     p->updates = t0;
   }
   KGE_PIPE_TRY(hipEventRecord(p->fork, main_st));
-  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan, p->s_rel}) KGE_PIPE_TRY(hipStreamWaitEvent(s, p->fork, 0));
-  // (events of an earlier epoch: everything they stand for precedes `fork` -- kge_pipeline_run joins the relation stream before it returns)
-  for (int j = 0; j < 2; ++j) { KGE_PIPE_TRY(hipEventRecord(p->ent_done[j], main_st)); KGE_PIPE_TRY(hipEventRecord(p->rel_done[j], main_st)); }
+  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan}) KGE_PIPE_TRY(hipStreamWaitEvent(s, p->fork, 0));
   p->started = true;
   p->nround = 0;
   if (p->ring) if (int rc = offer_round(p, -1)) return rc;  // the words of batches 0 .. R-1
@@ -326,26 +313,12 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
   for (int64_t i = 0; i < n_steps; ++i) {
     const int j = (int)(p->t & 1);
     KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->planned[j], 0));
-    if (p->split) {
-      // step k: entity half E_k, Rel_k -> E_k+1 here; relation half E_k, Rel_k -> Rel_k+1 on s_rel.  Each needs both halves of step
-      // k-1 (the tables it reads, and the buffers it writes were the inputs of step k-1); its own predecessor is stream order.
-      const int jp = j ^ 1;
-      KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->rel_done[jp], 0));
-      KGE_PIPE_TRY(hipStreamWaitEvent(p->s_rel, p->planned[j], 0));
-      KGE_PIPE_TRY(hipStreamWaitEvent(p->s_rel, p->ent_done[jp], 0));
-      if (int rc = launch(p, STEP, j, main_st, p->t)) return rc;
-      KGE_PIPE_TRY(hipEventRecord(p->ent_done[j], main_st));
-      if (int rc = launch(p, REL, j, p->s_rel, p->t)) return rc;
-      KGE_PIPE_TRY(hipEventRecord(p->rel_done[j], p->s_rel));
-    } else {
-      if (int rc = launch(p, STEP, j, main_st, p->t)) return rc;
-    }
+    if (int rc = launch(p, STEP, j, main_st, p->t)) return rc;
     if (p->swap) { p->parity ^= 1; p->updates += 1; }
     KGE_PIPE_TRY(hipEventRecord(p->pfreed[j], main_st));
     if (int rc = produce(p, p->t + 2)) return rc;
     p->t += 1;
   }
-  if (p->split && n_steps > 0) KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->rel_done[(p->t - 1) & 1], 0));  // the caller's stream owns the results
   if (p->swap && p->parity) {  // the caller reads (E, Rel)
     const kge_pipeline_desc& d = p->d;
     KGE_PIPE_TRY(hipMemcpyAsync(d.E, d.E_twin, (size_t)d.md.num_entities * d.md.d_e * sizeof(float), hipMemcpyDeviceToDevice, main_st));

@@ -34,16 +34,13 @@ struct OptFinish {
   int R;
 };
 
-// The whole step closed by the pull launch itself (kge_train_step_swap): the wave that has a destination row's gradient in registers
-// applies the optimizer to that row -- parameters read from the step's input tables, written to the twin tables (every other wave
-// still gathers the OLD rows), moments in place -- so neither a gradient table nor an optimizer sweep exists.  Workgroups [0, R) of
-// the launch close the relation rows (sum of the forward's partial rows, fixed order) the same way.  lr: device slot holding lr_t of
-// this update (written by the forward launch, StepAdvance).
+// The step between twin tables (kge_train_step_swap; pullself.hip, step1.hip): the wave that has a row's gradient in registers applies
+// the optimizer to that row -- parameters read from the step's input tables, written to the twin tables (every other wave still
+// gathers the OLD rows), moments in place -- so neither a gradient table nor an optimizer sweep exists.  lr_t travels by value.
 struct StepTail {
   int kind;                    // KGE_OPT_SGD | KGE_OPT_ADAM_TF
-  float *E_out, *mE, *vE;      // entity side (E_in is the kernel's E)
-  float *Rel_out, *mR, *vR;    // relation side (Rel_in is the kernel's Rel)
-  const float* lr;             // device slot with lr_t of this update, or null: lr_t below
+  float *E_out, *mE, *vE;      // entity side (E_in is the kernels' E)
+  float *Rel_out, *mR, *vR;    // relation side (Rel_in is the kernels' Rel)
   float lr_t;
   float b1, b2, eps;
   const int32_t* roff;         // [R] starts of the relation lists (last row: rtotal[1] - roff[R-1])
@@ -52,10 +49,7 @@ struct StepTail {
   const float* rslab;
   int32_t* rcnt;               // [R] zeroed here
   int R, d_r;
-  float* loss_acc;             // running sum of the step losses in the step state (may be null)
-  int self;                    // 1: the entity half forms its own scores (pullself.hip) and runs beside the relation half
-  int* ticket;                 // self, parts 3: a zero word of the workspace for the one-launch step's loss ticket (step1.hip)
-  int parts;                   // self: 1 = entity half, 2 = relation half (forward + relation rows + loss + step state), 3 = both
+  int parts;                   // 1 = entity half, 2 = relation half (forward + relation rows + loss + step state), 3 = both
 };
 
 struct PullPlan {
@@ -201,7 +195,7 @@ struct StepAdvance;  // kge_internal.hpp
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
                         hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail = nullptr);
-// pullself.hip / pullstep.hip: the step between twin tables
+// pullself.hip: the step between twin tables
 bool pull_step_supported(const kge_model_desc* md);
 
 // HolE (hole.hip)

@@ -530,20 +530,17 @@ int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, co
 int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st);
 // step1.hip
 int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRelArgs& fa, int rel_blocks, const PullPlan& e, const StepTail& tail,
-                 float* loss_partials, float* loss_out, const StepAdvance& adv, int* ticket, hipStream_t st);
-// pullstep.hip
-int pull2_entity_step(const kge_model_desc* md, const float* E, const float* Rel, const PullPlan& e, uint64_t seed, hipStream_t st,
-                      const LossFinish* lf, const StepTail* tail);
+                 float* loss_partials, float* loss_out, const StepAdvance& adv, hipStream_t st);
 
 template <int MODEL, int NORM, int LOSS>
 static void launch_fwd_rel(int nv, bool drop, int grid, hipStream_t st, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
                            const kge_model_desc* md, int nchunk, float margin, const Plan2& p, float* scores, float* partials,
-                           uint64_t seed, const StepAdvance& adv) {
+                           uint64_t seed) {
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
   const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, p.ent.coef,
                       scores, p.rslab, seed, thr, dscale};
-#define KGE_FR(NVV, DR) hipLaunchKernelGGL((fwd_rel_kernel<MODEL, NORM, LOSS, NVV, DR>), dim3(grid), dim3(256), 0, st, fa, partials, adv)
+#define KGE_FR(NVV, DR) hipLaunchKernelGGL((fwd_rel_kernel<MODEL, NORM, LOSS, NVV, DR>), dim3(grid), dim3(256), 0, st, fa, partials)
 #define KGE_FR2(NVV) do { if (drop) KGE_FR(NVV, true); else KGE_FR(NVV, false); } while (0)
   if (nv <= 1) KGE_FR2(1);
   else if (nv <= 2) KGE_FR2(2);
@@ -555,11 +552,11 @@ static void launch_fwd_rel(int nv, bool drop, int grid, hipStream_t st, const fl
 template <int MODEL, int NORM>
 static void launch_fwd_rel_loss(int loss, int nv, bool drop, int grid, hipStream_t st, const float* E, const float* Rel, int64_t m_pos,
                                 int64_t m_neg, const kge_model_desc* md, int nchunk, float margin, const Plan2& p, float* scores,
-                                float* partials, uint64_t seed, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}) {
-  if (loss == KGE_POINTWIZE_HINGE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
-  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
-  else if (loss == KGE_POINTWIZE_SQUARE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
-  else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed, adv);
+                                float* partials, uint64_t seed) {
+  if (loss == KGE_POINTWIZE_HINGE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
+  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
+  else if (loss == KGE_POINTWIZE_SQUARE) launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
+  else launch_fwd_rel<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, E, Rel, m_pos, m_neg, md, nchunk, margin, p, scores, partials, seed);
 }
 
 __global__ __launch_bounds__(256) void zero_words_kernel(int32_t* __restrict__ p, int64_t n) {
@@ -630,32 +627,29 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
                      uint64_t seed, hipStream_t st, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}, OptFinish* finish = nullptr,
                      const StepTail* tail = nullptr) {
   const int R = md->num_relations;
-  const StepAdvance none{nullptr, nullptr, 0, 0.f, 0.f, 0.f};
-  const StepAdvance& fadv = tail ? adv : none;  // closed by the pull launch: the forward moves the step state on
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const int nchunk = width / 4;
   const bool drop = md->dropout > 0.f;
   const int fgrid = (int)cdiv(p.max_units, 4);
   *n_partials = fgrid;
-  const bool self = tail && tail->self;
-  // both halves in one call: ONE launch (step1.hip; KGE_STEP1=0: the halves launch by launch, for A/B timing)
+  const bool self = tail != nullptr;
+  // both halves in one call: the forward and the entity half share ONE launch (step1.hip; KGE_STEP1=0: launch by launch, for A/B timing)
   static const bool one_launch = [] { const char* v = getenv("KGE_STEP1"); return !v || atoi(v) != 0; }();
   if (self && tail->parts == 3 && one_launch) {
     StepTail t = *tail;
     t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
     const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
                         nullptr, p.rslab, seed, 0u, 1.f};
-    return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, tail->ticket, st);
+    return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, st);
   }
   if (!self || (tail->parts & 2)) {
     ProfScope prof(KGE_PROF_FWD, st);
     const int nv = (int)cdiv(nchunk, 16);
-    const StepAdvance& fa = self ? none : fadv;
-    if (md->model == KGE_DISTMULT) launch_fwd_rel_loss<KGE_DISTMULT, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
-    else if (md->model == KGE_COMPLEX) launch_fwd_rel_loss<KGE_COMPLEX, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
-    else if (md->norm == 1) launch_fwd_rel_loss<KGE_TRANSE, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
-    else if (md->norm == 3) launch_fwd_rel_loss<KGE_TRANSE, 3>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
-    else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed, fa);
+    if (md->model == KGE_DISTMULT) launch_fwd_rel_loss<KGE_DISTMULT, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else if (md->model == KGE_COMPLEX) launch_fwd_rel_loss<KGE_COMPLEX, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else if (md->norm == 1) launch_fwd_rel_loss<KGE_TRANSE, 1>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else if (md->norm == 3) launch_fwd_rel_loss<KGE_TRANSE, 3>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
+    else launch_fwd_rel_loss<KGE_TRANSE, 2>(ld->loss, nv, drop, fgrid, st, E, Rel, m_pos, m_neg, md, nchunk, ld->margin, p, fwd_scores, loss_partials, seed);
   }
   if (self) {
     StepTail t = *tail;
@@ -667,12 +661,6 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     if (t.parts & 1)
       if (int rc = pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, p.ent, t, t.lr_t, st)) return rc;
     return KGE_OK;
-  }
-  if (tail) {
-    StepTail t = *tail;
-    t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
-    const LossFinish lf{loss_partials, *n_partials, loss_out, none};
-    return pull2_entity_step(md, E, Rel, p.ent, seed, st, &lf, &t);
   }
   if (finish) {
     // a whole step in one call: no finish kernel.  The pull launch carries one extra workgroup for the loss (and the step state);

@@ -1,17 +1,9 @@
-// pull_kernel and its launcher, shared by pull.hip (gradient rows into the dense accumulators / slabs) and pullstep.hip (the same
-// gather-reduce closing the whole step: optimizer update of the destination row in the same wave).
+// pull_kernel, its launcher and the element helpers of the gather-reduce kernels; shared by pull.hip and the kernels of the step
+// between twin tables (pull_self.hpp, step1.hip).
 #pragma once
 #include "kge_internal.hpp"
 #include "pull.hpp"
 #include "dropout.hpp"
-
-// build-time experiment switches (defaults = the measured best; profiles/r02_experiments.txt)
-#ifndef KGE_PULL_DIST2
-#define KGE_PULL_DIST2 0
-#endif
-#ifndef KGE_TAIL_PREFETCH
-#define KGE_TAIL_PREFETCH 1
-#endif
 
 namespace kge {
 
@@ -74,7 +66,7 @@ __device__ __forceinline__ void tail_upd(int kind, float lr, float b1, float b2,
   tail_upd(kind, lr, b1, b2, eps, w.w, g.w, m.w, v.w);
 }
 
-// StepTail: one workgroup per relation row.  Wave w sums the row's partial rows of units [w*per, (w+1)*per) with four loads in
+// StepTail (the step between twin tables): one workgroup per relation row.  Wave w sums the row's partial rows of units [w*per, (w+1)*per) with four loads in
 // flight, the four sums meet in LDS in wave order (fixed order: run-to-run deterministic), wave 0 applies the optimizer.
 __device__ __forceinline__ void tail_relation_row(const StepTail& t, const float* __restrict__ Rel, int row) {
   __shared__ float4 part[4][64];
@@ -84,7 +76,7 @@ __device__ __forceinline__ void tail_relation_row(const StepTail& t, const float
   const int nch = rel_units(c);
   const int per = (nch + 3) >> 2;
   const int j0 = min(wave * per, nch), j1 = min(j0 + per, nch);
-  const float lr = t.lr ? t.lr[0] : t.lr_t;
+  const float lr = t.lr_t;
   if (threadIdx.x == 0) t.rcnt[row] = 0;
   for (int q0 = 0; q0 < d4; q0 += 64) {
     const int q = q0 + lane;
@@ -120,8 +112,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
                                                     const int32_t* __restrict__ eoff, const int32_t* __restrict__ poff,
                                                     const int32_t* __restrict__ totals, const int2* __restrict__ emap,
                                                     const int4* __restrict__ entries, float* __restrict__ slab, int C,
-                                                    uint64_t seed, uint32_t thr, float dscale, const float* __restrict__ coef_of_row, LossFinish lf,
-                                                    StepTail tail) {
+                                                    uint64_t seed, uint32_t thr, float dscale, const float* __restrict__ coef_of_row, LossFinish lf) {
   if (lf.partials && blockIdx.x == gridDim.x - 1) {  // (launched with one workgroup more than the units need)
     __shared__ float red[16];
     float s = 0.f;
@@ -130,14 +121,8 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
     if (threadIdx.x == 0) {
       lf.loss_out[0] = b;
       step_advance(lf.adv, b);
-      if (TAIL && tail.loss_acc) tail.loss_acc[0] += b;
     }
     return;
-  }
-  int block = blockIdx.x;
-  if (TAIL) {  // the relation rows first: the longest chains of the launch
-    if (block < tail.R) { tail_relation_row(tail, Rel, block); return; }
-    block -= tail.R;
   }
   using T = typename V<VEC>::T;
   using L = V<VEC>;
@@ -147,7 +132,7 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
   const int lane = lane64 & (G - 1), sub = lane64 / G;
-  const int unit = block * 4 + wave;
+  const int unit = blockIdx.x * 4 + wave;
   int key, chunk;
   if (unit < NK) { key = unit; chunk = 0; }
   else {
@@ -156,9 +141,8 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
     const int2 kc = emap[x];
     key = kc.x; chunk = kc.y;
   }
-  // TAIL: the counter of a hub row is the ticket its chunk waves count down (below), so the length comes from the list starts
-  const int c = TAIL ? (key + 1 < NK ? off[key + 1] : totals[2]) - off[key] : cnt[key];
-  if (!TAIL && c == 0) return;
+  const int c = cnt[key];
+  if (c == 0) return;
   const int nch = (c + C - 1) / C;
   const int start = off[key] + chunk * C;
   const int len = min(C, c - chunk * C);
@@ -166,25 +150,6 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
   const int h = d_e >> 1;
   const float* self = is_rel ? Rel + (int64_t)(key - N) * d_e : E + (int64_t)key * d_e;
 
-  // TAIL: sub-group s applies the optimizer to the accumulators i = s, s + NSUB, ... of the finished row; their parameters and
-  // moments do not depend on the list and are fetched ahead of it
-  constexpr int NPER = TAIL ? (NACC + NSUB - 1) / NSUB : 1;
-  T tw[NPER], tm[NPER], tv[NPER];
-  float tail_lr = 0.f;
-  if (TAIL && KGE_TAIL_PREFETCH) {
-    tail_lr = tail.lr[0];
-#pragma unroll
-    for (int k = 0; k < NPER; ++k) {
-      const int i = sub + k * NSUB;  // accumulator index: half = i / NV (ComplEx), chunk = lane + (i % NV) * G
-      const int ch = lane + (i % NV) * G;
-      tw[k] = tm[k] = tv[k] = L::zero();
-      if (i < NACC && ch < nchunk) {
-        const int at = (i / NV) * h + ch * VEC;
-        tw[k] = L::ld(self + at);
-        if (tail.kind == KGE_OPT_ADAM_TF) { tm[k] = L::ld(tail.mE + (int64_t)key * d_e + at); tv[k] = L::ld(tail.vE + (int64_t)key * d_e + at); }
-      }
-    }
-  }
   T acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = L::zero();
@@ -197,22 +162,6 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
   // The coefficient rides in the entry (lists filled after the forward), or is looked up by row number (lists built ahead, ids
   // only).  Entry and coefficient of the NEXT round are fetched while this round's rows are gathered and multiplied: the lookup is
   // a dependent load (entry -> coefficient -> rows) that would otherwise sit in front of every round.
-#if KGE_PULL_DIST2
-  // entries two rounds ahead, coefficients one round ahead: every round issues entry(r+2), coefficient(r+1) and the rows of r, none
-  // of which waits for another
-  int4 e_nx = make_int4(0, 0, 0, 0), e_n2 = make_int4(0, 0, 0, 0);
-  float cf_nx = 0.f;
-  if (sub < len) e_nx = entries[start + sub];
-  if (sub + NSUB < len) e_n2 = entries[start + sub + NSUB];
-  if (sub < len) cf_nx = coef_of_row ? coef_of_row[e_nx.w] : __int_as_float(e_nx.z);
-#pragma unroll 2
-  for (int i = sub; i < len; i += NSUB) {
-    const int4 e = e_nx;
-    const float cf = cf_nx;
-    e_nx = e_n2;
-    if (i + 2 * NSUB < len) e_n2 = entries[start + i + 2 * NSUB];
-    if (i + NSUB < len) cf_nx = coef_of_row ? coef_of_row[e_nx.w] : __int_as_float(e_nx.z);
-#else
   int4 e_nx = make_int4(0, 0, 0, 0);
   float cf_nx = 0.f;
   if (sub < len) { e_nx = entries[start + sub]; cf_nx = coef_of_row ? coef_of_row[e_nx.w] : __int_as_float(e_nx.z); }
@@ -221,7 +170,6 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
     const int4 e = e_nx;
     const float cf = cf_nx;
     if (i + NSUB < len) { e_nx = entries[start + i + NSUB]; cf_nx = coef_of_row ? coef_of_row[e_nx.w] : __int_as_float(e_nx.z); }
-#endif
     if (cf == 0.f) continue;  // inactive hinge rows carry no gradient
     const int kind1 = is_rel ? 0 : ((unsigned)e.x >> 31);
     const float* ra = is_rel ? E + (int64_t)e.x * d_e : Rel + (int64_t)(e.x & 0x7fffffff) * d_e;
@@ -276,69 +224,6 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
   for (int o2 = G; o2 < 64; o2 <<= 1)
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = acc[i] + shx(acc[i], o2);
-  if (TAIL) {
-    if (nch > 1) {
-      // hub row: this chunk's partial row goes to the slab; the chunk wave that brings the row's counter to zero sums the slab rows in
-      // chunk order (fixed order) and carries on (release / acquire by the fences around the ticket)
-      float* part = slab + (int64_t)(poff[key] + chunk) * d_e;
-      if (sub == 0) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const int ch = lane + j * G;
-          if (ch < nchunk) {
-            L::st(part + ch * VEC, acc[j]);
-            if (MODEL == KGE_COMPLEX) L::st(part + h + ch * VEC, acc[NV + j]);
-          }
-        }
-      }
-      __threadfence();
-      int old = 0;
-      if (lane64 == 0) old = atomicSub(const_cast<int32_t*>(cnt) + key, len);
-      old = __shfl(old, 0, 64);
-      if (old != len) return;
-      __threadfence();
-#pragma unroll
-      for (int i = 0; i < NACC; ++i) acc[i] = L::zero();
-      const float* src = slab + (int64_t)poff[key] * d_e;
-      for (int jc = 0; jc < nch; ++jc) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const int ch = lane + j * G;
-          if (ch < nchunk) {
-            acc[j] = acc[j] + L::ld(src + (int64_t)jc * d_e + ch * VEC);
-            if (MODEL == KGE_COMPLEX) acc[NV + j] = acc[NV + j] + L::ld(src + (int64_t)jc * d_e + h + ch * VEC);
-          }
-        }
-      }
-    } else if (lane64 == 0 && c) {
-      const_cast<int32_t*>(cnt)[key] = 0;
-    }
-    float* wout = tail.E_out + (int64_t)key * d_e;
-    float* mrow = tail.mE + (int64_t)key * d_e;
-    float* vrow = tail.vE + (int64_t)key * d_e;
-#pragma unroll
-    for (int k = 0; k < NPER; ++k) {
-      // accumulator sub + k*NSUB of this lane, picked without a dynamic register index
-      T g = L::zero();
-#pragma unroll
-      for (int i = 0; i < NACC; ++i)
-        if (i % NSUB == sub && i / NSUB == k) g = acc[i];
-      const int i = sub + k * NSUB;
-      const int ch = lane + (i % NV) * G;
-      if (i < NACC && ch < nchunk) {
-        const int at = (i / NV) * h + ch * VEC;
-        if (!KGE_TAIL_PREFETCH) {
-          tail_lr = tail.lr[0];
-          tw[k] = L::ld(self + at);
-          if (tail.kind == KGE_OPT_ADAM_TF) { tm[k] = L::ld(mrow + at); tv[k] = L::ld(vrow + at); }
-        }
-        tail_upd(tail.kind, tail_lr, tail.b1, tail.b2, tail.eps, tw[k], g, tm[k], tv[k]);
-        L::st(wout + at, tw[k]);
-        if (tail.kind == KGE_OPT_ADAM_TF) { L::st(mrow + at, tm[k]); L::st(vrow + at, tv[k]); }
-      }
-    }
-    return;
-  }
   if (sub != 0) return;
   float* dst;
   bool add;
@@ -359,35 +244,31 @@ __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, 
   }
 }
 
-template <int MODEL, int NORM, int VEC, bool WITH_TAIL = false>
+template <int MODEL, int NORM, int VEC>
 static void launch_pull(int nchunk, int grid, hipStream_t st, const float* E, const float* Rel, float* gE, float* gR,
                         const kge_model_desc* md, const PullPlan& p, uint64_t seed, int nk_override = -1, const float* coef_of_row = nullptr,
-                        const LossFinish* lfp = nullptr, const StepTail* tailp = nullptr) {
+                        const LossFinish* lfp = nullptr) {
   const LossFinish lf = lfp ? *lfp : LossFinish{nullptr, 0, nullptr, StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}};
   if (lfp) grid += 1;
-  StepTail tail{};
-  if (tailp) { tail = *tailp; grid += tail.R; }
   const int N = md->num_entities, NK = nk_override >= 0 ? nk_override : N + md->num_relations;
   const bool drop = md->dropout > 0.f;
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
-#define KGE_PULL1(GW, NVV, DR, TL) hipLaunchKernelGGL((pull_kernel<MODEL, NORM, GW, NVV, VEC, DR, TL>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, N, NK, md->d_e, \
-                                                  nchunk, p.cnt, p.off, p.eoff, p.poff, p.totals, p.emap, p.entries, p.slab, p.chunk, seed, thr, dscale, coef_of_row, lf, tail)
-#define KGE_PULL(GW, NVV) do { if constexpr (WITH_TAIL) { if (!drop) KGE_PULL1(GW, NVV, false, true); } else { if (drop) KGE_PULL1(GW, NVV, true, false); else KGE_PULL1(GW, NVV, false, false); } } while (0)
-#define KGE_PULL_EXP(GW, NVV) do { if constexpr (!WITH_TAIL) KGE_PULL(GW, NVV); } while (0)
+#define KGE_PULL1(GW, NVV, DR) hipLaunchKernelGGL((pull_kernel<MODEL, NORM, GW, NVV, VEC, DR>), dim3(grid), dim3(256), 0, st, E, Rel, gE, gR, N, NK, md->d_e, \
+                                                  nchunk, p.cnt, p.off, p.eoff, p.poff, p.totals, p.emap, p.entries, p.slab, p.chunk, seed, thr, dscale, coef_of_row, lf)
+#define KGE_PULL(GW, NVV) do { if (drop) KGE_PULL1(GW, NVV, true); else KGE_PULL1(GW, NVV, false); } while (0)
   // 16-lane sub-groups: four list entries of a row in flight per wave (measured at d=200: 114.6 us vs 149.7 us with one
   // 64-lane group on lists of ~56 entries, 49.0 vs 53.7 us on lists of ~18)
   static const int exp_g = [] { const char* v = getenv("KGE_PULL_G"); return v ? atoi(v) : 0; }();  // experiments: sub-group width at 33..64 chunks
   if (nchunk <= 8) KGE_PULL(8, 1);
   else if (nchunk <= 16) KGE_PULL(16, 1);
   else if (nchunk <= 32) KGE_PULL(16, 2);
-  else if (nchunk <= 64 && exp_g == 8 && !WITH_TAIL) KGE_PULL_EXP(8, 8);
-  else if (nchunk <= 64 && exp_g == 32 && !WITH_TAIL) KGE_PULL_EXP(32, 2);
+  else if (nchunk <= 64 && exp_g == 8) KGE_PULL(8, 8);
+  else if (nchunk <= 64 && exp_g == 32) KGE_PULL(32, 2);
   else if (nchunk <= 64) KGE_PULL(16, 4);
-  else if (nchunk <= 128) KGE_PULL_EXP(64, 2);  // (TAIL: rows of at most 64 chunks, as the relation-grouped forward)
-  else KGE_PULL_EXP(64, 4);
+  else if (nchunk <= 128) KGE_PULL(64, 2);
+  else KGE_PULL(64, 4);
 #undef KGE_PULL
-#undef KGE_PULL_EXP
 #undef KGE_PULL1
 }
 

@@ -758,8 +758,8 @@ int train_grads_with_plan(const kge_model_desc* md, const kge_loss_desc* ld, con
   return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv, finish);
 }
 
-// The whole step in two launches (pullstep.hip): parameters read from (E_in, Rel_in), written to (E_out, Rel_out); moments in place;
-// no gradient tables.  Needs the device-resident step state and no L3 term.
+// The step between twin tables (step1.hip, pullself.hip): parameters read from (E_in, Rel_in), written to (E_out, Rel_out); moments in
+// place; no gradient tables.  Needs the device-resident step state and no L3 term.
 bool step_swap_supported(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od) {
   return plan_supported(md, ld) && pull_step_supported(md) && od->step_dev && ld->regularization == 0.f &&
          (od->kind == KGE_OPT_SGD || (od->kind == KGE_OPT_ADAM_TF && od->mE && od->vE && od->mRel && od->vRel));
@@ -776,21 +776,10 @@ int train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge
   t.E_out = E_out; t.mE = od->mE; t.vE = od->vE;
   t.Rel_out = Rel_out; t.mR = od->mRel; t.vR = od->vRel;
   t.b1 = od->beta1; t.b2 = od->beta2; t.eps = od->eps;
-  // KGE_SWAP_SELF=0 (A/B timing): the entity half takes dL/dscore from the forward (pullstep.hip) -- one stream, both halves in one call
-  static const bool self = [] { const char* v = getenv("KGE_SWAP_SELF"); return !v || atoi(v) != 0; }();
-  t.self = self ? 1 : 0;
   t.parts = parts;
-  t.ticket = reinterpret_cast<int*>(ws.lr_slot + 8);  // (the workspace is zero-filled at allocation; the launch leaves the word zero)
-  if (self) {
-    // the two halves may run side by side on two streams, so lr_t of this update travels by value: od->step is its number
-    if (od->step < 1) return fail(KGE_EINVAL, "kge_train_step_swap: od->step (the number of this update, 1-based) must be >= 1");
-    t.lr = nullptr;
-    t.lr_t = host_lr_t(od);
-  } else {
-    if (parts != 3) return fail(KGE_EUNSUPPORTED, "kge_train_step_swap: KGE_SWAP_SELF=0 runs both halves in one call");
-    t.lr = ws.lr_slot;
-    t.loss_acc = reinterpret_cast<float*>(od->step_dev + 1) + 1;
-  }
+  // the two halves may run side by side on two streams, so lr_t of this update travels by value: od->step is its number
+  if (od->step < 1) return fail(KGE_EINVAL, "kge_train_step_swap: od->step (the number of this update, 1-based) must be >= 1");
+  t.lr_t = host_lr_t(od);
   return train_grads_planned(md, ld, E_in, Rel_in, nullptr, nullptr, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv, nullptr, &t);
 }
 

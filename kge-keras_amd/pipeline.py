@@ -249,7 +249,7 @@ class TrainPipeline:
         cap = 4096
         out = (_lib.C.c_double * (4 * cap))()
         k = int(_lib.check(_lib.lib.kge_pipeline_trace(self._h, 0, out, cap)))
-        names = ("rounds", "draw", "plan", "step", "rel")
+        names = ("rounds", "draw", "plan", "step")
         return [(names[int(out[4 * i])], int(out[4 * i + 1]), out[4 * i + 2] * 1e3, out[4 * i + 3] * 1e3) for i in range(k)]
 
     def close(self):

@@ -1,5 +1,5 @@
-"""GPU tests of kge_train_step_swap: the planned step closed by its pull launch (optimizer applied by the wave that summed a row's
-gradient, tables written to twin buffers) against kge_train_step_planned and the oracle."""
+"""GPU tests of kge_train_step_swap: the planned step between twin tables (self-contained entity half with the optimizer applied by
+the wave that summed a row's gradient, relation half beside it) against kge_train_step_planned and the oracle."""
 import numpy as np
 import pytest
 import torch
@@ -108,3 +108,43 @@ def test_swap_leaves_input_tables_and_rejects_aliases():
     md2 = m._model_desc(True)
     md2.dropout = 0.2
     assert _lib.lib.kge_train_step_swap_supported(C.byref(md2), C.byref(ld), C.byref(od)) == 0
+
+
+@pytest.mark.parametrize("order", [(1, 2), (2, 1)])
+def test_swap_halves_equal_the_whole_step(order):
+    """parts = 1 (entity half) and parts = 2 (relation half) of a step, issued one after the other in either order, leave what
+    parts = 3 (both in one launch + the closing launch) leaves -- tables, moments, loss, step state -- to fp32 rounding (the same
+    per-wave functions compiled into different kernels: contraction differs by an ulp here and there)."""
+    from kge_keras_amd import _lib, models as M
+    C = _lib.C
+    N, R, d = 120, 4, 48
+    rs = np.random.RandomState(5)
+    E0 = rs.uniform(-0.5, 0.5, (N, 2 * d)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, 2 * d)).astype(np.float32)
+    batches = [(np.stack([rs.randint(0, N, 16), rs.randint(0, R, 16), rs.randint(0, N, 16)], 1).astype(np.int32),
+                np.stack([rs.randint(0, N, 900), rs.randint(0, R, 900), rs.randint(0, N, 900)], 1).astype(np.int32)) for _ in range(3)]
+    out = []
+    for parts_seq in ((3,), order):
+        m = M.ComplEx(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0, loss_function="pointwize_logistic")
+        m.compile("adam")
+        m._ensure_train_state(16, 900)
+        sd = _state(m)
+        cur, nxt = (m.E, m.Rel), (torch.empty_like(m.E), torch.empty_like(m.Rel))
+        losses = []
+        for k, (pos, neg) in enumerate(batches):
+            plan = m.plan_batch([pos, neg])
+            md, ld = m._model_desc(True), m._loss_desc()
+            m.optimizer.iterations = k + 1
+            od = m._opt_desc()
+            for parts in parts_seq:
+                _lib.check(_lib.lib.kge_train_step_swap(C.byref(md), C.byref(ld), C.byref(od), cur[0].data_ptr(), cur[1].data_ptr(), nxt[0].data_ptr(),
+                                                        nxt[1].data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), 16, 900, m._loss.data_ptr(), 0,
+                                                        m._ws.data_ptr(), m._ws.numel(), parts, _lib.stream_ptr()))
+            losses.append(float(m._loss[0].item()))
+            cur, nxt = nxt, cur
+        out.append((cur[0].clone(), cur[1].clone(), [x.clone() for x in m.optimizer.slots], losses, sd.clone()))
+    a, b = out
+    diffs = [float((x - y).abs().max()) for x, y in zip([a[0], a[1]] + a[2], [b[0], b[1]] + b[2])]
+    assert max(diffs) < 2e-7, diffs
+    assert a[3] == pytest.approx(b[3], rel=1e-6) and int(a[4][0].item()) == int(b[4][0].item()) == 3
+    assert a[4].view(torch.float32)[2].item() == b[4].view(torch.float32)[2].item()  # lr_t of the next update
