@@ -640,7 +640,20 @@ def main():
         # gradient rows per triple); push path: one fused kernel carrying A_TRAIN.
         kernels = {}
         variant = 1 if os.environ.get("KGE_PULL_VARIANT", "2") == "1" else 2
-        if f_n and variant == 2:
+        twin = pipe is not None and getattr(pipe, "_twins", None) is not None  # the step between twin tables (kge_train_step_swap)
+        # Bytes a launch has to fetch from beyond the L2s, on the rows really processed (the 190 KB relation table is L2 resident and
+        # is NOT counted; SURVEY 8(d)'s 4816 B per triple would also count three gradient rows, which this step keeps in registers):
+        #   forward role   two entity rows per row                                  8 d   B per row
+        #   entity role    one entity row per list entry, two entries per row       8 d   B per row
+        #                  optimizer on every entity row: read w, m, v; write w, m, v 24 N d B per launch
+        adam_e = 24 * CFG["N"] * CFG["d"]
+        if twin and k_n and not f_n:
+            kernels["step1_kernel (relation-grouped forward + per-entity-row gather, own scores, gradient row, optimizer: one launch)"] = (
+                k_ms / k_n * 1e-3, rows_launch * 16 * CFG["d"] + adam_e)
+        elif twin and k_n:
+            kernels["fwd_rel_kernel (gather+score+loss+relation gradient)"] = (f_ms / f_n * 1e-3, rows_launch * (A_FWD + 4 * CFG["d"]))
+            kernels["pull_self_kernel (per-entity-row gather, own scores, gradient row, optimizer)"] = (k_ms / k_n * 1e-3, rows_launch * 8 * CFG["d"] + adam_e)
+        elif f_n and variant == 2:
             kernels["fwd_rel_kernel (gather+score+loss+relation gradient)"] = (f_ms / f_n * 1e-3, rows_launch * (A_FWD + 4 * CFG["d"]))
             kernels["pull_kernel (per-entity-row gather-reduce of gradients)"] = (k_ms / max(1, k_n) * 1e-3, rows_launch * 8 * CFG["d"])
         elif f_n:
@@ -680,12 +693,15 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_source": (f"committed rocprofv3 --pmc passes ({traffic_tag or 'profiles/pmc_traffic.json'}; tools/pmc.sh), not this run" if traffic else None),
                          "algorithmic_bytes_per_launch": k_bytes, "avg_kernel_ms": k_avg * 1e3, "launches": k_n,
+                         "algorithmic_bytes_note": ("entity rows fetched (two per row in the forward role, one per list entry = two per row in the entity role) "
+                                                    "+ the optimizer's streams over the entity table; relation rows (190 KB table, L2 resident) not counted; "
+                                                    "SURVEY 8(d)'s 4816 B per triple on the same rows would be %.0f" % (rows_launch * A_TRAIN)) if twin else None,
                          "avg_kernel_ms_live_hipevents": k_live * 1e3,
                          "avg_kernel_ms_rocprofv3": rp[0] if rp else None, "rocprofv3_source": f"profiles/{rp[1]}" if rp else None,
                          "frac_live_hipevents": k_bytes / k_live / HBM_PEAK if k_live else None,
                          "all_kernels": {k: {"avg_ms": v[0] * 1e3, "algorithmic_GBps": v[1] / v[0] / 1e9} for k, v in kernels.items()},
                          # whole step on the rows really processed: gathers + gradient rows + the dense optimizer sweep
-                         "whole_step_algorithmic_GBps": (rows_launch * A_TRAIN + A_OPT) / (dt / args.steps) / 1e9,
+                         "whole_step_algorithmic_GBps": (rows_launch * A_TRAIN + A_OPT) / (dt / args.steps) / 1e9,  # SURVEY 8(d) figures: 4816 B per row + the 32 B per parameter of a dense TF-Adam sweep
                          "rows_per_launch": rows_launch, "batch_rows": per_step,
                          "duplicate_row_folding": ("on: the gather kernels run on the distinct rows of the batch; "
                                                    "bytes per launch are priced on those rows" if folded else "off"),
@@ -696,7 +712,7 @@ def main():
                          "host_wait_ms_per_step": host_stats["wait_prev_launch_ms"] / args.steps if host_stats else None,
                          "host_graph_launch_ms_per_step": host_stats["graph_launch_ms"] / args.steps if host_stats else None,
                          "host_wait_by_stage_ms_per_step": {k: v / args.steps for k, v in host_stats["wait_by_stage_ms"].items()} if host_stats else None,
-                         "launch": (("three hipGraph launches per step (draw | plan | step stages, one graph each, on three streams), issued by the library's native loop (kge_pipeline_run: one C call for the K timed steps)" if not dist_on else
+                         "launch": (("the library's native loop (kge_pipeline_run: one C call for the K timed steps) launches every stage's kernels on four streams (generator rounds | draw | plan | step); the step is two launches (step1_kernel, rel_tail_kernel) between twin tables" if not dist_on else
                                      "draw and plan stages replayed from hipGraphs on their streams; the step (gradient half, all-reduce, optimizer half) launched kernel by kernel")
                                     + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)"
                                     if pipe is not None
