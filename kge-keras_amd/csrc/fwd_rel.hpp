@@ -32,12 +32,11 @@ struct FwdRelArgs {
   uint64_t seed; uint32_t thr; float dscale;
 };
 
-// One wave per (relation, chunk).  4 sub-groups of 16 lanes take different triples; lane l of a sub-group owns float4
-// chunks l, l+16, ... (NV of them) of the row (of each half row for ComplEx).  Adds the unit's loss terms to lsum (lane 0 of every
+// One wave per (relation, chunk).  64/G sub-groups of G lanes take different triples; lane l of a sub-group owns float4
+// chunks l, l+G, ... (NV of them) of the row (of each half row for ComplEx).  Adds the unit's loss terms to lsum (lane 0 of every
 // sub-group), writes the unit's partial relation-gradient row to rslab[unit].  Returns the relation; *len_out = rows of the unit, *c_out = rows of the relation.
-template <int MODEL, int NORM, int LOSS, int NV, bool DROP>
+template <int MODEL, int NORM, int LOSS, int NV, bool DROP, int G = 16>
 __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R, float& lsum, int* len_out, int* c_out) {
-  constexpr int G = 16;
   constexpr int NA = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   const float* __restrict__ E = a.E;
   const float* __restrict__ Rel = a.Rel;
@@ -70,7 +69,7 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
     acc[j] = f4(0.f);
     if (MODEL == KGE_COMPLEX) { pv[NV + j] = ch < nchunk ? *reinterpret_cast<const float4*>(rp + h + ch * 4) : f4(0.f); acc[NV + j] = f4(0.f); }
   }
-  for (int i = sub; i < len; i += 4) {
+  for (int i = sub; i < len; i += 64 / G) {
     const int4 e = rentries[start + i];
     const int64_t t = e.z;
     const bool is_pos = e.w > 0;
@@ -79,33 +78,42 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
     const float* eo = E + (int64_t)e.y * d_e;
     DropKey ks{0, 0}, kp{0, 0}, ko{0, 0};
     if (DROP) { ks = drop_key(seed, t, 0); kp = drop_key(seed, t, 1); ko = drop_key(seed, t, 2); }
-    float4 sv[NA], ov[NA], pm[NA];
+    // tv: d score / d (relation row), element-wise (TransE: its element factor) -- for the trilinear models the score is
+    // <relation row, tv>, so the gathered rows die as soon as tv is formed (two row-sized register arrays less than keeping them)
+    float4 tv[NA];
     float part = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int ch = lane + j * G;
       const bool in = ch < nchunk;
-      sv[j] = in ? *reinterpret_cast<const float4*>(es + ch * 4) : f4(0.f);
-      ov[j] = in ? *reinterpret_cast<const float4*>(eo + ch * 4) : f4(0.f);
-      pm[j] = pv[j];
+      float4 s0 = in ? *reinterpret_cast<const float4*>(es + ch * 4) : f4(0.f);
+      float4 o0 = in ? *reinterpret_cast<const float4*>(eo + ch * 4) : f4(0.f);
+      float4 p0 = pv[j];
+      float4 s1 = f4(0.f), o1 = f4(0.f), p1 = f4(0.f);
       if (MODEL == KGE_COMPLEX) {
-        sv[NV + j] = in ? *reinterpret_cast<const float4*>(es + h + ch * 4) : f4(0.f);
-        ov[NV + j] = in ? *reinterpret_cast<const float4*>(eo + h + ch * 4) : f4(0.f);
-        pm[NV + j] = pv[NV + j];
+        s1 = in ? *reinterpret_cast<const float4*>(es + h + ch * 4) : f4(0.f);
+        o1 = in ? *reinterpret_cast<const float4*>(eo + h + ch * 4) : f4(0.f);
+        p1 = pv[NV + j];
       }
       if (DROP) {
-        sv[j] = mul4(sv[j], drop_mul4(ks, ch, thr, dscale)); ov[j] = mul4(ov[j], drop_mul4(ko, ch, thr, dscale));
-        pm[j] = mul4(pm[j], drop_mul4(kp, ch, thr, dscale));
+        s0 = mul4(s0, drop_mul4(ks, ch, thr, dscale)); o0 = mul4(o0, drop_mul4(ko, ch, thr, dscale));
+        p0 = mul4(p0, drop_mul4(kp, ch, thr, dscale));
         if (MODEL == KGE_COMPLEX) {
-          sv[NV + j] = mul4(sv[NV + j], drop_mul4(ks, hc + ch, thr, dscale)); ov[NV + j] = mul4(ov[NV + j], drop_mul4(ko, hc + ch, thr, dscale));
-          pm[NV + j] = mul4(pm[NV + j], drop_mul4(kp, hc + ch, thr, dscale));
+          s1 = mul4(s1, drop_mul4(ks, hc + ch, thr, dscale)); o1 = mul4(o1, drop_mul4(ko, hc + ch, thr, dscale));
+          p1 = mul4(p1, drop_mul4(kp, hc + ch, thr, dscale));
         }
       }
-      if (MODEL == KGE_DISTMULT) part += sum4(mul4(mul4(sv[j], pm[j]), ov[j]));
-      else if (MODEL == KGE_TRANSE) { const float4 x = sub4(add4(sv[j], pm[j]), ov[j]); part += NORM == 1 ? sum4(abs4(x)) : (NORM == 3 ? sum4(phase_abs4(x)) : sum4(mul4(x, x))); }
-      else {
-        const float4 sr = sv[j], si = sv[NV + j], pr = pm[j], pi = pm[NV + j], orr = ov[j], oi = ov[NV + j];
-        part += sum4(add4(add4(mul4(mul4(sr, pr), orr), mul4(mul4(pr, si), oi)), sub4(mul4(mul4(pi, sr), oi), mul4(mul4(pi, si), orr))));
+      if (MODEL == KGE_DISTMULT) {
+        tv[j] = mul4(s0, o0);
+        part += sum4(mul4(p0, tv[j]));
+      } else if (MODEL == KGE_TRANSE) {
+        const float4 x = sub4(add4(s0, p0), o0);
+        part += NORM == 1 ? sum4(abs4(x)) : (NORM == 3 ? sum4(phase_abs4(x)) : sum4(mul4(x, x)));
+        tv[j] = NORM == 1 ? sgn4(x) : (NORM == 3 ? phase_dterm4(x) : x);
+      } else {  // Re<s, p, conj o> = pr (sr or + si oi) + pi (sr oi - si or)
+        tv[j] = add4(mul4(s0, o0), mul4(s1, o1));
+        tv[NV + j] = sub4(mul4(s0, o1), mul4(s1, o0));
+        part += sum4(add4(mul4(p0, tv[j]), mul4(p1, tv[NV + j])));
       }
     }
     part = group_sum<G>(part);
@@ -130,28 +138,22 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
     if (g != 0.f) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        if (MODEL == KGE_DISTMULT) {
-          float4 term = mul4(sv[j], ov[j]);
-          if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
-          acc[j] = fma4(f4(g), term, acc[j]);
-        } else if (MODEL == KGE_TRANSE) {
-          const float4 x = sub4(add4(sv[j], pm[j]), ov[j]);
-          float4 term = NORM == 1 ? sgn4(x) : (NORM == 3 ? phase_dterm4(x) : x);
-          if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
-          acc[j] = fma4(f4(g), term, acc[j]);
-        } else {
-          const float4 sr = sv[j], si = sv[NV + j], orr = ov[j], oi = ov[NV + j];
-          float4 gr = add4(mul4(sr, orr), mul4(si, oi)), gi = sub4(mul4(sr, oi), mul4(si, orr));
-          if (DROP) { gr = mul4(gr, drop_mul4(kp, lane + j * G, thr, dscale)); gi = mul4(gi, drop_mul4(kp, hc + lane + j * G, thr, dscale)); }
-          acc[j] = fma4(f4(g), gr, acc[j]);
-          acc[NV + j] = fma4(f4(g), gi, acc[NV + j]);
+        float4 term = tv[j];
+        if (DROP) term = mul4(term, drop_mul4(kp, lane + j * G, thr, dscale));
+        acc[j] = fma4(f4(g), term, acc[j]);
+        if (MODEL == KGE_COMPLEX) {
+          float4 ti = tv[NV + j];
+          if (DROP) ti = mul4(ti, drop_mul4(kp, hc + lane + j * G, thr, dscale));
+          acc[NV + j] = fma4(f4(g), ti, acc[NV + j]);
         }
       }
     }
   }
   // meet the 4 sub-groups, one slab row per unit
 #pragma unroll
-  for (int i = 0; i < NA; ++i) { acc[i] = add4(acc[i], shx4(acc[i], 16)); acc[i] = add4(acc[i], shx4(acc[i], 32)); }
+  for (int o2 = G; o2 < 64; o2 <<= 1)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = add4(acc[i], shx4(acc[i], o2));
   if (sub == 0) {
     float* dst = rslab + (int64_t)unit * d_e;
 #pragma unroll

@@ -16,9 +16,9 @@ struct SelfArgs {
 };
 
 // One wave: entity unit `unit` (a destination row, or an extra chunk of a hub row); `mine`: NACC * 16 float4 of LDS of this wave.
-template <int MODEL, int NORM, int LOSS, int NV>
+template <int MODEL, int NORM, int LOSS, int NV, int G = 16>
 __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, float4* mine) {
-  constexpr int G = 16, NSUB = 4;
+  constexpr int NSUB = 64 / G;
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   constexpr int NPER = (NACC + NSUB - 1) / NSUB;
   using L = V<4>;
@@ -174,12 +174,12 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
   }
 }
 
-template <int MODEL, int NORM, int LOSS, int NV>
+template <int MODEL, int NORM, int LOSS, int NV, int G = 16>
 __global__ __launch_bounds__(256) void pull_self_kernel(SelfArgs a) {
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
-  __shared__ float4 selfrow[4][NACC * 16];
+  __shared__ float4 selfrow[4][NACC * G];
   const int wave = threadIdx.x >> 6;
-  pull_self_unit<MODEL, NORM, LOSS, NV>(a, blockIdx.x * 4 + wave, selfrow[wave]);
+  pull_self_unit<MODEL, NORM, LOSS, NV, G>(a, blockIdx.x * 4 + wave, selfrow[wave]);
 }
 
 }  // namespace kge

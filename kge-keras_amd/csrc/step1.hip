@@ -14,36 +14,43 @@
 
 namespace kge {
 
-template <int MODEL, int NORM, int LOSS, int NV>
+template <int MODEL, int NORM, int LOSS, int NV, int G>
 __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, float* __restrict__ loss_partials, int rel_blocks, int R) {
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
-  __shared__ float4 selfrow[4][NACC * 16];
+  __shared__ float4 selfrow[4][NACC * G];
   __shared__ float red[16];
   const int wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= rel_blocks) {
-    pull_self_unit<MODEL, NORM, LOSS, NV>(sa, ((int)blockIdx.x - rel_blocks) * 4 + wave, selfrow[wave]);
+    pull_self_unit<MODEL, NORM, LOSS, NV, G>(sa, ((int)blockIdx.x - rel_blocks) * 4 + wave, selfrow[wave]);
     return;
   }
   const int unit = blockIdx.x * 4 + wave;
   float lsum = 0.f;
   int len, c;
-  if (unit < fa.rtotal[0]) fwd_rel_unit<MODEL, NORM, LOSS, NV, false>(fa, unit, R, lsum, &len, &c);
+  if (unit < fa.rtotal[0]) fwd_rel_unit<MODEL, NORM, LOSS, NV, false, G>(fa, unit, R, lsum, &len, &c);
   const float b = block_sum(lsum, red);
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
 }
 
+// Sub-group width: rows of up to 32 float4 chunks on 16 lanes (NV = 1, 2).  Wider rows (33..64 chunks, d = 200): 16 lanes x NV = 4
+// or 32 lanes x NV = 2 -- the same instruction count per row, half the row-sized register arrays.  Measured at the FB15k-237 shape:
+// DistMult 65.7 us on 16 lanes (93 VGPRs, 5 waves per SIMD) against 67.2 us on 32 (59 VGPRs, 8 waves: the launch is bound by the
+// fabric, not by occupancy); TransE-L2 91.6 us (98 VGPRs, 4 waves) against 75.4 us.  So: DistMult 16 lanes, the others 32.
+// KGE_STEP_G=16 | 32 forces one (A/B timing).
 template <int MODEL, int NORM, int LOSS>
-static void launch_step1_nv(int nv, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
-  if (nv <= 1) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 1>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
-  else if (nv <= 2) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 2>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
-  else hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 4>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
+static void launch_step1_nv(int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
+  static const int force_g = [] { const char* v = getenv("KGE_STEP_G"); return v ? atoi(v) : 0; }();
+  if (nchunk <= 16) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 1, 16>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
+  else if (nchunk <= 32) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 2, 16>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
+  else if (force_g == 16 || (force_g != 32 && MODEL == KGE_DISTMULT)) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 4, 16>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
+  else hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 2, 32>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
 }
 template <int MODEL, int NORM>
-static void launch_step1(int loss, int nv, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
-  if (loss == KGE_POINTWIZE_HINGE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, grid, st, fa, sa, lp, rb, R);
-  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, grid, st, fa, sa, lp, rb, R);
-  else if (loss == KGE_POINTWIZE_SQUARE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, grid, st, fa, sa, lp, rb, R);
-  else launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, grid, st, fa, sa, lp, rb, R);
+static void launch_step1(int loss, int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
+  if (loss == KGE_POINTWIZE_HINGE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_HINGE>(nchunk, grid, st, fa, sa, lp, rb, R);
+  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nchunk, grid, st, fa, sa, lp, rb, R);
+  else if (loss == KGE_POINTWIZE_SQUARE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nchunk, grid, st, fa, sa, lp, rb, R);
+  else launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nchunk, grid, st, fa, sa, lp, rb, R);
 }
 
 int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st);  // pullself.hip
@@ -57,14 +64,13 @@ int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRel
   SelfArgs sa;
   self_args_of(md, ld, fa.E, fa.Rel, fa.m_pos, fa.m_neg, e, tail, tail.lr_t, fa.nchunk, &sa);
   const int grid = rel_blocks + (int)cdiv(sa.N + e.max_extra, 4);
-  const int nv = (int)cdiv(fa.nchunk, 16);
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
-    if (md->model == KGE_DISTMULT) launch_step1<KGE_DISTMULT, 1>(ld->loss, nv, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
-    else if (md->model == KGE_COMPLEX) launch_step1<KGE_COMPLEX, 1>(ld->loss, nv, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
-    else if (md->norm == 1) launch_step1<KGE_TRANSE, 1>(ld->loss, nv, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
-    else if (md->norm == 3) launch_step1<KGE_TRANSE, 3>(ld->loss, nv, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
-    else launch_step1<KGE_TRANSE, 2>(ld->loss, nv, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    if (md->model == KGE_DISTMULT) launch_step1<KGE_DISTMULT, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else if (md->model == KGE_COMPLEX) launch_step1<KGE_COMPLEX, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else if (md->norm == 1) launch_step1<KGE_TRANSE, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else if (md->norm == 3) launch_step1<KGE_TRANSE, 3>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else launch_step1<KGE_TRANSE, 2>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
   }
   KGE_HIP_TRY(hipGetLastError());
   const LossFinish lf{loss_partials, rel_blocks, loss_out, adv};
