@@ -631,7 +631,8 @@ def main():
     ev = eval_leg(torch, model) if rank == 0 or not dist_on else None
     if dist_on:
         dist.barrier()
-    ev_sh = eval_sharded_leg(torch, dist, rank, world) if dist_on else None
+    # (also at N = 1 -- one shard, no exchange: the baseline the N-GPU lines' eval_sharded rates are compared with)
+    ev_sh = eval_sharded_leg(torch, dist, rank, world)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
