@@ -205,6 +205,7 @@ def check_benched_path(model_name="DistMult", steps=3, rank=0, fp64=False, tol=1
                 err64[k] = max(err64[k], e)
                 assert e <= tol, f"step {t}: {k} differs from the fp64 oracle by {e:.3g} (> {tol})"
     pipe.finish()
+    pipe.close()  # (its streams go away: idle CU-masked queues left behind would oversubscribe the hardware queues of the timed run)
     torch.cuda.synchronize()
     model._raise_on_flag()
     assert int(dsamp.err.item()) == 0, "device sampler: rejection margin ran short"
@@ -466,7 +467,7 @@ def main():
             pipe.use_graphs, pipe.serial = False, True
         pipe.start()
         step = lambda i: pipe.tick()  # noqa: E731
-        steps_n = pipe.run            # n steps in ONE library call (kge_pipeline_run): the tick loop is native
+        steps_n = lambda n: pipe.run(n, join=False)  # noqa: E731  n steps in ONE library call (kge_pipeline_run): the tick loop is native; every timed region ends with a device synchronisation
     else:
         side = torch.cuda.Stream()
         nps = NumpyStream(rank)

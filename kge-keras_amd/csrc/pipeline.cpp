@@ -13,6 +13,7 @@
 // (measured: 0.162 ms per step against 0.150 ms).  Host-only translation unit.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <new>
@@ -45,6 +46,7 @@ enum { GEN = 0, DRAW = 1, PLAN = 2, STEP = 3 };
 struct Pipeline {
   kge_pipeline_desc d;
   hipStream_t s_gen = nullptr, s_draw = nullptr, s_plan = nullptr;
+  bool borrowed[3] = {false, false, false};  // the stream is one of the process-wide CU-masked streams: not destroyed with the pipeline
   hipEvent_t gen[2] = {}, ready[2] = {}, planned[2] = {}, pfreed[2] = {};
   int64_t updates = 0;             // swap: optimizer updates done (read back from the step state at kge_pipeline_start)
   hipEvent_t fork = nullptr;
@@ -193,8 +195,9 @@ void destroy(Pipeline* p) {
     for (hipEvent_t e : {p->gen[j], p->ready[j], p->planned[j], p->pfreed[j]})
       if (e) (void)hipEventDestroy(e);
   if (p->fork) (void)hipEventDestroy(p->fork);
-  for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan})
-    if (s) (void)hipStreamDestroy(s);
+  hipStream_t owned[3] = {p->s_gen, p->s_draw, p->s_plan};
+  for (int i = 0; i < 3; ++i)
+    if (owned[i] && !p->borrowed[i]) (void)hipStreamDestroy(owned[i]);
   delete p;
 }
 
@@ -208,7 +211,6 @@ extern "C" {
 
 int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void** handle) {
   (void)hipGetLastError();
-  (void)stream;
   if (!desc || !handle) return fail(KGE_EINVAL, "kge_pipeline_create: null argument");
   const kge_pipeline_desc& d = *desc;
   if (!d.od.step_dev) return fail(KGE_EINVAL, "kge_pipeline_create: the optimizer needs its device-resident step state (kge_opt_desc.step_dev)");
@@ -252,9 +254,55 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
     const char* e = std::getenv("KGE_PIPE_PRIO");
     const int prio = (e && std::atoi(e) == 0) ? 0 : lo;
-    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_gen, hipStreamNonBlocking, prio));
-    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_draw, hipStreamNonBlocking, prio));
-    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_plan, hipStreamNonBlocking, prio));
+    // The producer streams are confined to half of the compute units -- in EVERY shader engine of every XCD: the queue's CU mask
+    // numbers the units XCD-first, then shader engine, then unit (32 consecutive bits = unit i of all 8 x 4 engines), so "every other
+    // group of 32 bits" keeps units 0, 2, 4, 6 of each engine.  The step's waves then find half of the units free of producer waves
+    // (which hold registers and LDS for tens of microseconds): 0.1126 -> 0.1040 ms per step at the bench shape; every other XCD, or
+    // every other engine, does not help (profiles/r02_experiments.txt).  Such a stream (hipExtStreamCreateWithCUMask) has the default
+    // priority and is a BLOCKING stream: it synchronises with the legacy default stream, so this form needs the caller on a stream of
+    // its own (kge_pipeline_create's `stream` != 0; pipeline.py drives the loop from one); on the default stream, and with
+    // KGE_PIPE_CUMASK=0, the producers are plain low-priority streams over all units.
+    // KGE_PIPE_CUMASK=k / KGE_PIPE_CUGROUP=g / KGE_PIPE_CUKEEP=m: keep the first m of every k groups of g mask bits.
+    const char* em = std::getenv("KGE_PIPE_CUMASK");
+    const int stride = em ? std::atoi(em) : (stream ? 2 : 0);
+    if (stride > 1) {
+      const char* eg = std::getenv("KGE_PIPE_CUGROUP");
+      const int group = eg ? std::max(1, std::atoi(eg)) : 32;
+      const char* ek = std::getenv("KGE_PIPE_CUKEEP");
+      const int keep = ek ? std::max(1, std::atoi(ek)) : 1;
+      hipDeviceProp_t prop;
+      KGE_CREATE_TRY(hipGetDeviceProperties(&prop, 0));
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      for (int c = 0; c < ncu; ++c) if ((c / group) % stride < keep) mask[(size_t)c / 32] |= 1u << (c % 32);
+      // which producer streams are confined (KGE_PIPE_CUMASK_STREAMS: 1 generator rounds, 2 draw, 4 plan) [6: the rounds run thin and
+      // long, cost the step nothing where they are, and sit on the critical path of an epoch's first batches]
+      const char* es = std::getenv("KGE_PIPE_CUMASK_STREAMS");
+      const int which = es ? std::atoi(es) : 6;
+      // CU-masked streams are made once per process and shared by all pipelines: a masked queue that is destroyed goes back to the
+      // runtime's queue pool with its mask still set and is handed to the next stream that is created -- measured on ROCm 7.2: the
+      // steps of a second pipeline ran at half speed after the first one had been destroyed (profiles/r02_experiments.txt)
+      static hipStream_t shared[3] = {nullptr, nullptr, nullptr};
+      static int shared_key[3] = {0, 0, 0};
+      const int key = stride * 1000000 + group * 1000 + keep;
+      hipStream_t* ss[3] = {&p->s_gen, &p->s_draw, &p->s_plan};
+      for (int i = 0; i < 3; ++i) {
+        if ((which >> i) & 1) {
+          if (!shared[i] || shared_key[i] != key) {
+            KGE_CREATE_TRY(hipExtStreamCreateWithCUMask(&shared[i], (uint32_t)mask.size(), mask.data()));
+            shared_key[i] = key;
+          }
+          *ss[i] = shared[i];
+          p->borrowed[i] = true;
+        } else {
+          KGE_CREATE_TRY(hipStreamCreateWithPriority(ss[i], hipStreamNonBlocking, prio));
+        }
+      }
+    } else {
+      KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_gen, hipStreamNonBlocking, prio));
+      KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_draw, hipStreamNonBlocking, prio));
+      KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_plan, hipStreamNonBlocking, prio));
+    }
   }
   KGE_CREATE_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
   for (int j = 0; j < 2; ++j) {

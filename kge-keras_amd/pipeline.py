@@ -73,6 +73,7 @@ class TrainPipeline:
         self._h_sig = None
         self._native_active = False
         self._twins = None
+        self._nstream = None    # the stream the native driver's steps run on (see _on_native)
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
@@ -194,6 +195,23 @@ class TrainPipeline:
     def native_ok(self):
         return self.use_graphs and self.between is None and self.counted and not self.serial
 
+    def _on_native(self, fn, join=True):
+        """Run fn with the native driver's own stream current, ordered after the caller's stream and (join) joined back into it.  The
+        driver confines its producer streams to half of the compute units (csrc/pipeline.cpp); such CU-masked streams are blocking
+        streams, which synchronise with the legacy default stream -- PyTorch's default -- so the steps must not be issued from that
+        one.  join=False leaves the caller's stream alone: a stream-to-stream wait that stays pending behind hundreds of enqueued
+        steps slows the whole pipeline down on ROCm 7.2 (measured: 0.104 -> 0.17-0.21 ms per step), so long runs end with a host
+        synchronisation instead (finish(), torch.cuda.synchronize())."""
+        cur = torch.cuda.current_stream()
+        if self._nstream is None:
+            self._nstream = torch.cuda.Stream(device=self.dev)
+        self._nstream.wait_stream(cur)
+        with torch.cuda.stream(self._nstream):
+            out = fn()
+        if join:
+            cur.wait_stream(self._nstream)
+        return out
+
     def _ensure_native(self):
         mo, sa, C = self.model, self.sampler, _lib.C
         sig = self._signature()
@@ -267,17 +285,21 @@ class TrainPipeline:
     def _leave_native(self):
         """The flags changed mid-epoch (e.g. a profiling pass switches to serial launches): hand over to the Python loop.  The
         caller's stream then waits for the producer streams; batches t and t+1 are already drawn and planned."""
-        _lib.check(_lib.lib.kge_pipeline_finish(self._h, _lib.stream_ptr()))
+        if self._nstream is not None:
+            self._nstream.synchronize()  # (host wait, then a join that is satisfied at once: no stream-to-stream wait left pending)
+        self._on_native(lambda: _lib.check(_lib.lib.kge_pipeline_finish(self._h, _lib.stream_ptr())))
         self._native_active = False
         main = torch.cuda.current_stream()
         for st in (self.s1, self.s2, self.s3):
             st.wait_stream(main)
 
-    def run(self, n):
-        """n training steps (each followed by the draw and the plan of the batch two steps ahead); asynchronous."""
+    def run(self, n, join=True):
+        """n training steps (each followed by the draw and the plan of the batch two steps ahead); asynchronous.  join=False (native
+        driver only): the caller's stream is NOT made to wait for the steps -- the caller synchronises with the device (or calls
+        finish()) before it touches the tables; what long runs should use (see _on_native)."""
         n = int(n)
         if self._native_active and self.native_ok():
-            _lib.check(_lib.lib.kge_pipeline_run(self._h, n, _lib.stream_ptr()))
+            self._on_native(lambda: _lib.check(_lib.lib.kge_pipeline_run(self._h, n, _lib.stream_ptr())), join)
             self.t += n
             return
         for _ in range(n):
@@ -332,8 +354,10 @@ class TrainPipeline:
             _lib.check(_lib.lib.kge_opt_state_init(_lib.C.byref(od), _lib.stream_ptr()))
         self.sampler.prepare(self.B, self.ns, self.num_e)  # workspace + jump polynomials: nothing is allocated inside a capture
         if self.native_ok():
-            self._ensure_native()
-            _lib.check(_lib.lib.kge_pipeline_start(self._h, self.n, _lib.stream_ptr()))
+            def go():
+                self._ensure_native()
+                _lib.check(_lib.lib.kge_pipeline_start(self._h, self.n, _lib.stream_ptr()))
+            self._on_native(go)
             self._native_active = True
             return
         self._native_active = False
@@ -383,7 +407,7 @@ class TrainPipeline:
         self.load_epoch(index, order)
         try:
             self.start()
-            self.run(self.n)
+            self.run(self.n, join=False)  # (finish() synchronises)
         except BaseException:
             self.model._step_dev = self.model._step_twins = None  # never leave the model on the device step state
             raise
