@@ -387,6 +387,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of the benched path against the oracle (outside the timed region)")
+    ap.add_argument("--no-sharded-eval", action="store_true", help="skip the YAGO3-10-shape sharded evaluation leg (profiling passes: keeps the sweep kernel's statistics on one shape)")
     ap.add_argument("--sampler", default="device", choices=["device", "pre"],
                     help="device: every step's batch is drawn by the bit-exact MT19937 HIP sampler on a side stream, one batch ahead "
                          "(inside the timed region); pre: batches pre-built on the host before timing")
@@ -633,7 +634,7 @@ def main():
     if dist_on:
         dist.barrier()
     # (also at N = 1 -- one shard, no exchange: the baseline the N-GPU lines' eval_sharded rates are compared with)
-    ev_sh = eval_sharded_leg(torch, dist, rank, world)
+    ev_sh = eval_sharded_leg(torch, dist, rank, world) if not args.no_sharded_eval else None
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

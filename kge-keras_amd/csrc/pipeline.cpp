@@ -291,6 +291,16 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
           if (!shared[i] || shared_key[i] != key) {
             KGE_CREATE_TRY(hipExtStreamCreateWithCUMask(&shared[i], (uint32_t)mask.size(), mask.data()));
             shared_key[i] = key;
+            // gone before the runtime's own teardown (handlers run in reverse order of registration; the runtime registered its own
+            // when it was loaded): a masked stream still alive at that point crashed the process under rocprofv3
+            static bool registered = false;
+            if (!registered) {
+              registered = true;
+              std::atexit([] {
+                for (hipStream_t& s : shared)
+                  if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+              });
+            }
           }
           *ss[i] = shared[i];
           p->borrowed[i] = true;

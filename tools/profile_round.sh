@@ -9,8 +9,8 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_flags.jso
 python bench.py --gpus 2 --backend gloo --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_2ranks_gloo.json 2>> gpurun_out/${tag}_bench.err
 echo "bench lines done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_serial -- python3 $root/bench.py --steps 100 --warmup 5 --settle 0 --no-cpu-baseline --no-check --serial > $root/gpurun_out/prof_${tag}_serial.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag} -- python3 $root/bench.py --steps 100 --warmup 5 --settle 0 --no-cpu-baseline --no-check > $root/gpurun_out/prof_${tag}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_serial -- python3 $root/bench.py --steps 100 --warmup 5 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval --serial > $root/gpurun_out/prof_${tag}_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag} -- python3 $root/bench.py --steps 100 --warmup 5 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval > $root/gpurun_out/prof_${tag}.log 2>&1
 cd $root
 cp gpurun_out/prof_${tag}_serial/*/*kernel_stats.csv gpurun_out/${tag}_serial_kernel_stats.csv
 cp gpurun_out/prof_${tag}/*/*kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
