@@ -289,7 +289,13 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
       for (int i = 0; i < 3; ++i) {
         if ((which >> i) & 1) {
           if (!shared[i] || shared_key[i] != key) {
-            KGE_CREATE_TRY(hipExtStreamCreateWithCUMask(&shared[i], (uint32_t)mask.size(), mask.data()));
+            if (hipExtStreamCreateWithCUMask(&shared[i], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+              // (a runtime or partition mode without CU masks: the plain low-priority stream instead)
+              (void)hipGetLastError();
+              shared[i] = nullptr;
+              KGE_CREATE_TRY(hipStreamCreateWithPriority(ss[i], hipStreamNonBlocking, prio));
+              continue;
+            }
             shared_key[i] = key;
             // gone before the runtime's own teardown (handlers run in reverse order of registration; the runtime registered its own
             // when it was loaded): a masked stream still alive at that point crashed the process under rocprofv3
