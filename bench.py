@@ -151,7 +151,7 @@ def host_batches(w, rank, n_batches, folded=False):
 
 def check_benched_path(model_name="DistMult", steps=3, rank=0, fp64=False, tol=1e-4):
     """Parity of the benched code path at the benched size: a fresh model driven by TrainPipeline (device sampler, counted
-    plans, one hipGraph per stage) for `steps` steps on the bench workload.  (a) every batch the device drew == the host
+    plans, steps between twin tables) for `steps` steps on the bench workload.  (a) every batch the device drew == the host
     generator's, bit for bit (rows before oversampling and pick counts; tests.py:55-61, utils.py:114-147); (b) loss, entity
     table and relation table after every step against the oracle's C restatement (fp32; fp64=True: also the NumPy fp64 oracle)
     within `tol`.  The oracle is the checker only.  Returns a dict for the bench line; raises AssertionError on a mismatch."""
@@ -180,7 +180,7 @@ def check_benched_path(model_name="DistMult", steps=3, rank=0, fp64=False, tol=1
 
     pipe.start()
     torch.cuda.synchronize()
-    assert pipe._native_active and pipe.counted, "the benched path is the natively driven, graph-replayed pipeline with counted plans"
+    assert pipe._native_active and pipe.counted, "the benched path is the natively driven pipeline with counted plans"
     check_batch(0)
     check_batch(1)
     err = dict(loss=0.0, E=0.0, Rel=0.0)

@@ -419,13 +419,18 @@ int kge_allreduce_f32(void* comm, float* buf, int64_t n, kge_stream_t stream);
 /* ---- training pipeline: what Keras' fit() does for the reference with a prefetching Sequence (tests.py:29-61,130-134) as a native
  *      host loop over four device streams, one to two batches apart: word generation (kge_sampler_stream_produce), draw batch k
  *      (kge_sampler_stream_draw, folded output), plan batch k (kge_batch_plan_build_counted), train step k
- *      (kge_train_step_planned with the device-resident optimizer step state).  Everything that changes from step to step lives on
+ *      (kge_train_step_swap between the caller's tables and their twins where supported and E_twin / Rel_twin are given, else
+ *      kge_train_step_planned; the device-resident optimizer step state either way).  Everything that changes from step to step lives on
  *      the device (generator rings and states, batch cursor, step state): the loop only launches.  By default it launches every
  *      stage's kernels itself (about 15 launches per step, ~0.05 ms of host time); with KGE_PIPE_GRAPHS=1 in the environment every
  *      stage is captured once per buffer parity into a hipGraph and replayed (slower on ROCm 7.2: back-to-back graph launches on
- *      one stream leave 20-30 us of idle time each).  The descriptor's pointers are borrowed until kge_pipeline_destroy.
+ *      one stream leave 20-30 us of idle time each).  When `stream` of kge_pipeline_create is not the default stream (0), the draw
+ *      and plan streams are CU-masked streams over half of the compute units of every shader engine (blocking streams: they
+ *      synchronise with the legacy default stream, which is why the caller must then stay off that one); KGE_PIPE_CUMASK=0 turns that
+ *      off.  The descriptor's pointers are borrowed until kge_pipeline_destroy.
  *        kge_pipeline_start   (re)starts an epoch of n_batches batches: the caller has loaded index / starts / the generator states
- *                             and reset *cursor on `stream`; seeds the rings, issues rounds, draws and plans of batches 0 and 1;
+ *                             and reset *cursor on `stream`; seeds the rings, issues rounds, draws and plans of batches 0 and 1
+ *                             (with twin tables it reads the count of updates back from the step state: one stream synchronisation);
  *        kge_pipeline_run     n_steps training steps on `stream` (steps t .. t+n_steps-1 of the epoch), each followed by the round,
  *                             the draw and the plan of the batch two steps ahead; asynchronous (returns when everything is enqueued);
  *        kge_pipeline_finish  makes `stream` wait for the producer streams.

@@ -44,7 +44,7 @@ class OptDesc(C.Structure):
 
 
 class PipelineDesc(C.Structure):
-    """kge_pipeline_desc (include/kge_hip.h): everything the native three-stage pipeline driver borrows."""
+    """kge_pipeline_desc (include/kge_hip.h): everything the native pipeline driver borrows."""
     _fields_ = [("md", ModelDesc), ("ld", LossDesc), ("od", OptDesc),
                 ("E", C.c_void_p), ("Rel", C.c_void_p), ("gradE", C.c_void_p), ("gradRel", C.c_void_p), ("loss_out", C.c_void_p),
                 ("train_ws", C.c_void_p), ("train_ws_bytes", C.c_int64), ("err_flag", C.c_void_p),

@@ -4,13 +4,14 @@
 //   gen   G(k)  extend the two MT19937 word rings by one round if the consumers are close to their heads   (ahead of need)
 //   draw  S(k)  batch k: masked-rejection select, choices, assembly -> candidate rows + pick counts          (needs G(k))
 //   plan  P(k)  ids-only half of step k: histograms, list offsets, relation lists                            (needs S(k))
-//   step  T(k)  forward, loss, gradients, optimizer                                                          (needs P(k))
+//   step  T(k)  forward, loss, gradients, optimizer -- between twin tables where possible: two launches         (needs P(k))
 //
 // double-buffered batches and plans; per tick the loop issues T(t) and then G, S, P of batch t+2.  By default every stage is
 // launched kernel by kernel from this loop (about 15 launches and a dozen event operations per step, ~0.05 ms of host time: the
 // device, not the host, sets the pace).  KGE_PIPE_GRAPHS=1 replays each stage from a hipGraph captured once per buffer parity
 // instead; on ROCm 7.2 consecutive graph launches on one stream cost 20-30 us of idle time each, which makes that the slower form
-// (measured: 0.162 ms per step against 0.150 ms).  Host-only translation unit.
+// (measured: 0.162 ms per step against 0.150 ms).  The draw and plan streams are confined to half of the compute units of every
+// shader engine (see kge_pipeline_create).  Host-only translation unit.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>

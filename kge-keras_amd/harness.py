@@ -103,7 +103,7 @@ class DeviceDataGenerator:
         return [pos, neg], None
 
     def run_epoch(self, model, order, graphs=True):
-        """One epoch of model training over the batches `order` through the three-stage GPU pipeline (pipeline.TrainPipeline:
+        """One epoch of model training over the batches `order` through the GPU pipeline (pipeline.TrainPipeline:
         draw batch t+2 | plan batch t+1 | train step t, steady state replayed from hipGraphs).  Same draws and the same
         updates as `for i in order: model.train_step(self[i][0])`.  Returns the summed loss (device tensor)."""
         from .pipeline import TrainPipeline

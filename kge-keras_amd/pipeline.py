@@ -1,23 +1,24 @@
-"""The training hot path as a three-stage software pipeline on the GPU, every stage replayed from a hipGraph.
+"""The training hot path as a software pipeline on the GPU: generator rounds | draw | plan | step, one to two batches apart.
 
 What Keras does for the reference (tests.py:130-134: `fit` over a `Sequence`, batches prefetched by worker threads while the
-previous step runs) becomes three streams that run one to two batches apart:
+previous step runs) becomes streams that run next to the training stream:
 
-    stage S (stream 1)  draw batch k: bit-exact NumPy / CPython MT19937 streams on the device (utils.py:114-147)
+    rounds G            the word streams of NumPy's / CPython's MT19937 produced ahead into rings (native driver only)
+    stage S (stream 1)  draw batch k: bit-exact NumPy / CPython draws on the device (utils.py:114-147)
     stage P (stream 2)  plan of batch k: fold duplicate rows, per-relation / per-entity gradient lists (ids only)
     stage T (main)      train step k on the plan of batch k: forward, loss, gradients, optimizer (tests.py:63-89)
 
-with double-buffered batches and plans and four events per buffer pair (drawn / arrays free / planned / plan free).  A stage is
-6-10 short kernels, so launching them one by one is bound by the host; each stage is therefore captured once per buffer
-parity into a hipGraph and a training step costs three graph launches.  (One graph holding all three stages as branches
-does not overlap them on ROCm 7.2; separate graphs on separate streams do.)  Everything that changes from step to step lives
-on the device: the generator states, the batch cursor, the optimizer step state (kge_opt_desc.step_dev).
+with double-buffered batches and plans and events per buffer pair (drawn / arrays free / planned / plan free).  Everything that
+changes from step to step lives on the device: the generator states, the batch cursor, the optimizer step state
+(kge_opt_desc.step_dev).
 
-Without dropout and without a hook between the halves of a step the whole loop is native: kge_pipeline_create captures the
-stage graphs inside the library and kge_pipeline_run(n) issues n steps from C (csrc/pipeline.cpp) -- one ctypes call per
-`run`, no per-step Python.  The Python loop below remains for dropout (a per-step mask seed: kernel-by-kernel launches), for
-data-parallel training (`between`: the gradient all-reduce sits between the halves of the step, outside any graph) and for
-`serial` profiling runs.
+Without dropout and without a hook between the halves of a step the whole loop is native (csrc/pipeline.cpp): kge_pipeline_run(n)
+issues n steps from C, kernel by kernel on four streams -- one ctypes call per `run`, no per-step Python; the step runs between twin
+tables (kge_train_step_swap: two launches), the draw and plan streams are confined to half of the compute units, and the loop is
+issued from a stream of this object's own (see _on_native).  The Python loop below remains for dropout (a per-step mask seed:
+kernel-by-kernel launches), for data-parallel training (`between`: the gradient all-reduce sits between the halves of the step)
+and for `serial` profiling runs; it replays S and P from hipGraphs captured once per buffer parity where it can (one graph holding
+all stages as branches does not overlap them on ROCm 7.2; separate graphs on separate streams do).
 """
 import os
 import time

@@ -1,4 +1,4 @@
-"""GPU tests of the three-stage training pipeline (draw | plan | step, hipGraph replays) against the host generator + oracle."""
+"""GPU tests of the training pipeline (generator rounds | draw | plan | step; native driver and Python loop) against the host generator + oracle."""
 import random
 
 import numpy as np
@@ -270,7 +270,7 @@ def test_device_generator_fit_hole_frequency_domain(datasets):
 
 
 def test_pipeline_protate(datasets):
-    """pRotatE (TransE kernels, norm id 3) through the graph-replayed pipeline: same tables as the host generator + oracle."""
+    """pRotatE (TransE kernels, norm id 3) through the pipeline: same tables as the host generator + oracle."""
     from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
     hp = dict(num_entities=14, num_relations=55, dim=16, embedding_model="pRotatE", loss_function="pointwize_logistic", margin=1, dp=0.0, seed=2)
     np.random.seed(7)
