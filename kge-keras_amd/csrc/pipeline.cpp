@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -285,6 +286,8 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
       // steps of a second pipeline ran at half speed after the first one had been destroyed (profiles/r02_experiments.txt)
       static hipStream_t shared[3] = {nullptr, nullptr, nullptr};
       static int shared_key[3] = {0, 0, 0};
+      static std::mutex shared_mutex;  // (pipelines may be created from several host threads)
+      std::lock_guard<std::mutex> lock(shared_mutex);
       const int key = stride * 1000000 + group * 1000 + keep;
       hipStream_t* ss[3] = {&p->s_gen, &p->s_draw, &p->s_plan};
       for (int i = 0; i < 3; ++i) {
