@@ -129,22 +129,55 @@ def exchange_referenced_rows(shard, lo, ids, group=None):
     return ref
 
 
+class ResidentShardPlan:
+    """Everything of schedule (ii) that depends on the test set and on the shard boundaries only -- which rows the queries
+    reference, which of them this rank owns, the queries re-addressed into the referenced rows -- prepared once (a model is
+    validated on the same test set epoch after epoch) and kept on the device, so that an evaluation is: gather the owned rows,
+    ONE all-reduce of the referenced rows, and per side one kge_rank_counts over the shard + one all-reduce of int32 counts.
+    No host work and no host synchronisation per evaluation."""
+
+    def __init__(self, test, shard_rows, lo, device):
+        import numpy as np
+        t = np.ascontiguousarray(np.asarray(test).reshape(-1, 3))
+        ids = referenced_rows(t)
+        own = np.nonzero((ids >= lo) & (ids < lo + shard_rows))[0]
+        self.n = int(t.shape[0])
+        self.n_ref = int(ids.shape[0])
+        self.lo = int(lo)
+        self.own_pos = torch.as_tensor(own, dtype=torch.int64, device=device)             # positions in the referenced rows ...
+        self.own_rows = torch.as_tensor(ids[own] - lo, dtype=torch.int64, device=device)   # ... of these rows of the shard
+        local = t.copy()
+        local[:, 0] = np.searchsorted(ids, t[:, 0])
+        local[:, 2] = np.searchsorted(ids, t[:, 2])
+        self.local = torch.as_tensor(local, dtype=torch.int32, device=device).contiguous()
+        self.ref = None
+
+    def referenced(self, shard, group=None):
+        """(n_ref, d) referenced rows on every rank: owned rows filled in, zeros elsewhere, one all-reduce(sum) (x + 0 is exact)."""
+        if self.ref is None or self.ref.shape[1] != shard.shape[1] or self.ref.dtype != shard.dtype:
+            self.ref = torch.empty((self.n_ref, shard.shape[1]), dtype=shard.dtype, device=shard.device)
+        self.ref.zero_()
+        if self.own_pos.numel():
+            self.ref.index_copy_(0, self.own_pos, shard.index_select(0, self.own_rows))
+        allreduce_sum_([self.ref], group)
+        return self.ref
+
+    def run(self, count_fn, shard, group=None):
+        """(tail_ranks, head_ranks) int64 on every rank; count_fn(ref_rows, test_local (device int32), side) as in resident_shard_eval."""
+        ref = self.referenced(shard, group)
+        out = []
+        for side in (0, 1):
+            c = count_fn(ref, self.local, side).to(torch.int32)
+            allreduce_sum_([c], group)
+            out.append(1 + c.to(torch.int64))
+        return out[0], out[1]
+
+
 def resident_shard_eval(test, count_fn, shard, lo, group=None):
     """SURVEY 8(e) schedule (ii): filtered 1-vs-all ranks of `test` ((n,3) integer array) with the entity table row-sharded and
     never gathered.  count_fn(ref_rows, test_local, side) -> int32 (n,) tensor of #{kept c in this rank's shard:
-    score(q, c) > score(q, target)} where ref_rows holds the referenced rows and test_local is `test` with s / o replaced by
-    their positions in ref_rows (the GPU implementation is EmbeddingModel.rank_counts_shard = kge_rank_counts with E =
-    ref_rows, E_cand = shard, cand_offset = lo).  Returns (tail_ranks, head_ranks) int64 tensors on every rank."""
-    import numpy as np
-    t = np.ascontiguousarray(np.asarray(test).reshape(-1, 3))
-    ids = referenced_rows(t)
-    ref = exchange_referenced_rows(shard, lo, ids, group)
-    local = t.copy()
-    local[:, 0] = np.searchsorted(ids, t[:, 0])
-    local[:, 2] = np.searchsorted(ids, t[:, 2])
-    out = []
-    for side in (0, 1):
-        c = count_fn(ref, local, side).to(torch.int32)
-        allreduce_sum_([c], group)
-        out.append(1 + c.to(torch.int64))
-    return out[0], out[1]
+    score(q, c) > score(q, target)} where ref_rows holds the referenced rows and test_local is `test` (an int32 tensor on the shard's
+    device) with s / o replaced by their positions in ref_rows (the GPU implementation is EmbeddingModel.rank_counts_shard =
+    kge_rank_counts with E = ref_rows, E_cand = shard, cand_offset = lo).  Returns (tail_ranks, head_ranks) int64 tensors on every
+    rank.  One-shot form of ResidentShardPlan (prepare once, run per evaluation)."""
+    return ResidentShardPlan(test, shard.shape[0], lo, shard.device).run(count_fn, shard, group)

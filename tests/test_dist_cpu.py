@@ -110,6 +110,10 @@ def _resident_worker(rank, world):
         return torch.from_numpy(out)
 
     t, h = D.resident_shard_eval(test, count_fn, shard, lo)
+    plan = D.ResidentShardPlan(test, hi - lo, lo, "cpu")  # the prepared form, run twice on the same plan
+    for _ in range(2):
+        t2, h2 = plan.run(count_fn, shard)
+        assert torch.equal(t, t2) and torch.equal(h, h2)
     return t.numpy(), h.numpy()
 
 
