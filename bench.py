@@ -325,7 +325,7 @@ def eval_sharded_leg(torch, dist, rank, world, reps=3):
     fq2, fi2 = torch.from_numpy(fq_all).cuda(), torch.from_numpy(fi_all).cuda()
 
     # (what depends on the test set and the shard boundaries only is prepared once: dist.ResidentShardPlan)
-    plan2 = D.ResidentShardPlan(test, shard.shape[0], lo, shard.device)
+    plan2 = D.ResidentShardPlan(test, shard.shape[0], lo, shard.device, n_entities=N)
 
     def sched2():
         return plan2.run(lambda ref, local, side: model.rank_counts_shard(ref, local, side, fq2, fi2, shard, lo), shard)

@@ -110,10 +110,12 @@ def _resident_worker(rank, world):
         return torch.from_numpy(out)
 
     t, h = D.resident_shard_eval(test, count_fn, shard, lo)
-    plan = D.ResidentShardPlan(test, hi - lo, lo, "cpu")  # the prepared form, run twice on the same plan
-    for _ in range(2):
-        t2, h2 = plan.run(count_fn, shard)
-        assert torch.equal(t, t2) and torch.equal(h, h2)
+    for n_all in (None, N):  # the prepared form, run twice on the same plan: rows exchanged by all-reduce / by all-gather
+        plan = D.ResidentShardPlan(test, hi - lo, lo, "cpu", n_entities=n_all)
+        assert (plan.gather_idx is not None) == (n_all is not None)
+        for _ in range(2):
+            t2, h2 = plan.run(count_fn, shard)
+            assert torch.equal(t, t2) and torch.equal(h, h2)
     return t.numpy(), h.numpy()
 
 
