@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 CASES = [("DistMult", {}, 200), ("DistMult", {}, 24), ("TransE", dict(norm=1, gamma=12), 40), ("TransE", dict(norm=2, gamma=12), 200),
-         ("ComplEx", {}, 100), ("ComplEx", {}, 8), ("DistMult", {}, 256)]
+         ("ComplEx", {}, 100), ("ComplEx", {}, 8), ("DistMult", {}, 256), ("ComplEx", {}, 200), ("pRotatE", {}, 100), ("pRotatE", {}, 24)]
 
 
 def _state(mdl):
@@ -57,7 +57,7 @@ def test_swap_step_equals_planned_step_and_oracle(model, kw, d, opt):
         neg = np.stack([ent(n_neg), rel(n_neg), ent(n_neg)], 1).astype(np.int32)
         La = float(a.train_step(a.plan_batch([pos, neg]))["loss"].item())
         Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
-        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_hinge", 2.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_hinge", 2.0, 1, a.modulus if model == "pRotatE" else kw.get("norm", 1), kw.get("gamma", 12))
         tot += La
         assert La == pytest.approx(Lb, rel=1e-6, abs=1e-7) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), step
         np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-6)
