@@ -248,6 +248,18 @@ int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, c
 int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,
                            float* gradRel, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed,
                            void* workspace, int64_t workspace_bytes, kge_stream_t stream);
+/* kge_train_grads_planned in two halves (data-parallel training, SURVEY 8(e): the gradient tables are exchanged before the optimizer
+ * runs, and the entity table's 11.6 MB are the bulk of that exchange):
+ *   parts 1  the entity gradient rows -> gradE.  One launch; it forms its own scores and needs nothing from the forward, so the
+ *            caller can start the all-reduce of gradE behind it ...
+ *   parts 2  ... while the relation-grouped forward (loss, relation gradient rows -> gradRel, *loss_out) still runs;
+ *   parts 3  both, on `stream` (= kge_train_grads_planned).
+ * Either order; one plan serves both halves of ONE step.  kge_train_grads_halves_supported: 1 where the halves come apart (no
+ * dropout, rows of at most 256 floats; elsewhere only parts = 3 is accepted), 0 otherwise, negative for an invalid descriptor. */
+int kge_train_grads_halves_supported(const kge_model_desc* md, const kge_loss_desc* ld);
+int kge_train_grads_planned_parts(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
+                                  void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace,
+                                  int64_t workspace_bytes, int32_t parts, kge_stream_t stream);
 /* kge_train_step_planned between twin tables: the step reads the parameters from (E_in, Rel_in) and writes the updated tables to
  * (E_out, Rel_out) -- distinct buffers of the same shapes; the input tables are left as they were; the moments of `od` advance in
  * place.  Because no reader of this step can meet an updated row, the wave that has summed the gradient of a row applies the

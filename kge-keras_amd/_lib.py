@@ -92,6 +92,8 @@ SIGNATURES = {
     "kge_batch_plan_build_counted": (C.c_int, [_MD, _LD, _P, _P, _I32, _I64, _I64, _I64, _I64, _P, _I64, _I32, _P, _P]),
     "kge_train_grads_planned": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_train_step_planned": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
+    "kge_train_grads_halves_supported": (C.c_int, [_MD, _LD]),
+    "kge_train_grads_planned_parts": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
     "kge_train_step_swap_supported": (C.c_int, [_MD, _LD, _OD]),
     "kge_train_step_swap": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),

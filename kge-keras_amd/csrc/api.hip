@@ -154,7 +154,8 @@ int64_t batch_plan_bytes(const kge_model_desc*, int64_t);
 int batch_plan_build(const kge_model_desc*, const int32_t*, int64_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int, int64_t, int64_t, void*,
                      int, uint32_t*, hipStream_t);
 int train_grads_with_plan(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, float*, float*, void*, int64_t, int64_t, float*,
-                          uint64_t, void*, int64_t, hipStream_t, const kge_opt_desc* advance = nullptr, OptFinish* finish = nullptr);
+                          uint64_t, void*, int64_t, hipStream_t, const kge_opt_desc* advance = nullptr, OptFinish* finish = nullptr, int grad_parts = 3);
+bool grad_halves_supported(const kge_model_desc*);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
               int64_t, hipStream_t, bool advanced = false, const OptFinish* finish = nullptr);
 
@@ -372,6 +373,26 @@ int kge_train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, c
     return fail(KGE_EWORKSPACE, "kge_train_grads_planned: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
   return train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes,
                                static_cast<hipStream_t>(stream));
+}
+
+int kge_train_grads_halves_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
+  if (int rc = check_model(md, "kge_train_grads_halves_supported")) return rc;
+  if (!ld) return fail(KGE_EINVAL, "kge_train_grads_halves_supported: loss descriptor is null");
+  return plan_supported(md, ld) && grad_halves_supported(md) ? 1 : 0;
+}
+
+int kge_train_grads_planned_parts(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
+                                  void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace,
+                                  int64_t workspace_bytes, int32_t parts, kge_stream_t stream) {
+  if (parts < 1 || parts > 3) return fail(KGE_EINVAL, "kge_train_grads_planned_parts: parts mask %d outside 1..3", parts);
+  if (int rc = check_plan("kge_train_grads_planned_parts", md, ld, m_pos, m_neg)) return rc;
+  if (!E || !Rel || !gradE || !gradRel || !plan || !loss_out) return fail(KGE_EINVAL, "kge_train_grads_planned_parts: null pointer");
+  if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
+    return fail(KGE_EWORKSPACE, "kge_train_grads_planned_parts: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
+  if (parts != 3 && !grad_halves_supported(md))
+    return fail(KGE_EUNSUPPORTED, "kge_train_grads_planned_parts: the halves come apart only without dropout and for rows of at most 256 floats");
+  return train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes,
+                               static_cast<hipStream_t>(stream), nullptr, nullptr, parts);
 }
 
 int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, float* E, float* Rel, float* gradE,

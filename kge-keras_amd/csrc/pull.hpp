@@ -194,7 +194,8 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
 struct StepAdvance;  // kge_internal.hpp
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
-                        hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail = nullptr);
+                        hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail = nullptr, int grad_parts = 3);
+bool grad_halves_supported(const kge_model_desc* md);
 // pullself.hip: the step between twin tables
 bool pull_step_supported(const kge_model_desc* md);
 

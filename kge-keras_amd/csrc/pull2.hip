@@ -528,6 +528,8 @@ int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel
 int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
                            const PullPlan& e, const StepTail& tail, float lr_t, hipStream_t st);
 int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st);
+int pull2_entity_self_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
+                            const PullPlan& e, float* gE, hipStream_t st);
 // step1.hip
 int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRelArgs& fa, int rel_blocks, const PullPlan& e, const StepTail& tail,
                  float* loss_partials, float* loss_out, const StepAdvance& adv, hipStream_t st);
@@ -621,11 +623,17 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
   return KGE_OK;
 }
 
+// KGE_GRAD_SELF=0 (A/B timing): kge_train_grads_planned keeps the coefficient-lookup pull
+bool grad_halves_supported(const kge_model_desc* md) {
+  static const bool on = [] { const char* v = getenv("KGE_GRAD_SELF"); return !v || atoi(v) != 0; }();
+  return on && pull_step_supported(md);
+}
+
 // ---- step: everything that depends on the parameters.  Consumes the plan (the finish kernels leave its counters zero).
 static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, int64_t m_pos,
                      int64_t m_neg, const Plan2& p, const Src& src, float* fwd_scores, float* loss_partials, int* n_partials, float* loss_out,
                      uint64_t seed, hipStream_t st, const StepAdvance& adv = StepAdvance{nullptr, nullptr, 0, 0.f, 0.f, 0.f}, OptFinish* finish = nullptr,
-                     const StepTail* tail = nullptr) {
+                     const StepTail* tail = nullptr, int grad_parts = 3) {
   const int R = md->num_relations;
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
   const int nchunk = width / 4;
@@ -641,6 +649,13 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
                         nullptr, p.rslab, seed, 0u, 1.f};
     return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, st);
+  }
+  // gradient tables only (kge_train_grads_planned[_parts]), halves apart: the entity half forms its own scores (pullself.hip)
+  const bool split = !self && !finish && grad_halves_supported(md);
+  if (!split && grad_parts != 3) return fail(KGE_EUNSUPPORTED, "gradient halves apart: dropout or row width not covered");
+  if (split && (grad_parts & 1)) {
+    if (int rc = pull2_entity_self_grads(md, ld, E, Rel, m_pos, m_neg, p.ent, gE, st)) return rc;
+    if (!(grad_parts & 2)) return KGE_OK;
   }
   if (!self || (tail->parts & 2)) {
     ProfScope prof(KGE_PROF_FWD, st);
@@ -672,8 +687,9 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
-  if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st, nullptr)) return rc;
-  const int eb = (int)cdiv(md->num_entities, 4);
+  if (!split)
+    if (int rc = pull2_entity_pull(md, E, Rel, gE, gR, p.ent, seed, st, nullptr)) return rc;
+  const int eb = split ? 0 : (int)cdiv(md->num_entities, 4);  // (split: the entity half summed its hub rows and left its counters zero)
   hipLaunchKernelGGL(rel_finish_kernel, dim3(eb + R + 1), dim3(256), 0, st, gR, R, md->d_e, p.rcnt, p.ruoff, p.rslab, loss_partials,
                      *n_partials, loss_out, eb, gE, md->num_entities, p.ent.cnt, p.ent.poff, p.ent.slab, p.ent.chunk, adv);
   KGE_HIP_TRY(hipGetLastError());
@@ -729,13 +745,13 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
 
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
-                        hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail) {
+                        hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail, int grad_parts) {
   const int64_t n = m_pos + m_neg;
   Plan2 p;
   carve_plan_buffer(plan, md, n, &p);
   carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
   const Src src{nullptr, m_pos, nullptr, m_neg, p.dd.uniq, p.dd.nu};
-  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv, finish, tail);
+  return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv, finish, tail, grad_parts);
 }
 
 }  // namespace kge

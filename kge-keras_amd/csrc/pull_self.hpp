@@ -11,7 +11,8 @@ struct SelfArgs {
   float inv_pos, inv_neg, gamma, modulus, margin;
   const int32_t* off; const int32_t* poff; const int32_t* totals; const int2* emap; const int4* entries;
   float* slab; int32_t* cnt; int C;
-  int kind; float lr, b1, b2, eps;
+  int kind;  // KGE_OPT_SGD | KGE_OPT_ADAM_TF: apply the optimizer, E_in row -> E_out row; < 0: no optimizer, the gradient row -> E_out (= gradE)
+  float lr, b1, b2, eps;
   float *E_out, *mE, *vE;
 };
 
@@ -151,10 +152,11 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
   } else if (lane64 == 0 && c) {
     a.cnt[key] = 0;
   }
-  // optimizer: sub-group s takes the accumulators s, s + NSUB, ...
+  // optimizer (or, kind < 0: the gradient row itself into the dense accumulator E_out): sub-group s takes the accumulators s, s + NSUB, ...
   float* wout = a.E_out + (int64_t)key * d_e;
   float* mrow = a.mE + (int64_t)key * d_e;
   float* vrow = a.vE + (int64_t)key * d_e;
+  if (a.kind < 0 && c == 0) return;  // (gradient tables are all-zero between steps: a row nobody touched stays so)
 #pragma unroll
   for (int k = 0; k < NPER; ++k) {
     float4 g = L::zero();
@@ -165,6 +167,7 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
     const int ch = lane + (i % NV) * G;
     if (i < NACC && ch < nchunk) {
       const int at = (i / NV) * h + ch * 4;
+      if (a.kind < 0) { L::st(wout + at, L::ld(wout + at) + g); continue; }  // (accumulates, like every gradient path of the library)
       float4 w = mine[i * G + lane], m = L::zero(), v = L::zero();
       if (a.kind == KGE_OPT_ADAM_TF) { m = L::ld(mrow + at); v = L::ld(vrow + at); }
       tail_upd(a.kind, a.lr, a.b1, a.b2, a.eps, w, g, m, v);

@@ -79,6 +79,17 @@ int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, co
   return KGE_OK;
 }
 
+// The entity gradient rows alone (data-parallel training: the tables are exchanged before the optimizer runs): the same launch with
+// the gradient row written to gE instead of the optimizer applied.  Needs nothing from the forward, so the caller may start the
+// exchange of gE while the relation half still runs.
+int pull2_entity_self_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
+                            const PullPlan& e, float* gE, hipStream_t st) {
+  StepTail t{};
+  t.kind = -1;
+  t.E_out = gE; t.mE = gE; t.vE = gE;  // (moments unused)
+  return pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, e, t, 0.f, st);
+}
+
 // Relation half, second launch (the first is the relation-grouped forward): relation rows of Rel_out, relation counters left zero,
 // loss reduced, step state moved on.
 int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st) {

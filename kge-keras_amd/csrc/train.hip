@@ -749,13 +749,13 @@ bool plan_supported(const kge_model_desc* md, const kge_loss_desc* ld) {
 // its place (OptFinish); the optimizer half is then opt_apply(..., finish).
 int train_grads_with_plan(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                           int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace, int64_t wbytes, hipStream_t st,
-                          const kge_opt_desc* advance, OptFinish* finish) {
+                          const kge_opt_desc* advance, OptFinish* finish, int grad_parts) {
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   int nb = 0;
   StepAdvance adv{nullptr, nullptr, 0, 0.f, 0.f, 0.f};
   if (advance) adv = StepAdvance{advance->step_dev, ws.lr_slot, advance->kind, advance->lr, advance->beta1, advance->beta2};
-  return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv, finish);
+  return train_grads_planned(md, ld, E, Rel, gE, gR, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv, finish, nullptr, grad_parts);
 }
 
 // The step between twin tables (step1.hip, pullself.hip): parameters read from (E_in, Rel_in), written to (E_out, Rel_out); moments in

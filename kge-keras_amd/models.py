@@ -360,13 +360,21 @@ class EmbeddingModel:
                                        buf.numel(), int(parts), self._err.data_ptr(), _lib.stream_ptr()))
         return BatchPlan(buf, pos.shape[0], neg.shape[0])
 
-    def _step_planned(self, plan, apply):
+    def grad_halves_supported(self):
+        """True where train_grads(plan, parts=1 | 2) is available: the entity gradient rows and the relation half (forward, loss,
+        relation gradient rows) as two independent calls (kge_train_grads_planned_parts)."""
+        md, ld = self._model_desc(True), self._loss_desc()
+        return lib.kge_train_grads_halves_supported(C.byref(md), C.byref(ld)) == 1
+
+    def _step_planned(self, plan, apply, parts=3):
         md, ld = self._ensure_train_state(plan.m_pos, plan.m_neg)
-        self._seed += 1
+        if parts != 2:
+            self._seed += 1
         if not apply:
-            check(lib.kge_train_grads_planned(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
-                                              self._gR.data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), plan.m_pos, plan.m_neg,
-                                              self._loss.data_ptr(), self._seed, self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()))
+            check(lib.kge_train_grads_planned_parts(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                                    self._gR.data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), plan.m_pos, plan.m_neg,
+                                                    self._loss.data_ptr(), self._seed, self._ws.data_ptr(), self._ws.numel(), int(parts),
+                                                    _lib.stream_ptr()))
             return {"loss": self._loss[0]}
         self.optimizer.iterations += 1
         od = self._opt_desc()
@@ -429,11 +437,15 @@ class EmbeddingModel:
                                        _lib.stream_ptr()))
         return {"loss": self._loss[0]}
 
-    def train_grads(self, data, scores_out=None):
+    def train_grads(self, data, scores_out=None, parts=3):
         """First half of train_step (forward + loss + gradient accumulation); for data-parallel training an
-        all-reduce of `_gE` / `_gR` goes between this and apply_grads."""
+        all-reduce of `_gE` / `_gR` goes between this and apply_grads.  With a BatchPlan and grad_halves_supported(): parts = 1
+        the entity gradient rows (`_gE`) alone, parts = 2 the relation half (`_gR`, the loss) -- two independent calls on one plan,
+        so the exchange of `_gE`, the bulk of the bytes, can run while the relation half is still computing."""
         if isinstance(data, BatchPlan):
-            return self._step_planned(data, False)
+            return self._step_planned(data, False, parts)
+        if parts != 3:
+            raise ValueError("train_grads(parts=1 | 2) needs a BatchPlan")
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
         md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])

@@ -29,7 +29,7 @@ from . import _lib
 
 
 class TrainPipeline:
-    def __init__(self, model, kg, n_rows, batch_size, ns, num_e, sampler, graphs=True, between=None):
+    def __init__(self, model, kg, n_rows, batch_size, ns, num_e, sampler, graphs=True, between=None, between_halves=None):
         """kg: (n,3) int32 device rows; n_rows: length of the epoch permutation; sampler: DeviceSampler whose states are loaded.
         `between`: optional callable run between the gradient half and the optimizer half of every step (the data-parallel
         all-reduce); the optimizer half then stays outside the graphs."""
@@ -39,6 +39,9 @@ class TrainPipeline:
         self.model, self.kg, self.B, self.ns, self.num_e, self.sampler = model, kg, int(batch_size), int(ns), int(num_e), sampler
         self.dev = kg.device
         self.between = between
+        # optional callable run between the entity half and the relation half of the gradient computation (data-parallel training:
+        # start the exchange of the entity gradient table there); only with `between` and where the model's halves come apart
+        self.between_halves = between_halves if between is not None else None
         # a captured step cannot change its dropout seed: graphs only without dropout.  With a collective between the halves of
         # the step (one process per GPU) the draw and plan stages are still graph replays; the step itself (gradient half,
         # collective, optimizer half) is launched kernel by kernel, so that no collective ever sits inside a captured graph
@@ -75,6 +78,7 @@ class TrainPipeline:
         self._native_active = False
         self._twins = None
         self._nstream = None    # the stream the native driver's steps run on (see _on_native)
+        self._halves = None     # cached model.grad_halves_supported()
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
@@ -106,8 +110,17 @@ class TrainPipeline:
     def _stage_T(self, slot):
         if self.between is None:
             self.model.train_step(self.plans[slot])  # the step's last kernel adds its loss to the device step state
+        elif self.between_halves is not None and self._halves_ok():
+            self.model.train_grads(self.plans[slot], parts=1)
+            self.between_halves()
+            self.model.train_grads(self.plans[slot], parts=2)
         else:
             self.model.train_grads(self.plans[slot])
+
+    def _halves_ok(self):
+        if self._halves is None:
+            self._halves = bool(self.model.grad_halves_supported())
+        return self._halves
 
     def _after(self):
         if self.between is not None:

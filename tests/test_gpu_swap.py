@@ -148,3 +148,40 @@ def test_swap_halves_equal_the_whole_step(order):
     assert max(diffs) < 2e-7, diffs
     assert a[3] == pytest.approx(b[3], rel=1e-6) and int(a[4][0].item()) == int(b[4][0].item()) == 3
     assert a[4].view(torch.float32)[2].item() == b[4].view(torch.float32)[2].item()  # lr_t of the next update
+
+
+@pytest.mark.parametrize("model,kw,d", [("DistMult", {}, 200), ("TransE", dict(norm=2, gamma=12), 64), ("ComplEx", {}, 40)])
+def test_gradient_halves_equal_the_whole(model, kw, d):
+    """kge_train_grads_planned_parts: entity half (parts 1) + relation half (parts 2), in either order, fill the gradient tables and
+    the loss word like parts 3 and like the oracle's gradients; a hub entity and a dominant relation included."""
+    from kge_keras_amd import models as M
+    N, R = 200, 5
+    rs = np.random.RandomState(11)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    ent = lambda n: np.where(rs.rand(n) < 0.3, 3, rs.randint(0, N - 20, n))
+    rel = lambda n: np.where(rs.rand(n) < 0.6, 1, rs.randint(0, R, n))
+    pos = np.stack([ent(48), rel(48), ent(48)], 1).astype(np.int32)
+    neg = np.stack([ent(1200), rel(1200), ent(1200)], 1).astype(np.int32)
+    out = []
+    for seq in ((3,), (1, 2), (2, 1)):
+        m = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0,
+                              loss_function="pointwize_logistic", **kw)
+        m.compile("sgd")
+        assert m.grad_halves_supported()
+        plan = m.plan_batch([pos, neg])
+        for parts in seq:
+            m.train_grads(plan, parts=parts)
+        out.append((m._gE.clone(), m._gR.clone(), float(m._loss[0].item())))
+        m._raise_on_flag()
+    Lo, _sp, _sn, gEo, gRo = O.dense_grads(model, E0.astype(np.float64), R0.astype(np.float64), pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+    for gE, gR, L in out:
+        np.testing.assert_allclose(gE.cpu().numpy(), gEo, atol=1e-5)
+        np.testing.assert_allclose(gR.cpu().numpy(), gRo, atol=1e-5)
+        assert L == pytest.approx(Lo, rel=1e-5)
+    for gE, gR, L in out[1:]:
+        assert float((gE - out[0][0]).abs().max()) < 1e-7 and float((gR - out[0][1]).abs().max()) < 1e-7 and L == pytest.approx(out[0][2], rel=1e-6)
+    # a model with dropout keeps its halves together
+    md = M.DistMult(e_dim=16, r_dim=16, num_entities=N, num_relations=R, dp=0.3, loss_function="pointwize_logistic")
+    assert not md.grad_halves_supported()
