@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256) void lit_act_fwd(float* __restrict__ Z, float*
   }
 }
 
+constexpr int kLitHoleMax = 512;  // HolE rows in LDS: 4 waves x 3 rows x 512 floats = 24 KB
+
 // per triple: s_hat = H[t], o_hat = H[n+t], p' = Rel[p]*mask.  MODE 0: score.  MODE 1: row gradients dH[t], dH[n+t], dP[t] (masked).
 template <int MODEL, int NORM, int MODE, bool DROP>
 __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, const int32_t* __restrict__ pos, int64_t m_pos,
@@ -100,6 +102,47 @@ __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, c
     DropKey kp{0, 0};
     if (DROP) kp = drop_key(seed, t, 1);
     auto mp = [&](int e) { return DROP ? drop_mul(kp, e, thr, dscale) : 1.f; };
+    if (MODEL == KGE_HOLE) {
+      // models.py:231-237 on the transformed rows: score = sum_k p'_k c_k,  c_k = sum_i s_i o_{(i+k) mod d} (circular cross-correlation);
+      // d/ds_i = g sum_k p'_k o_{(i+k)},  d/do_j = g sum_k p'_k s_{(j-k)},  d/dp_k = g c_k (times p's dropout factor).
+      // The three rows of the triple sit in LDS (this wave's slice); direct O(d^2) sums, ascending index order.
+      __shared__ float hb[4][3][kLitHoleMax];
+      float* ls = hb[wave][0];
+      float* lo = hb[wave][1];
+      float* lp = hb[wave][2];
+      for (int k = lane; k < d; k += 64) { ls[k] = hs[k]; lo[k] = ho[k]; lp[k] = rp[k] * mp(k); }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float gi = 0.f;
+      if (MODE == 1) { gi = ok ? g[t] : 0.f; if (!(gi == gi)) gi = 0.f; }
+      float accp = 0.f;
+      for (int k = lane; k < d; k += 64) {
+        float c = 0.f;
+        int j = k;
+        for (int i = 0; i < d; ++i) { c += ls[i] * lo[j]; j = j + 1 == d ? 0 : j + 1; }
+        accp += lp[k] * c;
+        if (MODE == 1) dP[t * d + k] = gi * c * mp(k);
+      }
+      if (MODE == 0) {
+        accp = group_sum<64>(accp);
+        if (lane == 0) scores[t] = ok ? accp : __builtin_nanf("");
+      } else {
+        for (int i = lane; i < d; i += 64) {
+          float a = 0.f, b = 0.f;
+          int jo = i, js = i;                    // o index (i + k) mod d, s index (i - k) mod d
+          for (int k = 0; k < d; ++k) {
+            a += lp[k] * lo[jo];
+            b += lp[k] * ls[js];
+            jo = jo + 1 == d ? 0 : jo + 1;
+            js = js == 0 ? d - 1 : js - 1;
+          }
+          dH[t * d + i] = gi * a;
+          dH[(n + t) * d + i] = gi * b;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // (the next triple of this wave overwrites the slice)
+      continue;
+    }
     float acc = 0.f;
     for (int k = lane; k < width; k += 64) {
       if (MODEL == KGE_COMPLEX) {
@@ -206,8 +249,10 @@ __global__ __launch_bounds__(256) void lit_compact(const float* __restrict__ dA,
 static int64_t l256(int64_t x) { return align_up(x, 256); }
 
 static int lit_check(const kge_model_desc* md, int L, int act) {
-  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX)
-    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE and ComplEx are built)", md->model);
+  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX && md->model != KGE_HOLE)
+    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE, ComplEx and HolE are built)", md->model);
+  if (md->model == KGE_HOLE && md->d_e > kLitHoleMax)
+    return fail(KGE_EUNSUPPORTED, "literal path under HolE: rows of at most %d floats (e_dim = %d)", kLitHoleMax, md->d_e);
   if (md->model == KGE_TRANSE && (md->norm == 3 || md->norm == 5))
     return fail(KGE_EUNSUPPORTED, "literal path: the pRotatE phase distance (norm 3) and the general p-norm (norm 5) are not built here");
   if (L <= 0) return fail(KGE_EINVAL, "literal path: literal width %d", L);
@@ -275,6 +320,7 @@ static void launch_rows_model(bool drop, int grid, hipStream_t st, const float* 
                               uint64_t seed) {
   if (md->model == KGE_DISTMULT) launch_rows<KGE_DISTMULT, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->model == KGE_COMPLEX) launch_rows<KGE_COMPLEX, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+  else if (md->model == KGE_HOLE) launch_rows<KGE_HOLE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->norm == 1) launch_rows<KGE_TRANSE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else launch_rows<KGE_TRANSE, 2, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
 }

@@ -44,7 +44,8 @@ def test_literal_predict_parity(act):
     np.testing.assert_allclose(mdl.predict(t), ref, atol=TOL, rtol=1e-4)
 
 
-@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})])
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {}),
+                                      ("HolE", {})])
 @pytest.mark.parametrize("loss,act", [("pairwize_hinge", "tanh"), ("pointwize_logistic", "relu"), ("pointwize_hinge", "sigmoid")])
 @pytest.mark.parametrize("dp", [0.0, 0.25])
 def test_literal_train_step_parity(model, kw, loss, act, dp):
@@ -122,3 +123,23 @@ def test_reference_training_script_flow(datasets):
     assert model.num_entities == 14 and len(h.history["loss"]) == 4 and len(h.history["val_loss"]) == 4
     assert h.history["loss"][-1] < h.history["loss"][0]
     assert np.all(np.isfinite(h.history["val_loss"]))
+
+
+def test_literal_under_hole_predict_and_rank():
+    """models.py:152-158 is model agnostic: HolE on literal-transformed rows -- predict() and the filtered 1-vs-all ranks on the
+    transformed table equal the oracle's."""
+    N, R, d, L = 40, 5, 24, 5
+    mdl, E0, R0, lit, H, rs = _mk("HolE", N, R, d, L, "tanh", seed=4, dp=0.0)
+    t = _tri(rs, 200, N, R)
+    Hd = _f64(H)
+    ids = np.arange(N)
+    Et, _ = O.literal_transform(Hd, E0.astype(np.float64), lit.astype(np.float64), ids, "tanh")
+    ref = O.score_rows("HolE", Et[t[:, 0]], R0[t[:, 1]].astype(np.float64), Et[t[:, 2]])
+    np.testing.assert_allclose(mdl.predict(t), ref, atol=TOL, rtol=1e-4)
+    test = [tuple(int(v) for v in x) for x in t[:30]]
+    filt = [tuple(int(v) for v in x) for x in _tri(rs, 100, N, R)]
+    filt = [f for f in filt if f not in set(test)]
+    tr, hr = O.ranks_closed_form("HolE", Et, R0.astype(np.float64), test, filt)
+    fh, ft = O.build_filters(filt)
+    gt, gh = mdl.rank(test, N, ft, fh)
+    assert np.mean(gt == tr) > 0.95 and np.mean(gh == hr) > 0.95 and np.max(np.abs(gt - tr)) <= 1 and np.max(np.abs(gh - hr)) <= 1
