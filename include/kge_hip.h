@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 5
+#define KGE_ABI_VERSION 6
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -70,9 +70,12 @@ typedef struct {
                           * with p in `modulus`; scoring, push-path training and the VALU distance sweep of the ranking */
   float gamma;           /* TransE (models.py:179,187-190): score = gamma - dist if gamma > 0 else +dist */
   float dropout;         /* Dropout(dp) on the three gathered rows, training only (models.py:122,144-148) */
-  int32_t conv_filters;  /* ConvE: Conv2D filters (models.py:242; 8 is built) */
+  int32_t conv_filters;  /* ConvE: Conv2D filters (models.py:242) */
   float hidden_dropout;  /* ConvE: Dropout(hidden_dp) after each batch norm (models.py:241,257,262) */
   float modulus;         /* norm 3: models.py:476 modulus * embedding_range; norm 5: the exponent p */
+  int32_t conv_kh, conv_kw; /* ConvE: Conv2D kernel (conv_size_w, conv_size_h) of models.py:243-244,254 = (rows, columns) over the
+                             * (2w, h) image; 0 = the reference default 3.  8 filters of 3x3 take register-tiled kernels, every
+                             * other shape the general ones (ABI version 6) */
 } kge_model_desc;
 
 /* loss_function(true, false, margin, negative_samples) as called at tests.py:80-81. */

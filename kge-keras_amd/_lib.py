@@ -30,7 +30,8 @@ CAND_POS_LANES = 16  # KGE_CAND_POS_LANES
 class ModelDesc(C.Structure):
     _fields_ = [("model", C.c_int32), ("num_entities", C.c_int32), ("num_relations", C.c_int32), ("d_e", C.c_int32),
                 ("d_r", C.c_int32), ("norm", C.c_int32), ("gamma", C.c_float), ("dropout", C.c_float),
-                ("conv_filters", C.c_int32), ("hidden_dropout", C.c_float), ("modulus", C.c_float)]
+                ("conv_filters", C.c_int32), ("hidden_dropout", C.c_float), ("modulus", C.c_float),
+                ("conv_kh", C.c_int32), ("conv_kw", C.c_int32)]
 
 
 class LossDesc(C.Structure):

@@ -5,7 +5,7 @@
 // Everything around the GEMMs is hand-written HIP; the per-triple rows dS, dP, dO that come out of the backward pass are
 // summed into the embedding tables' gradients by the same per-destination lists as the other models (pull.hip).
 //
-// theta = [K(3,3,C) | bc(C) | g1(C) | b1(C) | Wd(F,d) | bd(d) | g2(d) | b2(d)],   stats = [mm1(C) | mv1(C) | mm2(d) | mv2(d)]
+// theta = [K(KH,KW,C) | bc(C) | g1(C) | b1(C) | Wd(F,d) | bd(d) | g2(d) | b2(d)],   stats = [mm1(C) | mv1(C) | mm2(d) | mv2(d)]
 // [TF semantics restated in oracle/kge_oracle.py conve_*]: BN eps 1e-3, momentum 0.99, the 4-D BN's moving variance takes
 // Bessel's correction (fused kernel), Flatten order (H, W, C); the two calls of the wrapper (pos, neg) are separate BN batches.
 // The biases bc and bd feed straight into a batch norm, so their gradients are identically zero; they are left untouched.
@@ -19,18 +19,29 @@ namespace kge {
 
 constexpr float kBnEps = 1e-3f, kBnMom = 0.99f;
 
-struct CvShape { int d, w, h, H, W, Ho, Wo, C, F; };
-static CvShape cv_shape(int d, int C) {
+struct CvShape { int d, w, h, H, W, Ho, Wo, C, F, KH, KW; };
+// Conv2D(conv_filters, (conv_size_w, conv_size_h)) of models.py:254: a (KH, KW) kernel over the (2w rows, h columns) image, 'valid',
+// stride 1.  kge_model_desc.conv_kh / conv_kw == 0 stand for the reference default 3.
+static CvShape cv_shape(const kge_model_desc* md) {
+  const int d = md->d_e;
   int w = 1;
   for (int i = 1; i * i <= d; ++i) if (d % i == 0) w = i;  // largest i <= sqrt(d) dividing d (models.py:250-251)
   CvShape s;
-  s.d = d; s.w = w; s.h = d / w; s.H = 2 * w; s.W = s.h; s.Ho = s.H - 2; s.Wo = s.W - 2; s.C = C; s.F = s.Ho * s.Wo * C;
+  s.KH = md->conv_kh > 0 ? md->conv_kh : 3;
+  s.KW = md->conv_kw > 0 ? md->conv_kw : 3;
+  s.C = md->conv_filters;
+  s.d = d; s.w = w; s.h = d / w; s.H = 2 * w; s.W = s.h; s.Ho = s.H - s.KH + 1; s.Wo = s.W - s.KW + 1; s.F = s.Ho * s.Wo * s.C;
   return s;
+}
+// the register-tiled kernels below are written for the reference defaults (8 filters of 3x3); every other shape takes the cvg_* kernels
+static bool cv_fast(const CvShape& s) {
+  static const bool force_generic = [] { const char* v = getenv("KGE_CONVE_GENERIC"); return v && atoi(v) != 0; }();
+  return s.C == 8 && s.KH == 3 && s.KW == 3 && !force_generic;
 }
 struct CvOff { int64_t K, bc, g1, b1, Wd, bd, g2, b2, total; };
 static CvOff cv_off(const CvShape& s) {
   CvOff o;
-  o.K = 0; o.bc = 9 * s.C; o.g1 = o.bc + s.C; o.b1 = o.g1 + s.C; o.Wd = o.b1 + s.C; o.bd = o.Wd + (int64_t)s.F * s.d;
+  o.K = 0; o.bc = (int64_t)s.KH * s.KW * s.C; o.g1 = o.bc + s.C; o.b1 = o.g1 + s.C; o.Wd = o.b1 + s.C; o.bd = o.Wd + (int64_t)s.F * s.d;
   o.g2 = o.bd + s.d; o.b2 = o.g2 + s.d; o.total = o.b2 + s.d;
   return o;
 }
@@ -525,6 +536,186 @@ __global__ __launch_bounds__(256) void cv_rowsum4_kernel(float* __restrict__ gE,
   }
 }
 
+// ------------------------------------------------------------------------------------------------ any conv shape
+// The same layers for any conv_filters / conv_size_* (models.py:241-245): one thread per output element, weights read through the
+// caches, runtime loop bounds; the accumulation order of the convolution is that of the register-tiled kernels (bias, then a, b
+// ascending), so the default shape gives the same Y either way.  No speed claims: the hot configurations take the kernels above.
+template <bool DROP>
+__global__ __launch_bounds__(256) void cvg_conv_fwd(const float* __restrict__ E, const float* __restrict__ Rel, const int32_t* __restrict__ tri,
+                                                     int64_t m, int N, int R, CvShape sh, const float* __restrict__ theta, float* __restrict__ Y,
+                                                     uint32_t* __restrict__ err, uint64_t seed, int64_t row_offset, uint32_t thr, float dscale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* img = lds + wave * (sh.H * sh.W);
+  const int C = sh.C, KK = sh.KH * sh.KW;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
+    const int s = tri[3 * i], p = tri[3 * i + 1], o = tri[3 * i + 2];
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+    if (!ok && lane == 0) atomicOr(err, 1u);
+    const float* es = E + (int64_t)(ok ? s : 0) * sh.d;
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * sh.d;
+    DropKey ks{0, 0}, kp{0, 0};
+    if (DROP) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
+    for (int k = lane; k < sh.d; k += 64) {
+      float a = es[k], b = rp[k];
+      if (DROP) { a *= drop_mul(ks, k, thr, dscale); b *= drop_mul(kp, k, thr, dscale); }
+      img[k] = ok ? a : 0.f;
+      img[sh.d + k] = ok ? b : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* yrow = Y + i * (int64_t)sh.F;
+    for (int e = lane; e < sh.F; e += 64) {
+      const int pos = e / C, c = e - pos * C;
+      const int r = pos / sh.Wo, q = pos - r * sh.Wo;
+      float acc = theta[KK * C + c];
+      for (int a = 0; a < sh.KH; ++a)
+        for (int b = 0; b < sh.KW; ++b) acc = fmaf(img[(r + a) * sh.W + q + b], theta[(a * sh.KW + b) * C + c], acc);
+      yrow[e] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Per-block partial channel sums over a slab of 16 rows of an (m, F) activation whose channel is index % C, laid out like the
+// partial sums of the kernels above (psum[block][2C]).  MODE 0: sums of y and y^2 (batch-norm statistics).  MODE 1 (backward):
+// dy1 = A > 0 ? dA * hscale : 0 written over V (= dA), sums of dy1 and dy1 * xhat1.  Thread t owns channel t % C and every
+// (256 / C)-th position; the phases meet in LDS in fixed order.
+template <int MODE>
+__global__ __launch_bounds__(256) void cvg_chan_sums(float* __restrict__ V, const float* __restrict__ A, const float* __restrict__ Y, int64_t m,
+                                                      int F, int C, const float* __restrict__ stat, float hscale, float* __restrict__ psum) {
+  __shared__ float red[2][256];
+  const int64_t r0 = (int64_t)blockIdx.x * 16, r1 = min(m, r0 + 16);
+  const int npos = F / C;
+  for (int c0 = 0; c0 < C; c0 += 256) {  // (C > 256: channel groups of 256, one phase)
+    const int Cg = min(C - c0, 256);
+    const int phases = 256 / Cg;
+    const int c = c0 + (int)threadIdx.x % Cg, ph = (int)threadIdx.x / Cg;
+    float s1 = 0.f, s2 = 0.f;
+    if (ph < phases) {
+      for (int64_t r = r0; r < r1; ++r)
+        for (int pos = ph; pos < npos; pos += phases) {
+          const int64_t idx = r * F + (int64_t)pos * C + c;
+          if (MODE == 0) {
+            const float y = V[idx];
+            s1 += y;
+            s2 = fmaf(y, y, s2);
+          } else {
+            const float dy = A[idx] > 0.f ? V[idx] * hscale : 0.f;
+            V[idx] = dy;
+            s1 += dy;
+            s2 = fmaf(dy, (Y[idx] - stat[c]) * stat[C + c], s2);
+          }
+        }
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < Cg) {
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < phases; ++q) { a += red[0][q * Cg + threadIdx.x]; b += red[1][q * Cg + threadIdx.x]; }
+      psum[(int64_t)blockIdx.x * 2 * C + c0 + threadIdx.x] = a;
+      psum[(int64_t)blockIdx.x * 2 * C + C + c0 + threadIdx.x] = b;
+    }
+    __syncthreads();
+  }
+}
+
+// A = Drop(ReLU(g1 * (Y - mu) * inv + b1)), one element per thread (channel = index % C).
+template <bool DROP>
+__global__ __launch_bounds__(256) void cvg_bn1_apply(const float* __restrict__ Y, float* __restrict__ A, int64_t m, int F, int C,
+                                                      const float* __restrict__ theta_g1, const float* __restrict__ theta_b1,
+                                                      const float* __restrict__ stat, uint64_t seed, int64_t row_offset, uint32_t thr, float dscale) {
+  const int64_t total = m * (int64_t)F;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int64_t row = idx / F;
+    const int e = (int)(idx - row * F);
+    float a = fmaf(theta_g1[c] * stat[C + c], Y[idx] - stat[c], theta_b1[c]);
+    a = a > 0.f ? a : 0.f;
+    if (DROP) a *= drop_mul(drop_key(seed, row_offset + row, 3), (uint32_t)e, thr, dscale);
+    A[idx] = a;
+  }
+}
+
+// One wave per triple: dY on the fly (dy1 in dA), dX -> dS, dP rows, and the kernel gradient: weight j = (a*KW + b)*C + c is owned by
+// lane j % 64 of the wave, summed over the positions in ascending order into the wave's LDS slice, the four slices meet at the end.
+template <bool DROP>
+__global__ __launch_bounds__(256) void cvg_conv_bwd(const float* __restrict__ E, const float* __restrict__ Rel, const int32_t* __restrict__ tri,
+                                                     int64_t m, int N, int R, CvShape sh, const float* __restrict__ theta,
+                                                     const float* __restrict__ stat, const float* __restrict__ bst, const float* __restrict__ dA,
+                                                     const float* __restrict__ Y, float* __restrict__ dS, float* __restrict__ dP,
+                                                     float* __restrict__ pk, uint64_t seed, int64_t row_offset, uint32_t thr, float dscale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int C = sh.C, KK = sh.KH * sh.KW, npos = sh.Ho * sh.Wo, nk = KK * C;
+  const int per = sh.H * sh.W + sh.F + nk;
+  float* img = lds + wave * per;
+  float* dy = img + sh.H * sh.W;  // [npos][C]
+  float* dk = dy + sh.F;          // [KK][C]
+  const float* g1 = theta + (int64_t)nk + C;
+  for (int j = lane; j < nk; j += 64) dk[j] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
+    const int s = tri[3 * i], p = tri[3 * i + 1], o = tri[3 * i + 2];
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+    const float* es = E + (int64_t)(ok ? s : 0) * sh.d;
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * sh.d;
+    DropKey ks{0, 0}, kp{0, 0};
+    if (DROP) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
+    for (int k = lane; k < sh.d; k += 64) {
+      float a = es[k], b = rp[k];
+      if (DROP) { a *= drop_mul(ks, k, thr, dscale); b *= drop_mul(kp, k, thr, dscale); }
+      img[k] = ok ? a : 0.f;
+      img[sh.d + k] = ok ? b : 0.f;
+    }
+    const float* da = dA + i * (int64_t)sh.F;
+    const float* yr = Y + i * (int64_t)sh.F;
+    for (int e = lane; e < sh.F; e += 64) {
+      const int c = e % C;
+      const float inv = stat[C + c];
+      const float xh = (yr[e] - stat[c]) * inv;
+      dy[e] = ok ? inv * (g1[c] * da[e] - bst[c] - xh * bst[C + c]) : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < nk; j += 64) {  // dK[a][b][c] += sum_pos X[r+a][q+b] * dY[pos][c]
+      const int ab = j / C, c = j - ab * C, a = ab / sh.KW, b = ab - a * sh.KW;
+      float acc = 0.f;
+      for (int pos = 0; pos < npos; ++pos) {
+        const int r = pos / sh.Wo, q = pos - r * sh.Wo;
+        acc = fmaf(img[(r + a) * sh.W + q + b], dy[pos * C + c], acc);
+      }
+      dk[j] += acc;
+    }
+    for (int k = lane; k < 2 * sh.d; k += 64) {  // dX[u][v] = sum_{a,b,c} dY[u-a][v-b][c] * K[a][b][c]
+      const int u = k / sh.W, v = k - u * sh.W;
+      float acc = 0.f;
+      for (int a = 0; a < sh.KH; ++a) {
+        const int r = u - a;
+        if (r < 0 || r >= sh.Ho) continue;
+        for (int b = 0; b < sh.KW; ++b) {
+          const int q = v - b;
+          if (q < 0 || q >= sh.Wo) continue;
+          for (int c = 0; c < C; ++c) acc = fmaf(dy[(r * sh.Wo + q) * C + c], theta[(a * sh.KW + b) * C + c], acc);
+        }
+      }
+      if (k < sh.d) {
+        if (DROP) acc *= drop_mul(ks, k, thr, dscale);
+        dS[i * sh.d + k] = acc;
+      } else {
+        const int kk2 = k - sh.d;
+        if (DROP) acc *= drop_mul(kp, kk2, thr, dscale);
+        dP[i * sh.d + kk2] = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nk; j += 256)
+    pk[(int64_t)blockIdx.x * nk + j] = ((lds[0 * per + sh.H * sh.W + sh.F + j] + lds[1 * per + sh.H * sh.W + sh.F + j]) + lds[2 * per + sh.H * sh.W + sh.F + j]) +
+                                       lds[3 * per + sh.H * sh.W + sh.F + j];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -565,12 +756,12 @@ int pull_finish_launch(const kge_model_desc* md, float* gE, float* gR, const Pul
 static int64_t cv_psum_floats(const CvShape& s, int64_t m) {
   const int64_t nb_conv = std::min<int64_t>(cdiv(m, 4), 2048);
   const int64_t nb_rows = cdiv(m, 64);
-  const int64_t nb_bn1 = cdiv(m * s.F / 4, 4096);
-  return std::max<int64_t>({nb_conv * 9 * s.C, nb_rows * 2 * s.d, nb_bn1 * 2 * s.C, nb_conv * 2 * s.C}) + 64;
+  const int64_t nb_bn1 = std::max<int64_t>(cdiv(m * s.F / 4, 4096), cdiv(m, 16));  // (register-tiled / cvg_chan_sums partials)
+  return std::max<int64_t>({nb_conv * (int64_t)s.KH * s.KW * s.C, nb_rows * 2 * s.d, nb_bn1 * 2 * s.C, nb_conv * 2 * s.C}) + 64;
 }
 
 int64_t conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
-  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const CvShape s = cv_shape(md);
   const int64_t n = m_pos + m_neg, mm = std::max(m_pos, m_neg);
   int64_t b = 0;
   for (int64_t m : {m_pos, m_neg}) b += 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4);
@@ -580,7 +771,7 @@ int64_t conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m
 }
 
 static void cv_carve(void* ws, const kge_model_desc* md, int64_t m_pos, int64_t m_neg, CvWs* w, void** loss_ws, int64_t* loss_ws_bytes) {
-  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const CvShape s = cv_shape(md);
   const int64_t n = m_pos + m_neg, mm = std::max(m_pos, m_neg);
   char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   auto take = [&](int64_t bytes) { char* r = q; q += c256(bytes); return r; };
@@ -609,10 +800,14 @@ static void cv_carve(void* ws, const kge_model_desc* md, int64_t m_pos, int64_t 
 }
 
 int conve_sizes(const kge_model_desc* md, int64_t* n_theta, int64_t* n_stats) {
-  if (md->conv_filters != 8) return fail(KGE_EUNSUPPORTED, "ConvE: conv_filters = %d (8, the reference default, is built)", md->conv_filters);
-  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  if (md->conv_filters < 1 || md->conv_kh < 0 || md->conv_kw < 0)
+    return fail(KGE_EINVAL, "ConvE: conv_filters = %d, kernel %d x %d", md->conv_filters, md->conv_kh, md->conv_kw);
+  const CvShape s = cv_shape(md);
   if (s.w < 2 && s.h < 2) return fail(KGE_ESHAPE, "ConvE: e_dim %d has no factor pair with w > 1 or h > 1 (models.py:252)", md->d_e);
-  if (s.Ho < 1 || s.Wo < 1) return fail(KGE_ESHAPE, "ConvE: image %dx%d is smaller than the 3x3 kernel", s.H, s.W);
+  if (s.Ho < 1 || s.Wo < 1) return fail(KGE_ESHAPE, "ConvE: image %dx%d is smaller than the %dx%d kernel", s.H, s.W, s.KH, s.KW);
+  if ((size_t)4 * (s.H * s.W + s.F + (cv_fast(s) ? 0 : s.KH * s.KW * s.C)) * sizeof(float) > 64 * 1024)
+    return fail(KGE_EUNSUPPORTED, "ConvE: %d filters of %dx%d on a %dx%d image need more than 64 KB of LDS per workgroup in the backward pass", s.C,
+                s.KH, s.KW, s.H, s.W);
   if (s.d > 1024) return fail(KGE_EUNSUPPORTED, "ConvE: e_dim above 1024 is not built");
   *n_theta = cv_off(s).total;
   *n_stats = 2 * s.C + 2 * s.d;
@@ -623,23 +818,38 @@ int conve_sizes(const kge_model_desc* md, int64_t* n_theta, int64_t* n_stats) {
 static int cv_forward(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* stats, const int32_t* tri,
                       int64_t m, int64_t row_offset, bool training, const CvBuf& b, float* psum, float* scores, int want_score,
                       uint32_t* err, uint64_t seed, hipStream_t st) {
-  constexpr int C = 8;
-  const CvShape s = cv_shape(md->d_e, C);
+  const CvShape s = cv_shape(md);
+  const int C = s.C;
+  const bool fast = cv_fast(s);
   const CvOff o = cv_off(s);
   const bool drop_e = training && md->dropout > 0.f, drop_h = training && md->hidden_dropout > 0.f;
   const uint32_t thr_e = drop_thr(md->dropout), thr_h = drop_thr(md->hidden_dropout);
   const float ds_e = 1.f / (1.f - md->dropout), ds_h = 1.f / (1.f - md->hidden_dropout);
   const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
   const size_t smem = (size_t)4 * s.H * s.W * sizeof(float);
-#define KGE_CONV(TR, DR) hipLaunchKernelGGL((cv_conv_fwd<TR, DR, C>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, \
+#define KGE_CONV(TR, DR) hipLaunchKernelGGL((cv_conv_fwd<TR, DR, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, \
                                             md->num_relations, s, theta, b.Y, psum, err, seed, row_offset, thr_e, ds_e)
-  if (training) { if (drop_e) KGE_CONV(true, true); else KGE_CONV(true, false); }
-  else KGE_CONV(false, false);
+  int nb_stat1 = nb_conv;
+  if (fast) {
+    if (training) { if (drop_e) KGE_CONV(true, true); else KGE_CONV(true, false); }
+    else KGE_CONV(false, false);
+  } else {
+    if (drop_e) hipLaunchKernelGGL((cvg_conv_fwd<true>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.Y, err, seed, row_offset, thr_e, ds_e);
+    else hipLaunchKernelGGL((cvg_conv_fwd<false>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.Y, err, seed, row_offset, thr_e, ds_e);
+    nb_stat1 = (int)cdiv(m, 16);
+    if (training) hipLaunchKernelGGL((cvg_chan_sums<0>), dim3(nb_stat1), dim3(256), 0, st, b.Y, nullptr, nullptr, m, s.F, C, nullptr, 1.f, psum);
+  }
 #undef KGE_CONV
-  hipLaunchKernelGGL(cv_bn_finalize, dim3(C), dim3(256), 0, st, psum, nb_conv, C, (double)m * s.Ho * s.Wo, 1, b.stat1, stats, stats + C, training ? 0 : 1);
-  const int nb_el = (int)std::min<int64_t>(cdiv(m * s.F / 4, 256), 8192);
-  if (drop_h) hipLaunchKernelGGL((cv_bn1_apply<true, C>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
-  else hipLaunchKernelGGL((cv_bn1_apply<false, C>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+  hipLaunchKernelGGL(cv_bn_finalize, dim3(C), dim3(256), 0, st, psum, nb_stat1, C, (double)m * s.Ho * s.Wo, 1, b.stat1, stats, stats + C, training ? 0 : 1);
+  if (fast) {
+    const int nb_el = (int)std::min<int64_t>(cdiv(m * s.F / 4, 256), 8192);
+    if (drop_h) hipLaunchKernelGGL((cv_bn1_apply<true, 8>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+    else hipLaunchKernelGGL((cv_bn1_apply<false, 8>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+  } else {
+    const int nb_el = (int)std::min<int64_t>(cdiv(m * s.F, 256), 8192);
+    if (drop_h) hipLaunchKernelGGL((cvg_bn1_apply<true>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, C, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+    else hipLaunchKernelGGL((cvg_bn1_apply<false>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, C, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+  }
   rocblas_handle h = blas_handle();
   if (!h) return fail(KGE_EHIP, "ConvE: rocblas handle could not be created");
   KGE_BLAS_TRY(rocblas_set_stream(h, st));
@@ -663,8 +873,9 @@ static int cv_forward(const kge_model_desc* md, const float* E, const float* Rel
 
 static int cv_backward(const kge_model_desc* md, const float* E, const float* Rel, const float* theta, float* gtheta, const int32_t* tri,
                        int64_t m, int64_t row_offset, const CvBuf& b, const CvWs& w, const float* g, uint64_t seed, hipStream_t st) {
-  constexpr int C = 8;
-  const CvShape s = cv_shape(md->d_e, C);
+  const CvShape s = cv_shape(md);
+  const int C = s.C, nk = s.KH * s.KW * s.C;
+  const bool fast = cv_fast(s);
   const CvOff o = cv_off(s);
   const bool drop_e = md->dropout > 0.f, drop_h = md->hidden_dropout > 0.f;
   const uint32_t thr_e = drop_thr(md->dropout);
@@ -693,18 +904,33 @@ static int cv_backward(const kge_model_desc* md, const float* E, const float* Re
   // dWd(F,d) += A^T(F,m) * dZ(m,d)  ==  dWd'(d,F) += dZ'(d,m) * A'(F,m)^T
   KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, s.d, s.F, (rocblas_int)m, &one, b.Z, s.d, b.A, s.F, &one, gtheta + o.Wd, s.d));
   const int64_t total4 = m * (int64_t)s.F / 4;
-  const int nb_bn1 = (int)cdiv(total4, 4096);
-  hipLaunchKernelGGL((cv_bn1_bwd_stats<C>), dim3(nb_bn1), dim3(256), 0, st, w.dA, b.A, b.Y, total4, b.stat1, ds_h, w.psum);
+  int nb_bn1 = (int)cdiv(total4, 4096);
+  if (fast) {
+    hipLaunchKernelGGL((cv_bn1_bwd_stats<8>), dim3(nb_bn1), dim3(256), 0, st, w.dA, b.A, b.Y, total4, b.stat1, ds_h, w.psum);
+  } else {
+    nb_bn1 = (int)cdiv(m, 16);
+    hipLaunchKernelGGL((cvg_chan_sums<1>), dim3(nb_bn1), dim3(256), 0, st, w.dA, b.A, b.Y, m, s.F, C, b.stat1, ds_h, w.psum);
+  }
   hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(C), dim3(256), 0, st, w.psum, nb_bn1, C, (double)m * s.Ho * s.Wo, theta + o.g1, bst1, gtheta + o.g1, gtheta + o.b1);
   const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
-  const size_t smem = (size_t)4 * (s.H * s.W + s.Ho * s.Wo * C) * sizeof(float);
-  if (drop_e)
-    hipLaunchKernelGGL((cv_conv_bwd<true, C>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
-                       bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
-  else
-    hipLaunchKernelGGL((cv_conv_bwd<false, C>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
-                       bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
-  hipLaunchKernelGGL(cv_sum_partials, dim3(9 * C), dim3(256), 0, st, w.psum, nb_conv, 9 * C, gtheta + o.K);
+  if (fast) {
+    const size_t smem = (size_t)4 * (s.H * s.W + s.Ho * s.Wo * C) * sizeof(float);
+    if (drop_e)
+      hipLaunchKernelGGL((cv_conv_bwd<true, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
+                         bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
+    else
+      hipLaunchKernelGGL((cv_conv_bwd<false, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
+                         bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
+  } else {
+    const size_t smem = (size_t)4 * (s.H * s.W + s.F + nk) * sizeof(float);
+    if (drop_e)
+      hipLaunchKernelGGL((cvg_conv_bwd<true>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
+                         bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
+    else
+      hipLaunchKernelGGL((cvg_conv_bwd<false>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
+                         bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
+  }
+  hipLaunchKernelGGL(cv_sum_partials, dim3(nk), dim3(256), 0, st, w.psum, nb_conv, nk, gtheta + o.K);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
@@ -714,7 +940,7 @@ int conve_infer(const kge_model_desc* md, const float* E, const float* Rel, cons
                 float* out, int want_hidden, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
   int64_t nt, ns;
   if (int rc = conve_sizes(md, &nt, &ns)) return rc;
-  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const CvShape s = cv_shape(md);
   const int64_t CH = 32768;  // rows per pass: bounds the activation buffers
   const int64_t m = std::min(n, CH);
   const int64_t need = 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 1024;
@@ -756,7 +982,7 @@ int cv_rowsum_launch(const kge_model_desc* md, float* gE, float* gR, const PullP
 }
 
 int64_t conve_infer_workspace_bytes(const kge_model_desc* md, int64_t n) {
-  const CvShape s = cv_shape(md->d_e, md->conv_filters);
+  const CvShape s = cv_shape(md);
   const int64_t m = std::min<int64_t>(n, 32768);
   return 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 2048;
 }

@@ -203,7 +203,8 @@ class EmbeddingModel:
         return ModelDesc(MODEL_IDS[self.MODEL], self.num_entities, self.num_relations, int(self.e_dim), int(self.r_dim),
                          nid, float(getattr(self, "gamma", 0.0)), float(self.dp) if training else 0.0,
                          int(getattr(self, "conv_filters", 0)), float(getattr(self, "hidden_dp", 0.0)) if training else 0.0,
-                         float(getattr(self, "modulus", 0.0)) if self.MODEL == "TransE" else 0.0)
+                         float(getattr(self, "modulus", 0.0)) if self.MODEL == "TransE" else 0.0,
+                         int(getattr(self, "conv_size_w", 0)), int(getattr(self, "conv_size_h", 0)))
 
     def _loss_desc(self):
         if self.loss_function not in LOSS_IDS:
@@ -899,14 +900,17 @@ class HolE(EmbeddingModel):
 
 
 class ConvE(EmbeddingModel):
-    """models.py:239-275: x = Drop(ReLU(BN(Dense(Flatten(Drop(ReLU(BN(Conv2D(8,3x3)([s ; p] as a 2w x h image)))))))), score = <x, o>.
-    The layer parameters live in one flat vector `theta` (+ the batch norms' moving statistics `bn_stats`), see csrc/conve.hip."""
+    """models.py:239-275: x = Drop(ReLU(BN(Dense(Flatten(Drop(ReLU(BN(Conv2D(conv_filters, (conv_size_w, conv_size_h))([s ; p] as a
+    2w x h image)))))))), score = <x, o>.  The layer parameters live in one flat vector `theta` (+ the batch norms' moving statistics
+    `bn_stats`), see csrc/conve.hip (8 filters of 3x3, the reference defaults, take register-tiled kernels; any other shape the
+    general ones)."""
     MODEL = "ConvE"
 
     def __init__(self, name='ConvE', hidden_dp=0.2, conv_filters=8, conv_size_w=3, conv_size_h=3, **kwargs):
         super().__init__(name=name, **kwargs)
-        if (conv_size_w, conv_size_h) != (3, 3) or conv_filters != 8:
-            raise NotImplementedError("ConvE is built for the reference's defaults (8 filters of 3x3)")
+        self.conv_size_w, self.conv_size_h = int(conv_size_w), int(conv_size_h)  # Conv2D kernel (rows, columns), models.py:254
+        if self.conv_size_w < 1 or self.conv_size_h < 1 or int(conv_filters) < 1:
+            raise ValueError("ConvE: conv_filters and conv_size_* must be positive")
         self.dim = kwargs['e_dim']
         factors = [(int(i), int(self.dim / i)) for i in range(1, int(self.dim ** 0.5) + 1) if self.dim % i == 0]
         self.w, self.h = factors.pop(-1)
@@ -917,7 +921,8 @@ class ConvE(EmbeddingModel):
         nt, ns = C.c_int64(0), C.c_int64(0)
         check(lib.kge_conve_sizes(C.byref(md), C.byref(nt), C.byref(ns)))
         Cc, d = self.conv_filters, int(self.dim)
-        Ho, Wo = 2 * self.w - 2, self.h - 2
+        KK = self.conv_size_w * self.conv_size_h
+        Ho, Wo = 2 * self.w - self.conv_size_w + 1, self.h - self.conv_size_h + 1
         F = Ho * Wo * Cc
         self._F = F
         seed = kwargs.get("seed", None)
@@ -927,11 +932,11 @@ class ConvE(EmbeddingModel):
             gen.manual_seed(int(seed) + 1)
         theta = torch.zeros(nt.value, dtype=torch.float32, device=self.device)
         # Keras defaults: Glorot-uniform kernels, zero biases, gamma 1, beta 0, moving mean 0 / variance 1
-        limk = float(np.sqrt(6.0 / (9 + 9 * Cc)))
+        limk = float(np.sqrt(6.0 / (KK + KK * Cc)))
         limd = float(np.sqrt(6.0 / (F + d)))
-        theta[:9 * Cc].uniform_(-limk, limk, generator=gen)
-        theta[10 * Cc:11 * Cc] = 1.0
-        off_wd = 12 * Cc
+        theta[:KK * Cc].uniform_(-limk, limk, generator=gen)
+        theta[(KK + 1) * Cc:(KK + 2) * Cc] = 1.0
+        off_wd = (KK + 3) * Cc
         theta[off_wd:off_wd + F * d].uniform_(-limd, limd, generator=gen)
         theta[off_wd + F * d + d:off_wd + F * d + 2 * d] = 1.0
         self.theta = theta
@@ -947,7 +952,7 @@ class ConvE(EmbeddingModel):
     # theta <-> named parameters (K, bc, g1, b1, Wd, bd, g2, b2) and stats <-> (mm1, mv1, mm2, mv2)
     def _layout(self):
         Cc, d, F = self.conv_filters, int(self.dim), self._F
-        sizes = [("K", 9 * Cc), ("bc", Cc), ("g1", Cc), ("b1", Cc), ("Wd", F * d), ("bd", d), ("g2", d), ("b2", d)]
+        sizes = [("K", self.conv_size_w * self.conv_size_h * Cc), ("bc", Cc), ("g1", Cc), ("b1", Cc), ("Wd", F * d), ("bd", d), ("g2", d), ("b2", d)]
         out, o = {}, 0
         for k, n in sizes:
             out[k] = (o, n)
@@ -960,7 +965,7 @@ class ConvE(EmbeddingModel):
         th = self.theta.cpu().numpy()
         st = self.bn_stats.cpu().numpy()
         P = {k: th[o:o + n].copy() for k, (o, n) in lay.items()}
-        P["K"] = P["K"].reshape(3, 3, Cc)
+        P["K"] = P["K"].reshape(self.conv_size_w, self.conv_size_h, Cc)
         P["Wd"] = P["Wd"].reshape(F, d)
         P.update(mm1=st[:Cc].copy(), mv1=st[Cc:2 * Cc].copy(), mm2=st[2 * Cc:2 * Cc + d].copy(), mv2=st[2 * Cc + d:].copy())
         return P

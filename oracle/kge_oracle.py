@@ -570,22 +570,23 @@ def sorted_id_maps(*splits):
 # takes Bessel's correction, the 2-D one is not fused and does not), ReLU, Dropout, Flatten in (H, W, C) order, Dense.
 # The two calls of the wrapper (tests.py:77-78) are separate invocations: batch statistics are per call.
 # ----------------------------------------------------------------------------------------------
-def conve_shape(dim, filters=8):
-    """models.py:250-251: (w, h) = the largest factor pair i <= sqrt(dim); image (2w, h); conv output (2w-2, h-2, filters)."""
+def conve_shape(dim, filters=8, kh=3, kw=3):
+    """models.py:250-251: (w, h) = the largest factor pair i <= sqrt(dim); image (2w, h); Conv2D(filters, (conv_size_w,
+    conv_size_h)) (models.py:254: kernel (kh, kw) over (rows, columns), 'valid', stride 1) -> (2w-kh+1, h-kw+1, filters)."""
     fac = [(int(i), int(dim / i)) for i in range(1, int(dim ** 0.5) + 1) if dim % i == 0]
     w, h = fac[-1]
     assert w > 1 or h > 1  # models.py:252
-    Ho, Wo = 2 * w - 2, h - 2
+    Ho, Wo = 2 * w - kh + 1, h - kw + 1
     return w, h, Ho, Wo, Ho * Wo * filters
 
 
-def conve_init(dim, rs, filters=8, dtype=np.float32):
+def conve_init(dim, rs, filters=8, dtype=np.float32, kh=3, kw=3):
     """Trainable parameters with the Keras default initialisers (Glorot uniform kernels, zero biases, BN gamma 1 / beta 0)
     and the non-trainable moving statistics (mean 0, variance 1)."""
-    w, h, Ho, Wo, F = conve_shape(dim, filters)
-    lim_k = np.sqrt(6.0 / (9 * 1 + 9 * filters))  # fan_in = 3*3*1, fan_out = 3*3*filters
+    w, h, Ho, Wo, F = conve_shape(dim, filters, kh, kw)
+    lim_k = np.sqrt(6.0 / (kh * kw * 1 + kh * kw * filters))  # fan_in = kh*kw*1, fan_out = kh*kw*filters
     lim_d = np.sqrt(6.0 / (F + dim))
-    return dict(K=rs.uniform(-lim_k, lim_k, (3, 3, filters)).astype(dtype), bc=np.zeros(filters, dtype), g1=np.ones(filters, dtype),
+    return dict(K=rs.uniform(-lim_k, lim_k, (kh, kw, filters)).astype(dtype), bc=np.zeros(filters, dtype), g1=np.ones(filters, dtype),
                 b1=np.zeros(filters, dtype), Wd=rs.uniform(-lim_d, lim_d, (F, dim)).astype(dtype), bd=np.zeros(dim, dtype),
                 g2=np.ones(dim, dtype), b2=np.zeros(dim, dtype),
                 mm1=np.zeros(filters, dtype), mv1=np.ones(filters, dtype), mm2=np.zeros(dim, dtype), mv2=np.ones(dim, dtype))
@@ -598,12 +599,12 @@ BN_EPS, BN_MOMENTUM = 1e-3, 0.99
 def conve_forward(P, s, p, o, training=False, hidden_dp=0.0, seed=0, row_offset=0, cache=None, update_moving=True):
     """x = ConvE.func's hidden vector (m, dim) and score = sum(x * o, -1) (models.py:265-275)."""
     m, dim = s.shape
-    C = P["K"].shape[2]
-    w, h, Ho, Wo, F = conve_shape(dim, C)
+    kh, kw, C = P["K"].shape
+    w, h, Ho, Wo, F = conve_shape(dim, C, kh, kw)
     X = np.concatenate([s.reshape(m, w, h), p.reshape(m, w, h)], axis=1)  # (m, 2w, h): tf.concat axis=1
     Y = np.zeros((m, Ho, Wo, C), dtype=s.dtype)
-    for a in range(3):
-        for b in range(3):
+    for a in range(kh):
+        for b in range(kw):
             Y += X[:, a:a + Ho, b:b + Wo, None] * P["K"][a, b][None, None, None, :]
     Y += P["bc"]
     if training:
@@ -668,8 +669,8 @@ def conve_backward(P, cache, o, g):
     X = cache["X"]
     dK = np.zeros_like(P["K"])
     dX = np.zeros_like(X)
-    for a in range(3):
-        for b in range(3):
+    for a in range(P["K"].shape[0]):
+        for b in range(P["K"].shape[1]):
             dK[a, b] = np.einsum("mij,mijc->c", X[:, a:a + Ho, b:b + Wo], dY)
             dX[:, a:a + Ho, b:b + Wo] += dY @ P["K"][a, b]
     ds = dX[:, :w, :].reshape(m, w * h)

@@ -16,7 +16,7 @@ def _mk(N, R, d, seed=0, **kw):
     E0 = rs.uniform(-0.5, 0.5, (N, d)).astype(np.float32)
     R0 = rs.uniform(-0.5, 0.5, (R, d)).astype(np.float32)
     mdl = ConvE(e_dim=d, r_dim=d, num_entities=N, num_relations=R, init_entities=E0, init_relations=R0, **kw)
-    P = O.conve_init(d, rs)
+    P = O.conve_init(d, rs, filters=kw.get("conv_filters", 8), kh=kw.get("conv_size_w", 3), kw=kw.get("conv_size_h", 3))
     # non-trivial values everywhere so that every term of the formulas is exercised
     for k in ("bc", "b1", "bd", "b2", "mm1", "mm2"):
         P[k] += rs.uniform(-0.2, 0.2, P[k].shape).astype(np.float32)
@@ -115,3 +115,53 @@ def test_conve_fit_runs(datasets):
     assert mdl.dp == 0.2 and mdl.hidden_dp == 0.2  # reference defaults (models.py:22,241)
     h = mdl.fit(DataGenerator(datasets["nations_train"], ns=10, batch_size=32), epochs=5, verbose=0)
     assert h.history["loss"][-1] < h.history["loss"][0]
+
+
+# models.py:241-245: conv_filters / conv_size_w / conv_size_h other than the defaults (the general kernels of csrc/conve.hip)
+SHAPES = [dict(conv_filters=4, conv_size_w=2, conv_size_h=3), dict(conv_filters=6, conv_size_w=1, conv_size_h=1),
+          dict(conv_filters=3, conv_size_w=3, conv_size_h=2), dict(conv_filters=16, conv_size_w=4, conv_size_h=2),
+          dict(conv_filters=1, conv_size_w=2, conv_size_h=2)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("d", [12, 40])
+def test_conve_general_shape_predict_parity(shape, d):
+    mdl, E0, R0, P, rs = _mk(40, 5, d, seed=2, **shape)
+    assert P["K"].shape == (shape["conv_size_w"], shape["conv_size_h"], shape["conv_filters"])
+    t = _tri(rs, 300, 40, 5)
+    Pd = _f64(P)
+    xr, ref = O.conve_forward(Pd, E0[t[:, 0]].astype(np.float64), R0[t[:, 1]].astype(np.float64), E0[t[:, 2]].astype(np.float64), False)
+    np.testing.assert_allclose(mdl.predict(t), ref, atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(mdl.hidden(t).cpu().numpy(), xr, atol=TOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dp,hdp", [(0.0, 0.0), (0.2, 0.3)])
+def test_conve_general_shape_train_step_parity(shape, dp, hdp):
+    N, R, d, m = 30, 4, 12, 200
+    mdl, E0, R0, P, rs = _mk(N, R, d, seed=3, dp=dp, hidden_dp=hdp, loss_function="pointwize_logistic", margin=0.5, **shape)
+    mdl._seed = 7
+    mdl.compile("adam")
+    Eo, Ro, Po = E0.astype(np.float64), R0.astype(np.float64), _f64(P)
+    oo = O.make_optimizer("adam")
+    for step in range(2):
+        pos, neg = _tri(rs, m, N, R), _tri(rs, m, N, R)
+        sc = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        L = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+        Lo, sp, sn = O.conve_train_step(Po, Eo, Ro, oo, pos, neg, "pointwize_logistic", 0.5, 1, dp, hdp, seed=mdl._seed)
+        np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-4), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        got = mdl.get_head_params()
+        for k in ("K", "g1", "b1", "Wd", "g2", "b2", "mm1", "mv1", "mm2", "mv2"):
+            np.testing.assert_allclose(got[k], Po[k], atol=2e-4, rtol=1e-3, err_msg=k)
+        Po["bc"][...] = P["bc"]
+        Po["bd"][...] = P["bd"]
+    mdl._raise_on_flag()
+
+
+def test_conve_kernel_larger_than_image_is_a_shape_error():
+    from kge_keras_amd.models import ConvE
+    with pytest.raises(ValueError):  # 2w x h = 6 x 4 image, 7 rows of kernel: the reference's Conv2D raises at build time
+        ConvE(e_dim=12, r_dim=12, num_entities=5, num_relations=2, conv_size_w=7)

@@ -36,7 +36,7 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_abi_struct_layouts():
-    assert ctypes.sizeof(_lib.ModelDesc) == 44 and _lib.ModelDesc.modulus.offset == 40
+    assert ctypes.sizeof(_lib.ModelDesc) == 52 and _lib.ModelDesc.modulus.offset == 40 and _lib.ModelDesc.conv_kw.offset == 48
     assert ctypes.sizeof(_lib.LossDesc) == 16
     assert ctypes.sizeof(_lib.OptDesc) == 72
     assert _lib.OptDesc.step.offset == 24 and _lib.OptDesc.mE.offset == 32
