@@ -185,3 +185,48 @@ def test_gradient_halves_equal_the_whole(model, kw, d):
     # a model with dropout keeps its halves together
     md = M.DistMult(e_dim=16, r_dim=16, num_entities=N, num_relations=R, dp=0.3, loss_function="pointwize_logistic")
     assert not md.grad_halves_supported()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_swap_step_random_shapes(case):
+    """Seeded random shapes for the twin-table step: row widths 4..256 (every sub-group shape, widths that do not fill the last
+    chunk), tiny and skewed tables (a single relation, three entities, every row on one entity), batches of one row -- against the
+    three-launch step (fp32 rounding) and the oracle (1e-4), two steps each."""
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(1000 + case)
+    model, kw = [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})][case % 4]
+    d = int(rs.choice([4, 8, 12, 20, 36, 64, 68, 100, 128, 132, 200, 256]))
+    if model == "ComplEx":
+        d = min(d, 128)
+    N = int(rs.choice([3, 7, 50, 400]))
+    R = int(rs.choice([1, 2, 9]))
+    n_pos, n_neg = int(rs.choice([1, 5, 64])), int(rs.choice([1, 37, 900, 2500]))
+    loss = ["pointwize_hinge", "pointwize_logistic", "pointwize_square_loss", "pointwize_cross_entropy"][int(rs.randint(4))]
+    opt = ["adam", "sgd"][int(rs.randint(2))]
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    a, b = (getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0,
+                              loss_function=loss, margin=1.0, **kw) for _ in range(2))
+    for m in (a, b):
+        m.compile(opt)
+        m._ensure_train_state(n_pos, n_neg)
+    _state(a), _state(b)
+    a._step_twins = (torch.empty_like(a.E), torch.empty_like(a.Rel))
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.make_optimizer(opt)
+    skew = rs.rand() < 0.4
+    for step in range(2):
+        ent = (lambda n: np.where(rs.rand(n) < 0.8, 0, rs.randint(0, N, n))) if skew else (lambda n: rs.randint(0, N, n))
+        pos = np.stack([ent(n_pos), rs.randint(0, R, n_pos), ent(n_pos)], 1).astype(np.int32)
+        neg = np.stack([ent(n_neg), rs.randint(0, R, n_neg), ent(n_neg)], 1).astype(np.int32)
+        La = float(a.train_step(a.plan_batch([pos, neg]))["loss"].item())
+        Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
+        info = (case, model, d, N, R, n_pos, n_neg, loss, opt, skew, step)
+        assert La == pytest.approx(Lb, rel=2e-6, abs=1e-6) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), info
+        np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=5e-6, err_msg=str(info))
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=5e-6, err_msg=str(info))
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL, err_msg=str(info))
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL, err_msg=str(info))
+    a._raise_on_flag()
