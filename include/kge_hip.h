@@ -448,9 +448,10 @@ int kge_allreduce_f32(void* comm, float* buf, int64_t n, kge_stream_t stream);
  *                             (with twin tables it reads the count of updates back from the step state: one stream synchronisation);
  *        kge_pipeline_run     n_steps training steps on `stream` (steps t .. t+n_steps-1 of the epoch), each followed by the round,
  *                             the draw and the plan of the batch two steps ahead; asynchronous (returns when everything is enqueued);
- *        kge_pipeline_finish  makes `stream` wait for the producer streams.
- *      No dropout (every oversampled row would need its own mask: no folded batches) and no hook between the halves of a step:
- *      data-parallel training and dropout steps drive the same library calls themselves. */
+ *        kge_pipeline_finish  makes `stream` wait for the producer streams;
+ *        kge_pipeline_set_seed  dropout only (md.dropout > 0 needs the pos / neg arrays of the descriptor): the dropout seed of the
+ *                             step issued next is seed + 1, of the one after it seed + 2, ... (the masks of kge_train_step_planned).
+ *      No hook between the halves of a step: data-parallel training drives the same library calls itself. */
 typedef struct {
   kge_model_desc md;
   kge_loss_desc ld;
@@ -478,6 +479,11 @@ typedef struct {
   int32_t* cand_counts[2];    /* KGE_CAND_POS_LANES*B + B*ns per buffer parity */
   void* plan[2];              /* kge_batch_plan_bytes(md, ld, B*ns, B*ns) per buffer parity */
   int64_t plan_bytes;
+  int32_t* pos[2];            /* optional, with neg (all four or none): (B*ns, 3) oversampled arrays per buffer parity.  With them the
+                               * batches travel as plain arrays -- draw -> kge_batch_plan_build -> kge_train_step_planned with the
+                               * dropout seed of the step -- which is what a model with dropout needs (every oversampled row has
+                               * its own mask: no folded batches); cand_rows / cand_counts may then be NULL */
+  int32_t* neg[2];
   float *E_twin, *Rel_twin;   /* optional (both or neither): second buffers of the two tables' shapes.  With them, and where
                                * kge_train_step_swap_supported, the steps alternate between (E, Rel) and the twins
                                * (kge_train_step_swap: two launches per step instead of three); every kge_pipeline_run leaves the
@@ -485,6 +491,7 @@ typedef struct {
 } kge_pipeline_desc;
 int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void** handle);
 int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream);
+int kge_pipeline_set_seed(void* handle, uint64_t seed);
 int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream);
 int kge_pipeline_finish(void* handle, kge_stream_t stream);
 /* Host-side accounting of kge_pipeline_run since the last reset: out = {ms inside run, ms inside the stage launchers, stage launches;

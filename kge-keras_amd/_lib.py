@@ -54,7 +54,7 @@ class PipelineDesc(C.Structure):
                 ("sampler_plan", C.c_void_p), ("sampler_ws", C.c_void_p), ("sampler_ws_bytes", C.c_int64), ("sampler_err", C.c_void_p),
                 ("sampler_stream", C.c_void_p), ("sampler_stream_bytes", C.c_int64), ("sampler_stream_plan", C.c_void_p),
                 ("cand_rows", C.c_void_p * 2), ("cand_counts", C.c_void_p * 2), ("plan", C.c_void_p * 2), ("plan_bytes", C.c_int64),
-                ("E_twin", C.c_void_p), ("Rel_twin", C.c_void_p)]
+                ("pos", C.c_void_p * 2), ("neg", C.c_void_p * 2), ("E_twin", C.c_void_p), ("Rel_twin", C.c_void_p)]
 
 
 _P, _I64, _I32, _U64, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float
@@ -93,6 +93,7 @@ SIGNATURES = {
     "kge_batch_plan_build_counted": (C.c_int, [_MD, _LD, _P, _P, _I32, _I64, _I64, _I64, _I64, _P, _I64, _I32, _P, _P]),
     "kge_train_grads_planned": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
     "kge_train_step_planned": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P]),
+    "kge_pipeline_set_seed": (C.c_int, [_P, C.c_uint64]),
     "kge_train_grads_halves_supported": (C.c_int, [_MD, _LD]),
     "kge_train_grads_planned_parts": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
     "kge_train_step_swap_supported": (C.c_int, [_MD, _LD, _OD]),

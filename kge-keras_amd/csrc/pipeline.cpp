@@ -68,6 +68,8 @@ struct Pipeline {
   struct Rec { int stage; int64_t batch; hipEvent_t a, b; };
   std::vector<Rec> trace;
   int64_t trace_left = 0;
+  bool arrays = false;             // batches as plain oversampled arrays (dropout): no folded form, plan from the arrays
+  uint64_t seed = 0;               // arrays: dropout seed of the last step issued (kge_pipeline_set_seed)
   bool swap = false;               // steps alternate between the caller's tables and their twins (kge_train_step_swap)
   int parity = 0;                  // swap: 1 = the current tables are the twins
   int stage_mask = 15;  // experiments only (KGE_PIPE_STAGES): bit s clear = stage s is not launched (its events still are recorded)
@@ -81,13 +83,21 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
   switch (stage) {
     case GEN:
       return p->ring ? sampler_stream_produce(d.sampler_stream, d.sampler_stream_bytes, d.B, d.ns, d.num_e, d.sampler_stream_plan, st) : KGE_OK;
-    case DRAW:  // positives read in place, folded output only (candidate rows + pick counts); the last kernel moves the cursor
+    case DRAW: {  // positives read in place; folded output (candidate rows + pick counts) or, arrays mode, the oversampled arrays;
+                  // the last kernel moves the cursor
+      int32_t* po = p->arrays ? d.pos[slot] : nullptr;
+      int32_t* ne = p->arrays ? d.neg[slot] : nullptr;
+      int32_t* cr = p->arrays ? nullptr : d.cand_rows[slot];
+      int32_t* cc = p->arrays ? nullptr : d.cand_counts[slot];
       if (p->ring)
         return sampler_stream_draw(d.sampler_stream, d.sampler_stream_bytes, d.np_state, d.py_state, nullptr, d.kg, d.index, d.starts, d.cursor, d.B, d.ns,
-                                   d.num_e, nullptr, nullptr, d.cand_rows[slot], d.cand_counts[slot], d.sampler_err, st);
-      return kge_build_batch_device_indexed(d.np_state, d.py_state, d.kg, d.index, d.starts, d.cursor, d.B, d.ns, d.num_e, nullptr, nullptr,
-                                            d.cand_rows[slot], d.cand_counts[slot], d.sampler_plan, d.sampler_ws, d.sampler_ws_bytes, d.sampler_err, st);
+                                   d.num_e, po, ne, cr, cc, d.sampler_err, st);
+      return kge_build_batch_device_indexed(d.np_state, d.py_state, d.kg, d.index, d.starts, d.cursor, d.B, d.ns, d.num_e, po, ne, cr, cc, d.sampler_plan,
+                                            d.sampler_ws, d.sampler_ws_bytes, d.sampler_err, st);
+    }
     case PLAN:  // (8: the plan buffers' counters are zero -- zero-filled by the caller, left zero by every step)
+      if (p->arrays)
+        return kge_batch_plan_build(&d.md, &d.ld, d.pos[slot], m, d.neg[slot], m, d.plan[slot], d.plan_bytes, 7 | 8, d.err_flag, st);
       return kge_batch_plan_build_counted(&d.md, &d.ld, d.cand_rows[slot], d.cand_counts[slot], KGE_CAND_POS_LANES, d.B, m, m, m, d.plan[slot],
                                           d.plan_bytes, 7 | 8, d.err_flag, st);
     default:
@@ -99,8 +109,8 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
         return kge_train_step_swap(&d.md, &d.ld, &od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, d.plan[slot],
                                    d.plan_bytes, m, m, d.loss_out, 0, d.train_ws, d.train_ws_bytes, parts, st);
       }
-      return kge_train_step_planned(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, d.plan[slot], d.plan_bytes, m, m, d.loss_out, 0, d.train_ws,
-                                    d.train_ws_bytes, st);
+      return kge_train_step_planned(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, d.plan[slot], d.plan_bytes, m, m, d.loss_out,
+                                    p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, st);
   }
 }
 
@@ -216,10 +226,14 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   if (!desc || !handle) return fail(KGE_EINVAL, "kge_pipeline_create: null argument");
   const kge_pipeline_desc& d = *desc;
   if (!d.od.step_dev) return fail(KGE_EINVAL, "kge_pipeline_create: the optimizer needs its device-resident step state (kge_opt_desc.step_dev)");
-  if (d.md.dropout > 0.f) return fail(KGE_EUNSUPPORTED, "kge_pipeline_create: folded batches and dropout exclude each other (dropout must be 0)");
+  const int n_arr = (d.pos[0] != nullptr) + (d.pos[1] != nullptr) + (d.neg[0] != nullptr) + (d.neg[1] != nullptr);
+  if (n_arr != 0 && n_arr != 4) return fail(KGE_EINVAL, "kge_pipeline_create: pos / neg arrays: all four or none");
+  const bool arrays = n_arr == 4;
+  if (d.md.dropout > 0.f && !arrays)
+    return fail(KGE_EUNSUPPORTED, "kge_pipeline_create: folded batches and dropout exclude each other (dropout needs the pos / neg arrays of the descriptor)");
   if (!d.E || !d.Rel || !d.gradE || !d.gradRel || !d.loss_out || !d.train_ws || !d.err_flag || !d.np_state || !d.py_state || !d.kg || !d.index ||
-      !d.starts || !d.cursor || !d.sampler_ws || !d.sampler_err || !d.cand_rows[0] || !d.cand_rows[1] || !d.cand_counts[0] || !d.cand_counts[1] ||
-      !d.plan[0] || !d.plan[1])
+      !d.starts || !d.cursor || !d.sampler_ws || !d.sampler_err || !d.plan[0] || !d.plan[1] ||
+      (!arrays && (!d.cand_rows[0] || !d.cand_rows[1] || !d.cand_counts[0] || !d.cand_counts[1])))
     return fail(KGE_EINVAL, "kge_pipeline_create: null pointer in the descriptor");
   if (d.B <= 0 || d.ns <= 0 || d.num_e <= 0) return fail(KGE_EINVAL, "kge_pipeline_create: bad batch shape");
   const int64_t need = kge_batch_plan_bytes(&d.md, &d.ld, d.B * d.ns, d.B * d.ns);
@@ -231,9 +245,11 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   Pipeline* p = new (std::nothrow) Pipeline();
   if (!p) return fail(KGE_EINVAL, "kge_pipeline_create: out of host memory");
   p->d = d;
+  p->arrays = arrays;
   p->ring = d.sampler_stream != nullptr;
   if (const char* e = std::getenv("KGE_PIPE_STAGES")) p->stage_mask = std::atoi(e) & 15;
   if (const char* e = std::getenv("KGE_PIPE_GRAPHS")) p->graphs = std::atoi(e) != 0;
+  if (arrays) p->graphs = false;  // (a captured step would replay one dropout seed)
   if (const char* e = std::getenv("KGE_PIPE_RING")) { if (std::atoi(e) == 0) p->ring = false; }
   // twin tables: the step closed by its pull launch (direct launches only: a captured step has its table pointers baked in)
   if ((d.E_twin != nullptr) != (d.Rel_twin != nullptr)) { delete p; return fail(KGE_EINVAL, "kge_pipeline_create: E_twin and Rel_twin go together"); }
@@ -367,6 +383,13 @@ int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream) {
   if (p->ring) if (int rc = offer_round(p, -1)) return rc;  // the words of batches 0 .. R-1
   if (int rc = produce(p, 0)) return rc;
   return produce(p, 1);
+}
+
+int kge_pipeline_set_seed(void* handle, uint64_t seed) {
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p) return fail(KGE_EINVAL, "kge_pipeline_set_seed: null handle");
+  p->seed = seed;
+  return KGE_OK;
 }
 
 int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {

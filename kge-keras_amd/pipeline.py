@@ -46,6 +46,7 @@ class TrainPipeline:
         # the step (one process per GPU) the draw and plan stages are still graph replays; the step itself (gradient half,
         # collective, optimizer half) is launched kernel by kernel, so that no collective ever sits inside a captured graph
         self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0
+        self.native_wanted = bool(graphs)  # the native driver launches kernel by kernel: dropout (a seed per step) is no obstacle
         self.graph_stages = ("S", "P", "T") if between is None else ("S", "P")
         m = self.B * self.ns
         # the batch before oversampling + how often each row was picked: the sampler's by-product the plans are built from when
@@ -134,6 +135,7 @@ class TrainPipeline:
         t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.starts,
              getattr(sa, "_stream", None)]
         t += [x for c in self.cand if c is not None for x in c]
+        t += [x for b in self.bufs if b is not None for x in b]
         if self._twins is not None:
             t += list(self._twins)
         if mo.optimizer.slots:
@@ -207,7 +209,7 @@ class TrainPipeline:
 
     # ------------------------------------------------------------------ native driver (csrc/pipeline.cpp)
     def native_ok(self):
-        return self.use_graphs and self.between is None and self.counted and not self.serial
+        return self.native_wanted and self.between is None and not self.serial
 
     def _on_native(self, fn, join=True):
         """Run fn with the native driver's own stream current, ordered after the caller's stream and (join) joined back into it.  The
@@ -251,7 +253,10 @@ class TrainPipeline:
         splan = sa.stream_plan(self.B, self.ns, self.num_e)
         d.sampler_stream_plan = splan.data_ptr() if splan is not None else None
         for j in (0, 1):
-            d.cand_rows[j], d.cand_counts[j] = self.cand[j][0].data_ptr(), self.cand[j][1].data_ptr()
+            if self.counted:
+                d.cand_rows[j], d.cand_counts[j] = self.cand[j][0].data_ptr(), self.cand[j][1].data_ptr()
+            else:  # dropout: the oversampled arrays themselves (a mask per row: no folded form)
+                d.pos[j], d.neg[j] = self.bufs[j][0].data_ptr(), self.bufs[j][1].data_ptr()
             d.plan[j] = self.plans[j].buf.data_ptr()
         d.plan_bytes = min(self.plans[0].buf.numel(), self.plans[1].buf.numel())
         # twin tables: steps alternate between (E, Rel) and these (kge_train_step_swap); run() leaves the current ones in (E, Rel)
@@ -313,6 +318,9 @@ class TrainPipeline:
         finish()) before it touches the tables; what long runs should use (see _on_native)."""
         n = int(n)
         if self._native_active and self.native_ok():
+            if not self.counted:  # dropout: the steps take the seeds model._seed + 1, + 2, ... like n calls of train_step would
+                _lib.check(_lib.lib.kge_pipeline_set_seed(self._h, int(self.model._seed)))
+                self.model._seed += n
             self._on_native(lambda: _lib.check(_lib.lib.kge_pipeline_run(self._h, n, _lib.stream_ptr())), join)
             self.t += n
             return

@@ -48,24 +48,36 @@ def test_pipeline_epochs_equal_host_generator_and_oracle(datasets, opt):
 
 
 def test_pipeline_stream_launches_with_dropout(datasets):
-    """dropout > 0: no graphs (the mask seed changes every step), no folding (every row has its own mask); the pipeline then
-    launches its stages kernel by kernel and must equal train_step on the same batches."""
+    """dropout > 0: no folding (every row has its own mask) and a new mask seed every step; the native driver then moves the batches
+    as plain arrays (kge_pipeline_desc.pos / neg, kge_pipeline_set_seed) and must equal train_step on the same batches -- also with
+    the Python loop (serial launches)."""
     from kge_keras_amd.harness import DeviceDataGenerator, build_model
     hp = dict(num_entities=14, num_relations=55, dim=16, embedding_model="TransE", loss_function="pointwize_hinge", margin=1, dp=0.25, seed=3)
     out = []
-    for mode in ("pipeline", "steps"):
+    for mode in ("pipeline", "python-loop", "steps"):
         np.random.seed(5)
         random.seed(6)
         mdl = build_model(hp)
         gen = DeviceDataGenerator(datasets["nations_train"], ns=20, batch_size=128)
         if mode == "pipeline":
-            mdl.fit(gen, epochs=1, verbose=0, shuffle=False)
-            assert not gen._pipe.use_graphs
+            mdl.fit(gen, epochs=2, verbose=0, shuffle=False)
+            assert not gen._pipe.use_graphs and gen._pipe._h is not None and not gen._pipe.counted  # native driver, arrays mode
+        elif mode == "python-loop":
+            from kge_keras_amd.pipeline import TrainPipeline
+            gen._pipe = TrainPipeline(mdl, gen.kg, gen.n, gen.batch_size, gen.ns, gen.num_e, gen.sampler, graphs=True)
+            gen._pipe.native_wanted = False
+            mdl.fit(gen, epochs=2, verbose=0, shuffle=False)
+            assert gen._pipe._h is None
         else:
-            for i in range(len(gen)):
-                mdl.train_step(gen[i][0])
-        out.append(mdl.E.cpu().numpy())
-    np.testing.assert_allclose(out[0], out[1], atol=2e-5)
+            for _ in range(2):
+                for i in range(len(gen)):
+                    mdl.train_step(gen[i][0])
+                gen.on_epoch_end()
+        out.append((mdl.E.cpu().numpy(), mdl.Rel.cpu().numpy(), mdl.optimizer.iterations))
+    for k in (1, 2):
+        np.testing.assert_allclose(out[0][0], out[k][0], atol=2e-5)
+        np.testing.assert_allclose(out[0][1], out[k][1], atol=2e-5)
+        assert out[0][2] == out[k][2]
 
 
 def test_indexed_batch_builder_walks_the_epoch(datasets):
