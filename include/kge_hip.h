@@ -257,8 +257,8 @@ int kge_train_step_planned(const kge_model_desc* md, const kge_loss_desc* ld, co
  *            caller can start the all-reduce of gradE behind it ...
  *   parts 2  ... while the relation-grouped forward (loss, relation gradient rows -> gradRel, *loss_out) still runs;
  *   parts 3  both, on `stream` (= kge_train_grads_planned).
- * Either order; one plan serves both halves of ONE step.  kge_train_grads_halves_supported: 1 where the halves come apart (no
- * dropout, rows of at most 256 floats; elsewhere only parts = 3 is accepted), 0 otherwise, negative for an invalid descriptor. */
+ * Either order; one plan serves both halves of ONE step.  kge_train_grads_halves_supported: 1 where the halves come apart (rows
+ * of at most 256 floats; elsewhere only parts = 3 is accepted), 0 otherwise, negative for an invalid descriptor. */
 int kge_train_grads_halves_supported(const kge_model_desc* md, const kge_loss_desc* ld);
 int kge_train_grads_planned_parts(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gradE, float* gradRel,
                                   void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace,
@@ -275,7 +275,7 @@ int kge_train_grads_planned_parts(const kge_model_desc* md, const kge_loss_desc*
  *   3  both, on `stream`.
  * A caller may issue the halves of one step on two streams (both read (E_in, Rel_in) and the plan; they share nothing they write);
  * the next step needs both.  od->step = the number of this update (1-based): lr_t travels by value.  The caller alternates the two
- * table pairs from step to step.  Needs od->step_dev (kge_opt_state_init), no L3 term, no dropout, rows of at most 256 floats (per
+ * table pairs from step to step.  Needs od->step_dev (kge_opt_state_init), no L3 term, rows of at most 256 floats (per
  * half row for ComplEx); kge_train_step_swap_supported says so ahead of time (1 / 0; a negative status for an invalid descriptor),
  * the step itself returns KGE_EUNSUPPORTED otherwise.  Same results as kge_train_step_planned up to fp32 summation order. */
 int kge_train_step_swap_supported(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od);

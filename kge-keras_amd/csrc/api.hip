@@ -390,7 +390,7 @@ int kge_train_grads_planned_parts(const kge_model_desc* md, const kge_loss_desc*
   if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
     return fail(KGE_EWORKSPACE, "kge_train_grads_planned_parts: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
   if (parts != 3 && !grad_halves_supported(md))
-    return fail(KGE_EUNSUPPORTED, "kge_train_grads_planned_parts: the halves come apart only without dropout and for rows of at most 256 floats");
+    return fail(KGE_EUNSUPPORTED, "kge_train_grads_planned_parts: the halves come apart only for rows of at most 256 floats (per half row for ComplEx)");
   return train_grads_with_plan(md, ld, E, Rel, gradE, gradRel, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes,
                                static_cast<hipStream_t>(stream), nullptr, nullptr, parts);
 }
@@ -429,7 +429,7 @@ int kge_train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const
   if (!E_in || !Rel_in || !E_out || !Rel_out || !plan || !loss_out) return fail(KGE_EINVAL, "kge_train_step_swap: null pointer");
   if (E_in == E_out || Rel_in == Rel_out) return fail(KGE_EINVAL, "kge_train_step_swap: input and output tables must be distinct buffers");
   if (!step_swap_supported(md, ld, od))
-    return fail(KGE_EUNSUPPORTED, "kge_train_step_swap: needs the device-resident step state, no L3 term, no dropout, rows of at most 1024 floats");
+    return fail(KGE_EUNSUPPORTED, "kge_train_step_swap: needs the device-resident step state, no L3 term, rows of at most 256 floats (per half row for ComplEx)");
   if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
     return fail(KGE_EWORKSPACE, "kge_train_step_swap: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
   return train_step_swap(md, ld, od, E_in, Rel_in, E_out, Rel_out, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, parts,

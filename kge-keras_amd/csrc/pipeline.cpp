@@ -107,7 +107,7 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
         od.step = p->updates + 1;
         const int parts = 3;
         return kge_train_step_swap(&d.md, &d.ld, &od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, d.plan[slot],
-                                   d.plan_bytes, m, m, d.loss_out, 0, d.train_ws, d.train_ws_bytes, parts, st);
+                                   d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, parts, st);
       }
       return kge_train_step_planned(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, d.plan[slot], d.plan_bytes, m, m, d.loss_out,
                                     p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, st);
@@ -253,7 +253,9 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   if (const char* e = std::getenv("KGE_PIPE_RING")) { if (std::atoi(e) == 0) p->ring = false; }
   // twin tables: the step closed by its pull launch (direct launches only: a captured step has its table pointers baked in)
   if ((d.E_twin != nullptr) != (d.Rel_twin != nullptr)) { delete p; return fail(KGE_EINVAL, "kge_pipeline_create: E_twin and Rel_twin go together"); }
-  p->swap = d.E_twin && !p->graphs && kge_train_step_swap_supported(&d.md, &d.ld, &d.od) == 1;
+  // (with dropout the twin step is available but measured slower than the three-launch step -- 0.46 against 0.39 ms per step at the
+  // bench shape, where nothing is folded: 409 600 rows, three masks per element and entry in a kernel that is already register bound)
+  p->swap = d.E_twin && !p->graphs && d.md.dropout == 0.f && kge_train_step_swap_supported(&d.md, &d.ld, &d.od) == 1;
   if (const char* e = std::getenv("KGE_PIPE_SWAP")) { if (std::atoi(e) == 0) p->swap = false; }
   if (p->graphs && prof_is_on()) {
     delete p;

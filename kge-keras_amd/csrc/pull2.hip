@@ -526,10 +526,10 @@ int pull2_entity_pull(const kge_model_desc* md, const float* E, const float* Rel
                       hipStream_t st, const LossFinish* lf);
 // pullself.hip
 int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
-                           const PullPlan& e, const StepTail& tail, float lr_t, hipStream_t st);
+                           const PullPlan& e, const StepTail& tail, float lr_t, uint64_t seed, hipStream_t st);
 int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st);
 int pull2_entity_self_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
-                            const PullPlan& e, float* gE, hipStream_t st);
+                            const PullPlan& e, float* gE, uint64_t seed, hipStream_t st);
 // step1.hip
 int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRelArgs& fa, int rel_blocks, const PullPlan& e, const StepTail& tail,
                  float* loss_partials, float* loss_out, const StepAdvance& adv, hipStream_t st);
@@ -647,14 +647,14 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     StepTail t = *tail;
     t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
     const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
-                        nullptr, p.rslab, seed, 0u, 1.f};
+                        nullptr, p.rslab, seed, drop ? drop_thr(md->dropout) : 0u, drop ? 1.f / (1.f - md->dropout) : 1.f};
     return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, st);
   }
   // gradient tables only (kge_train_grads_planned[_parts]), halves apart: the entity half forms its own scores (pullself.hip)
   const bool split = !self && !finish && grad_halves_supported(md);
   if (!split && grad_parts != 3) return fail(KGE_EUNSUPPORTED, "gradient halves apart: dropout or row width not covered");
   if (split && (grad_parts & 1)) {
-    if (int rc = pull2_entity_self_grads(md, ld, E, Rel, m_pos, m_neg, p.ent, gE, st)) return rc;
+    if (int rc = pull2_entity_self_grads(md, ld, E, Rel, m_pos, m_neg, p.ent, gE, seed, st)) return rc;
     if (!(grad_parts & 2)) return KGE_OK;
   }
   if (!self || (tail->parts & 2)) {
@@ -674,7 +674,7 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
       if (int rc = rel_tail_launch(t, Rel, lf, st)) return rc;
     }
     if (t.parts & 1)
-      if (int rc = pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, p.ent, t, t.lr_t, st)) return rc;
+      if (int rc = pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, p.ent, t, t.lr_t, seed, st)) return rc;
     return KGE_OK;
   }
   if (finish) {

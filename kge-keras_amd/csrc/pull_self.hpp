@@ -11,13 +11,14 @@ struct SelfArgs {
   float inv_pos, inv_neg, gamma, modulus, margin;
   const int32_t* off; const int32_t* poff; const int32_t* totals; const int2* emap; const int4* entries;
   float* slab; int32_t* cnt; int C;
+  uint64_t seed; uint32_t thr; float dscale;  // dropout (DROP): step seed, keep threshold, 1 / (1 - rate)
   int kind;  // KGE_OPT_SGD | KGE_OPT_ADAM_TF: apply the optimizer, E_in row -> E_out row; < 0: no optimizer, the gradient row -> E_out (= gradE)
   float lr, b1, b2, eps;
   float *E_out, *mE, *vE;
 };
 
 // One wave: entity unit `unit` (a destination row, or an extra chunk of a hub row); `mine`: NACC * 16 float4 of LDS of this wave.
-template <int MODEL, int NORM, int LOSS, int NV, int G = 16>
+template <int MODEL, int NORM, int LOSS, int NV, int G = 16, bool DROP = false>
 __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, float4* mine) {
   constexpr int NSUB = 64 / G;
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
@@ -65,6 +66,11 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
     const float* rb = a.E + (int64_t)e.y * d_e;
     const bool is_pos = e.z > 0;
     const float mult = fabsf((float)e.z);  // how many input rows this one stands for
+    // dropout (models.py:122,144-148): the masks of the triple's three gathered rows, regenerated from (seed, batch row, role)
+    // exactly as the forward does; this row's own mask multiplies both its value in the score and its gradient
+    DropKey kd{0, 0}, ka{0, 0}, kb{0, 0};
+    const int hc = h >> 2;
+    if (DROP) { kd = drop_key(a.seed, e.w, dest_o ? 2 : 0); ka = drop_key(a.seed, e.w, 1); kb = drop_key(a.seed, e.w, dest_o ? 0 : 2); }
     float4 t[NACC];                         // d score / d (own row), element-wise
     float part = 0.f;
 #pragma unroll
@@ -72,21 +78,29 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
       const int ch = lane + j * G;
       const bool in = ch < nchunk;
       if (MODEL == KGE_DISTMULT) {
-        const float4 av = in ? L::ld(ra + ch * 4) : L::zero(), bv = in ? L::ld(rb + ch * 4) : L::zero();
+        float4 av = in ? L::ld(ra + ch * 4) : L::zero(), bv = in ? L::ld(rb + ch * 4) : L::zero();
+        if (DROP) av = av * drop_mul4(ka, ch, a.thr, a.dscale) * drop_mul4(kb, ch, a.thr, a.dscale) * drop_mul4(kd, ch, a.thr, a.dscale);
         t[j] = av * bv;
         part += hsum(mine[j * G + lane] * t[j]);
       } else if (MODEL == KGE_TRANSE) {
-        const float4 av = in ? L::ld(ra + ch * 4) : L::zero(), bv = in ? L::ld(rb + ch * 4) : L::zero();
-        const float4 m = mine[j * G + lane];
+        float4 av = in ? L::ld(ra + ch * 4) : L::zero(), bv = in ? L::ld(rb + ch * 4) : L::zero();
+        float4 m = mine[j * G + lane], md1 = L::zero();
+        if (DROP) { md1 = drop_mul4(kd, ch, a.thr, a.dscale); av = av * drop_mul4(ka, ch, a.thr, a.dscale); bv = bv * drop_mul4(kb, ch, a.thr, a.dscale); m = m * md1; }
         const float4 x = dest_o ? (bv + av) - m : (m + av) - bv;  // s + p - o
         part += NORM == 1 ? hsum(vabs(x)) : (NORM == 3 ? hsum(vphase_abs(x)) : hsum(x * x));
         t[j] = NORM == 1 ? vsgn(x) : (NORM == 3 ? vphase_dterm(x) : x);
+        if (DROP) t[j] = t[j] * md1;
       } else {
-        const float4 ar = in ? L::ld(ra + ch * 4) : L::zero(), ai = in ? L::ld(ra + h + ch * 4) : L::zero();
-        const float4 br = in ? L::ld(rb + ch * 4) : L::zero(), bi = in ? L::ld(rb + h + ch * 4) : L::zero();
+        float4 ar = in ? L::ld(ra + ch * 4) : L::zero(), ai = in ? L::ld(ra + h + ch * 4) : L::zero();
+        float4 br = in ? L::ld(rb + ch * 4) : L::zero(), bi = in ? L::ld(rb + h + ch * 4) : L::zero();
+        if (DROP) {
+          ar = ar * drop_mul4(ka, ch, a.thr, a.dscale); ai = ai * drop_mul4(ka, hc + ch, a.thr, a.dscale);
+          br = br * drop_mul4(kb, ch, a.thr, a.dscale); bi = bi * drop_mul4(kb, hc + ch, a.thr, a.dscale);
+        }
         // subject: d/dsr = pr*or + pi*oi, d/dsi = pr*oi - pi*or;  object: d/dor = sr*pr - pi*si, d/doi = pr*si + pi*sr   (a = p, b = other)
         t[j] = dest_o ? br * ar - ai * bi : ar * br + ai * bi;
         t[NV + j] = dest_o ? ar * bi + ai * br : ar * bi - ai * br;
+        if (DROP) { t[j] = t[j] * drop_mul4(kd, ch, a.thr, a.dscale); t[NV + j] = t[NV + j] * drop_mul4(kd, hc + ch, a.thr, a.dscale); }
         part += hsum(mine[j * G + lane] * t[j] + mine[(NV + j) * G + lane] * t[NV + j]);  // trilinear: score = <own row, d score / d own row>
       }
     }
@@ -177,12 +191,12 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
   }
 }
 
-template <int MODEL, int NORM, int LOSS, int NV, int G = 16>
+template <int MODEL, int NORM, int LOSS, int NV, int G = 16, bool DROP = false>
 __global__ __launch_bounds__(256) void pull_self_kernel(SelfArgs a) {
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   __shared__ float4 selfrow[4][NACC * G];
   const int wave = threadIdx.x >> 6;
-  pull_self_unit<MODEL, NORM, LOSS, NV, G>(a, blockIdx.x * 4 + wave, selfrow[wave]);
+  pull_self_unit<MODEL, NORM, LOSS, NV, G, DROP>(a, blockIdx.x * 4 + wave, selfrow[wave]);
 }
 
 }  // namespace kge

@@ -28,21 +28,24 @@ __global__ __launch_bounds__(256) void rel_tail_kernel(StepTail t, const float* 
 
 bool pull_step_supported(const kge_model_desc* md) {
   const int width = md->model == KGE_COMPLEX ? md->d_e / 2 : md->d_e;
-  return md->dropout == 0.f && width % 4 == 0 && md->d_r % 4 == 0 && width / 4 <= 64;
+  return width % 4 == 0 && md->d_r % 4 == 0 && width / 4 <= 64;
 }
 
 template <int MODEL, int NORM, int LOSS>
-static void launch_self_nv(int nv, int grid, hipStream_t st, const SelfArgs& a) {
-  if (nv <= 1) hipLaunchKernelGGL((pull_self_kernel<MODEL, NORM, LOSS, 1>), dim3(grid), dim3(256), 0, st, a);
-  else if (nv <= 2) hipLaunchKernelGGL((pull_self_kernel<MODEL, NORM, LOSS, 2>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((pull_self_kernel<MODEL, NORM, LOSS, 4>), dim3(grid), dim3(256), 0, st, a);
+static void launch_self_nv(int nv, bool drop, int grid, hipStream_t st, const SelfArgs& a) {
+#define KGE_PS(NVV) do { if (drop) hipLaunchKernelGGL((pull_self_kernel<MODEL, NORM, LOSS, NVV, 16, true>), dim3(grid), dim3(256), 0, st, a); \
+                         else hipLaunchKernelGGL((pull_self_kernel<MODEL, NORM, LOSS, NVV, 16, false>), dim3(grid), dim3(256), 0, st, a); } while (0)
+  if (nv <= 1) KGE_PS(1);
+  else if (nv <= 2) KGE_PS(2);
+  else KGE_PS(4);
+#undef KGE_PS
 }
 template <int MODEL, int NORM>
-static void launch_self(int loss, int nv, int grid, hipStream_t st, const SelfArgs& a) {
-  if (loss == KGE_POINTWIZE_HINGE) launch_self_nv<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, grid, st, a);
-  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_self_nv<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, grid, st, a);
-  else if (loss == KGE_POINTWIZE_SQUARE) launch_self_nv<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, grid, st, a);
-  else launch_self_nv<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, grid, st, a);
+static void launch_self(int loss, int nv, bool drop, int grid, hipStream_t st, const SelfArgs& a) {
+  if (loss == KGE_POINTWIZE_HINGE) launch_self_nv<MODEL, NORM, KGE_POINTWIZE_HINGE>(nv, drop, grid, st, a);
+  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_self_nv<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nv, drop, grid, st, a);
+  else if (loss == KGE_POINTWIZE_SQUARE) launch_self_nv<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nv, drop, grid, st, a);
+  else launch_self_nv<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nv, drop, grid, st, a);
 }
 
 void self_args_of(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg, const PullPlan& e,
@@ -53,27 +56,29 @@ void self_args_of(const kge_model_desc* md, const kge_loss_desc* ld, const float
   a.inv_pos = 1.f / (float)m_pos; a.inv_neg = 1.f / (float)m_neg;
   a.gamma = md->gamma; a.modulus = md->modulus; a.margin = ld->margin;
   a.off = e.off; a.poff = e.poff; a.totals = e.totals; a.emap = e.emap; a.entries = e.entries; a.slab = e.slab; a.cnt = e.cnt; a.C = e.chunk;
+  a.seed = 0; a.thr = drop_thr(md->dropout); a.dscale = 1.f / (1.f - md->dropout);  // (the caller sets the step's seed)
   a.kind = tail.kind; a.lr = lr_t; a.b1 = tail.b1; a.b2 = tail.b2; a.eps = tail.eps;
   a.E_out = tail.E_out; a.mE = tail.mE; a.vE = tail.vE;
 }
 
 // Entity half: every entity row of E_out, moments in place, entity counters of the plan left zero.  lr_t by value.
 int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
-                           const PullPlan& e, const StepTail& tail, float lr_t, hipStream_t st) {
-  if (!pull_step_supported(md)) return fail(KGE_EUNSUPPORTED, "step between twin tables: dropout or row width not covered");
+                           const PullPlan& e, const StepTail& tail, float lr_t, uint64_t seed, hipStream_t st) {
+  if (!pull_step_supported(md)) return fail(KGE_EUNSUPPORTED, "step between twin tables: row width not covered");
   const Shape sh = shape_of(md, E, Rel, tail.E_out, tail.mE);
   if (!sh.v4) return fail(KGE_EINVAL, "tables must be 16-byte aligned");
   SelfArgs a;
   self_args_of(md, ld, E, Rel, m_pos, m_neg, e, tail, lr_t, sh.nchunk, &a);
+  a.seed = seed;
   const int grid = (int)cdiv(a.N + e.max_extra, 4);
   const int nv = (int)cdiv(sh.nchunk, 16);
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
-    if (md->model == KGE_DISTMULT) launch_self<KGE_DISTMULT, 1>(ld->loss, nv, grid, st, a);
-    else if (md->model == KGE_COMPLEX) launch_self<KGE_COMPLEX, 1>(ld->loss, nv, grid, st, a);
-    else if (md->norm == 1) launch_self<KGE_TRANSE, 1>(ld->loss, nv, grid, st, a);
-    else if (md->norm == 3) launch_self<KGE_TRANSE, 3>(ld->loss, nv, grid, st, a);
-    else launch_self<KGE_TRANSE, 2>(ld->loss, nv, grid, st, a);
+    if (md->model == KGE_DISTMULT) launch_self<KGE_DISTMULT, 1>(ld->loss, nv, md->dropout > 0.f, grid, st, a);
+    else if (md->model == KGE_COMPLEX) launch_self<KGE_COMPLEX, 1>(ld->loss, nv, md->dropout > 0.f, grid, st, a);
+    else if (md->norm == 1) launch_self<KGE_TRANSE, 1>(ld->loss, nv, md->dropout > 0.f, grid, st, a);
+    else if (md->norm == 3) launch_self<KGE_TRANSE, 3>(ld->loss, nv, md->dropout > 0.f, grid, st, a);
+    else launch_self<KGE_TRANSE, 2>(ld->loss, nv, md->dropout > 0.f, grid, st, a);
   }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
@@ -83,11 +88,11 @@ int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, co
 // the gradient row written to gE instead of the optimizer applied.  Needs nothing from the forward, so the caller may start the
 // exchange of gE while the relation half still runs.
 int pull2_entity_self_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
-                            const PullPlan& e, float* gE, hipStream_t st) {
+                            const PullPlan& e, float* gE, uint64_t seed, hipStream_t st) {
   StepTail t{};
   t.kind = -1;
   t.E_out = gE; t.mE = gE; t.vE = gE;  // (moments unused)
-  return pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, e, t, 0.f, st);
+  return pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, e, t, 0.f, seed, st);
 }
 
 // Relation half, second launch (the first is the relation-grouped forward): relation rows of Rel_out, relation counters left zero,

@@ -14,20 +14,20 @@
 
 namespace kge {
 
-template <int MODEL, int NORM, int LOSS, int NV, int G>
+template <int MODEL, int NORM, int LOSS, int NV, int G, bool DROP>
 __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, float* __restrict__ loss_partials, int rel_blocks, int R) {
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   __shared__ float4 selfrow[4][NACC * G];
   __shared__ float red[16];
   const int wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= rel_blocks) {
-    pull_self_unit<MODEL, NORM, LOSS, NV, G>(sa, ((int)blockIdx.x - rel_blocks) * 4 + wave, selfrow[wave]);
+    pull_self_unit<MODEL, NORM, LOSS, NV, G, DROP>(sa, ((int)blockIdx.x - rel_blocks) * 4 + wave, selfrow[wave]);
     return;
   }
   const int unit = blockIdx.x * 4 + wave;
   float lsum = 0.f;
   int len, c;
-  if (unit < fa.rtotal[0]) fwd_rel_unit<MODEL, NORM, LOSS, NV, false, G>(fa, unit, R, lsum, &len, &c);
+  if (unit < fa.rtotal[0]) fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP, G>(fa, unit, R, lsum, &len, &c);
   const float b = block_sum(lsum, red);
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
 }
@@ -40,10 +40,14 @@ __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, 
 template <int MODEL, int NORM, int LOSS>
 static void launch_step1_nv(int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
   static const int force_g = [] { const char* v = getenv("KGE_STEP_G"); return v ? atoi(v) : 0; }();
-  if (nchunk <= 16) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 1, 16>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
-  else if (nchunk <= 32) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 2, 16>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
-  else if (force_g == 16 || (force_g != 32 && MODEL == KGE_DISTMULT)) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 4, 16>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
-  else hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, 2, 32>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R);
+  const bool drop = fa.thr != 0u;
+#define KGE_S1(NVV, GW) do { if (drop) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, true>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R); \
+                             else hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, false>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R); } while (0)
+  if (nchunk <= 16) KGE_S1(1, 16);
+  else if (nchunk <= 32) KGE_S1(2, 16);
+  else if (force_g == 16 || (force_g != 32 && MODEL == KGE_DISTMULT)) KGE_S1(4, 16);
+  else KGE_S1(2, 32);
+#undef KGE_S1
 }
 template <int MODEL, int NORM>
 static void launch_step1(int loss, int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
@@ -60,9 +64,10 @@ void self_args_of(const kge_model_desc* md, const kge_loss_desc* ld, const float
 // fa: the forward's arguments as pull2.hip fills them (coef / scores may be null); tail.{roff, rtotal, ruoff, rslab, rcnt, R, d_r} set.
 int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRelArgs& fa, int rel_blocks, const PullPlan& e, const StepTail& tail,
                  float* loss_partials, float* loss_out, const StepAdvance& adv, hipStream_t st) {
-  if (!pull_step_supported(md)) return fail(KGE_EUNSUPPORTED, "step between twin tables: dropout or row width not covered");
+  if (!pull_step_supported(md)) return fail(KGE_EUNSUPPORTED, "step between twin tables: row width not covered");
   SelfArgs sa;
   self_args_of(md, ld, fa.E, fa.Rel, fa.m_pos, fa.m_neg, e, tail, tail.lr_t, fa.nchunk, &sa);
+  sa.seed = fa.seed;
   const int grid = rel_blocks + (int)cdiv(sa.N + e.max_extra, 4);
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);

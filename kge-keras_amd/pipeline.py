@@ -366,7 +366,7 @@ class TrainPipeline:
             pl.buf.zero_()
         if self.between is None:
             mo._step_dev = self.step_dev
-            if os.environ.get("KGE_PIPE_SWAP", "1") != "0":
+            if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0:  # (dropout: the three-launch step is faster)
                 if self._twins is None or self._twins[0].shape != mo.E.shape or self._twins[1].shape != mo.Rel.shape:
                     self._twins = (torch.empty_like(mo.E), torch.empty_like(mo.Rel))
                 mo._step_twins = self._twins

@@ -102,12 +102,15 @@ def test_swap_leaves_input_tables_and_rejects_aliases():
     torch.cuda.synchronize()
     assert torch.equal(m.E, E_before) and torch.equal(m.Rel, R_before)
     assert not torch.equal(Et, E_before) and float((Et - E_before).abs().max()) < 0.01
-    # without the device step state, with dropout or an L3 term the twin step is not offered
+    # without the device step state or with an L3 term the twin step is not offered; with dropout it is
     od2 = _lib.OptDesc(od.kind, od.lr, od.beta1, od.beta2, od.eps, 1, od.mE, od.vE, od.mRel, od.vRel, None)
     assert _lib.lib.kge_train_step_swap_supported(C.byref(md), C.byref(ld), C.byref(od2)) == 0
+    ld2 = m._loss_desc()
+    ld2.regularization = 0.01
+    assert _lib.lib.kge_train_step_swap_supported(C.byref(md), C.byref(ld2), C.byref(od)) == 0
     md2 = m._model_desc(True)
     md2.dropout = 0.2
-    assert _lib.lib.kge_train_step_swap_supported(C.byref(md2), C.byref(ld), C.byref(od)) == 0
+    assert _lib.lib.kge_train_step_swap_supported(C.byref(md2), C.byref(ld), C.byref(od)) == 1
 
 
 @pytest.mark.parametrize("order", [(1, 2), (2, 1)])
@@ -182,9 +185,8 @@ def test_gradient_halves_equal_the_whole(model, kw, d):
         assert L == pytest.approx(Lo, rel=1e-5)
     for gE, gR, L in out[1:]:
         assert float((gE - out[0][0]).abs().max()) < 1e-7 and float((gR - out[0][1]).abs().max()) < 1e-7 and L == pytest.approx(out[0][2], rel=1e-6)
-    # a model with dropout keeps its halves together
-    md = M.DistMult(e_dim=16, r_dim=16, num_entities=N, num_relations=R, dp=0.3, loss_function="pointwize_logistic")
-    assert not md.grad_halves_supported()
+    assert M.DistMult(e_dim=16, r_dim=16, num_entities=N, num_relations=R, dp=0.3, loss_function="pointwize_logistic").grad_halves_supported()
+    assert not M.DistMult(e_dim=320, r_dim=320, num_entities=N, num_relations=R, dp=0.0, loss_function="pointwize_logistic").grad_halves_supported()
 
 
 @pytest.mark.parametrize("case", range(24))
@@ -230,3 +232,49 @@ def test_swap_step_random_shapes(case):
         np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL, err_msg=str(info))
         np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL, err_msg=str(info))
     a._raise_on_flag()
+
+
+@pytest.mark.parametrize("model,kw,d", [("DistMult", {}, 200), ("TransE", dict(norm=1, gamma=12), 24), ("TransE", dict(norm=2, gamma=12), 100),
+                                        ("ComplEx", {}, 40), ("ComplEx", {}, 200), ("pRotatE", {}, 100)])
+def test_swap_step_with_dropout(model, kw, d):
+    """dp > 0 (models.py:122,144-148): the twin-table step regenerates the masks of the three gathered rows from (seed, batch row,
+    role) in both roles of its launch -- equal to the three-launch step (same masks, fp32 rounding) and to the oracle with the same
+    masks (1e-4); gradient halves likewise."""
+    from kge_keras_amd import models as M
+    N, R, dp = 150, 5, 0.3
+    rs = np.random.RandomState(21)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    a, b, c = (getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=dp, init_entities=E0, init_relations=R0,
+                                 loss_function="pointwize_logistic", margin=1.0, seed=5, **kw) for _ in range(3))
+    for m in (a, b, c):
+        m.compile("adam")
+        m._ensure_train_state(40, 700)
+    _state(a), _state(b)
+    a._step_twins = (torch.empty_like(a.E), torch.empty_like(a.Rel))
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.make_optimizer("adam")
+    for step in range(2):
+        ent = lambda n: np.where(rs.rand(n) < 0.3, 3, rs.randint(0, N, n))
+        pos = np.stack([ent(40), rs.randint(0, R, 40), ent(40)], 1).astype(np.int32)
+        neg = np.stack([ent(700), rs.randint(0, R, 700), ent(700)], 1).astype(np.int32)
+        La = float(a.train_step(a.plan_batch([pos, neg]))["loss"].item())
+        Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
+        assert a._seed == b._seed
+        Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, a.modulus if model == "pRotatE" else kw.get("norm", 1),
+                          kw.get("gamma", 12), dropout=dp, seed=a._seed)
+        assert La == pytest.approx(Lb, rel=2e-6, abs=1e-6) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), step
+        np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=5e-6)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=5e-6)
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+    # gradient halves under dropout == the whole == the oracle's gradients with the same masks
+    plan = c.plan_batch([pos, neg])
+    c.train_grads(plan, parts=1)
+    c.train_grads(plan, parts=2)
+    Lg, _sp, _sn, gEo, gRo = O.dense_grads(model, E0.astype(np.float64), R0.astype(np.float64), pos, neg, "pointwize_logistic", 1.0, 1,
+                                           c.modulus if model == "pRotatE" else kw.get("norm", 1), kw.get("gamma", 12), dropout=dp, seed=c._seed)
+    np.testing.assert_allclose(c._gE.cpu().numpy(), gEo, atol=1e-5)
+    np.testing.assert_allclose(c._gR.cpu().numpy(), gRo, atol=1e-5)
+    assert float(c._loss[0].item()) == pytest.approx(Lg, rel=1e-5)
