@@ -651,7 +651,8 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, st);
   }
   // gradient tables only (kge_train_grads_planned[_parts]), halves apart: the entity half forms its own scores (pullself.hip)
-  const bool split = !self && !finish && grad_halves_supported(md);
+  // (under dropout only on request -- parts 1 | 2 --: the whole gradient half keeps the coefficient-lookup pull there, which measures faster)
+  const bool split = !self && !finish && grad_halves_supported(md) && (grad_parts != 3 || !drop);
   if (!split && grad_parts != 3) return fail(KGE_EUNSUPPORTED, "gradient halves apart: dropout or row width not covered");
   if (split && (grad_parts & 1)) {
     if (int rc = pull2_entity_self_grads(md, ld, E, Rel, m_pos, m_neg, p.ent, gE, seed, st)) return rc;
