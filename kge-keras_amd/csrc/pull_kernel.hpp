@@ -105,7 +105,7 @@ __device__ __forceinline__ void tail_relation_row(const StepTail& t, const float
   }
 }
 
-template <int MODEL, int NORM, int G, int NV, int VEC, bool DROP, bool TAIL = false>
+template <int MODEL, int NORM, int G, int NV, int VEC, bool DROP>
 __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                     float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,
                                                     int nchunk, const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
