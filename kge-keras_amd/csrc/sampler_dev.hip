@@ -770,7 +770,10 @@ struct StreamPlan {
   int64_t bytes;
 };
 
-constexpr int kStreamRound = 4;  // batches per production round
+#ifndef KGE_STREAM_ROUND
+#define KGE_STREAM_ROUND 4
+#endif
+constexpr int kStreamRound = KGE_STREAM_ROUND;  // batches per production round
 
 static StreamPlan plan_stream(int64_t B, int64_t ns, int64_t num_e, void* buf) {
   StreamPlan q;
