@@ -488,6 +488,8 @@ typedef struct {
                                * kge_train_step_swap_supported, the steps alternate between (E, Rel) and the twins
                                * (kge_train_step_swap: two launches per step instead of three); every kge_pipeline_run leaves the
                                * current tables in (E, Rel) -- one device copy behind its last step when it issued an odd number */
+  void* plan3;                /* optional third plan buffer (plan_bytes, zero-filled like the others): the plan of batch k+2 then waits for
+                               * step k-1 instead of step k -- no plan stage trails the last step of a run */
 } kge_pipeline_desc;
 int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void** handle);
 int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream);

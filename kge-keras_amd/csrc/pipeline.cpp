@@ -49,7 +49,8 @@ struct Pipeline {
   kge_pipeline_desc d;
   hipStream_t s_gen = nullptr, s_draw = nullptr, s_plan = nullptr;
   bool borrowed[3] = {false, false, false};  // the stream is one of the process-wide CU-masked streams: not destroyed with the pipeline
-  hipEvent_t gen[2] = {}, ready[2] = {}, planned[2] = {}, pfreed[2] = {};
+  hipEvent_t gen[2] = {}, ready[2] = {}, planned[3] = {}, pfreed[3] = {};  // (planned / pfreed: per plan buffer)
+  int np = 2;                      // plan buffers: 3 with kge_pipeline_desc.plan3 (the plan of batch k+2 then only waits for step k-1)
   int64_t updates = 0;             // swap: optimizer updates done (read back from the step state at kge_pipeline_start)
   hipEvent_t fork = nullptr;
   hipEvent_t done[kStages][2] = {};      // graphs only: behind the last launch of graph (stage, slot)
@@ -77,9 +78,14 @@ struct Pipeline {
 
 inline double now_ns() { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// slot: DRAW the candidate / array buffer (batch & 1); PLAN that buffer in the low nibble, the plan buffer (batch % np) above it;
+// STEP the plan buffer
 int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
   const kge_pipeline_desc& d = p->d;
   const int64_t m = d.B * d.ns;
+  const int pslot = stage == PLAN && !p->graphs ? slot >> 4 : slot;  // (captured stages: two plan buffers, one index)
+  if (stage == PLAN && !p->graphs) slot &= 15;
+  void* const plan_buf = pslot < 2 ? d.plan[pslot] : d.plan3;
   switch (stage) {
     case GEN:
       return p->ring ? sampler_stream_produce(d.sampler_stream, d.sampler_stream_bytes, d.B, d.ns, d.num_e, d.sampler_stream_plan, st) : KGE_OK;
@@ -97,8 +103,8 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
     }
     case PLAN:  // (8: the plan buffers' counters are zero -- zero-filled by the caller, left zero by every step)
       if (p->arrays)
-        return kge_batch_plan_build(&d.md, &d.ld, d.pos[slot], m, d.neg[slot], m, d.plan[slot], d.plan_bytes, 7 | 8, d.err_flag, st);
-      return kge_batch_plan_build_counted(&d.md, &d.ld, d.cand_rows[slot], d.cand_counts[slot], KGE_CAND_POS_LANES, d.B, m, m, m, d.plan[slot],
+        return kge_batch_plan_build(&d.md, &d.ld, d.pos[slot], m, d.neg[slot], m, plan_buf, d.plan_bytes, 7 | 8, d.err_flag, st);
+      return kge_batch_plan_build_counted(&d.md, &d.ld, d.cand_rows[slot], d.cand_counts[slot], KGE_CAND_POS_LANES, d.B, m, m, m, plan_buf,
                                           d.plan_bytes, 7 | 8, d.err_flag, st);
     default:
       if (p->swap) {  // (the caller moves parity / updates on)
@@ -106,10 +112,10 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
         kge_opt_desc od = d.od;
         od.step = p->updates + 1;
         const int parts = 3;
-        return kge_train_step_swap(&d.md, &d.ld, &od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, d.plan[slot],
+        return kge_train_step_swap(&d.md, &d.ld, &od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, plan_buf,
                                    d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, parts, st);
       }
-      return kge_train_step_planned(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, d.plan[slot], d.plan_bytes, m, m, d.loss_out,
+      return kge_train_step_planned(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, plan_buf, d.plan_bytes, m, m, d.loss_out,
                                     p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, st);
   }
 }
@@ -187,13 +193,14 @@ int produce(Pipeline* p, int64_t k) {
     KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->gen[(p->nround - 1) & 1], 0));
     if (int rc = offer_round(p, j)) return rc;
   }
-  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->planned[j], 0));  // (still the record behind plan k-2: its candidate buffers are free)
+  const int pj = (int)(k % p->np);
+  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->planned[(int)((k + p->np - 2) % p->np)], 0));  // (still the record behind plan k-2: its candidate buffers are free)
   if (int rc = launch(p, DRAW, j, p->s_draw, k)) return rc;
   KGE_PIPE_TRY(hipEventRecord(p->ready[j], p->s_draw));
   KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->ready[j], 0));
-  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[j], 0));
-  if (int rc = launch(p, PLAN, j, p->s_plan, k)) return rc;
-  KGE_PIPE_TRY(hipEventRecord(p->planned[j], p->s_plan));
+  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[pj], 0));  // (the step that consumed this plan buffer: k-2, or k-3 with three buffers)
+  if (int rc = launch(p, PLAN, p->graphs ? j : (j | (pj << 4)), p->s_plan, k)) return rc;
+  KGE_PIPE_TRY(hipEventRecord(p->planned[pj], p->s_plan));
   return KGE_OK;
 }
 
@@ -204,7 +211,10 @@ void destroy(Pipeline* p) {
       if (p->done[s][j]) (void)hipEventDestroy(p->done[s][j]);
     }
   for (int j = 0; j < 2; ++j)
-    for (hipEvent_t e : {p->gen[j], p->ready[j], p->planned[j], p->pfreed[j]})
+    for (hipEvent_t e : {p->gen[j], p->ready[j]})
+      if (e) (void)hipEventDestroy(e);
+  for (int j = 0; j < 3; ++j)
+    for (hipEvent_t e : {p->planned[j], p->pfreed[j]})
       if (e) (void)hipEventDestroy(e);
   if (p->fork) (void)hipEventDestroy(p->fork);
   hipStream_t owned[3] = {p->s_gen, p->s_draw, p->s_plan};
@@ -250,6 +260,10 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   if (const char* e = std::getenv("KGE_PIPE_STAGES")) p->stage_mask = std::atoi(e) & 15;
   if (const char* e = std::getenv("KGE_PIPE_GRAPHS")) p->graphs = std::atoi(e) != 0;
   if (arrays) p->graphs = false;  // (a captured step would replay one dropout seed)
+  // a third plan buffer (direct launches only: the captured stages are per buffer pair): the plan of batch k+2 then waits for step
+  // k-1 instead of step k, so at the end of a run no plan stage is left behind the last step (measured at --steps 20: see DESIGN 3.4)
+  p->np = d.plan3 && !p->graphs ? 3 : 2;
+  if (const char* e = std::getenv("KGE_PIPE_PLANS")) { if (std::atoi(e) == 2) p->np = 2; }
   if (const char* e = std::getenv("KGE_PIPE_RING")) { if (std::atoi(e) == 0) p->ring = false; }
   // twin tables: the step closed by its pull launch (direct launches only: a captured step has its table pointers baked in)
   if ((d.E_twin != nullptr) != (d.Rel_twin != nullptr)) { delete p; return fail(KGE_EINVAL, "kge_pipeline_create: E_twin and Rel_twin go together"); }
@@ -343,8 +357,10 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
     }
   }
   KGE_CREATE_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+  for (int j = 0; j < 3; ++j)
+    for (hipEvent_t* e : {&p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (int j = 0; j < 2; ++j) {
-    for (hipEvent_t* e : {&p->gen[j], &p->ready[j], &p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&p->gen[j], &p->ready[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int s = 0; s < kStages; ++s) KGE_CREATE_TRY(hipEventCreateWithFlags(&p->done[s][j], hipEventDisableTiming));
   }
 #undef KGE_CREATE_TRY
@@ -404,7 +420,7 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
   if (const char* e = std::getenv("KGE_PIPE_STAGES")) p->stage_mask = std::atoi(e) & 15;  // (experiments: may change between calls)
   const double t_in = now_ns();
   for (int64_t i = 0; i < n_steps; ++i) {
-    const int j = (int)(p->t & 1);
+    const int j = (int)(p->t % p->np);
     KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->planned[j], 0));
     if (int rc = launch(p, STEP, j, main_st, p->t)) return rc;
     if (p->swap) { p->parity ^= 1; p->updates += 1; }

@@ -80,6 +80,7 @@ class TrainPipeline:
         self._twins = None
         self._nstream = None    # the stream the native driver's steps run on (see _on_native)
         self._halves = None     # cached model.grad_halves_supported()
+        self._plan3 = None
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
@@ -259,6 +260,9 @@ class TrainPipeline:
                 d.pos[j], d.neg[j] = self.bufs[j][0].data_ptr(), self.bufs[j][1].data_ptr()
             d.plan[j] = self.plans[j].buf.data_ptr()
         d.plan_bytes = min(self.plans[0].buf.numel(), self.plans[1].buf.numel())
+        if self._plan3 is None or self._plan3.numel() < d.plan_bytes:  # third plan buffer of the native driver (kge_pipeline_desc.plan3)
+            self._plan3 = torch.zeros(int(d.plan_bytes), dtype=torch.uint8, device=self.dev)
+        d.plan3 = self._plan3.data_ptr()
         # twin tables: steps alternate between (E, Rel) and these (kge_train_step_swap); run() leaves the current ones in (E, Rel)
         if self._twins is not None:
             d.E_twin, d.Rel_twin = self._twins[0].data_ptr(), self._twins[1].data_ptr()
@@ -364,6 +368,8 @@ class TrainPipeline:
         mo._ensure_train_state(self.B * self.ns, self.B * self.ns)
         for pl in self.plans:  # counters of a plan that was built but never consumed (an epoch cut short) would poison the next build
             pl.buf.zero_()
+        if self._plan3 is not None:
+            self._plan3.zero_()
         if self.between is None:
             mo._step_dev = self.step_dev
             if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0:  # (dropout: the three-launch step is faster)
