@@ -305,7 +305,9 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
       const char* ek = std::getenv("KGE_PIPE_CUKEEP");
       const int keep = ek ? std::max(1, std::atoi(ek)) : 1;
       hipDeviceProp_t prop;
-      KGE_CREATE_TRY(hipGetDeviceProperties(&prop, 0));
+      int dev = 0;
+      KGE_CREATE_TRY(hipGetDevice(&dev));  // (one process per GPU: the rank's own device)
+      KGE_CREATE_TRY(hipGetDeviceProperties(&prop, dev));
       const int ncu = prop.multiProcessorCount;
       std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
       for (int c = 0; c < ncu; ++c) if ((c / group) % stride < keep) mask[(size_t)c / 32] |= 1u << (c % 32);
