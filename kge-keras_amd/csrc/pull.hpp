@@ -11,7 +11,10 @@ namespace kge {
 // rows per forward work unit of the relation-grouped path (pull2.hip): 32, or 128 for a relation with more than 4096 rows in the batch,
 // so that a dominant relation (real graphs: the top relation of FB15k-237 carries 16 % of the triples) leaves a few hundred partial
 // gradient rows to sum, not thousands
-constexpr int kRelChunk = 32;
+#ifndef KGE_REL_CHUNK
+#define KGE_REL_CHUNK 64
+#endif
+constexpr int kRelChunk = KGE_REL_CHUNK;
 __host__ __device__ __forceinline__ int rel_chunk_rows(int c) { return c > 4096 ? 4 * kRelChunk : kRelChunk; }
 __host__ __device__ __forceinline__ int rel_units(int c) { const int ch = rel_chunk_rows(c); return (c + ch - 1) / ch; }
 

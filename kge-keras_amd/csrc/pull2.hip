@@ -10,7 +10,7 @@
 //                     offsets and the (relation, chunk) unit map
 //   rel_fill_kernel   relation lists {s, o, t, multiplicity}
 //   step (parameters)
-//   fwd_rel_kernel    one wave per (relation, chunk of 32): score, loss, coef[t], partial d/dp row -> slab
+//   fwd_rel_kernel    one wave per (relation, chunk of 64): score, loss, coef[t], partial d/dp row -> slab
 //   ent_fill_kernel   entity lists {p | role, other entity, coef, t}
 //   pull_kernel       (pull.hip) over entity keys only
 //   rel_finish_kernel d/dp rows = sum of the relation's slab rows (chunk order); pull_finish for hub entities
