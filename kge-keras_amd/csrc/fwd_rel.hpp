@@ -69,8 +69,12 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
     acc[j] = f4(0.f);
     if (MODEL == KGE_COMPLEX) { pv[NV + j] = ch < nchunk ? *reinterpret_cast<const float4*>(rp + h + ch * 4) : f4(0.f); acc[NV + j] = f4(0.f); }
   }
+  // the next entry is fetched while this one's rows are gathered and multiplied (entry -> rows is a dependent load per round otherwise)
+  int4 e_nx = make_int4(0, 0, 0, 0);
+  if (sub < len) e_nx = rentries[start + sub];
   for (int i = sub; i < len; i += 64 / G) {
-    const int4 e = rentries[start + i];
+    const int4 e = e_nx;
+    if (i + 64 / G < len) e_nx = rentries[start + i + 64 / G];
     const int64_t t = e.z;
     const bool is_pos = e.w > 0;
     const float mult = fabsf((float)e.w);  // how many input rows this one stands for
