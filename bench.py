@@ -705,7 +705,7 @@ def main():
             "config": {"workload": f"FB15k-237 {args.model if args.model == 'DistMult' else 'TransE-L2 (gamma 12)'} d=200, B=2048, 100 negatives (409600 scored triples/step), pointwize_hinge + Adam(TF semantics)",
                        "N": CFG["N"], "R": CFG["R"], "d": CFG["d"], "B": CFG["B"], "ns": CFG["ns"],
                        "parallelism": f"dp{world}" if dist_on else "single",
-                       "sampler": ("bit-exact MT19937 HIP sampler inside the timed region (side stream, one batch ahead)" if args.sampler == "device"
+                       "sampler": ("bit-exact MT19937 HIP sampler inside the timed region (generator words ahead in rings, batches drawn two steps ahead on their own stream)" if args.sampler == "device"
                                    else "bit-exact MT19937 batches pre-built on host, resident in HBM"),
                        "final_loss": loss},
             # value counts every row of both oversampled arrays (what the reference's step scores); the step folds duplicate rows, so
