@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 6
+#define KGE_ABI_VERSION 7
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -88,15 +88,16 @@ typedef struct {
 
 /* Keras optimizer state for both tables.  ADAM_TF: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); dense moment decay and
  * dense update over every row; eps outside the bias correction (tests.py:86 `optimizer='adam'`). */
+#define KGE_STEP_STATE_BYTES 24
 typedef struct {
   int32_t kind;  /* kge_opt */
   float lr, beta1, beta2, eps;
   int64_t step;  /* t of THIS update, 1-based (ignored when step_dev is set) */
   float *mE, *vE, *mRel, *vRel; /* Adam slots, same shapes as the tables (unused for SGD) */
   /* Optional device-resident step state, for steps replayed from a hipGraph where no host value can change between
-   * launches.  16 bytes: {int64 t = updates done so far, float lr_t of update t+1, float running sum of the step losses}.
-   * kge_opt_state_init seeds it from `step`; every kge_opt_apply / kge_train_step* then reads lr_t from it and, as its last
-   * kernel, advances t, prepares the next lr_t and adds *loss_out to the running sum.  NULL: `step` above is used. */
+   * launches.  KGE_STEP_STATE_BYTES = 24: {int64 t = updates done so far, float lr_t of update t+1, float unused, double running sum
+   * of the step losses}.  kge_opt_state_init seeds it from `step`; every kge_opt_apply / kge_train_step* then reads lr_t from it
+   * and, as its last kernel, advances t, prepares the next lr_t and adds *loss_out to the running sum.  NULL: `step` above is used. */
   int64_t* step_dev;
 } kge_opt_desc;
 
@@ -274,7 +275,9 @@ int kge_train_grads_planned_parts(const kge_model_desc* md, const kge_loss_desc*
  *                    the plan's relation counters left zero, the step state od->step_dev moved on (t += 1, loss sum);
  *   3  both, on `stream`.
  * A caller may issue the halves of one step on two streams (both read (E_in, Rel_in) and the plan; they share nothing they write);
- * the next step needs both.  od->step = the number of this update (1-based): lr_t travels by value.  The caller alternates the two
+ * the next step needs both.  parts = 3: lr_t of the update is read from the step state like everywhere else (od->step ignored; the step
+ * may be captured into a hipGraph); parts = 1 | 2: od->step = the number of this update (1-based), lr_t then travels by value, because
+ * the relation half moves the state on while the entity half may still be running.  The caller alternates the two
  * table pairs from step to step.  Needs od->step_dev (kge_opt_state_init), no L3 term, rows of at most 256 floats (per
  * half row for ComplEx); kge_train_step_swap_supported says so ahead of time (1 / 0; a negative status for an invalid descriptor),
  * the step itself returns KGE_EUNSUPPORTED otherwise.  Same results as kge_train_step_planned up to fp32 summation order. */
@@ -445,10 +448,11 @@ int kge_allreduce_f32(void* comm, float* buf, int64_t n, kge_stream_t stream);
  *      off.  The descriptor's pointers are borrowed until kge_pipeline_destroy.
  *        kge_pipeline_start   (re)starts an epoch of n_batches batches: the caller has loaded index / starts / the generator states
  *                             and reset *cursor on `stream`; seeds the rings, issues rounds, draws and plans of batches 0 and 1
- *                             (with twin tables it reads the count of updates back from the step state: one stream synchronisation);
  *        kge_pipeline_run     n_steps training steps on `stream` (steps t .. t+n_steps-1 of the epoch), each followed by the round,
  *                             the draw and the plan of the batch two steps ahead; asynchronous (returns when everything is enqueued);
  *        kge_pipeline_finish  makes `stream` wait for the producer streams;
+ *        kge_pipeline_state   {plan buffers in use, steps issued, table parity, batches}: what a caller needs to carry an epoch on
+ *                             itself -- batch k sits planned in plan buffer k % out[0] (plan[0], plan[1], plan3), candidate buffer k & 1;
  *        kge_pipeline_set_seed  dropout only (md.dropout > 0 needs the pos / neg arrays of the descriptor): the dropout seed of the
  *                             step issued next is seed + 1, of the one after it seed + 2, ... (the masks of kge_train_step_planned).
  *      No hook between the halves of a step: data-parallel training drives the same library calls itself. */
@@ -487,7 +491,8 @@ typedef struct {
   float *E_twin, *Rel_twin;   /* optional (both or neither): second buffers of the two tables' shapes.  With them, and where
                                * kge_train_step_swap_supported, the steps alternate between (E, Rel) and the twins
                                * (kge_train_step_swap: two launches per step instead of three); every kge_pipeline_run leaves the
-                               * current tables in (E, Rel) -- one device copy behind its last step when it issued an odd number */
+                               * current tables in (E, Rel) -- one device copy behind its last step when it issued an odd number,
+                               * also when it fails half way (should even that copy fail, kge_pipeline_state reports parity 1) */
   void* plan3;                /* optional third plan buffer (plan_bytes, zero-filled like the others): the plan of batch k+2 then waits for
                                * step k-1 instead of step k -- no plan stage trails the last step of a run */
 } kge_pipeline_desc;
@@ -496,6 +501,7 @@ int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream);
 int kge_pipeline_set_seed(void* handle, uint64_t seed);
 int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream);
 int kge_pipeline_finish(void* handle, kge_stream_t stream);
+int kge_pipeline_state(void* handle, int64_t out[4]);
 /* Host-side accounting of kge_pipeline_run since the last reset: out = {ms inside run, ms inside the stage launchers, stage launches;
  * graph mode only: ms waiting for a graph's previous launch to finish, launches that had to wait, that wait by stage} in the
  * order {run, wait, launch, launches, waited, wait draw, wait plan, wait step}. */

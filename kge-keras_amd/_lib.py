@@ -25,6 +25,7 @@ OPT_IDS = {"sgd": 0, "adam": 1}
 ACT_IDS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "softsign": 5, "elu": 6, "selu": 7, "exponential": 8}
 MT_STATE_BYTES = 2504
 CAND_POS_LANES = 16  # KGE_CAND_POS_LANES
+STEP_STATE_WORDS = 3  # KGE_STEP_STATE_BYTES / 8: {int64 updates done, float lr_t of the next update + pad, double loss sum}
 
 
 class ModelDesc(C.Structure):
@@ -141,6 +142,7 @@ SIGNATURES = {
     "kge_pipeline_start": (C.c_int, [_P, _I64, _P]),
     "kge_pipeline_run": (C.c_int, [_P, _I64, _P]),
     "kge_pipeline_finish": (C.c_int, [_P, _P]),
+    "kge_pipeline_state": (C.c_int, [_P, _P]),
     "kge_pipeline_stats": (C.c_int, [_P, _P, _I32]),
     "kge_pipeline_trace": (_I64, [_P, _I64, _P, _I64]),
     "kge_pipeline_destroy": (C.c_int, [_P]),

@@ -84,8 +84,10 @@ __device__ __forceinline__ float phase_dterm(float x) {
   return r > 0.f ? c : (r < 0.f ? -c : 0.f);
 }
 
-// Device-resident optimizer step state (kge_opt_desc.step_dev, 16 bytes): {int64 t = updates done, float lr_t of update t+1,
-// float running sum of the step losses}.
+// Device-resident optimizer step state (kge_opt_desc.step_dev, KGE_STEP_STATE_BYTES = 24): {int64 t = updates done, float lr_t of
+// update t+1, float unused, double running sum of the step losses (an epoch of 1e5 steps keeps the digits Keras' running mean keeps)}.
+__device__ __forceinline__ float* step_state_lr(int64_t* step) { return reinterpret_cast<float*>(step + 1); }
+__device__ __forceinline__ double* step_state_loss(int64_t* step) { return reinterpret_cast<double*>(step + 2); }
 __device__ __forceinline__ float lr_of_step(int kind, float lr, float b1, float b2, int64_t t) {
   if (kind != KGE_OPT_ADAM_TF) return lr;
   return (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));  // Keras Adam
@@ -98,10 +100,9 @@ __device__ __forceinline__ void step_advance(const StepAdvance& a, float loss) {
   if (!a.step) return;
   const int64_t t = a.step[0] + 1;
   a.step[0] = t;
-  a.lr_slot[0] = lr_of_step(a.kind, a.lr, a.b1, a.b2, t);
-  float* f = reinterpret_cast<float*>(a.step + 1);
-  f[0] = lr_of_step(a.kind, a.lr, a.b1, a.b2, t + 1);
-  f[1] += loss;
+  if (a.lr_slot) a.lr_slot[0] = lr_of_step(a.kind, a.lr, a.b1, a.b2, t);  // (null: the launch's waves still read the slot -- step1.hip filled it)
+  step_state_lr(a.step)[0] = lr_of_step(a.kind, a.lr, a.b1, a.b2, t + 1);
+  step_state_loss(a.step)[0] += (double)loss;
 }
 
 // One extra workgroup of the pull launch reduces the forward's loss partials (fixed order) and advances the step state, when the

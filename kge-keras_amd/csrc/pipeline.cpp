@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <mutex>
 #include <cstdlib>
 #include <new>
@@ -51,7 +52,6 @@ struct Pipeline {
   bool borrowed[3] = {false, false, false};  // the stream is one of the process-wide CU-masked streams: not destroyed with the pipeline
   hipEvent_t gen[2] = {}, ready[2] = {}, planned[3] = {}, pfreed[3] = {};  // (planned / pfreed: per plan buffer)
   int np = 2;                      // plan buffers: 3 with kge_pipeline_desc.plan3 (the plan of batch k+2 then only waits for step k-1)
-  int64_t updates = 0;             // swap: optimizer updates done (read back from the step state at kge_pipeline_start)
   hipEvent_t fork = nullptr;
   hipEvent_t done[kStages][2] = {};      // graphs only: behind the last launch of graph (stage, slot)
   bool launched[kStages][2] = {};
@@ -107,12 +107,10 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
       return kge_batch_plan_build_counted(&d.md, &d.ld, d.cand_rows[slot], d.cand_counts[slot], KGE_CAND_POS_LANES, d.B, m, m, m, plan_buf,
                                           d.plan_bytes, 7 | 8, d.err_flag, st);
     default:
-      if (p->swap) {  // (the caller moves parity / updates on)
+      if (p->swap) {  // (the caller moves the parity on; lr_t of the update comes from the device-resident step state)
         const int q = p->parity;
-        kge_opt_desc od = d.od;
-        od.step = p->updates + 1;
         const int parts = 3;
-        return kge_train_step_swap(&d.md, &d.ld, &od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, plan_buf,
+        return kge_train_step_swap(&d.md, &d.ld, &d.od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, plan_buf,
                                    d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, parts, st);
       }
       return kge_train_step_planned(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, plan_buf, d.plan_bytes, m, m, d.loss_out,
@@ -318,35 +316,39 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
       // CU-masked streams are made once per process and shared by all pipelines: a masked queue that is destroyed goes back to the
       // runtime's queue pool with its mask still set and is handed to the next stream that is created -- measured on ROCm 7.2: the
       // steps of a second pipeline ran at half speed after the first one had been destroyed (profiles/r02_experiments.txt)
-      static hipStream_t shared[3] = {nullptr, nullptr, nullptr};
-      static int shared_key[3] = {0, 0, 0};
+      // One set per device (a stream belongs to the device that was current when it was made).  Pipelines that are alive at the same
+      // time on one device share these producer streams, i.e. their draw / plan stages queue behind each other: correct, not concurrent.
+      struct SharedSet { hipStream_t s[3] = {nullptr, nullptr, nullptr}; int key[3] = {0, 0, 0}; };
+      static std::map<int, SharedSet> shared_by_device;
       static std::mutex shared_mutex;  // (pipelines may be created from several host threads)
       std::lock_guard<std::mutex> lock(shared_mutex);
+      SharedSet& sh = shared_by_device[dev];
       const int key = stride * 1000000 + group * 1000 + keep;
       hipStream_t* ss[3] = {&p->s_gen, &p->s_draw, &p->s_plan};
       for (int i = 0; i < 3; ++i) {
         if ((which >> i) & 1) {
-          if (!shared[i] || shared_key[i] != key) {
-            if (hipExtStreamCreateWithCUMask(&shared[i], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+          if (!sh.s[i] || sh.key[i] != key) {
+            if (hipExtStreamCreateWithCUMask(&sh.s[i], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
               // (a runtime or partition mode without CU masks: the plain low-priority stream instead)
               (void)hipGetLastError();
-              shared[i] = nullptr;
+              sh.s[i] = nullptr;
               KGE_CREATE_TRY(hipStreamCreateWithPriority(ss[i], hipStreamNonBlocking, prio));
               continue;
             }
-            shared_key[i] = key;
+            sh.key[i] = key;
             // gone before the runtime's own teardown (handlers run in reverse order of registration; the runtime registered its own
             // when it was loaded): a masked stream still alive at that point crashed the process under rocprofv3
             static bool registered = false;
             if (!registered) {
               registered = true;
               std::atexit([] {
-                for (hipStream_t& s : shared)
-                  if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+                for (auto& kv : shared_by_device)
+                  for (hipStream_t& s : kv.second.s)
+                    if (s) { (void)hipStreamDestroy(s); s = nullptr; }
               });
             }
           }
-          *ss[i] = shared[i];
+          *ss[i] = sh.s[i];
           p->borrowed[i] = true;
         } else {
           KGE_CREATE_TRY(hipStreamCreateWithPriority(ss[i], hipStreamNonBlocking, prio));
@@ -390,12 +392,6 @@ int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream) {
   if (p->ring)
     if (int rc = sampler_stream_init(d.sampler_stream, d.sampler_stream_bytes, d.np_state, d.py_state, d.B, d.ns, d.num_e, main_st)) return rc;
   // everything the caller enqueued so far (epoch permutation, cursor reset, generator states) precedes the first draw and plan
-  if (p->swap) {  // lr_t of every update travels by value (kge_train_step_swap): the count of updates done so far, once per epoch
-    int64_t t0 = 0;
-    KGE_PIPE_TRY(hipMemcpyAsync(&t0, d.od.step_dev, sizeof(t0), hipMemcpyDeviceToHost, main_st));
-    KGE_PIPE_TRY(hipStreamSynchronize(main_st));
-    p->updates = t0;
-  }
   KGE_PIPE_TRY(hipEventRecord(p->fork, main_st));
   for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan}) KGE_PIPE_TRY(hipStreamWaitEvent(s, p->fork, 0));
   p->started = true;
@@ -421,22 +417,34 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
   hipStream_t main_st = static_cast<hipStream_t>(stream);
   if (const char* e = std::getenv("KGE_PIPE_STAGES")) p->stage_mask = std::atoi(e) & 15;  // (experiments: may change between calls)
   const double t_in = now_ns();
-  for (int64_t i = 0; i < n_steps; ++i) {
+  int rc = KGE_OK;
+  for (int64_t i = 0; i < n_steps && rc == KGE_OK; ++i) {
     const int j = (int)(p->t % p->np);
-    KGE_PIPE_TRY(hipStreamWaitEvent(main_st, p->planned[j], 0));
-    if (int rc = launch(p, STEP, j, main_st, p->t)) return rc;
-    if (p->swap) { p->parity ^= 1; p->updates += 1; }
-    KGE_PIPE_TRY(hipEventRecord(p->pfreed[j], main_st));
-    if (int rc = produce(p, p->t + 2)) return rc;
-    p->t += 1;
+    if (hipStreamWaitEvent(main_st, p->planned[j], 0) != hipSuccess) { rc = fail(KGE_EHIP, "kge_pipeline_run: hipStreamWaitEvent failed"); break; }
+    if ((rc = launch(p, STEP, j, main_st, p->t)) != KGE_OK) break;
+    if (p->swap) p->parity ^= 1;
+    p->t += 1;  // (the step is issued: what follows may fail, the step count and the parity of the tables stay true)
+    if (hipEventRecord(p->pfreed[j], main_st) != hipSuccess) { rc = fail(KGE_EHIP, "kge_pipeline_run: hipEventRecord failed"); break; }
+    rc = produce(p, p->t + 1);
   }
-  if (p->swap && p->parity) {  // the caller reads (E, Rel)
+  // the caller reads (E, Rel) -- also after a failure half way: the steps issued so far must not be left in the twins
+  if (p->swap && p->parity) {
     const kge_pipeline_desc& d = p->d;
-    KGE_PIPE_TRY(hipMemcpyAsync(d.E, d.E_twin, (size_t)d.md.num_entities * d.md.d_e * sizeof(float), hipMemcpyDeviceToDevice, main_st));
-    KGE_PIPE_TRY(hipMemcpyAsync(d.Rel, d.Rel_twin, (size_t)d.md.num_relations * d.md.d_r * sizeof(float), hipMemcpyDeviceToDevice, main_st));
-    p->parity = 0;
+    const hipError_t e1 = hipMemcpyAsync(d.E, d.E_twin, (size_t)d.md.num_entities * d.md.d_e * sizeof(float), hipMemcpyDeviceToDevice, main_st);
+    const hipError_t e2 = hipMemcpyAsync(d.Rel, d.Rel_twin, (size_t)d.md.num_relations * d.md.d_r * sizeof(float), hipMemcpyDeviceToDevice, main_st);
+    if (e1 == hipSuccess && e2 == hipSuccess) p->parity = 0;
+    else if (rc == KGE_OK) rc = fail(KGE_EHIP, "kge_pipeline_run: copying the twin tables back failed (kge_pipeline_state reports the parity)");
   }
   p->ns_total += now_ns() - t_in;
+  return rc;
+}
+
+// out[0..3] = {plan buffers in use (batch k is planned into buffer k % that), steps issued in this epoch, 1 if the current tables are
+// the twins (only after a failed kge_pipeline_run), batches of the epoch}.  What a caller needs to take an epoch over from the driver.
+int kge_pipeline_state(void* handle, int64_t out[4]) {
+  Pipeline* p = static_cast<Pipeline*>(handle);
+  if (!p || !out) return fail(KGE_EINVAL, "kge_pipeline_state: null argument");
+  out[0] = p->np; out[1] = p->t; out[2] = p->parity; out[3] = p->n_batches;
   return KGE_OK;
 }
 

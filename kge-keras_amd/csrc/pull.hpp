@@ -39,12 +39,15 @@ struct OptFinish {
 
 // The step between twin tables (kge_train_step_swap; pullself.hip, step1.hip): the wave that has a row's gradient in registers applies
 // the optimizer to that row -- parameters read from the step's input tables, written to the twin tables (every other wave still
-// gathers the OLD rows), moments in place -- so neither a gradient table nor an optimizer sweep exists.  lr_t travels by value.
+// gathers the OLD rows), moments in place -- so neither a gradient table nor an optimizer sweep exists.  lr_t of the update: read from
+// the device-resident step state when the whole step is one call (lr_state / lr_slot), by value (lr_t) when its halves are issued apart.
 struct StepTail {
   int kind;                    // KGE_OPT_SGD | KGE_OPT_ADAM_TF
   float *E_out, *mE, *vE;      // entity side (E_in is the kernels' E)
   float *Rel_out, *mR, *vR;    // relation side (Rel_in is the kernels' Rel)
-  float lr_t;
+  float lr_t;                  // used when lr_state is null
+  const float* lr_state;       // the step state's "lr_t of the next update" word: what the first launch of a whole step reads ...
+  float* lr_slot;              // ... and copies here for the closing launch (whose last workgroup overwrites the state word)
   float b1, b2, eps;
   const int32_t* roff;         // [R] starts of the relation lists (last row: rtotal[1] - roff[R-1])
   const int32_t* rtotal;

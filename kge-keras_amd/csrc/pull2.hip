@@ -658,6 +658,13 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     if (int rc = pull2_entity_self_grads(md, ld, E, Rel, m_pos, m_neg, p.ent, gE, seed, st)) return rc;
     if (!(grad_parts & 2)) return KGE_OK;
   }
+  // (a whole step launch by launch -- KGE_STEP1=0 -- with lr_t read from the step state: the entity half first, it keeps lr_t for the
+  // closing launch, which moves the state on)
+  const bool ent_first = self && tail->parts == 3 && tail->lr_state;
+  if (ent_first) {
+    StepTail t = *tail;
+    if (int rc = pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, p.ent, t, t.lr_t, seed, st)) return rc;
+  }
   if (!self || (tail->parts & 2)) {
     ProfScope prof(KGE_PROF_FWD, st);
     const int nv = (int)cdiv(nchunk, 16);
@@ -674,7 +681,7 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
       const LossFinish lf{loss_partials, *n_partials, loss_out, adv};
       if (int rc = rel_tail_launch(t, Rel, lf, st)) return rc;
     }
-    if (t.parts & 1)
+    if ((t.parts & 1) && !ent_first)
       if (int rc = pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, p.ent, t, t.lr_t, seed, st)) return rc;
     return KGE_OK;
   }

@@ -76,7 +76,7 @@ __device__ __forceinline__ void tail_relation_row(const StepTail& t, const float
   const int nch = rel_units(c);
   const int per = (nch + 3) >> 2;
   const int j0 = min(wave * per, nch), j1 = min(j0 + per, nch);
-  const float lr = t.lr_t;
+  const float lr = t.lr_slot ? t.lr_slot[0] : t.lr_t;
   if (threadIdx.x == 0) t.rcnt[row] = 0;
   for (int q0 = 0; q0 < d4; q0 += 64) {
     const int q = q0 + lane;

@@ -14,6 +14,8 @@ struct SelfArgs {
   uint64_t seed; uint32_t thr; float dscale;  // dropout (DROP): step seed, keep threshold, 1 / (1 - rate)
   int kind;  // KGE_OPT_SGD | KGE_OPT_ADAM_TF: apply the optimizer, E_in row -> E_out row; < 0: no optimizer, the gradient row -> E_out (= gradE)
   float lr, b1, b2, eps;
+  const float* lr_state;  // non-null: lr_t of this update is read from the device-resident step state (a whole step in one call) ...
+  float* lr_keep;         // ... and copied here by the launch's first thread, for the closing launch (rel_tail_kernel)
   float *E_out, *mE, *vE;
 };
 
@@ -184,7 +186,7 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
       if (a.kind < 0) { L::st(wout + at, L::ld(wout + at) + g); continue; }  // (accumulates, like every gradient path of the library)
       float4 w = mine[i * G + lane], m = L::zero(), v = L::zero();
       if (a.kind == KGE_OPT_ADAM_TF) { m = L::ld(mrow + at); v = L::ld(vrow + at); }
-      tail_upd(a.kind, a.lr, a.b1, a.b2, a.eps, w, g, m, v);
+      tail_upd(a.kind, a.lr_state ? a.lr_state[0] : a.lr, a.b1, a.b2, a.eps, w, g, m, v);
       L::st(wout + at, w);
       if (a.kind == KGE_OPT_ADAM_TF) { L::st(mrow + at, m); L::st(vrow + at, v); }
     }
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256) void pull_self_kernel(SelfArgs a) {
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   __shared__ float4 selfrow[4][NACC * G];
   const int wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.lr_keep) a.lr_keep[0] = a.lr_state[0];
   pull_self_unit<MODEL, NORM, LOSS, NV, G, DROP>(a, blockIdx.x * 4 + wave, selfrow[wave]);
 }
 

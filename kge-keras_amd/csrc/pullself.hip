@@ -57,7 +57,7 @@ void self_args_of(const kge_model_desc* md, const kge_loss_desc* ld, const float
   a.gamma = md->gamma; a.modulus = md->modulus; a.margin = ld->margin;
   a.off = e.off; a.poff = e.poff; a.totals = e.totals; a.emap = e.emap; a.entries = e.entries; a.slab = e.slab; a.cnt = e.cnt; a.C = e.chunk;
   a.seed = 0; a.thr = drop_thr(md->dropout); a.dscale = 1.f / (1.f - md->dropout);  // (the caller sets the step's seed)
-  a.kind = tail.kind; a.lr = lr_t; a.b1 = tail.b1; a.b2 = tail.b2; a.eps = tail.eps;
+  a.kind = tail.kind; a.lr = lr_t; a.lr_state = nullptr; a.lr_keep = nullptr; a.b1 = tail.b1; a.b2 = tail.b2; a.eps = tail.eps;
   a.E_out = tail.E_out; a.mE = tail.mE; a.vE = tail.vE;
 }
 
@@ -70,6 +70,8 @@ int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, co
   SelfArgs a;
   self_args_of(md, ld, E, Rel, m_pos, m_neg, e, tail, lr_t, sh.nchunk, &a);
   a.seed = seed;
+  a.lr_state = tail.lr_state;  // (a whole step launch by launch: this launch comes first and keeps lr_t for the closing one)
+  a.lr_keep = tail.lr_state ? tail.lr_slot : nullptr;
   const int grid = (int)cdiv(a.N + e.max_extra, 4);
   const int nv = (int)cdiv(sh.nchunk, 16);
   {

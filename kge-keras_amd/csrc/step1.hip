@@ -24,6 +24,8 @@ __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, 
     pull_self_unit<MODEL, NORM, LOSS, NV, G, DROP>(sa, ((int)blockIdx.x - rel_blocks) * 4 + wave, selfrow[wave]);
     return;
   }
+  // lr_t of this update for the closing launch (rel_tail_kernel), whose last workgroup overwrites the state word
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sa.lr_keep) sa.lr_keep[0] = sa.lr_state[0];
   const int unit = blockIdx.x * 4 + wave;
   float lsum = 0.f;
   int len, c;
@@ -68,6 +70,8 @@ int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRel
   SelfArgs sa;
   self_args_of(md, ld, fa.E, fa.Rel, fa.m_pos, fa.m_neg, e, tail, tail.lr_t, fa.nchunk, &sa);
   sa.seed = fa.seed;
+  sa.lr_state = tail.lr_state;
+  sa.lr_keep = tail.lr_state ? tail.lr_slot : nullptr;
   const int grid = rel_blocks + (int)cdiv(sa.N + e.max_extra, 4);
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);

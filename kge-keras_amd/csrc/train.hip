@@ -690,20 +690,19 @@ int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* 
   return KGE_OK;
 }
 
-// Device-resident optimizer step state (kge_opt_desc.step_dev, 16 bytes): {int64 t = updates done, float lr_t of update t+1,
-// float running sum of the step losses}.  Advanced by one tiny kernel at the end of every kge_opt_apply.
+// Device-resident optimizer step state (kge_opt_desc.step_dev; layout: kge_internal.hpp).  Advanced by one tiny kernel at the end of
+// every kge_opt_apply.
 __global__ void opt_state_init_kernel(int64_t* step, int64_t done, int kind, float lr, float b1, float b2) {
   step[0] = done;
-  float* f = reinterpret_cast<float*>(step + 1);
-  f[0] = lr_of_step(kind, lr, b1, b2, done + 1);
-  f[1] = 0.f;
+  step_state_lr(step)[0] = lr_of_step(kind, lr, b1, b2, done + 1);
+  step_state_lr(step)[1] = 0.f;
+  step_state_loss(step)[0] = 0.0;
 }
 __global__ void opt_state_post_kernel(int64_t* step, int kind, float lr, float b1, float b2, const float* loss) {
   const int64_t t = step[0] + 1;
   step[0] = t;
-  float* f = reinterpret_cast<float*>(step + 1);
-  f[0] = lr_of_step(kind, lr, b1, b2, t + 1);
-  if (loss) f[1] += loss[0];
+  step_state_lr(step)[0] = lr_of_step(kind, lr, b1, b2, t + 1);
+  if (loss) step_state_loss(step)[0] += (double)loss[0];
 }
 
 int opt_state_init(const kge_opt_desc* od, hipStream_t st) {
@@ -770,16 +769,25 @@ int train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   int nb = 0;
-  const StepAdvance adv{od->step_dev, ws.lr_slot, od->kind, od->lr, od->beta1, od->beta2};
+  StepAdvance adv{od->step_dev, ws.lr_slot, od->kind, od->lr, od->beta1, od->beta2};
   StepTail t{};
   t.kind = od->kind;
   t.E_out = E_out; t.mE = od->mE; t.vE = od->vE;
   t.Rel_out = Rel_out; t.mR = od->mRel; t.vR = od->vRel;
   t.b1 = od->beta1; t.b2 = od->beta2; t.eps = od->eps;
   t.parts = parts;
-  // the two halves may run side by side on two streams, so lr_t of this update travels by value: od->step is its number
-  if (od->step < 1) return fail(KGE_EINVAL, "kge_train_step_swap: od->step (the number of this update, 1-based) must be >= 1");
-  t.lr_t = host_lr_t(od);
+  if (parts == 3) {
+    // the whole step on one stream: lr_t of this update is read from the step state (prepared by the previous update, or by
+    // kge_opt_state_init) -- nothing of the step is a host value, so a captured step replays right.  The first launch copies it into
+    // the workspace slot the closing launch reads, whose last workgroup meanwhile moves the state on.
+    t.lr_state = reinterpret_cast<const float*>(od->step_dev + 1);
+    t.lr_slot = ws.lr_slot;
+    adv.lr_slot = nullptr;
+  } else {
+    // the halves may be issued apart, even side by side on two streams, so lr_t of this update travels by value: od->step is its number
+    if (od->step < 1) return fail(KGE_EINVAL, "kge_train_step_swap: od->step (the number of this update, 1-based) must be >= 1 when the halves are issued apart");
+    t.lr_t = host_lr_t(od);
+  }
   return train_grads_planned(md, ld, E_in, Rel_in, nullptr, nullptr, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv, nullptr, &t);
 }
 

@@ -59,17 +59,20 @@ class TrainPipeline:
         md, ld = model._model_desc(True), model._loss_desc()
         need = _lib.check(_lib.lib.kge_batch_plan_bytes(_lib.C.byref(md), _lib.C.byref(ld), m, m))
         from .models import BatchPlan
-        self.plans = [BatchPlan(torch.zeros(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(2)]
+        # plans[0], plans[1]: one per buffer parity; plans[2]: the native driver's third buffer (kge_pipeline_desc.plan3), which the
+        # Python loop also uses when it takes an epoch over from the driver (batch k sits in plans[k % self._np])
+        self.plans = [BatchPlan(torch.zeros(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(3)]
+        self._np = 2
         self.index = torch.zeros(int(n_rows), dtype=torch.int64, device=self.dev)   # epoch permutation (tests.py:50-53)
         self.starts = None                                                          # batch numbers in drawing order
         self.cursor = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.loss_sum = torch.zeros((), dtype=torch.float64, device=self.dev)
-        self.step_dev = torch.zeros(2, dtype=torch.int64, device=self.dev)          # kge_opt_desc.step_dev: {t, lr_t, sum of losses}
+        self.step_dev = torch.zeros(_lib.STEP_STATE_WORDS, dtype=torch.int64, device=self.dev)  # kge_opt_desc.step_dev: {t, lr_t, sum of losses}
         self.s1, self.s2, self.s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
         self.ready = [torch.cuda.Event() for _ in range(2)]     # batch arrays drawn
         self.freed = [torch.cuda.Event() for _ in range(2)]     # batch arrays no longer needed (their plan is built)
-        self.planned = [torch.cuda.Event() for _ in range(2)]   # plan built
-        self.pfreed = [torch.cuda.Event() for _ in range(2)]    # plan consumed
+        self.planned = [torch.cuda.Event() for _ in range(3)]   # plan built (per plan buffer)
+        self.pfreed = [torch.cuda.Event() for _ in range(3)]    # plan consumed
         self.graphs = {}
         self._done = {}  # (stage, slot) -> event recorded behind the last replay of that graph
         self._sig = None
@@ -80,7 +83,7 @@ class TrainPipeline:
         self._twins = None
         self._nstream = None    # the stream the native driver's steps run on (see _on_native)
         self._halves = None     # cached model.grad_halves_supported()
-        self._plan3 = None
+        self._taken_over = False  # this epoch was begun by the native driver and is finished by the Python loop (kernel by kernel)
 
     # ------------------------------------------------------------------ stages (each on the current stream)
     def _stage_S(self, slot):
@@ -90,10 +93,11 @@ class TrainPipeline:
         self.sampler.build_batch(None, self.ns, self.num_e, pos, neg, indexed=(self.kg, self.index, self.starts, self.cursor, self.B),
                                  counted=self.cand[slot])
 
-    def _stage_P(self, slot, fork=None):
+    def _stage_P(self, slot, fork=None, pslot=None):
         """rows first, then the entity lists and the relation lists -- side by side on `fork` (a stream that already follows
-        the caller's origin stream and is joined by the caller) when given: they only share the rows."""
-        cur, pl = torch.cuda.current_stream(), self.plans[slot]
+        the caller's origin stream and is joined by the caller) when given: they only share the rows.  slot: candidate / array
+        buffer; pslot: plan buffer (default: the same number)."""
+        cur, pl = torch.cuda.current_stream(), self.plans[slot if pslot is None else pslot]
         b = None if self.counted else list(self.bufs[slot])
         m = self.B * self.ns
         if self.counted:
@@ -133,7 +137,7 @@ class TrainPipeline:
     # ------------------------------------------------------------------ graphs
     def _signature(self):
         mo, sa = self.model, self.sampler
-        t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.starts,
+        t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.plans[2].buf, self.starts,
              getattr(sa, "_stream", None)]
         t += [x for c in self.cand if c is not None for x in c]
         t += [x for b in self.bufs if b is not None for x in b]
@@ -168,7 +172,7 @@ class TrainPipeline:
         mo._seed, mo.optimizer.iterations = seed, it
         self._sig = self._signature()
 
-    def _stage_P_forked(self, slot):
+    def _stage_P_forked(self, slot, pslot=None):
         """Stage P with its two list builds side by side on a forked stream -- kernel-by-kernel launches only, never inside a
         capture.  (Round 1 saw the ROCm 7.2 runtime crash once with this fork inside a captured stage; the failing call and its
         error were not kept, and the two notes written then disagree on whether it died at hipStreamEndCapture or at the first
@@ -178,13 +182,18 @@ class TrainPipeline:
             raise RuntimeError("TrainPipeline._stage_P_forked must not be captured into a hipGraph (see its docstring)")
         cur = torch.cuda.current_stream()
         self.s3.wait_stream(cur)
-        self._stage_P(slot, fork=self.s3)
+        self._stage_P(slot, fork=self.s3, pslot=pslot)
         cur.wait_stream(self.s3)
 
-    def _run(self, name, slot):
-        if self.use_graphs and not self.graphs:  # (start() re-captures when a tensor the graphs hold has moved)
+    def _run(self, name, slot, pslot=None):
+        """slot: candidate / array buffer of the batch (stage S, P) or its plan buffer (stage T); pslot: plan buffer of stage P.  The
+        captured stages exist per buffer parity (plan buffer == candidate buffer); an epoch taken over from the native driver, which
+        plans into three buffers, is launched kernel by kernel."""
+        graphs = self.use_graphs and not self._taken_over
+        if graphs and not self.graphs:  # (start() re-captures when a tensor the graphs hold has moved)
             self._capture()  # may switch use_graphs off (capture not possible on this runtime)
-        if self.use_graphs and name in self.graph_stages:
+            graphs = self.use_graphs
+        if graphs and name in self.graph_stages:
             # A graph exec cannot run twice at once: launching it again while its previous launch is still in flight blocks
             # inside the runtime, and that wait sleeps (milliseconds on a busy host).  Spin on an event instead.
             ev = self._done.get((name, slot))
@@ -204,7 +213,7 @@ class TrainPipeline:
         elif name == "P":
             # kernel-by-kernel launches are bound by the host: the forked variant (shorter chain, more launches and event
             # traffic) only pays where nothing else sits on the step's critical path
-            self._stage_P(slot) if (self.serial or self.between is not None) else self._stage_P_forked(slot)
+            self._stage_P(slot, pslot=pslot) if (self.serial or self.between is not None) else self._stage_P_forked(slot, pslot)
         else:
             self._stage_T(slot)
 
@@ -259,10 +268,8 @@ class TrainPipeline:
             else:  # dropout: the oversampled arrays themselves (a mask per row: no folded form)
                 d.pos[j], d.neg[j] = self.bufs[j][0].data_ptr(), self.bufs[j][1].data_ptr()
             d.plan[j] = self.plans[j].buf.data_ptr()
-        d.plan_bytes = min(self.plans[0].buf.numel(), self.plans[1].buf.numel())
-        if self._plan3 is None or self._plan3.numel() < d.plan_bytes:  # third plan buffer of the native driver (kge_pipeline_desc.plan3)
-            self._plan3 = torch.zeros(int(d.plan_bytes), dtype=torch.uint8, device=self.dev)
-        d.plan3 = self._plan3.data_ptr()
+        d.plan_bytes = min(pl.buf.numel() for pl in self.plans)
+        d.plan3 = self.plans[2].buf.data_ptr()  # third plan buffer of the native driver
         # twin tables: steps alternate between (E, Rel) and these (kge_train_step_swap); run() leaves the current ones in (E, Rel)
         if self._twins is not None:
             d.E_twin, d.Rel_twin = self._twins[0].data_ptr(), self._twins[1].data_ptr()
@@ -307,12 +314,23 @@ class TrainPipeline:
 
     def _leave_native(self):
         """The flags changed mid-epoch (e.g. a profiling pass switches to serial launches): hand over to the Python loop.  The
-        caller's stream then waits for the producer streams; batches t and t+1 are already drawn and planned."""
+        caller's stream then waits for the producer streams; batches t and t+1 are already drawn and planned -- batch k into plan
+        buffer k % np of the driver (three buffers by default), candidate buffer k & 1 -- and the Python loop carries on with the
+        driver's buffer numbering, kernel by kernel (its captured stages are per buffer parity).  Step count and learning rate live
+        in the device step state, which both loops advance; model.optimizer.iterations is brought up to it here."""
         if self._nstream is not None:
             self._nstream.synchronize()  # (host wait, then a join that is satisfied at once: no stream-to-stream wait left pending)
         self._on_native(lambda: _lib.check(_lib.lib.kge_pipeline_finish(self._h, _lib.stream_ptr())))
+        st4 = (_lib.C.c_int64 * 4)()
+        _lib.check(_lib.lib.kge_pipeline_state(self._h, st4))
+        if int(st4[2]):
+            raise RuntimeError("TrainPipeline: the native driver left the current tables in the twins (a failed run); the epoch cannot be carried on")
+        assert int(st4[1]) == self.t, (int(st4[1]), self.t)
+        self._np, self._taken_over = int(st4[0]), True
         self._native_active = False
         main = torch.cuda.current_stream()
+        main.synchronize()
+        self.model.optimizer.iterations = int(self.step_dev[0].item())
         for st in (self.s1, self.s2, self.s3):
             st.wait_stream(main)
 
@@ -348,7 +366,7 @@ class TrainPipeline:
         """Issue the draw and the plan of batch k on their streams."""
         if k >= self.n:
             return
-        j = k % 2
+        j, pj = k % 2, k % self._np
         s1, s2 = (self.s1, self.s2) if not self.serial else (torch.cuda.current_stream(),) * 2
         with torch.cuda.stream(s1):
             s1.wait_event(self.freed[j])
@@ -356,9 +374,9 @@ class TrainPipeline:
             self.ready[j].record(s1)
         with torch.cuda.stream(s2):
             s2.wait_event(self.ready[j])
-            s2.wait_event(self.pfreed[j])
-            self._run("P", j)
-            self.planned[j].record(s2)
+            s2.wait_event(self.pfreed[pj])
+            self._run("P", j, pj)
+            self.planned[pj].record(s2)
             self.freed[j].record(s2)
 
     def start(self):
@@ -368,11 +386,12 @@ class TrainPipeline:
         mo._ensure_train_state(self.B * self.ns, self.B * self.ns)
         for pl in self.plans:  # counters of a plan that was built but never consumed (an epoch cut short) would poison the next build
             pl.buf.zero_()
-        if self._plan3 is not None:
-            self._plan3.zero_()
+        self._np, self._taken_over = 2, False
         if self.between is None:
             mo._step_dev = self.step_dev
-            if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0:  # (dropout: the three-launch step is faster)
+            # twin tables (kge_train_step_swap: lr_t of every update comes from the device step state, so the step may also be one
+            # of this object's captured stages); with dropout the three-launch step is the faster one
+            if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0:
                 if self._twins is None or self._twins[0].shape != mo.E.shape or self._twins[1].shape != mo.Rel.shape:
                     self._twins = (torch.empty_like(mo.E), torch.empty_like(mo.Rel))
                 mo._step_twins = self._twins
@@ -403,7 +422,7 @@ class TrainPipeline:
                 return self.run(1)
             self._leave_native()
         main = torch.cuda.current_stream()
-        j = self.t % 2
+        j = self.t % self._np
         main.wait_event(self.planned[j])
         self._run("T", j)
         self._after()
@@ -427,7 +446,7 @@ class TrainPipeline:
         if getattr(mo, "_step_dev", None) is not None:
             mo.optimizer.iterations = int(self.step_dev[0].item())
             mo._step_dev = mo._step_twins = None
-            return self.step_dev.view(torch.float32)[3].double()  # running sum kept by the library (kge_opt_desc.step_dev)
+            return self.step_dev.view(torch.float64)[2].clone()  # running sum kept by the library (kge_opt_desc.step_dev), a double
         return self.loss_sum
 
     def run_epoch(self, index, order):

@@ -317,3 +317,86 @@ def test_benched_path_at_benched_size(model):
     res = bench.check_benched_path(model, steps=3, fp64=True, tol=TOL)
     assert res["checked"] and res["check_batches_bit_exact"] == [0, 1, 2, 3, 4]
     assert res["max_abs_err"] <= TOL and res["max_abs_err_fp64"] <= TOL
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6])
+def test_native_driver_hands_the_epoch_over_to_the_python_loop(datasets, k):
+    """k steps issued by the native driver (three plan buffers: batch j sits in buffer j % 3), then `serial` flips mid-epoch and the
+    Python loop finishes the epoch from the driver's buffers, with the step count and Adam's lr_t taken from the device step state.
+    Tables, epoch loss and optimizer.iterations == host generator + oracle for every hand-over phase k mod 6."""
+    from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
+    from kge_keras_amd.pipeline import TrainPipeline
+    hp = dict(num_entities=14, num_relations=55, dim=32, embedding_model="DistMult", loss_function="pointwize_logistic", margin=1, dp=0.0, seed=9)
+    np.random.seed(31)
+    random.seed(32)
+    mdl = build_model(hp)
+    E0, R0 = mdl.E.cpu().numpy().astype(np.float64), mdl.Rel.cpu().numpy().astype(np.float64)
+    gen = DeviceDataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    n = 12
+    # one plain step first: the hand-over must also be right when the optimizer has updates behind it (lr_t of update k + 2, not k + 1)
+    first = gen[0][0]
+    mdl.train_step(first)
+    pipe = TrainPipeline(mdl, gen.kg, gen.n, gen.batch_size, gen.ns, gen.num_e, gen.sampler)
+    gen._upload_global()
+    pipe.load_epoch(gen.index, list(range(n)))
+    pipe.start()
+    assert pipe._native_active
+    pipe.run(k)
+    pipe.serial = True          # what a profiling pass does: the rest of the epoch on the Python loop, kernel by kernel
+    pipe.run(n - k)
+    assert not pipe._native_active and pipe._taken_over and pipe._np == 3
+    tot = float(pipe.finish().item())
+    gen.release_global()
+    assert mdl.optimizer.iterations == n + 1
+    mdl._raise_on_flag()
+    np.random.seed(31)
+    random.seed(32)
+    hgen = DataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    oo = O.make_optimizer("adam")
+    (p0, n0), _y = hgen[0]
+    assert np.array_equal(p0, first[0].cpu().numpy())
+    O.train_step("DistMult", E0, R0, oo, p0, n0, "pointwize_logistic", 1.0, 1)
+    ref = 0.0
+    for i in range(n):
+        (pos, neg), _y = hgen[i]
+        ref += O.train_step("DistMult", E0, R0, oo, pos, neg, "pointwize_logistic", 1.0, 1)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
+    assert tot == pytest.approx(ref, rel=1e-5)
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_python_loop_with_captured_twin_step(datasets, opt):
+    """The Python loop with every stage replayed from a hipGraph (native driver switched off) and the step between twin tables inside
+    the captured step stage: Adam's lr_t must move on from replay to replay -- it is read from the device step state, not baked into
+    the graph.  Two epochs (the second reuses the captured graphs) == host generator + oracle."""
+    from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
+    from kge_keras_amd.pipeline import TrainPipeline
+    hp = dict(num_entities=14, num_relations=55, dim=32, embedding_model="DistMult", loss_function="pointwize_hinge", margin=1, dp=0.0, seed=9)
+    np.random.seed(41)
+    random.seed(42)
+    mdl = build_model(hp)
+    mdl.compile(opt)
+    E0, R0 = mdl.E.cpu().numpy().astype(np.float64), mdl.Rel.cpu().numpy().astype(np.float64)
+    gen = DeviceDataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    gen._pipe = TrainPipeline(mdl, gen.kg, gen.n, gen.batch_size, gen.ns, gen.num_e, gen.sampler, graphs=True)
+    gen._pipe.native_wanted = False
+    h = mdl.fit(gen, epochs=2, verbose=0, shuffle=False)
+    pipe = gen._pipe
+    assert pipe._h is None and pipe.use_graphs and ("T", 0) in pipe.graphs and pipe._twins is not None
+    assert mdl.optimizer.iterations == 2 * len(gen)
+    np.random.seed(41)
+    random.seed(42)
+    hgen = DataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    oo = O.make_optimizer(opt)
+    losses = []
+    for _ in range(2):
+        tot = 0.0
+        for i in range(len(hgen)):
+            (pos, neg), _y = hgen[i]
+            tot += O.train_step("DistMult", E0, R0, oo, pos, neg, "pointwize_hinge", 1.0, 1)
+        losses.append(tot / len(hgen))
+        hgen.on_epoch_end()
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
+    np.testing.assert_allclose(h.history["loss"], losses, rtol=1e-4)

@@ -17,7 +17,7 @@ CASES = [("DistMult", {}, 200), ("DistMult", {}, 24), ("TransE", dict(norm=1, ga
 
 def _state(mdl):
     from kge_keras_amd import _lib
-    sd = torch.zeros(2, dtype=torch.int64, device=mdl.device)
+    sd = torch.zeros(_lib.STEP_STATE_WORDS, dtype=torch.int64, device=mdl.device)
     o = mdl.optimizer
     od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, int(o.iterations) + 1, None, None, None, None, sd.data_ptr())
     _lib.check(_lib.lib.kge_opt_state_init(_lib.C.byref(od), _lib.stream_ptr()))
@@ -69,7 +69,8 @@ def test_swap_step_equals_planned_step_and_oracle(model, kw, d, opt):
     assert int(sa[0].item()) == int(sb[0].item()) == 3
     fa, fb = sa.view(torch.float32).cpu().numpy(), sb.view(torch.float32).cpu().numpy()
     assert fa[2] == fb[2]                                  # learning rate of the next update
-    assert fa[3] == pytest.approx(tot, rel=1e-6) and fb[3] == pytest.approx(tot, rel=1e-5)
+    la, lb = float(sa.view(torch.float64)[2].item()), float(sb.view(torch.float64)[2].item())  # loss sum (a double)
+    assert la == pytest.approx(tot, rel=1e-7) and lb == pytest.approx(tot, rel=1e-5)
     a._raise_on_flag()
     # the plans' counters are left zero: a fourth build with "counters known to be zero" (parts | 8) still trains right
     pos = np.stack([rs.randint(0, N, 32), rs.randint(0, R, 32), rs.randint(0, N, 32)], 1).astype(np.int32)
