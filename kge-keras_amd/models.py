@@ -702,9 +702,24 @@ class EmbeddingModel:
         torch.save(st, path)
 
     def load_weights(self, path):
+        """Restores what save_weights wrote.  Checkpoints of the first layout of this package ({E, Rel, model[, opt]}: tables and
+        optimizer only, no `format` key) are read as format 1: models with further trainable tensors (literal Dense, ConvE head)
+        cannot be resumed from those.  A checkpoint that carries optimizer state loaded into a model that is not compiled yet
+        would silently lose the moments and the step count, so that warns: compile first, then load."""
         st = torch.load(path, map_location="cpu")
-        if st.get("format") != 2:
-            raise ValueError(f"{path}: not a checkpoint of this package (format {st.get('format')!r})")
+        if not isinstance(st, dict) or "E" not in st or "Rel" not in st or "model" not in st:
+            raise ValueError(f"{path}: not a checkpoint of this package")
+        fmt = st.get("format", 1)
+        if fmt == 1:
+            if self._extra_state():
+                raise ValueError(f"{path} is a format-1 checkpoint (tables and optimizer only); this model has further trainable tensors {sorted(self._extra_state())}")
+            st = dict(st, extra={}, format=2)
+        elif fmt != 2:
+            raise ValueError(f"{path}: checkpoint format {fmt!r} is newer than this package reads (1, 2)")
+        if "opt" in st and self.optimizer is None:
+            import warnings
+            warnings.warn(f"{path} holds optimizer state ({st['opt']['kind']}, {st['opt']['iterations']} updates) but the model is not compiled: "
+                          "only the tables are restored -- call compile() before load_weights() to resume training", stacklevel=2)
         if st["model"] != type(self).__name__:
             raise ValueError(f"{path} holds a {st['model']} model, this is a {type(self).__name__}")
         for k, t in (("E", self.E), ("Rel", self.Rel)):

@@ -77,6 +77,36 @@ def test_load_rejects_mismatches(tmp_path):
     sgd.compile("sgd")
     with pytest.raises(ValueError, match="optimizer"):
         sgd.load_weights(path)
+    # optimizer state in the file, model not compiled: the tables load, and that is said out loud
+    fresh, _, _, _ = _make("DistMult", seed=8)
+    with pytest.warns(UserWarning, match="not compiled"):
+        fresh.load_weights(path)
+    assert torch.equal(fresh.E, a.E) and fresh.optimizer is None
+
+
+def test_format_1_checkpoints_still_load(tmp_path):
+    """The first checkpoint layout of this package ({E, Rel, model, opt}: no `format`, `extra`, `seed` keys) is read as format 1."""
+    a, N, R, rs = _make("DistMult")
+    a.compile("adam")
+    a.train_step([_tri(rs, 50, N, R), _tri(rs, 50, N, R)])
+    path = str(tmp_path / "old.pt")
+    torch.save({"E": a.E.cpu(), "Rel": a.Rel.cpu(), "model": "DistMult",
+                "opt": dict(kind="adam", iterations=a.optimizer.iterations, slots=[s.cpu() for s in a.optimizer.slots])}, path)
+    b, _, _, _ = _make("DistMult", seed=6)
+    b.compile("adam")
+    b.load_weights(path)
+    assert torch.equal(a.E, b.E) and torch.equal(a.Rel, b.Rel) and b.optimizer.iterations == a.optimizer.iterations
+    assert all(torch.equal(x, y) for x, y in zip(a.optimizer.slots, b.optimizer.slots))
+    batch = [_tri(rs, 50, N, R), _tri(rs, 50, N, R)]
+    a.train_step(batch)
+    b.train_step(batch)
+    assert torch.equal(a.E, b.E)
+    lit, _, _, _ = _make("literal")
+    with pytest.raises(ValueError, match="format-1"):
+        lit.load_weights(path)
+    torch.save({"format": 3, "E": a.E.cpu(), "Rel": a.Rel.cpu(), "model": "DistMult"}, path)
+    with pytest.raises(ValueError, match="newer"):
+        b.load_weights(path)
 
 
 def test_val_loss_goes_through_the_literal_transform():
