@@ -576,6 +576,262 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
 #undef KGE_ST1
 }
 
+// The sweep on 256 x 128 block tiles: ONE 512-thread workgroup per CU (8 waves as 4 x 2 of 64 x 64, two per SIMD), the k chunks
+// double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without passing through registers).
+// What rank_sweep4_kernel loses (tools/mfma_probe.cpp: the pipe itself delivers 96-98 % of its peak to this MFMA stream, fragments
+// from LDS and barriers included; the sweep reached 65-78 %, ~1 500 idle pipe cycles per chunk of 5 120):
+//   * its single LDS image forces barrier -> 10 ds_write_b128 per thread -> barrier between any two chunks;
+//   * the address arithmetic, fragment reads and staging loads of a group of 16 MFMAs stand in front of the group as one burst of ~50
+//     instructions; the two waves of a SIMD run in step, so a burst in one is a burst in both and the pipe idles for its length.
+// Here chunk k+1 lands in the other image while the MFMAs of chunk k run (one barrier per chunk, no LDS store instruction at all: a
+// wave issues 9 DMA loads per chunk), a candidate tile feeds 256 query rows (25 % fewer bytes into LDS per flop), the addresses are a
+// wave-uniform base pointer + a 32-bit offset per lane (three vector instructions per DMA and chunk), and every non-MFMA instruction
+// of a group is interleaved with the group's MFMAs (sched_group_barrier).  Fragment reads, MFMA order and epilogue are
+// rank_sweep4_kernel's: the k order of every accumulation chain is the one documented at the top of the file, so the target / filter
+// kernels (chain_dot) still see bit-identical scores.
+// LDS-DMA writes 64 lanes x 16 bytes = one contiguous KiB per instruction ("segment"); the images keep their padded rows (BK + 4
+// floats: conflict-free ds_read_b128 fragments), so lane l of segment g fills float4 number 64 g + l of the image -- row (64 g + l) /
+// (C4 + 1), column (64 g + l) % (C4 + 1) -- from wherever that float4 lives in global memory; the pad column repeats column 0 (never
+// read).  Segments are dealt to the waves round-robin; where the count does not divide by 8 the last slot of some waves wraps around and
+// repeats a segment (the same bytes to the same place) rather than being predicated: a branch would cut the chunk's instruction stream
+// into separately scheduled pieces.  TAIL (K < Kpad): candidate float4s past K come from the zero padding of the first query row.
+constexpr int kQT5 = 256;
+template <int BK, bool TAIL, int EPI = 0>
+__global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
+                                                           int nq, const float* __restrict__ Ec, int K, int Kpad,
+                                                           int cand_rows, int32_t* __restrict__ counts,
+                                                           const float* __restrict__ en_c = nullptr, int parts = 0) {
+  constexpr int LS = BK + 4;
+  constexpr int C4 = BK / 4, S4 = C4 + 1;         // float4s per row: data, data + pad
+  constexpr int G = BK / 8;                       // groups of 16 MFMAs per chunk
+  constexpr int SEG_A = kQT5 * S4 / 64, SEG_B = kTile * S4 / 64;   // KiB segments of the two images: 44 / 22 (BK 40), 36 / 18 (BK 32)
+  constexpr int SA = (SEG_A + 7) / 8, SB = (SEG_B + 7) / 8;        // DMA slots of a wave: 6 + 3 (BK 40), 5 + 3 (BK 32)
+  constexpr int NS = SA + SB;
+  static_assert(kQT5 * S4 % 64 == 0 && kTile * S4 % 64 == 0, "images are whole segments");
+  static_assert(NS <= 9 && G >= 4, "slots 0..8, issued in groups 0..2");
+  __shared__ __attribute__((aligned(1024))) float As[2][kQT5 * LS];
+  __shared__ __attribute__((aligned(1024))) float Bs[2][kTile * LS];
+  __shared__ int cnt_s[kQT5];
+  __shared__ float tg_s[kQT5];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int nqt = (nq + kQT5 - 1) / kQT5, nct = (cand_rows + kTile - 1) / kTile;
+  const int64_t total = (int64_t)nqt * nct;
+  const int nb = gridDim.x;
+  // workgroups are dealt round-robin to the 8 XCDs: logical block lb makes the workgroups of an XCD neighbours in the unit order
+  const int lb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int64_t u_begin, u_end;
+  if (parts > 0) {  // (see rank_sweep4_kernel: every workgroup sweeps 1/parts of ONE query tile's candidate tiles)
+    const int q_ = lb / parts, p_ = lb - q_ * parts;
+    u_begin = (int64_t)q_ * nct + (int64_t)nct * p_ / parts;
+    u_end = (int64_t)q_ * nct + (int64_t)nct * (p_ + 1) / parts;
+  } else {
+    u_begin = total * lb / nb;
+    u_end = total * (lb + 1) / nb;
+  }
+  if (u_begin >= u_end) return;
+  // (the tile coordinates index scalar base pointers: say so to the compiler, which computes the 64-bit division in vector registers)
+  int qt = __builtin_amdgcn_readfirstlane((int)(u_begin / nct));
+  int ct = __builtin_amdgcn_readfirstlane((int)(u_begin - (int64_t)qt * nct));
+  int q0 = qt * kQT5;
+
+  int cnt[2][16];  // one counter per accumulator row (both candidate halves of the wave tile add into it)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cnt[rt][r] = 0;
+  if (tid < kQT5) {
+    cnt_s[tid] = 0;
+    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : (EPI == 1 ? -__builtin_inff() : __builtin_inff());
+  }
+
+  // DMA slots as named scalars (slot U < SA fills a segment of the query image, the others of the candidate image; slots past NS are
+  // compiled out): sg = the segment; rb = byte offset of this lane's float4 from the tile's base pointer, cb = the part of it inside
+  // the row.  Rows past the tile's last valid row are clamped to that row (queries past nq never store their counters, candidates past
+  // cand_rows are masked in the epilogue): of = min(rb, last valid row's offset + cb), two vector instructions per slot and chunk.
+  const int last_row = cand_rows - 1, last_q = nq - 1;
+  const int nchunk = Kpad / BK;
+#define KGE5_SLOT(U)                                                                                     \
+  const int sg##U = U < SA ? (wave + 8 * U) % SEG_A : (wave + 8 * (U - SA)) % SEG_B;                     \
+  const int f##U = sg##U * 64 + lane;                                                                    \
+  const int r##U = f##U / S4, c##U = f##U - r##U * S4;                                                   \
+  const unsigned cb##U = (unsigned)(c##U == C4 ? 0 : c##U) * 16u;                                        \
+  const unsigned rb##U = (unsigned)r##U * (unsigned)(U < SA ? Kpad : K) * 4u + cb##U;                    \
+  unsigned of##U = 0;
+  KGE5_SLOT(0) KGE5_SLOT(1) KGE5_SLOT(2) KGE5_SLOT(3) KGE5_SLOT(4) KGE5_SLOT(5) KGE5_SLOT(6) KGE5_SLOT(7) KGE5_SLOT(8)
+#undef KGE5_SLOT
+  // limA / limB: byte offset of the last valid row of the query / candidate tile (uniform)
+#define KGE5_OFF(U)                                                                                      \
+  if (U < NS) of##U = min(rb##U, (U < SA ? limA : limB) + cb##U);
+  // gA / gB: base pointers of the two tiles at the chunk's first k (TAIL: gB at k = 0, kB_ = the chunk's first k); BUF: the image.
+  // The DMA loads are inline assembly: issued through the compiler's builtin, every later ds_read of the OTHER image would wait for
+  // them (the compiler cannot tell the two images apart: s_waitcnt vmcnt(0) in front of each group's fragment reads).  What the
+  // compiler therefore does not do is done here: M0 (the LDS destination of the wave's 64 x 16 bytes) is written in the statement
+  // that reads it, and the loads are waited for by an explicit s_waitcnt vmcnt(0) in front of the chunk's barrier.  A load whose
+  // address is a scalar base + a 32-bit byte offset per lane takes the saddr form.
+  const unsigned lds_a = (unsigned)(uintptr_t)&As[0][0], lds_b = (unsigned)(uintptr_t)&Bs[0][0];
+  unsigned keep_m0;
+#define KGE5_DMA_S(BASE, BOFF, LDS)                                                                                           \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"        \
+               : "=&s"(keep_m0) : "v"(BOFF), "s"(LDS), "s"(BASE) : "memory")
+#define KGE5_DMA_V(PTR, LDS)                                                                                                  \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"       \
+               : "=&s"(keep_m0) : "v"(PTR), "s"(LDS) : "memory")
+#define KGE5_LD(U, BUF)                                                                                  \
+  if (U < NS) {                                                                                          \
+    if (U < SA) {                                                                                        \
+      KGE5_DMA_S(gA, of##U, lds_a + (unsigned)(((BUF) * (kQT5 * LS) + sg##U * 256) * 4));           \
+    } else if (TAIL) { /* K % 4 == 0: a float4 is inside the row or entirely in the padding */           \
+      const float* s_ = kB_ + (int)(cb##U >> 2) < K ? gB + ((of##U >> 2) + (unsigned)kB_) : Qv + K;                         \
+      KGE5_DMA_V(s_, lds_b + (unsigned)(((BUF) * (kTile * LS) + sg##U * 256) * 4));                      \
+    } else {                                                                                             \
+      KGE5_DMA_S(gB, of##U, lds_b + (unsigned)(((BUF) * (kTile * LS) + sg##U * 256) * 4));          \
+    }                                                                                                    \
+  }
+  // the instruction stream of one group: 16 x { one MFMA, at most one memory instruction (LDS read / DMA load), at most two ALU
+  // instructions } -- fragment reads, DMA loads and address arithmetic ride between the MFMAs instead of standing in front of them
+#define KGE5_PIPE()                                                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x100 | 0x010, 1, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004, 2, 0);                                           \
+  }
+  const int a_off = (wq * 64 + l31) * LS + 4 * half;
+  const int b_off = (wc * 64 + l31) * LS + 4 * half;
+
+  // prologue: the first chunk of the first unit into image 0
+  {
+    const int c0_ = ct * kTile;
+    const float* gA = Qv + (int64_t)q0 * Kpad;
+    const float* gB = Ec + (int64_t)c0_ * K;
+    const int kB_ = 0;
+    (void)kB_;
+    const unsigned limA = (unsigned)min(last_q - q0, kQT5 - 1) * (unsigned)Kpad * 4u, limB = (unsigned)min(last_row - c0_, kTile - 1) * (unsigned)K * 4u;
+    KGE5_OFF(0) KGE5_OFF(1) KGE5_OFF(2) KGE5_OFF(3) KGE5_OFF(4) KGE5_OFF(5) KGE5_OFF(6) KGE5_OFF(7) KGE5_OFF(8)
+    KGE5_LD(0, 0) KGE5_LD(1, 0) KGE5_LD(2, 0) KGE5_LD(3, 0) KGE5_LD(4, 0) KGE5_LD(5, 0) KGE5_LD(6, 0) KGE5_LD(7, 0) KGE5_LD(8, 0)
+  }
+  int p = 0;  // image the running chunk is read from
+  for (int64_t u = u_begin; u < u_end; ++u) {
+    // coordinates of the next unit of this workgroup's range (after the last one: this unit again, its values are dropped)
+    const bool has_next = u + 1 < u_end;
+    int nqt_ = qt, nct_ = ct;
+    if (has_next) {
+      nct_ = ct + 1;
+      if (nct_ == nct) { nct_ = 0; nqt_ = qt + 1; }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int kc = 0; kc < nchunk; ++kc) {
+      // every wave's DMA loads of image p have landed (issued in the first three groups of the previous chunk); everyone is done
+      // reading image p ^ 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const float* a_rd = &As[p][a_off];
+      const float* b_rd = &Bs[p][b_off];
+      // the chunk staged next (the first chunk of the next unit behind the last chunk of this one)
+      const bool wrap = kc + 1 == nchunk;
+      const int nq0 = wrap ? nqt_ * kQT5 : q0, nc0 = (wrap ? nct_ : ct) * kTile, nk0 = wrap ? 0 : (kc + 1) * BK;
+      const float* gA = Qv + (int64_t)nq0 * Kpad + nk0;
+      const float* gB = Ec + (int64_t)nc0 * K + (TAIL ? 0 : nk0);
+      const int kB_ = nk0;
+      (void)kB_;
+      const unsigned limA = (unsigned)min(last_q - nq0, kQT5 - 1) * (unsigned)Kpad * 4u, limB = (unsigned)min(last_row - nc0, kTile - 1) * (unsigned)K * 4u;
+      float4 fa[2][2], fb[2][2];  // [buffer][row tile]: the fragments of group j+1 are read while group j multiplies
+#define KGE_FRAG(BUF, J)                                                                          \
+  _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                 \
+    fa[BUF][x] = *reinterpret_cast<const float4*>(a_rd + x * 32 * LS + 8 * (J));                  \
+    fb[BUF][x] = *reinterpret_cast<const float4*>(b_rd + x * 32 * LS + 8 * (J));                  \
+  }
+#define KGE_STEP(BUF, comp)                                                                                           \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][0].comp, acc[0][0], 0, 0, 0);             \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][1].comp, acc[0][1], 0, 0, 0);             \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][0].comp, acc[1][0], 0, 0, 0);             \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][1].comp, acc[1][1], 0, 0, 0);
+      KGE_FRAG(0, 0)
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < G) {
+          if ((j & 1) == 0) { KGE_FRAG(1, j + 1) } else { KGE_FRAG(0, j + 1) }
+        }
+        // next chunk into the other image: three DMA loads (offset, then load) in each of the first three groups
+        if (j == 0) { KGE5_OFF(0) KGE5_OFF(1) KGE5_OFF(2) KGE5_LD(0, p ^ 1) KGE5_LD(1, p ^ 1) KGE5_LD(2, p ^ 1) }
+        if (j == 1) { KGE5_OFF(3) KGE5_OFF(4) KGE5_OFF(5) KGE5_LD(3, p ^ 1) KGE5_LD(4, p ^ 1) KGE5_LD(5, p ^ 1) }
+        if (j == 2) { KGE5_OFF(6) KGE5_OFF(7) KGE5_OFF(8) KGE5_LD(6, p ^ 1) KGE5_LD(7, p ^ 1) KGE5_LD(8, p ^ 1) }
+        if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
+        else { KGE_STEP(1, x) KGE_STEP(1, y) KGE_STEP(1, z) KGE_STEP(1, w) }
+        KGE5_PIPE()
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#undef KGE_STEP
+#undef KGE_FRAG
+      p ^= 1;
+    }
+    // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
+    const int c0 = ct * kTile;
+    float en0 = 0.f, en1 = 0.f;  // squared norms of this lane's two candidate columns (EPI != 0)
+    if (EPI != 0) {
+      en0 = en_c[min(c0 + wc * 64 + l31, last_row)];
+      en1 = en_c[min(c0 + wc * 64 + 32 + l31, last_row)];
+    }
+    auto hit = [&](float dot, float en, float tgv) {
+      if (EPI == 0) return dot > tgv;
+      const float D = __fmaf_rn(-2.f, dot, en);
+      return EPI == 1 ? D < tgv : D > tgv;
+    };
+    if (c0 + kTile <= cand_rows) {  // uniform: every candidate column of the tile exists
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+          cnt[rt][r] += (hit(acc[rt][0][r], en0, tgv) ? 1 : 0) + (hit(acc[rt][1][r], en1, tgv) ? 1 : 0);
+        }
+    } else {
+      const bool v0 = c0 + wc * 64 + l31 < cand_rows, v1 = c0 + wc * 64 + 32 + l31 < cand_rows;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+          cnt[rt][r] += ((v0 && hit(acc[rt][0][r], en0, tgv)) ? 1 : 0) + ((v1 && hit(acc[rt][1][r], en1, tgv)) ? 1 : 0);
+        }
+    }
+    if (!has_next || nqt_ != qt) {  // uniform: the range leaves this query tile -> flush its counters
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
+          cnt[rt][r] = 0;
+        }
+      __syncthreads();
+      if (tid < kQT5) {
+        if (q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
+        if (has_next) {  // (read again only after the barrier at the top of the next chunk)
+          const int nq0_ = nqt_ * kQT5;
+          cnt_s[tid] = 0;
+          tg_s[tid] = nq0_ + tid < nq ? tgt[nq0_ + tid] : (EPI == 1 ? -__builtin_inff() : __builtin_inff());
+        }
+      }
+    }
+    qt = nqt_;
+    ct = nct_;
+    q0 = qt * kQT5;
+  }
+#undef KGE5_LD
+#undef KGE5_DMA_S
+#undef KGE5_DMA_V
+#undef KGE5_OFF
+#undef KGE5_PIPE
+}
+
 // One thread per CSR entry (query pair_q[e], filtered global id filt_ids[e]); un-counts it if it was counted.
 __global__ __launch_bounds__(256) void rank_filter_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                            const float* __restrict__ Ec, int cand_offset, int cand_rows,
@@ -808,13 +1064,47 @@ static int sweep_slots() {  // workgroups of the persistent sweep: two per CU (r
   return v;
 }
 
+static bool sweep5_on() {  // KGE_RANK_SWEEP=4: the 128 x 128 kernel with two 256-thread workgroups per CU (A/B timing)
+  return sweep_variant() != 4;
+}
+static int sweep5_slots() {  // workgroups of rank_sweep5_kernel: one per CU (137 KB of LDS, 512 threads)
+  static const int v = [] { const char* e = getenv("KGE_RANK_SLOTS5"); const int x = e ? atoi(e) : 0; return x > 0 ? x : kCUs; }();
+  return v;
+}
+
 static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float* Qv, const float* tgt, int64_t nq, const float* Ec,
                          int K, int Kpad, int cand_rows, int tpb, int32_t* counts, int epi = 0, const float* en_c = nullptr) {
   if (nq <= 0 || cand_rows <= 0) return;
   ProfScope prof_sweep(KGE_PROF_RANK_SWEEP, st);
 #define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
-  if (v4 && sweep_variant() == 0 && nq < (int64_t)1 << 30) {
+  if (v4 && (sweep_variant() == 0 || sweep_variant() == 4) && nq < (int64_t)1 << 30) {
     const bool tail = Kpad != K;
+    if (sweep5_on()) {
+      // 256 x 128 tiles, one 512-thread workgroup per CU.  The phase-aligned cut is taken when it leaves at most 1/32 of the CUs
+      // without a workgroup (it cuts the fabric traffic, not the run time); otherwise equal contiguous cuts of the unit list.
+      const int64_t nqt = cdiv(nq, kQT5), nct = cdiv(cand_rows, kTile);
+      const int64_t units = nqt * nct;
+      const int slots = sweep5_slots();
+      int parts = 0;
+      {
+        static const bool align = [] { const char* e = getenv("KGE_RANK_ALIGN"); return !(e && atoi(e) == 0); }();
+        if (align && nqt <= slots && units > slots) {
+          const int64_t g = std::min<int64_t>(slots / nqt, nct);
+          if (g >= 1 && nqt * g * 32 >= (int64_t)slots * 31) parts = (int)g;
+        }
+      }
+      const dim3 pgrid((unsigned)(parts ? nqt * parts : std::min<int64_t>(units, slots)));
+#define KGE_SWEEP5(BKV, FLAG)                                                                                                                        \
+  do {                                                                                                                                               \
+    if (epi == 1) hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 1>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);      \
+    else if (epi == 2) hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 2>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts); \
+    else hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 0>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);               \
+  } while (0)
+      if (BK == 40) { if (tail) KGE_SWEEP5(40, true); else KGE_SWEEP5(40, false); }
+      else { if (tail) KGE_SWEEP5(32, true); else KGE_SWEEP5(32, false); }
+#undef KGE_SWEEP5
+      return;
+    }
     const int64_t nqt = cdiv(nq, kTile), nct = cdiv(cand_rows, kTile);
     const int64_t units = nqt * nct;
     const int slots = sweep_slots();
@@ -914,7 +1204,7 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
   // candidates must be rows of E itself; a row shard held apart from the query table takes the direct distance sweep)
   const bool cand_in_table = Ec == E + (int64_t)cand_offset * K && cand_offset + cand_rows <= md->num_entities;
   if (md->model == KGE_TRANSE && md->norm == 2 && !tgt_out && rank_l2_mfma() && (K % 4 == 0) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) &&
-      nq < (int64_t)1 << 30 && sweep_variant() == 0 && cand_in_table) {
+      nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4) && cand_in_table) {
     float* en = tgt + align_up(nq, 64);  // behind the target values (the query block is sized for align_up(K, 32) >= rank_kpad(K) floats per row)
     Kpad = rank_kpad(K);
     launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
@@ -955,7 +1245,7 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
-  if ((K % 4 == 0) && ((uintptr_t)E % 16 == 0) && nq < (int64_t)1 << 30 && sweep_variant() == 0) {
+  if ((K % 4 == 0) && ((uintptr_t)E % 16 == 0) && nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4)) {
     if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
     else hipLaunchKernelGGL((rank_target4_kernel<32>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
   } else {
