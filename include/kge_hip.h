@@ -150,6 +150,10 @@ int kge_opt_apply(const kge_model_desc* md, const kge_loss_desc* ld, const kge_o
  *      sorted or not: filt_query[e] = query index, filt_ids[e] = global entity id to exclude (the reference's
  *      filter_t[(s,p)] / filter_h[(p,o)]); it must not contain the target (the reference raises ValueError).
  *      accumulate != 0 adds into counts (multi-shard loops); otherwise counts is overwritten.
+ *      side 2 ranks BOTH sides of the n_queries test triples in one sweep of the candidate table (what `validate` does per test
+ *      triple, utils.py:210-236): query i in [0, n) is the tail query of triple i, query n + i its head query; counts,
+ *      target_scores_out and the query numbers in filt_query follow that numbering (2 n entries), and the workspace is
+ *      kge_rank_workspace_bytes(md, 2 n).  One launch with fuller query tiles instead of two; same counts as side 0 + side 1.
  *      DistMult, ComplEx, HolE and TransE-L2 (ordered by |e|^2 - 2<q,e>; target_scores_out must be NULL for that form, otherwise
  *      the VALU distance sweep runs) use the fp32 matrix cores; score comparisons are made on bit-identical fmaf chains. */
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries);

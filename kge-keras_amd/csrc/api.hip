@@ -449,13 +449,13 @@ int kge_rank_counts(const kge_model_desc* md, const float* E, const float* Rel, 
   if (int rc = check_model(md, "kge_rank_counts")) return rc;
   if (n_queries < 0 || n_filt < 0) return fail(KGE_EINVAL, "kge_rank_counts: negative size");
   if (n_queries == 0) return KGE_OK;
-  if (side != 0 && side != 1) return fail(KGE_EINVAL, "kge_rank_counts: side must be 0 (tail) or 1 (head)");
+  if (side < 0 || side > 2) return fail(KGE_EINVAL, "kge_rank_counts: side must be 0 (tail), 1 (head) or 2 (both: tail queries, then head queries)");
   if (!E || !Rel || (!E_cand && cand_rows > 0) || !triples || !counts || !workspace || !err_flag || (n_filt && (!filt_query || !filt_ids)))
     return fail(KGE_EINVAL, "kge_rank_counts: null pointer");
   if (cand_offset < 0 || cand_rows < 0 || (int64_t)cand_offset + cand_rows > 0x7FFFFFFFll)
     return fail(KGE_EINVAL, "kge_rank_counts: bad candidate range [%d,%d+%d)", cand_offset, cand_offset, cand_rows);
   if (cand_rows == 0) {  // an empty row shard counts nothing
-    if (!accumulate) KGE_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * n_queries, static_cast<hipStream_t>(stream)));
+    if (!accumulate) KGE_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * n_queries * (side == 2 ? 2 : 1), static_cast<hipStream_t>(stream)));
     return KGE_OK;
   }
   return rank_counts(md, E, Rel, E_cand, cand_offset, cand_rows, triples, n_queries, side, filt_query, filt_ids, n_filt, counts,

@@ -223,10 +223,11 @@ __global__ __launch_bounds__(256) void rank_filter_l2_kernel(const float* __rest
                                                               const float* __restrict__ Ec, const float* __restrict__ en_c, int cand_offset,
                                                               int cand_rows, int K, int Kpad, const int32_t* __restrict__ pair_q,
                                                               const int32_t* __restrict__ filt_ids, int64_t npairs,
-                                                              int32_t* __restrict__ counts) {
+                                                              int32_t* __restrict__ counts, int q_lo = 0, int q_n = 0x7fffffff) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= npairs) return;
-  const int q = pair_q[e];
+  const int q = pair_q[e] - q_lo;
+  if ((unsigned)q >= (unsigned)q_n) return;  // (a pair of the other side's queries: see rank_counts, side 2)
   const int c = filt_ids[e] - cand_offset;
   if ((unsigned)c >= (unsigned)cand_rows) return;  // another shard owns this candidate
   const float D = __fmaf_rn(-2.f, chain_dot(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, Kpad), en_c[c]);
@@ -596,6 +597,10 @@ __global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restric
 // repeats a segment (the same bytes to the same place) rather than being predicated: a branch would cut the chunk's instruction stream
 // into separately scheduled pieces.  TAIL (K < Kpad): candidate float4s past K come from the zero padding of the first query row.
 constexpr int kQT5 = 256;
+#ifdef KGE_SWEEP5_STAMP  // diagnostic build (tools/sweep_stamps.py): wall-clock stamp (100 MHz) of every unit end, per workgroup
+constexpr int kStampUnits = 512;
+__device__ unsigned long long g_sweep5_stamps[256 * kStampUnits];
+#endif
 template <int BK, bool TAIL, int EPI = 0>
 __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
                                                            int nq, const float* __restrict__ Ec, int K, int Kpad,
@@ -824,6 +829,12 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
     qt = nqt_;
     ct = nct_;
     q0 = qt * kQT5;
+#ifdef KGE_SWEEP5_STAMP
+    if (tid == 0 && blockIdx.x < 256 && u - u_begin < kStampUnits - 1) {
+      if (u == u_begin) g_sweep5_stamps[blockIdx.x * kStampUnits] = (unsigned long long)(u_end - u_begin);
+      g_sweep5_stamps[blockIdx.x * kStampUnits + 1 + (u - u_begin)] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
   }
 #undef KGE5_LD
 #undef KGE5_DMA_S
@@ -837,10 +848,11 @@ __global__ __launch_bounds__(256) void rank_filter_kernel(const float* __restric
                                                            const float* __restrict__ Ec, int cand_offset, int cand_rows,
                                                            int K, int Kpad, const int32_t* __restrict__ pair_q,
                                                            const int32_t* __restrict__ filt_ids, int64_t npairs,
-                                                           int32_t* __restrict__ counts) {
+                                                           int32_t* __restrict__ counts, int q_lo = 0, int q_n = 0x7fffffff) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= npairs) return;
-  const int q = pair_q[e];
+  const int q = pair_q[e] - q_lo;
+  if ((unsigned)q >= (unsigned)q_n) return;
   const int c = filt_ids[e] - cand_offset;
   if ((unsigned)c >= (unsigned)cand_rows) return;  // another shard owns this candidate
   const float sc = chain_dot(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, Kpad);
@@ -1012,10 +1024,11 @@ __global__ __launch_bounds__(256) void rank_dist_filter_kernel(const float* __re
                                                                 const float* __restrict__ Ec, int cand_offset, int cand_rows,
                                                                 int K, int Kpad, float gamma, float modulus, const int32_t* __restrict__ pair_q,
                                                                 const int32_t* __restrict__ filt_ids, int64_t npairs,
-                                                                int32_t* __restrict__ counts) {
+                                                                int32_t* __restrict__ counts, int q_lo = 0, int q_n = 0x7fffffff) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= npairs) return;
-  const int q = pair_q[e];
+  const int q = pair_q[e] - q_lo;
+  if ((unsigned)q >= (unsigned)q_n) return;
   const int c = filt_ids[e] - cand_offset;
   if ((unsigned)c >= (unsigned)cand_rows) return;
   if (dist_chain<NORM>(Qv + (int64_t)q * Kpad, Ec + (int64_t)c * K, K, gamma, modulus) > tgt[q]) atomicSub(&counts[q], 1);
@@ -1135,6 +1148,12 @@ static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float
 #undef KGE_SWEEP
 }
 
+#ifdef KGE_SWEEP5_STAMP
+extern "C" int kge_debug_sweep5_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep5_stamps), sizeof(unsigned long long) * 256 * kStampUnits) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int rank_kpad(int K) { return (int)align_up(K, pick_bk(K)); }
 static int rank_kpad_model(const kge_model_desc* md) { return md->model == KGE_TRANSE ? (int)align_up(md->d_e, 32) : rank_kpad(md->d_e); }
 
@@ -1176,7 +1195,7 @@ static void launch_build_q(const kge_model_desc* md, const float* E, const float
 template <int NORM>
 static void launch_dist(const kge_model_desc* md, const float* E, const float* Ec, int cand_offset, int cand_rows, const int32_t* triples,
                         int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs, int32_t* counts,
-                        int accumulate, const float* Qv, float* tgt, int Kpad, hipStream_t st) {
+                        int accumulate, const float* Qv, float* tgt, int Kpad, hipStream_t st, int q_lo = 0) {
   const int K = md->d_e;
   hipLaunchKernelGGL((rank_dist_target_kernel<NORM>), dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, md->gamma, md->modulus, tgt, counts, accumulate ? 0 : 1);
   const int nqt = (int)cdiv(nq, 64), nct = (int)cdiv(cand_rows, 64);
@@ -1185,37 +1204,57 @@ static void launch_dist(const kge_model_desc* md, const float* E, const float* E
   splits = (int)cdiv(nct, tpb);
   hipLaunchKernelGGL((rank_dist_sweep_kernel<NORM>), dim3(nqt, splits), dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, md->gamma, md->modulus, counts);
   if (npairs > 0)
-    hipLaunchKernelGGL((rank_dist_filter_kernel<NORM>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, md->gamma, md->modulus, pair_q, filt_ids, npairs, counts);
+    hipLaunchKernelGGL((rank_dist_filter_kernel<NORM>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, md->gamma, md->modulus, pair_q, filt_ids, npairs, counts, q_lo, (int)nq);
 }
 
-int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* Ec, int cand_offset, int cand_rows,
-                const int32_t* triples, int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs,
-                int32_t* counts, int accumulate, float* tgt_out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
+// side 0 / 1: nt tail / head queries.  side 2: both sides of the nt test triples in ONE sweep -- queries [0, nt) are the tail queries,
+// [nt, 2 nt) the head queries (counts, target scores and the filter list's query numbers follow that numbering): the candidate table
+// is swept once for twice the queries (fewer, fuller query tiles; one launch instead of two).  Where the model's sweep is not one of
+// the matrix-core sweeps the two sides run one after the other inside this call.  q_lo: the number of this call's first query in the
+// filter list (inner calls of side 2).
+static int rank_counts_impl(const kge_model_desc* md, const float* E, const float* Rel, const float* Ec, int cand_offset, int cand_rows,
+                            const int32_t* triples, int64_t nt, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs,
+                            int32_t* counts, int accumulate, float* tgt_out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st, int q_lo) {
   if (md->model == KGE_HOLE && md->d_e > 1024) return fail(KGE_EUNSUPPORTED, "kge_rank_counts: HolE rows wider than 1024 floats are not built");
   const int K = md->d_e, BK = pick_bk(K);
   int Kpad = rank_kpad_model(md);
+  const int nside = side == 2 ? 2 : 1;
+  const int64_t nq = nside * nt;  // queries of this call
   if (wbytes < rank_workspace_bytes(md, nq)) return fail(KGE_EWORKSPACE, "kge_rank_counts: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)rank_workspace_bytes(md, nq));
   uintptr_t p = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
   float* Qv = reinterpret_cast<float*>(p);
   float* tgt = tgt_out ? tgt_out : Qv + nq * Kpad;
-  ProfScope prof(KGE_PROF_RANK, st);
+  const bool cand_in_table0 = Ec == E + (int64_t)cand_offset * K && cand_offset + cand_rows <= md->num_entities;
+  const bool mfma_ok = (K % 4 == 0) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) && nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4);
+  const bool merged = md->model == KGE_TRANSE ? (md->norm == 2 && !tgt_out && rank_l2_mfma() && mfma_ok && cand_in_table0) : mfma_ok;
+  if (side == 2 && !merged) {
+    for (int h = 0; h < 2; ++h)
+      if (int rc = rank_counts_impl(md, E, Rel, Ec, cand_offset, cand_rows, triples, nt, h, pair_q, filt_ids, npairs, counts + h * nt, accumulate,
+                                    tgt_out ? tgt_out + h * nt : nullptr, workspace, wbytes, err, st, q_lo + (int)(h * nt))) return rc;
+    return KGE_OK;
+  }
+  const int qn = (int)nq;  // the filter kernels' query window: [q_lo, q_lo + qn)
   // TransE-L2 on the matrix cores (target scores are not produced on this path: a caller asking for them gets the distance sweep)
   // (the per-row tables of the two forms below -- squared norms, (sin, cos) pairs -- are built from E and indexed by global id, so the
   // candidates must be rows of E itself; a row shard held apart from the query table takes the direct distance sweep)
-  const bool cand_in_table = Ec == E + (int64_t)cand_offset * K && cand_offset + cand_rows <= md->num_entities;
+  const bool cand_in_table = cand_in_table0;
   if (md->model == KGE_TRANSE && md->norm == 2 && !tgt_out && rank_l2_mfma() && (K % 4 == 0) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) &&
       nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4) && cand_in_table) {
     float* en = tgt + align_up(nq, 64);  // behind the target values (the query block is sized for align_up(K, 32) >= rank_kpad(K) floats per row)
     Kpad = rank_kpad(K);
-    launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
     hipLaunchKernelGGL(rank_sumsq_kernel, dim3((int)cdiv((int64_t)md->num_entities * 16, 256)), dim3(256), 0, st, E, md->num_entities, K, en);
-    if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40, true>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1, en);
-    else hipLaunchKernelGGL((rank_target4_kernel<32, true>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1, en);
+    for (int h = 0; h < nside; ++h) {
+      const int sd = side == 2 ? h : side;
+      float* Qh = Qv + h * nt * Kpad;
+      launch_build_q(md, E, Rel, triples, nt, sd, Kpad, Qh, err, st);
+      if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40, true>), dim3((int)cdiv(nt, 64)), dim3(64), 0, st, Qh, E, triples, (int)nt, sd, md->num_entities, K, Kpad, tgt + h * nt, counts + h * nt, accumulate ? 0 : 1, en);
+      else hipLaunchKernelGGL((rank_target4_kernel<32, true>), dim3((int)cdiv(nt, 64)), dim3(64), 0, st, Qh, E, triples, (int)nt, sd, md->num_entities, K, Kpad, tgt + h * nt, counts + h * nt, accumulate ? 0 : 1, en);
+    }
     const bool less = md->gamma > 0.f;
     launch_sweep(BK, true, dim3(1), st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, 1, counts, less ? 1 : 2, en + cand_offset);
     if (npairs > 0) {
-      if (less) hipLaunchKernelGGL((rank_filter_l2_kernel<true>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
-      else hipLaunchKernelGGL((rank_filter_l2_kernel<false>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
+      if (less) hipLaunchKernelGGL((rank_filter_l2_kernel<true>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts, q_lo, qn);
+      else hipLaunchKernelGGL((rank_filter_l2_kernel<false>), dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, en + cand_offset, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts, q_lo, qn);
     }
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
@@ -1232,23 +1271,30 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
     kge_model_desc m2 = *md;
     m2.d_e = m2.d_r = K2;
     launch_dist<4>(&m2, EP, EP + (int64_t)cand_offset * K2, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tg,
-                   Kpad2, st);
+                   Kpad2, st, q_lo);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
-  launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
+  if (md->model != KGE_TRANSE) {
+    for (int h = 0; h < nside; ++h) launch_build_q(md, E, Rel, triples, nt, side == 2 ? h : side, Kpad, Qv + h * nt * Kpad, err, st);
+  } else {
+    launch_build_q(md, E, Rel, triples, nq, side, Kpad, Qv, err, st);
+  }
   if (md->model == KGE_TRANSE) {
-    if (md->norm == 1) launch_dist<1>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
-    else if (md->norm == 3) launch_dist<3>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
-    else if (md->norm == 5) launch_dist<5>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
-    else launch_dist<2>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st);
+    if (md->norm == 1) launch_dist<1>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st, q_lo);
+    else if (md->norm == 3) launch_dist<3>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st, q_lo);
+    else if (md->norm == 5) launch_dist<5>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st, q_lo);
+    else launch_dist<2>(md, E, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, Qv, tgt, Kpad, st, q_lo);
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
   if ((K % 4 == 0) && ((uintptr_t)E % 16 == 0) && nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4)) {
-    if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
-    else hipLaunchKernelGGL((rank_target4_kernel<32>), dim3((int)cdiv(nq, 64)), dim3(64), 0, st, Qv, E, triples, (int)nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
-  } else {
+    for (int h = 0; h < nside; ++h) {
+      const int sd = side == 2 ? h : side;
+      if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40>), dim3((int)cdiv(nt, 64)), dim3(64), 0, st, Qv + h * nt * Kpad, E, triples, (int)nt, sd, md->num_entities, K, Kpad, tgt + h * nt, counts + h * nt, accumulate ? 0 : 1);
+      else hipLaunchKernelGGL((rank_target4_kernel<32>), dim3((int)cdiv(nt, 64)), dim3(64), 0, st, Qv + h * nt * Kpad, E, triples, (int)nt, sd, md->num_entities, K, Kpad, tgt + h * nt, counts + h * nt, accumulate ? 0 : 1);
+    }
+  } else {  // (never with side 2: that needs the conditions of this branch's `if`)
     hipLaunchKernelGGL(rank_target_kernel, dim3((int)cdiv(nq, 256)), dim3(256), 0, st, Qv, E, triples, nq, side, md->num_entities, K, Kpad, tgt, counts, accumulate ? 0 : 1);
   }
   {
@@ -1262,9 +1308,17 @@ int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, cons
     launch_sweep(BK, v4, grid, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts);
   }
   if (npairs > 0)
-    hipLaunchKernelGGL(rank_filter_kernel, dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts);
+    hipLaunchKernelGGL(rank_filter_kernel, dim3((int)cdiv(npairs, 256)), dim3(256), 0, st, Qv, tgt, Ec, cand_offset, cand_rows, K, Kpad, pair_q, filt_ids, npairs, counts, q_lo, qn);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
+}
+
+int rank_counts(const kge_model_desc* md, const float* E, const float* Rel, const float* Ec, int cand_offset, int cand_rows,
+                const int32_t* triples, int64_t nq, int side, const int32_t* pair_q, const int32_t* filt_ids, int64_t npairs,
+                int32_t* counts, int accumulate, float* tgt_out, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  ProfScope prof(KGE_PROF_RANK, st);
+  return rank_counts_impl(md, E, Rel, Ec, cand_offset, cand_rows, triples, nq, side, pair_q, filt_ids, npairs, counts, accumulate, tgt_out, workspace,
+                          wbytes, err, st, 0);
 }
 
 // ---- generic entry: queries given as vectors (ConvE's hidden vectors; head queries against a per-relation candidate matrix)

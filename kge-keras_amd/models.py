@@ -574,9 +574,11 @@ class EmbeddingModel:
         return np.asarray(qs, dtype=np.int32), np.asarray(ids, dtype=np.int32)
 
     def rank_counts(self, triples, side, filt_q, filt_ids, num_entities=None, cand_offset=0, cand_rows=None, counts=None):
-        """counts[i] = #{kept candidates c in the range with score(i,c) > score(i,target_i)} on the GPU."""
+        """counts[i] = #{kept candidates c in the range with score(i,c) > score(i,target_i)} on the GPU.  side 0: tail queries,
+        1: head queries, 2: both in one sweep -- 2 n counts, tail queries first; filt_q numbers the queries the same way."""
         t = as_triples(triples, self.device, self.num_entities, self.num_relations)
-        nq = t.shape[0]
+        nt = t.shape[0]
+        nq = nt * (2 if int(side) == 2 else 1)
         num_entities = self.num_entities if num_entities is None else int(num_entities)
         cand_rows = num_entities - cand_offset if cand_rows is None else cand_rows
         md = self._model_desc(False)
@@ -594,7 +596,7 @@ class EmbeddingModel:
         Et = self._eval_table() if self._lit is not None else self.E
         ec_ptr = Et.data_ptr() + 4 * int(cand_offset) * int(self.e_dim)
         check(lib.kge_rank_counts(C.byref(md), Et.data_ptr(), self.Rel.data_ptr(), ec_ptr, int(cand_offset), int(cand_rows),
-                                  t.data_ptr(), nq, int(side), fq.data_ptr() if fq.numel() else None,
+                                  t.data_ptr(), nt, int(side), fq.data_ptr() if fq.numel() else None,
                                   fi.data_ptr() if fi.numel() else None, fq.numel(), counts.data_ptr(), 1 if acc else 0, None,
                                   self._rank_ws.data_ptr(), self._rank_ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
         return counts
@@ -627,33 +629,33 @@ class EmbeddingModel:
     def rank(self, test_data, num_entities, filter_t, filter_h, chunk=32768):
         """(tail_ranks, head_ranks) of `validate` (utils.py:199-264): real_rank = 1 + #{kept c: score_c > score_target}."""
         test = [tuple(int(v) for v in t) for t in test_data]
-        out = []
-        for side, filt in ((0, filter_t), (1, filter_h)):
-            ranks = np.empty(len(test), dtype=np.int64)
-            for a in range(0, len(test), chunk):
-                part = test[a:a + chunk]
-                fq, fi = self._filter_coo(part, num_entities, filt, side)
-                cnt = self.rank_counts(np.asarray(part, dtype=np.int32), side, fq, fi, num_entities)
-                ranks[a:a + chunk] = 1 + cnt.cpu().numpy().astype(np.int64)
-            self._raise_on_flag()
-            out.append(ranks)
-        return out[0], out[1]
+        tails, heads = np.empty(len(test), dtype=np.int64), np.empty(len(test), dtype=np.int64)
+        for a in range(0, len(test), chunk):  # both sides of a chunk in one sweep of the table (kge_rank_counts, side 2)
+            part = test[a:a + chunk]
+            n = len(part)
+            fq0, fi0 = self._filter_coo(part, num_entities, filter_t, 0)
+            fq1, fi1 = self._filter_coo(part, num_entities, filter_h, 1)
+            cnt = self.rank_counts(np.asarray(part, dtype=np.int32), 2, np.concatenate([fq0, fq1 + n]).astype(np.int32),
+                                   np.concatenate([fi0, fi1]).astype(np.int32), num_entities).cpu().numpy().astype(np.int64)
+            tails[a:a + n], heads[a:a + n] = 1 + cnt[:n], 1 + cnt[n:]
+        self._raise_on_flag()
+        return tails, heads
 
     def rank_triples(self, test, num_entities, filt, chunk=65536):
         """Same as rank(), from raw (n,3) arrays: the filter index is built by the C++ front-end (utils.filter_coo)."""
         from .utils import filter_coo
         test = np.ascontiguousarray(np.asarray(test, dtype=np.int32).reshape(-1, 3))
-        out = []
-        for side in (0, 1):
-            ranks = np.empty(len(test), dtype=np.int64)
-            for a in range(0, len(test), chunk):
-                part = test[a:a + chunk]
-                fq, fi = filter_coo(part, side, filt, num_entities)
-                cnt = self.rank_counts(part, side, fq, fi, num_entities)
-                ranks[a:a + chunk] = 1 + cnt.cpu().numpy().astype(np.int64)
-            self._raise_on_flag()
-            out.append(ranks)
-        return out[0], out[1]
+        tails, heads = np.empty(len(test), dtype=np.int64), np.empty(len(test), dtype=np.int64)
+        for a in range(0, len(test), chunk):  # both sides of a chunk in one sweep of the table (kge_rank_counts, side 2)
+            part = test[a:a + chunk]
+            n = len(part)
+            fq0, fi0 = filter_coo(part, 0, filt, num_entities)
+            fq1, fi1 = filter_coo(part, 1, filt, num_entities)
+            cnt = self.rank_counts(part, 2, np.concatenate([fq0, fq1 + n]).astype(np.int32), np.concatenate([fi0, fi1]).astype(np.int32),
+                                   num_entities).cpu().numpy().astype(np.int64)
+            tails[a:a + n], heads[a:a + n] = 1 + cnt[:n], 1 + cnt[n:]
+        self._raise_on_flag()
+        return tails, heads
 
     # ------------------------------------------------------------------ weights I/O (checkpointing)
     def _extra_state(self):

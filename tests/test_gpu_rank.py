@@ -445,3 +445,32 @@ def test_rccl_wrappers_one_rank_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("model,kw", [("DistMult", {}), ("ComplEx", {}), ("HolE", {}), ("RotatE", {}), ("pRotatE", {}), ("TransE", dict(norm=1, gamma=12)),
+                                      ("TransE", dict(norm=2, gamma=12)), ("TransE", dict(norm=3.5, gamma=12))])
+@pytest.mark.parametrize("N,d,nq", [(300, 40, 257), (1000, 24, 513)])
+def test_rank_both_sides_in_one_sweep(model, kw, N, d, nq):
+    """kge_rank_counts with side = 2 (tail queries [0, n), head queries [n, 2n), one sweep of the table where the model ranks on the
+    matrix cores, the two sides one after the other inside the call elsewhere) == side 0 and side 1 apart, bit for bit, with an
+    UNSORTED filter list that mixes pairs of both sides, and when accumulating over two row shards."""
+    mdl, E0, R0, rs = _mk(model, N, 5, d, **kw)
+    test = np.stack([rs.randint(0, N, nq), rs.randint(0, 5, nq), rs.randint(0, N, nq)], 1).astype(np.int32)
+    def pairs(col):
+        q = rs.randint(0, nq, 4 * nq).astype(np.int32)
+        ids = rs.randint(0, N, 4 * nq).astype(np.int32)
+        keep = ids != test[q, col]
+        return q[keep], ids[keep]
+    (q0, i0), (q1, i1) = pairs(2), pairs(0)
+    c0 = mdl.rank_counts(test, 0, q0, i0).cpu().numpy()
+    c1 = mdl.rank_counts(test, 1, q1, i1).cpu().numpy()
+    fq, fi = np.concatenate([q0, q1 + nq]), np.concatenate([i0, i1])
+    perm = rs.permutation(len(fq))
+    both = mdl.rank_counts(test, 2, fq[perm], fi[perm]).cpu().numpy()
+    assert both.shape == (2 * nq,)
+    assert np.array_equal(both[:nq], c0) and np.array_equal(both[nq:], c1)
+    cut = N // 3
+    acc = mdl.rank_counts(test, 2, fq[perm], fi[perm], cand_offset=0, cand_rows=cut)
+    acc = mdl.rank_counts(test, 2, fq[perm], fi[perm], cand_offset=cut, cand_rows=N - cut, counts=acc).cpu().numpy()
+    assert np.array_equal(acc, both)
+    mdl._raise_on_flag()
