@@ -310,8 +310,10 @@ def eval_sharded_leg(torch, dist, rank, world, reps=3):
     idx = D.split_queries(nt, rank, world).numpy()
     mine = torch.from_numpy(test[idx]).cuda()
     sel = np.isin(fq_all, idx)
-    fq1 = torch.from_numpy(np.searchsorted(idx, fq_all[sel]).astype(np.int32)).cuda()
-    fi1 = torch.from_numpy(fi_all[sel]).cuda()
+    fq1 = np.searchsorted(idx, fq_all[sel]).astype(np.int32)
+    # (both sides of a rank's test triples in one sweep: kge_rank_counts side 2, head queries numbered behind the tail queries)
+    fq1 = torch.from_numpy(np.concatenate([fq1, fq1 + len(idx)])).cuda()
+    fi1 = torch.from_numpy(np.concatenate([fi_all[sel], fi_all[sel]])).cuda()
     ag = [0.0]
 
     def sched1():
@@ -319,21 +321,20 @@ def eval_sharded_leg(torch, dist, rank, world, reps=3):
         e0.record()
         model.E.copy_(D.allgather_rows(shard, N))
         e1.record()
-        t = 1 + model.rank_counts(mine, 0, fq1, fi1).long()
-        h = 1 + model.rank_counts(mine, 1, fq1, fi1).long()
-        out = D.gather_ranks(t, nt), D.gather_ranks(h, nt)
+        c = 1 + model.rank_counts(mine, 2, fq1, fi1).long()
+        out = D.gather_ranks(c[:len(idx)], nt), D.gather_ranks(c[len(idx):], nt)
         torch.cuda.synchronize()
         ag[0] += e0.elapsed_time(e1)
         return out
 
     # schedule (ii): resident shards, referenced rows exchanged, counts all-reduced
-    fq2, fi2 = torch.from_numpy(fq_all).cuda(), torch.from_numpy(fi_all).cuda()
+    fq2, fi2 = torch.from_numpy(np.concatenate([fq_all, fq_all + nt])).cuda(), torch.from_numpy(np.concatenate([fi_all, fi_all])).cuda()
 
     # (what depends on the test set and the shard boundaries only is prepared once: dist.ResidentShardPlan)
     plan2 = D.ResidentShardPlan(test, shard.shape[0], lo, shard.device, n_entities=N)
 
     def sched2():
-        return plan2.run(lambda ref, local, side: model.rank_counts_shard(ref, local, side, fq2, fi2, shard, lo), shard)
+        return plan2.run(lambda ref, local, side: model.rank_counts_shard(ref, local, side, fq2, fi2, shard, lo), shard, both=True)
 
     def timed(fn):
         fn()

@@ -193,9 +193,16 @@ class ResidentShardPlan:
         allreduce_sum_([self.ref], group)
         return self.ref
 
-    def run(self, count_fn, shard, group=None):
-        """(tail_ranks, head_ranks) int64 on every rank; count_fn(ref_rows, test_local (device int32), side) as in resident_shard_eval."""
+    def run(self, count_fn, shard, group=None, both=False):
+        """(tail_ranks, head_ranks) int64 on every rank; count_fn(ref_rows, test_local (device int32), side) as in resident_shard_eval.
+        both=True: count_fn is called ONCE with side 2 and returns the 2 n counts of both sides, tail queries first (kge_rank_counts,
+        side 2: one sweep of the shard for all queries) -- one launch and one all-reduce of the counts instead of two."""
         ref = self.referenced(shard, group)
+        if both:
+            c = count_fn(ref, self.local, 2).to(torch.int32)
+            allreduce_sum_([c], group)
+            r = 1 + c.to(torch.int64)
+            return r[:self.n], r[self.n:]
         out = []
         for side in (0, 1):
             c = count_fn(ref, self.local, side).to(torch.int32)

@@ -609,7 +609,8 @@ class EmbeddingModel:
         ref_rows = ref_rows.contiguous()
         shard = shard.contiguous()
         t = as_triples(triples_local, self.device, ref_rows.shape[0], self.num_relations)
-        nq = t.shape[0]
+        nt = t.shape[0]
+        nq = nt * (2 if int(side) == 2 else 1)  # (side 2: both sides in one sweep of the shard, 2 n counts, tail queries first)
         md = self._model_desc(False)
         md.num_entities = int(ref_rows.shape[0])
         need = check(lib.kge_rank_workspace_bytes(C.byref(md), nq))
@@ -621,7 +622,7 @@ class EmbeddingModel:
         if counts is None:
             counts = torch.empty(nq, dtype=torch.int32, device=self.device)
         check(lib.kge_rank_counts(C.byref(md), ref_rows.data_ptr(), self.Rel.data_ptr(), shard.data_ptr(), int(lo), int(shard.shape[0]),
-                                  t.data_ptr(), nq, int(side), fq.data_ptr() if fq.numel() else None,
+                                  t.data_ptr(), nt, int(side), fq.data_ptr() if fq.numel() else None,
                                   fi.data_ptr() if fi.numel() else None, fq.numel(), counts.data_ptr(), 1 if acc else 0, None,
                                   self._rank_ws.data_ptr(), self._rank_ws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
         return counts

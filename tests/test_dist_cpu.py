@@ -91,6 +91,8 @@ def _resident_worker(rank, world):
     shard = torch.from_numpy(E[lo:hi].copy())
 
     def count_fn(ref, local, side):  # what kge_rank_counts does on the GPU, restated with NumPy on this rank's rows
+        if side == 2:  # both sides in one call: 2 n counts, tail queries first
+            return torch.cat([count_fn(ref, local, 0), count_fn(ref, local, 1)])
         ref = ref.numpy()
         out = np.zeros(len(local), dtype=np.int32)
         for i, (s, p, o) in enumerate(local.tolist()):
@@ -116,6 +118,8 @@ def _resident_worker(rank, world):
         for _ in range(2):
             t2, h2 = plan.run(count_fn, shard)
             assert torch.equal(t, t2) and torch.equal(h, h2)
+            t3, h3 = plan.run(count_fn, shard, both=True)  # one count call and one all-reduce for both sides
+            assert torch.equal(t, t3) and torch.equal(h, h3)
     return t.numpy(), h.numpy()
 
 

@@ -28,19 +28,20 @@ for world in (1, 2, 4, 8):
     idx = D.split_queries(nt, rank, world).numpy()
     mine = torch.from_numpy(test[idx]).cuda()
     sel = np.isin(fq_all, idx)
-    fq1 = torch.from_numpy(np.searchsorted(idx, fq_all[sel]).astype(np.int32)).cuda()
-    fi1 = torch.from_numpy(fi_all[sel]).cuda()
+    fq1 = np.searchsorted(idx, fq_all[sel]).astype(np.int32)
+    fq1 = torch.from_numpy(np.concatenate([fq1, fq1 + len(idx)])).cuda()  # side 2: head queries numbered behind the tail queries
+    fi1 = torch.from_numpy(np.concatenate([fi_all[sel], fi_all[sel]])).cuda()
     lo, hi = D.shard_range(N, rank, world)
     shard = model.E[lo:hi].clone()
-    fq2, fi2 = torch.from_numpy(fq_all).cuda(), torch.from_numpy(fi_all).cuda()
+    fq2, fi2 = torch.from_numpy(np.concatenate([fq_all, fq_all + nt])).cuda(), torch.from_numpy(np.concatenate([fi_all, fi_all])).cuda()
 
     def s1():
-        return 1 + model.rank_counts(mine, 0, fq1, fi1).long(), 1 + model.rank_counts(mine, 1, fq1, fi1).long()
+        return 1 + model.rank_counts(mine, 2, fq1, fi1).long()
 
     plan2 = D.ResidentShardPlan(test, shard.shape[0], lo, shard.device)
 
     def s2():
-        return plan2.run(lambda ref, local, side: model.rank_counts_shard(ref, local, side, fq2, fi2, shard, lo), shard)
+        return plan2.run(lambda ref, local, side: model.rank_counts_shard(ref, local, side, fq2, fi2, shard, lo), shard, both=True)
 
     for name, fn in (("i ", s1), ("ii", s2)):
         fn()
