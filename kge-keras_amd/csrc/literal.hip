@@ -85,7 +85,7 @@ constexpr int kLitHoleMax = 512;  // HolE rows in LDS: 4 waves x 3 rows x 512 fl
 // per triple: s_hat = H[t], o_hat = H[n+t], p' = Rel[p]*mask.  MODE 0: score.  MODE 1: row gradients dH[t], dH[n+t], dP[t] (masked).
 template <int MODEL, int NORM, int MODE, bool DROP>
 __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, const int32_t* __restrict__ pos, int64_t m_pos,
-                                                 const int32_t* __restrict__ neg, int64_t m_neg, int R, int d, float gamma,
+                                                 const int32_t* __restrict__ neg, int64_t m_neg, int R, int d, float gamma, float modulus,
                                                  const float* __restrict__ H, const float* __restrict__ g, float* __restrict__ scores,
                                                  float* __restrict__ dH, float* __restrict__ dP, uint64_t seed, uint32_t thr, float dscale) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -151,13 +151,18 @@ __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, c
       } else {
         const float sv = hs[k], pv = rp[k] * mp(k), ov = ho[k];
         if (MODEL == KGE_DISTMULT) acc += sv * pv * ov;
-        else { const float x = sv + pv - ov; acc += NORM == 1 ? fabsf(x) : x * x; }
+        else {  // NORM 1 / 2: |x|, x^2;  3: the pRotatE phase distance |sin(x/2)| (models.py:479-489);  5: |x|^p, p in `modulus`
+          const float x = sv + pv - ov;
+          acc += NORM == 1 ? fabsf(x) : (NORM == 3 ? phase_abs(x) : (NORM == 5 ? powf(fabsf(x), modulus) : x * x));
+        }
       }
     }
     acc = group_sum<64>(acc);
     float dist = acc, score = acc;
     if (MODEL == KGE_TRANSE) {
       if (NORM == 2) dist = sqrtf(acc);
+      if (NORM == 3) dist = modulus * acc;
+      if (NORM == 5) dist = powf(acc, 1.f / modulus);
       score = gamma > 0.f ? gamma - dist : dist;
     }
     if (MODE == 0) {
@@ -171,11 +176,18 @@ __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, c
     float* dp = dP + t * d;
     if (MODEL == KGE_TRANSE) {
       const float sgn = gamma > 0.f ? -gi : gi;
-      const float rn = NORM == 2 ? (dist > 0.f ? sgn / dist : 0.f) : sgn;
+      // d dist / d x_k:  1: sign(x);  2: x / dist;  3: modulus/2 * sign(sin(x/2)) cos(x/2);  5: sign(x) |x|^(p-1) dist^(1-p)
+      float rn = NORM == 2 ? (dist > 0.f ? sgn / dist : 0.f) : sgn;
+      if (NORM == 3) rn = 0.5f * modulus * sgn;
+      if (NORM == 5) rn = dist > 0.f ? sgn * powf(dist, 1.f - modulus) : 0.f;
       for (int k = lane; k < width; k += 64) {
         const float b = mp(k);
         const float x = hs[k] + rp[k] * b - ho[k];
-        const float dx = NORM == 1 ? (x > 0.f ? rn : (x < 0.f ? -rn : 0.f)) : rn * x;
+        float dx;
+        if (NORM == 1) dx = x > 0.f ? rn : (x < 0.f ? -rn : 0.f);
+        else if (NORM == 3) dx = rn * phase_dterm(x);
+        else if (NORM == 5) dx = x == 0.f ? 0.f : rn * copysignf(powf(fabsf(x), modulus - 1.f), x);
+        else dx = rn * x;
         ds[k] = dx; dob[k] = -dx; dp[k] = dx * b;
       }
     } else if (MODEL == KGE_DISTMULT) {
@@ -253,8 +265,6 @@ static int lit_check(const kge_model_desc* md, int L, int act) {
     return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE, ComplEx and HolE are built)", md->model);
   if (md->model == KGE_HOLE && md->d_e > kLitHoleMax)
     return fail(KGE_EUNSUPPORTED, "literal path under HolE: rows of at most %d floats (e_dim = %d)", kLitHoleMax, md->d_e);
-  if (md->model == KGE_TRANSE && (md->norm == 3 || md->norm == 5))
-    return fail(KGE_EUNSUPPORTED, "literal path: the pRotatE phase distance (norm 3) and the general p-norm (norm 5) are not built here");
   if (L <= 0) return fail(KGE_EINVAL, "literal path: literal width %d", L);
   if (act < 0 || act > 8) return fail(KGE_EUNSUPPORTED, "literal path: activation id %d (softmax and custom callables are not built)", act);
   return KGE_OK;
@@ -310,8 +320,8 @@ static void launch_rows(bool drop, int grid, hipStream_t st, const float* Rel, c
                         const kge_model_desc* md, const float* H, const float* g, float* scores, float* dH, float* dP, uint64_t seed) {
   const uint32_t thr = drop_thr(md->dropout);
   const float dscale = 1.f / (1.f - md->dropout);
-  if (drop) hipLaunchKernelGGL((lit_rows<MODEL, NORM, MODE, true>), dim3(grid), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, md->d_e, md->gamma, H, g, scores, dH, dP, seed, thr, dscale);
-  else hipLaunchKernelGGL((lit_rows<MODEL, NORM, MODE, false>), dim3(grid), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, md->d_e, md->gamma, H, g, scores, dH, dP, seed, thr, dscale);
+  if (drop) hipLaunchKernelGGL((lit_rows<MODEL, NORM, MODE, true>), dim3(grid), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, md->d_e, md->gamma, md->modulus, H, g, scores, dH, dP, seed, thr, dscale);
+  else hipLaunchKernelGGL((lit_rows<MODEL, NORM, MODE, false>), dim3(grid), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, md->d_e, md->gamma, md->modulus, H, g, scores, dH, dP, seed, thr, dscale);
 }
 
 template <int MODE>
@@ -322,6 +332,8 @@ static void launch_rows_model(bool drop, int grid, hipStream_t st, const float* 
   else if (md->model == KGE_COMPLEX) launch_rows<KGE_COMPLEX, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->model == KGE_HOLE) launch_rows<KGE_HOLE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->norm == 1) launch_rows<KGE_TRANSE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+  else if (md->norm == 3) launch_rows<KGE_TRANSE, 3, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+  else if (md->norm == 5) launch_rows<KGE_TRANSE, 5, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else launch_rows<KGE_TRANSE, 2, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
 }
 

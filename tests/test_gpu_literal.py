@@ -69,6 +69,38 @@ def test_literal_train_step_parity(model, kw, loss, act, dp):
         np.testing.assert_allclose(b, Ho["b"], atol=TOL)
 
 
+@pytest.mark.parametrize("model,kw", [("pRotatE", {}), ("pRotatE", dict(gamma=0)), ("TransE", dict(norm=3.5, gamma=12)), ("TransE", dict(norm=1.5, gamma=0))])
+@pytest.mark.parametrize("dp", [0.0, 0.25])
+def test_literal_under_protate_and_general_p_norm(model, kw, dp):
+    """models.py:152-158 is model agnostic: the literal transform in front of pRotatE's phase distance (:479-489) and of TransE with any
+    positive real tf.norm order (:188) -- two steps (scores, loss, both tables, the Dense) against the oracle, with and without dropout;
+    predict and the 1-vs-all ranks on the transformed table."""
+    N, R, d, L, m = 30, 4, 16, 5, 200
+    mdl, E0, R0, lit, H, rs = _mk(model, N, R, d, L, "tanh", seed=4, dp=dp, loss_function="pointwize_logistic", margin=0.5, **kw)
+    mdl.compile("adam")
+    norm = mdl.modulus if model == "pRotatE" else kw["norm"]
+    gamma = kw.get("gamma", 12)
+    Eo, Ro, Ho, Lo = E0.astype(np.float64), R0.astype(np.float64), _f64(H), lit.astype(np.float64)
+    oo = O.AdamTF()
+    for step in range(2):
+        pos, neg = _tri(rs, m, N, R), _tri(rs, m, N, R)
+        sc = torch.empty(2 * m, dtype=torch.float32, device="cuda")
+        L_ = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+        Lr, sp, sn = O.literal_train_step(model, Ho, "tanh", Eo, Ro, Lo, oo, pos, neg, "pointwize_logistic", 0.5, 1, norm, gamma, dropout=dp, seed=mdl._seed)
+        np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
+        assert L_ == pytest.approx(Lr, abs=TOL, rel=1e-4), (step, L_, Lr)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        W, b = mdl.get_literal_dense()
+        np.testing.assert_allclose(W, Ho["W"], atol=TOL)
+        np.testing.assert_allclose(b, Ho["b"], atol=TOL)
+    t = _tri(rs, 100, N, R)
+    s_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 0], "tanh")
+    o_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 2], "tanh")
+    np.testing.assert_allclose(mdl.predict(t), O.score_rows(model, s_, Ro[t[:, 1]], o_, norm, gamma), atol=TOL, rtol=1e-4)
+    mdl._raise_on_flag()
+
+
 def test_literal_weight_gradient_split_contraction():
     """Batches large enough for the Dense layer's weight gradient to be computed as slabs of the contraction over the stacked
     rows (strided-batched GEMM + ordered sum, plus a tail GEMM for the rows that do not fill a slab): 2n = 8310 rows = 4 slabs of 2077 + a tail of 2."""
