@@ -105,7 +105,7 @@ def make_model(w):
     return model
 
 
-def make_pipeline(torch, model, w, rank, total_steps, graphs=True, between=None, between_halves=None):
+def make_pipeline(torch, model, w, rank, total_steps, graphs=True, between=None, between_halves=None, comm=None, world=1):
     """The benched object: TrainPipeline over the device sampler seeded like the host generator of make_batches()."""
     from kge_keras_amd.pipeline import TrainPipeline
     from kge_keras_amd.sampler import NumpyStream, PythonStream, DeviceSampler
@@ -113,7 +113,8 @@ def make_pipeline(torch, model, w, rank, total_steps, graphs=True, between=None,
     perm = nps.shuffle(np.arange(CFG["n_train"], dtype=np.int64))  # epoch permutation (host, once per epoch)
     train_dev, perm_dev = torch.from_numpy(w["train"]).cuda(), torch.from_numpy(perm).cuda()
     dsamp = DeviceSampler(nps, PythonStream(rank))
-    pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=graphs, between=between, between_halves=between_halves)
+    pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=graphs, between=between, between_halves=between_halves,
+                         comm=comm, world=world)
     nb_epoch = CFG["n_train"] // CFG["B"]
     pipe.load_epoch(perm_dev, [i % nb_epoch for i in range(total_steps)])
     return pipe, dsamp
@@ -398,6 +399,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of the benched path against the oracle (outside the timed region)")
     ap.add_argument("--no-sharded-eval", action="store_true", help="skip the YAGO3-10-shape sharded evaluation leg (profiling passes: keeps the sweep kernel's statistics on one shape)")
     ap.add_argument("--dp-overlap", choices=["auto", "on", "off"], default="auto", help="N > 1: start the all-reduce of the entity gradient table behind the entity half of the gradients, beside the relation half (auto: nccl backend only)")
+    ap.add_argument("--dp-native", choices=["auto", "on", "off"], default="auto", help="N > 1: the data-parallel step inside the native pipeline driver, all-reduces on an RCCL communicator of the library's own (auto: nccl backend, falls back to the Python loop over torch.distributed when the communicator cannot be made)")
     ap.add_argument("--sampler", default="device", choices=["device", "pre"],
                     help="device: every step's batch is drawn by the bit-exact MT19937 HIP sampler on a side stream, one batch ahead "
                          "(inside the timed region); pre: batches pre-built on the host before timing")
@@ -469,6 +471,7 @@ def main():
     launch = args.launch if args.launch != "auto" else "graph"
     use_pipe = args.sampler == "device" and plan_ahead and launch == "graph"
     pipe = dsamp = None
+    comm = comm_destroy = dp_native_note = None
     if use_pipe:
         # gradient tables and the loss word are one flat buffer.  The entity half of the gradients needs nothing from the forward
         # (kge_train_grads_planned_parts): the all-reduce of its table -- 11.6 of the 11.8 MB -- starts right behind it and runs while
@@ -490,8 +493,25 @@ def main():
                 dist.all_reduce(model._gall, op=dist.ReduceOp.SUM)
             return 1.0 / world
         between = between_fn if dist_on else None
+        # the data-parallel step inside the native driver (kge_pipeline_desc.comm): an RCCL communicator of the library's own
+        if dist_on and (args.dp_native == "on" or (args.dp_native == "auto" and args.backend == "nccl")):
+            try:
+                comm, comm_destroy = D.make_rccl_comm()
+            except Exception as e:  # (e.g. the gloo rehearsal with two ranks on one GPU: RCCL refuses duplicate devices)
+                if args.dp_native == "on":
+                    raise
+                dp_native_note = f"native data-parallel step not available ({e!r}): Python loop over torch.distributed"
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks or none
+            if int(ok.item()) == 0 and comm is not None:
+                comm_destroy()
+                comm = None
+        if comm is not None:
+            between = None
         total = args.warmup + args.settle + 3 * args.steps + 8
-        pipe, dsamp = make_pipeline(torch, model, w, rank, total, graphs=True, between=between, between_halves=between_halves if dist_on and overlap else None)
+        pipe, dsamp = make_pipeline(torch, model, w, rank, total, graphs=True, between=between, between_halves=between_halves if dist_on and overlap and comm is None else None,
+                                    comm=comm, world=world)
         if args.serial:
             pipe.use_graphs, pipe.serial = False, True
         pipe.start()
@@ -763,7 +783,8 @@ def main():
                          "host_graph_launch_ms_per_step": host_stats["graph_launch_ms"] / args.steps if host_stats else None,
                          "host_wait_by_stage_ms_per_step": {k: v / args.steps for k, v in host_stats["wait_by_stage_ms"].items()} if host_stats else None,
                          "launch": (("the library's native loop (kge_pipeline_run: one C call for the K timed steps) launches every stage's kernels on four streams (generator rounds | draw | plan | step); the step is two launches (step1_kernel, rel_tail_kernel) between twin tables" if not dist_on else
-                                     "draw and plan stages replayed from hipGraphs on their streams; the step (gradient half, all-reduce, optimizer half) launched kernel by kernel")
+                                     ("the library's native loop issues every stage on its streams; the step is the data-parallel one (entity half of the gradients, all-reduce of its table on an RCCL communicator of the library's own beside the relation half, all-reduce of the rest, optimizer half)" if comm is not None else
+                                      "draw and plan stages replayed from hipGraphs on their streams; the step (gradient half, all-reduce, optimizer half) launched kernel by kernel from Python over torch.distributed" + (f" [{dp_native_note}]" if dp_native_note else "")))
                                     + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap)"
                                     if pipe is not None
                                     else "kernel-by-kernel stream launches"),
@@ -789,6 +810,10 @@ def main():
         print(json.dumps(res), flush=True)
     if dist_on:
         dist.barrier()
+        if pipe is not None:
+            pipe.close()
+        if comm_destroy is not None:
+            comm_destroy()
         dist.destroy_process_group()
 
 

@@ -499,6 +499,19 @@ typedef struct {
                                * also when it fails half way (should even that copy fail, kge_pipeline_state reports parity 1) */
   void* plan3;                /* optional third plan buffer (plan_bytes, zero-filled like the others): the plan of batch k+2 then waits for
                                * step k-1 instead of step k -- no plan stage trails the last step of a run */
+  void* plan_more[3];         /* optional further plan buffers behind plan3 (plan_bytes each, zero-filled, NULL-terminated).  With four or
+                               * more buffers in all the loop records "plan consumed" on the step stream behind every (buffers - 2)-th
+                               * step only (an experiment knob: at the bench shape three buffers measure fastest) */
+  void* comm;                 /* optional: an RCCL communicator (ncclComm_t) the caller made over `world` ranks, one process per GPU.  With
+                               * it every step is a data-parallel step: gradient half into gradE / gradRel, all-reduce(sum)
+                               * of grad_flat over the ranks, kge_opt_apply(grad_scale = 1 / world) -- issued by the same native loop.
+                               * Where the halves of the gradient computation come apart (kge_train_grads_halves_supported) the
+                               * all-reduce of gradE runs on a stream of its own while the relation half still computes.  The twin
+                               * tables are not used (the gradient tables must exist to be exchanged).  *loss_out and the step state's
+                               * loss sum then hold the SUM of the ranks' losses */
+  int32_t world;
+  float* grad_flat;           /* with comm: the flat buffer one all-reduce covers -- gradE first ([gradE | gradRel | ... | loss word]) */
+  int64_t grad_flat_n;        /* its length in floats */
 } kge_pipeline_desc;
 int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void** handle);
 int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream);

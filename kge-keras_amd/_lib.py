@@ -55,7 +55,8 @@ class PipelineDesc(C.Structure):
                 ("sampler_plan", C.c_void_p), ("sampler_ws", C.c_void_p), ("sampler_ws_bytes", C.c_int64), ("sampler_err", C.c_void_p),
                 ("sampler_stream", C.c_void_p), ("sampler_stream_bytes", C.c_int64), ("sampler_stream_plan", C.c_void_p),
                 ("cand_rows", C.c_void_p * 2), ("cand_counts", C.c_void_p * 2), ("plan", C.c_void_p * 2), ("plan_bytes", C.c_int64),
-                ("pos", C.c_void_p * 2), ("neg", C.c_void_p * 2), ("E_twin", C.c_void_p), ("Rel_twin", C.c_void_p), ("plan3", C.c_void_p)]
+                ("pos", C.c_void_p * 2), ("neg", C.c_void_p * 2), ("E_twin", C.c_void_p), ("Rel_twin", C.c_void_p), ("plan3", C.c_void_p), ("plan_more", C.c_void_p * 3),
+                ("comm", C.c_void_p), ("world", C.c_int32), ("grad_flat", C.c_void_p), ("grad_flat_n", C.c_int64)]
 
 
 _P, _I64, _I32, _U64, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_float

@@ -50,9 +50,24 @@ struct Pipeline {
   kge_pipeline_desc d;
   hipStream_t s_gen = nullptr, s_draw = nullptr, s_plan = nullptr;
   bool borrowed[3] = {false, false, false};  // the stream is one of the process-wide CU-masked streams: not destroyed with the pipeline
-  hipEvent_t gen[2] = {}, ready[2] = {}, planned[3] = {}, pfreed[3] = {};  // (planned / pfreed: per plan buffer)
-  int np = 2;                      // plan buffers: 3 with kge_pipeline_desc.plan3 (the plan of batch k+2 then only waits for step k-1)
+  static constexpr int kMaxPlans = 6, kRecs = 8;
+  hipEvent_t gen[2] = {}, ready[2] = {}, planned[kMaxPlans] = {}, pfreed[kMaxPlans] = {};  // (planned / pfreed: per plan buffer)
+  void* plan_buf[kMaxPlans] = {};  // plan[0], plan[1], plan3, plan_more[...]
+  int np = 2;                      // plan buffers in use: batch k is planned into buffer k % np, which step k - np read last
+  // "plan consumed" records of the step stream: behind every rec_every-th step (rec_every = max(1, np - 2)); the plan of batch k waits
+  // for the first record at or behind step k - np -- one of the steps k - np .. k - 3, i.e. never later than what three buffers with a
+  // record per step wait for.  Every kge_pipeline_run ends with a record behind its last step, so nothing ever waits for a record
+  // that a later call would have to make.  (More than three buffers were an experiment -- fewer records on the step stream -- and
+  // measured slower: 0.0999 / 0.1005 / 0.102 / 0.104 ms per step with 3 / 4 / 5 / 6 buffers of 53 MB; the default stays three.)
+  int rec_every = 1;
+  struct StepRec { int64_t step; hipEvent_t ev; };
+  StepRec recs[kRecs] = {};        // ring of the last records (direct launches; the captured form keeps a record per step and buffer)
+  hipEvent_t rec_pool[kRecs] = {};
+  int64_t n_recs = 0, last_rec_step = -1;
   hipEvent_t fork = nullptr;
+  hipStream_t s_comm = nullptr;    // data-parallel steps: the stream the all-reduces run on (beside the relation half of the gradients)
+  hipEvent_t half = nullptr, grads = nullptr, reduced = nullptr;
+  bool dp_halves = false;          // the gradient half comes in two independent halves (kge_train_grads_halves_supported)
   hipEvent_t done[kStages][2] = {};      // graphs only: behind the last launch of graph (stage, slot)
   bool launched[kStages][2] = {};
   hipGraphExec_t exec[kStages][2] = {};
@@ -85,7 +100,7 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
   const int64_t m = d.B * d.ns;
   const int pslot = stage == PLAN && !p->graphs ? slot >> 4 : slot;  // (captured stages: two plan buffers, one index)
   if (stage == PLAN && !p->graphs) slot &= 15;
-  void* const plan_buf = pslot < 2 ? d.plan[pslot] : d.plan3;
+  void* const plan_buf = p->plan_buf[pslot];
   switch (stage) {
     case GEN:
       return p->ring ? sampler_stream_produce(d.sampler_stream, d.sampler_stream_bytes, d.B, d.ns, d.num_e, d.sampler_stream_plan, st) : KGE_OK;
@@ -107,6 +122,31 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
       return kge_batch_plan_build_counted(&d.md, &d.ld, d.cand_rows[slot], d.cand_counts[slot], KGE_CAND_POS_LANES, d.B, m, m, m, plan_buf,
                                           d.plan_bytes, 7 | 8, d.err_flag, st);
     default:
+      if (d.comm) {
+        // data-parallel step: [entity half | all-reduce of gradE beside the relation half] -> all-reduce of the rest -> optimizer
+        const uint64_t seed = p->arrays ? ++p->seed : 0;
+        const int64_t nE = (int64_t)d.md.num_entities * d.md.d_e;
+        const float scale = 1.f / (float)d.world;
+        if (p->dp_halves) {
+          if (int rc = kge_train_grads_planned_parts(&d.md, &d.ld, d.E, d.Rel, d.gradE, d.gradRel, plan_buf, d.plan_bytes, m, m, d.loss_out, seed, d.train_ws,
+                                                     d.train_ws_bytes, 1, st)) return rc;
+          KGE_PIPE_TRY(hipEventRecord(p->half, st));
+          KGE_PIPE_TRY(hipStreamWaitEvent(p->s_comm, p->half, 0));
+          if (int rc = kge_allreduce_f32(d.comm, d.grad_flat, nE, p->s_comm)) return rc;
+          if (int rc = kge_train_grads_planned_parts(&d.md, &d.ld, d.E, d.Rel, d.gradE, d.gradRel, plan_buf, d.plan_bytes, m, m, d.loss_out, seed, d.train_ws,
+                                                     d.train_ws_bytes, 2, st)) return rc;
+          KGE_PIPE_TRY(hipEventRecord(p->grads, st));
+          KGE_PIPE_TRY(hipStreamWaitEvent(p->s_comm, p->grads, 0));
+          if (int rc = kge_allreduce_f32(d.comm, d.grad_flat + nE, d.grad_flat_n - nE, p->s_comm)) return rc;
+          KGE_PIPE_TRY(hipEventRecord(p->reduced, p->s_comm));
+          KGE_PIPE_TRY(hipStreamWaitEvent(st, p->reduced, 0));
+        } else {
+          if (int rc = kge_train_grads_planned(&d.md, &d.ld, d.E, d.Rel, d.gradE, d.gradRel, plan_buf, d.plan_bytes, m, m, d.loss_out, seed, d.train_ws,
+                                               d.train_ws_bytes, st)) return rc;
+          if (int rc = kge_allreduce_f32(d.comm, d.grad_flat, d.grad_flat_n, st)) return rc;
+        }
+        return kge_opt_apply(&d.md, &d.ld, &d.od, d.E, d.Rel, d.gradE, d.gradRel, scale, d.loss_out, d.train_ws, d.train_ws_bytes, st);
+      }
       if (p->swap) {  // (the caller moves the parity on; lr_t of the update comes from the device-resident step state)
         const int q = p->parity;
         const int parts = 3;
@@ -196,7 +236,16 @@ int produce(Pipeline* p, int64_t k) {
   if (int rc = launch(p, DRAW, j, p->s_draw, k)) return rc;
   KGE_PIPE_TRY(hipEventRecord(p->ready[j], p->s_draw));
   KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->ready[j], 0));
-  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[pj], 0));  // (the step that consumed this plan buffer: k-2, or k-3 with three buffers)
+  if (p->graphs) {
+    KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[pj], 0));  // (the step that consumed this plan buffer: k-2)
+  } else if (k - p->np >= 0) {  // the first record at or behind step k - np (see Pipeline::rec_every)
+    const int64_t need = k - p->np;
+    const int64_t first = std::max<int64_t>(0, p->n_recs - Pipeline::kRecs);
+    bool found = false;
+    for (int64_t r = first; r < p->n_recs && !found; ++r)
+      if (p->recs[r % Pipeline::kRecs].step >= need) { KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->recs[r % Pipeline::kRecs].ev, 0)); found = true; }
+    if (!found) return fail(KGE_EINVAL, "kge_pipeline: no record of step %lld for the plan of batch %lld (internal)", (long long)need, (long long)k);
+  }
   if (int rc = launch(p, PLAN, p->graphs ? j : (j | (pj << 4)), p->s_plan, k)) return rc;
   KGE_PIPE_TRY(hipEventRecord(p->planned[pj], p->s_plan));
   return KGE_OK;
@@ -211,10 +260,15 @@ void destroy(Pipeline* p) {
   for (int j = 0; j < 2; ++j)
     for (hipEvent_t e : {p->gen[j], p->ready[j]})
       if (e) (void)hipEventDestroy(e);
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < Pipeline::kMaxPlans; ++j)
     for (hipEvent_t e : {p->planned[j], p->pfreed[j]})
       if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->rec_pool)
+    if (e) (void)hipEventDestroy(e);
   if (p->fork) (void)hipEventDestroy(p->fork);
+  for (hipEvent_t e : {p->half, p->grads, p->reduced})
+    if (e) (void)hipEventDestroy(e);
+  if (p->s_comm) (void)hipStreamDestroy(p->s_comm);
   hipStream_t owned[3] = {p->s_gen, p->s_draw, p->s_plan};
   for (int i = 0; i < 3; ++i)
     if (owned[i] && !p->borrowed[i]) (void)hipStreamDestroy(owned[i]);
@@ -244,6 +298,12 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
       (!arrays && (!d.cand_rows[0] || !d.cand_rows[1] || !d.cand_counts[0] || !d.cand_counts[1])))
     return fail(KGE_EINVAL, "kge_pipeline_create: null pointer in the descriptor");
   if (d.B <= 0 || d.ns <= 0 || d.num_e <= 0) return fail(KGE_EINVAL, "kge_pipeline_create: bad batch shape");
+  if (d.comm) {
+    const int64_t nE = (int64_t)d.md.num_entities * d.md.d_e, nR = (int64_t)d.md.num_relations * d.md.d_r;
+    if (d.world < 1 || !d.grad_flat || d.grad_flat != d.gradE || d.grad_flat_n < nE + nR || d.gradRel < d.grad_flat + nE ||
+        d.gradRel + nR > d.grad_flat + d.grad_flat_n || d.loss_out < d.grad_flat + nE || d.loss_out >= d.grad_flat + d.grad_flat_n)
+      return fail(KGE_EINVAL, "kge_pipeline_create: with comm, grad_flat = gradE must cover gradE, gradRel and the loss word (world >= 1)");
+  }
   const int64_t need = kge_batch_plan_bytes(&d.md, &d.ld, d.B * d.ns, d.B * d.ns);
   if (need < 0) return (int)need;
   if (d.plan_bytes < need) return fail(KGE_EWORKSPACE, "kge_pipeline_create: plan buffers have %lld bytes, need %lld", (long long)d.plan_bytes, (long long)need);
@@ -260,14 +320,27 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   if (arrays) p->graphs = false;  // (a captured step would replay one dropout seed)
   // a third plan buffer (direct launches only: the captured stages are per buffer pair): the plan of batch k+2 then waits for step
   // k-1 instead of step k, so at the end of a run no plan stage is left behind the last step (measured at --steps 20: see DESIGN 3.4)
-  p->np = d.plan3 && !p->graphs ? 3 : 2;
-  if (const char* e = std::getenv("KGE_PIPE_PLANS")) { if (std::atoi(e) == 2) p->np = 2; }
+  {
+    int avail = 2;
+    p->plan_buf[0] = d.plan[0]; p->plan_buf[1] = d.plan[1];
+    if (d.plan3) {
+      p->plan_buf[avail++] = d.plan3;
+      for (void* b : d.plan_more) { if (!b || avail == Pipeline::kMaxPlans) break; p->plan_buf[avail++] = b; }
+    }
+    p->np = p->graphs ? 2 : avail;
+    if (const char* e = std::getenv("KGE_PIPE_PLANS")) { const int x = std::atoi(e); if (x >= 2 && x <= avail && !p->graphs) p->np = x; }
+    p->rec_every = std::max(1, p->np - 2);
+    if (const char* e = std::getenv("KGE_PIPE_REC_EVERY")) { const int x = std::atoi(e); if (x >= 1 && x <= p->rec_every) p->rec_every = x; }
+  }
   if (const char* e = std::getenv("KGE_PIPE_RING")) { if (std::atoi(e) == 0) p->ring = false; }
   // twin tables: the step closed by its pull launch (direct launches only: a captured step has its table pointers baked in)
   if ((d.E_twin != nullptr) != (d.Rel_twin != nullptr)) { delete p; return fail(KGE_EINVAL, "kge_pipeline_create: E_twin and Rel_twin go together"); }
   // (with dropout the twin step is available but measured slower than the three-launch step -- 0.46 against 0.39 ms per step at the
   // bench shape, where nothing is folded: 409 600 rows, three masks per element and entry in a kernel that is already register bound)
-  p->swap = d.E_twin && !p->graphs && d.md.dropout == 0.f && kge_train_step_swap_supported(&d.md, &d.ld, &d.od) == 1;
+  p->swap = !d.comm && d.E_twin && !p->graphs && d.md.dropout == 0.f && kge_train_step_swap_supported(&d.md, &d.ld, &d.od) == 1;
+  if (d.comm) p->graphs = false;  // (a collective never sits inside a captured graph)
+  p->dp_halves = d.comm && kge_train_grads_halves_supported(&d.md, &d.ld) == 1;
+  if (const char* e = std::getenv("KGE_PIPE_DP_HALVES")) { if (std::atoi(e) == 0) p->dp_halves = false; }
   if (const char* e = std::getenv("KGE_PIPE_SWAP")) { if (std::atoi(e) == 0) p->swap = false; }
   if (p->graphs && prof_is_on()) {
     delete p;
@@ -361,8 +434,15 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
     }
   }
   KGE_CREATE_TRY(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
-  for (int j = 0; j < 3; ++j)
+  if (d.comm) {
+    int lo2 = 0, hi2 = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo2, &hi2);  // the exchange is on the step's critical path: highest priority
+    KGE_CREATE_TRY(hipStreamCreateWithPriority(&p->s_comm, hipStreamNonBlocking, hi2));
+    for (hipEvent_t* e : {&p->half, &p->grads, &p->reduced}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  for (int j = 0; j < Pipeline::kMaxPlans; ++j)
     for (hipEvent_t* e : {&p->planned[j], &p->pfreed[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipEvent_t& e : p->rec_pool) KGE_CREATE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (int j = 0; j < 2; ++j) {
     for (hipEvent_t* e : {&p->gen[j], &p->ready[j]}) KGE_CREATE_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int s = 0; s < kStages; ++s) KGE_CREATE_TRY(hipEventCreateWithFlags(&p->done[s][j], hipEventDisableTiming));
@@ -396,6 +476,8 @@ int kge_pipeline_start(void* handle, int64_t n_batches, kge_stream_t stream) {
   for (hipStream_t s : {p->s_gen, p->s_draw, p->s_plan}) KGE_PIPE_TRY(hipStreamWaitEvent(s, p->fork, 0));
   p->started = true;
   p->nround = 0;
+  p->n_recs = 0;
+  p->last_rec_step = -1;
   if (p->ring) if (int rc = offer_round(p, -1)) return rc;  // the words of batches 0 .. R-1
   if (int rc = produce(p, 0)) return rc;
   return produce(p, 1);
@@ -424,7 +506,17 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
     if ((rc = launch(p, STEP, j, main_st, p->t)) != KGE_OK) break;
     if (p->swap) p->parity ^= 1;
     p->t += 1;  // (the step is issued: what follows may fail, the step count and the parity of the tables stay true)
-    if (hipEventRecord(p->pfreed[j], main_st) != hipSuccess) { rc = fail(KGE_EHIP, "kge_pipeline_run: hipEventRecord failed"); break; }
+    const int64_t step = p->t - 1;  // the step just issued
+    if (p->graphs) {
+      if (hipEventRecord(p->pfreed[j], main_st) != hipSuccess) { rc = fail(KGE_EHIP, "kge_pipeline_run: hipEventRecord failed"); break; }
+    } else if ((step + 1) % p->rec_every == 0 || i + 1 == n_steps) {
+      Pipeline::StepRec& r = p->recs[p->n_recs % Pipeline::kRecs];
+      r.step = step;
+      r.ev = p->rec_pool[p->n_recs % Pipeline::kRecs];
+      if (hipEventRecord(r.ev, main_st) != hipSuccess) { rc = fail(KGE_EHIP, "kge_pipeline_run: hipEventRecord failed"); break; }
+      p->n_recs += 1;
+      p->last_rec_step = step;
+    }
     rc = produce(p, p->t + 1);
   }
   // the caller reads (E, Rel) -- also after a failure half way: the steps issued so far must not be left in the twins

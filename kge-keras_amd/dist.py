@@ -99,6 +99,38 @@ def dp_train_step(grads_fn, apply_fn, grad_tensors, loss_tensor=None, group=None
     apply_fn(1.0 / ws)
 
 
+def make_rccl_comm(group=None):
+    """An RCCL communicator of this process group's ranks, made through RCCL's own C API (torch.distributed does not hand its
+    communicators out): rank 0 draws the ncclUniqueId, the group broadcasts its 128 bytes (any backend), every rank joins with
+    ncclCommInitRank on its current device.  What the library's collectives (kge_allreduce_f32 / kge_allgather_rows /
+    kge_allreduce_counts) and the native data-parallel pipeline (kge_pipeline_desc.comm) take.  Returns (comm as an int, destroy()).
+    Raises when RCCL is not in the process or refuses (e.g. two ranks on one device)."""
+    import ctypes as C
+    rank, ws = world(group)
+    path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln), "librccl.so.1")
+    rccl = C.CDLL(path)  # (the copy PyTorch-ROCm mapped, as the library's own run-time lookup does)
+
+    class UniqueId(C.Structure):  # ncclUniqueId: passed BY VALUE to ncclCommInitRank
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    if rank == 0:
+        rc = rccl.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError(f"ncclGetUniqueId failed ({rc})")
+    if ws > 1:
+        box = [bytes(uid) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        C.memmove(C.byref(uid), box[0], 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rc = rccl.ncclCommInitRank(C.byref(comm), ws, uid, rank)
+    if rc != 0 or not comm.value:
+        raise RuntimeError(f"ncclCommInitRank failed ({rc}) for rank {rank} of {ws}")
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    handle = int(comm.value)
+    return handle, (lambda: rccl.ncclCommDestroy(C.c_void_p(handle)))
+
+
 def sharded_eval(test, side_fn, n_entities, table_shard=None, set_table=None, group=None):
     """Filtered 1-vs-all ranks of `test` (list of triples) with the entity table row-sharded across ranks.
     table_shard/set_table: this rank's rows and a callback installing the gathered full table (skipped when None).

@@ -29,10 +29,16 @@ from . import _lib
 
 
 class TrainPipeline:
-    def __init__(self, model, kg, n_rows, batch_size, ns, num_e, sampler, graphs=True, between=None, between_halves=None):
+    def __init__(self, model, kg, n_rows, batch_size, ns, num_e, sampler, graphs=True, between=None, between_halves=None, comm=None, world=1):
         """kg: (n,3) int32 device rows; n_rows: length of the epoch permutation; sampler: DeviceSampler whose states are loaded.
         `between`: optional callable run between the gradient half and the optimizer half of every step (the data-parallel
-        all-reduce); the optimizer half then stays outside the graphs."""
+        all-reduce); the optimizer half then stays outside the graphs.
+        `comm`, `world`: an RCCL communicator (ncclComm_t as an integer / c_void_p: dist.make_rccl_comm) over `world` ranks -- the
+        data-parallel step then runs inside the native driver (gradient half, all-reduce of the flat gradient buffer with the entity
+        table's share beside the relation half, optimizer half with scale 1 / world); excludes `between`."""
+        if comm is not None and between is not None:
+            raise ValueError("TrainPipeline: either an RCCL communicator (native data-parallel steps) or a `between` hook, not both")
+        self.comm, self.world = comm, int(world)
         if not model.pipeline_supported():
             # (HolE's frequency-domain step takes plans too, but is a composite of library calls, not one captured step)
             raise NotImplementedError("TrainPipeline needs a model / loss with batch plans (EmbeddingModel.plan_supported)")
@@ -61,7 +67,11 @@ class TrainPipeline:
         from .models import BatchPlan
         # plans[0], plans[1]: one per buffer parity; plans[2]: the native driver's third buffer (kge_pipeline_desc.plan3), which the
         # Python loop also uses when it takes an epoch over from the driver (batch k sits in plans[k % self._np])
-        self.plans = [BatchPlan(torch.zeros(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(3)]
+        # (KGE_PIPE_PLAN_BUFFERS = 4..6: further buffers, with which the driver records "plan consumed" on the step stream behind every
+        # (buffers - 2)-th step only -- measured at the bench shape: 0.0999 ms per step with 3, 0.1005 with 4, 0.102 with 5, 0.104 with 6,
+        # so three it is: profiles/r03_experiments.txt)
+        n_plans = max(3, min(6, int(os.environ.get("KGE_PIPE_PLAN_BUFFERS", "3"))))
+        self.plans = [BatchPlan(torch.zeros(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(n_plans)]
         self._np = 2
         self.index = torch.zeros(int(n_rows), dtype=torch.int64, device=self.dev)   # epoch permutation (tests.py:50-53)
         self.starts = None                                                          # batch numbers in drawing order
@@ -71,8 +81,8 @@ class TrainPipeline:
         self.s1, self.s2, self.s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
         self.ready = [torch.cuda.Event() for _ in range(2)]     # batch arrays drawn
         self.freed = [torch.cuda.Event() for _ in range(2)]     # batch arrays no longer needed (their plan is built)
-        self.planned = [torch.cuda.Event() for _ in range(3)]   # plan built (per plan buffer)
-        self.pfreed = [torch.cuda.Event() for _ in range(3)]    # plan consumed
+        self.planned = [torch.cuda.Event() for _ in range(len(self.plans))]   # plan built (per plan buffer)
+        self.pfreed = [torch.cuda.Event() for _ in range(len(self.plans))]    # plan consumed
         self.graphs = {}
         self._done = {}  # (stage, slot) -> event recorded behind the last replay of that graph
         self._sig = None
@@ -114,7 +124,12 @@ class TrainPipeline:
         build(4)
 
     def _stage_T(self, slot):
-        if self.between is None:
+        if self.comm is not None:  # (the Python loop's form of the native data-parallel step: serial / profiling runs)
+            self.model.train_grads(self.plans[slot])
+            g = self.model._gall
+            _lib.check(_lib.lib.kge_allreduce_f32(self.comm if isinstance(self.comm, int) else self.comm.value, g.data_ptr(), g.numel(), _lib.stream_ptr()))
+            self.model.apply_grads(1.0 / self.world)
+        elif self.between is None:
             self.model.train_step(self.plans[slot])  # the step's last kernel adds its loss to the device step state
         elif self.between_halves is not None and self._halves_ok():
             self.model.train_grads(self.plans[slot], parts=1)
@@ -137,7 +152,7 @@ class TrainPipeline:
     # ------------------------------------------------------------------ graphs
     def _signature(self):
         mo, sa = self.model, self.sampler
-        t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws, self.plans[0].buf, self.plans[1].buf, self.plans[2].buf, self.starts,
+        t = [mo.E, mo.Rel, mo._gall, mo._ws, mo._err, sa.np_state, sa.py_state, sa._ws] + [pl.buf for pl in self.plans] + [self.starts,
              getattr(sa, "_stream", None)]
         t += [x for c in self.cand if c is not None for x in c]
         t += [x for b in self.bufs if b is not None for x in b]
@@ -145,7 +160,8 @@ class TrainPipeline:
             t += list(self._twins)
         if mo.optimizer.slots:
             t += list(mo.optimizer.slots)
-        return tuple(x.data_ptr() for x in t if x is not None) + (mo.optimizer.kind, mo.optimizer.lr, mo.loss_function, float(mo.margin or 1))
+        return tuple(x.data_ptr() for x in t if x is not None) + (mo.optimizer.kind, mo.optimizer.lr, mo.loss_function, float(mo.margin or 1),
+                                                                  None if self.comm is None else (self.comm if isinstance(self.comm, int) else self.comm.value), self.world)
 
     def _capture(self):
         """Capture the three stages for both buffer parities.  Capturing enqueues nothing; host-side counters the stages bump
@@ -269,10 +285,15 @@ class TrainPipeline:
                 d.pos[j], d.neg[j] = self.bufs[j][0].data_ptr(), self.bufs[j][1].data_ptr()
             d.plan[j] = self.plans[j].buf.data_ptr()
         d.plan_bytes = min(pl.buf.numel() for pl in self.plans)
-        d.plan3 = self.plans[2].buf.data_ptr()  # third plan buffer of the native driver
+        d.plan3 = self.plans[2].buf.data_ptr()  # third plan buffer of the native driver, and the further ones
+        for i, pl in enumerate(self.plans[3:6]):
+            d.plan_more[i] = pl.buf.data_ptr()
         # twin tables: steps alternate between (E, Rel) and these (kge_train_step_swap); run() leaves the current ones in (E, Rel)
         if self._twins is not None:
             d.E_twin, d.Rel_twin = self._twins[0].data_ptr(), self._twins[1].data_ptr()
+        if self.comm is not None:  # native data-parallel steps: one flat buffer [gradE | gradRel | pad | loss word] to all-reduce
+            d.comm = self.comm if isinstance(self.comm, int) else self.comm.value
+            d.world, d.grad_flat, d.grad_flat_n = self.world, mo._gall.data_ptr(), mo._gall.numel()
         h = C.c_void_p()
         _lib.check(_lib.lib.kge_pipeline_create(C.byref(d), _lib.stream_ptr(), C.byref(h)))
         self._h, self._h_sig = h, sig
@@ -391,7 +412,7 @@ class TrainPipeline:
             mo._step_dev = self.step_dev
             # twin tables (kge_train_step_swap: lr_t of every update comes from the device step state, so the step may also be one
             # of this object's captured stages); with dropout the three-launch step is the faster one
-            if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0:
+            if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0 and self.comm is None:
                 if self._twins is None or self._twins[0].shape != mo.E.shape or self._twins[1].shape != mo.Rel.shape:
                     self._twins = (torch.empty_like(mo.E), torch.empty_like(mo.Rel))
                 mo._step_twins = self._twins

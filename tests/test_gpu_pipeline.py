@@ -344,7 +344,7 @@ def test_native_driver_hands_the_epoch_over_to_the_python_loop(datasets, k):
     pipe.run(k)
     pipe.serial = True          # what a profiling pass does: the rest of the epoch on the Python loop, kernel by kernel
     pipe.run(n - k)
-    assert not pipe._native_active and pipe._taken_over and pipe._np == 3
+    assert not pipe._native_active and pipe._taken_over and pipe._np == len(pipe.plans) == 3
     tot = float(pipe.finish().item())
     gen.release_global()
     assert mdl.optimizer.iterations == n + 1
@@ -400,3 +400,46 @@ def test_python_loop_with_captured_twin_step(datasets, opt):
     np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
     np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
     np.testing.assert_allclose(h.history["loss"], losses, rtol=1e-4)
+
+
+@pytest.mark.parametrize("halves", [True, False])
+@pytest.mark.parametrize("model,opt", [("DistMult", "adam"), ("TransE", "sgd")])
+def test_native_data_parallel_step_on_a_one_rank_communicator(datasets, model, opt, halves, monkeypatch):
+    """kge_pipeline_desc.comm: the data-parallel step inside the native driver -- entity half of the gradients, all-reduce of its
+    table on the communicator's own stream beside the relation half, all-reduce of the rest, optimizer half with scale 1 / world.
+    One GPU allows a one-rank RCCL communicator (every collective the identity), which exercises everything but the wire: with it an
+    epoch must equal the host generator + the oracle's steps, with the gradient halves apart and in one piece."""
+    from kge_keras_amd import dist as D
+    from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
+    from kge_keras_amd.pipeline import TrainPipeline
+    if not halves:
+        monkeypatch.setenv("KGE_PIPE_DP_HALVES", "0")
+    hp = dict(num_entities=14, num_relations=55, dim=32, embedding_model=model, loss_function="pointwize_logistic", margin=1, dp=0.0, seed=9)
+    np.random.seed(51)
+    random.seed(52)
+    mdl = build_model(hp)
+    mdl.compile(opt)
+    E0, R0 = mdl.E.cpu().numpy().astype(np.float64), mdl.Rel.cpu().numpy().astype(np.float64)
+    gen = DeviceDataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    comm, destroy = D.make_rccl_comm()
+    try:
+        pipe = TrainPipeline(mdl, gen.kg, gen.n, gen.batch_size, gen.ns, gen.num_e, gen.sampler, comm=comm, world=1)
+        gen._upload_global()
+        tot = float(pipe.run_epoch(gen.index, list(range(len(gen)))).item())
+        gen.release_global()
+        assert pipe._h is not None and pipe._twins is None and mdl.optimizer.iterations == len(gen)
+        pipe.close()
+    finally:
+        destroy()
+    mdl._raise_on_flag()
+    np.random.seed(51)
+    random.seed(52)
+    hgen = DataGenerator(datasets["nations_train"], ns=100, batch_size=64)
+    oo = O.make_optimizer(opt)
+    ref = 0.0
+    for i in range(len(hgen)):
+        (pos, neg), _y = hgen[i]
+        ref += O.train_step(model, E0, R0, oo, pos, neg, "pointwize_logistic", 1.0, 1)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), E0, atol=TOL)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), R0, atol=TOL)
+    assert tot == pytest.approx(ref, rel=1e-5)
