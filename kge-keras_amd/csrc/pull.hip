@@ -205,9 +205,36 @@ __global__ __launch_bounds__(256) void hist_kernel(const int32_t* __restrict__ p
 // Offsets of the per-key lists: one workgroup per tile of 1024 keys (scan_tile_body, pull.hpp); also writes the (key, chunk) map.
 __global__ __launch_bounds__(256) void scan_mb_kernel(const int32_t* __restrict__ cnt, int NK, int C, int32_t* __restrict__ off,
                                                        int32_t* __restrict__ eoff, int32_t* __restrict__ poff,
-                                                       int32_t* __restrict__ totals, int2* __restrict__ emap, int max_extra) {
+                                                       int32_t* __restrict__ totals, int2* __restrict__ emap, int max_extra,
+                                                       const Tri* __restrict__ tsum, const Tri* __restrict__ ssum) {
   __shared__ Tri red[8];
-  scan_tile_body(cnt, NK, C, blockIdx.x, off, eoff, poff, totals, emap, max_extra, red);
+  scan_tile_body(cnt, NK, C, blockIdx.x, off, eoff, poff, totals, emap, max_extra, red, tsum, ssum);
+}
+
+// Large tables (more than kScanDirect tiles): the sum of every tile of 1024 counters, then of every group of 1024 tile sums.
+__device__ __forceinline__ Tri tri_block_sum(Tri v, Tri* red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = tri_add(v, Tri{__shfl_xor(v.a, d, 64), __shfl_xor(v.b, d, 64), __shfl_xor(v.c, d, 64)});
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return tri_add(tri_add(red[0], red[1]), tri_add(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void scan_tsum_kernel(const int32_t* __restrict__ cnt, int NK, int C, Tri* __restrict__ tsum) {
+  __shared__ Tri red[4];
+  const int k0 = blockIdx.x * kScanTile + threadIdx.x * 4;
+  Tri v{0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (k0 + j < NK) v = tri_add(v, tri_of(cnt[k0 + j], C));
+  v = tri_block_sum(v, red);
+  if (threadIdx.x == 0) tsum[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(256) void scan_ssum_kernel(const Tri* __restrict__ tsum, int tiles, Tri* __restrict__ ssum) {
+  __shared__ Tri red[4];
+  Tri v{0, 0, 0};
+  for (int i = blockIdx.x * kScanGroup + threadIdx.x; i < min(tiles, (int)(blockIdx.x + 1) * kScanGroup); i += 256) v = tri_add(v, tsum[i]);
+  v = tri_block_sum(v, red);
+  if (threadIdx.x == 0) ssum[blockIdx.x] = v;
 }
 
 // Atomic-free list fill: position = list start of the destination + the rank handed out by hist_kernel.
@@ -244,6 +271,18 @@ int fwd_group_width(int nchunk);
 
 static int64_t a256(int64_t x) { return align_up(x, 256); }
 
+int64_t scan_sums_bytes(int64_t NK) {
+  const int64_t tiles = cdiv(NK, kScanTile);
+  return a256(tiles * (int64_t)sizeof(Tri)) + a256(cdiv(tiles, kScanGroup) * (int64_t)sizeof(Tri));
+}
+bool scan_sums_launch(const int32_t* cnt, int NK, int C, void* tsum, void* ssum, hipStream_t st) {
+  const int tiles = (int)cdiv(NK, kScanTile);
+  if (tiles <= kScanDirect || !tsum || !ssum) return false;
+  hipLaunchKernelGGL(scan_tsum_kernel, dim3(tiles), dim3(256), 0, st, cnt, NK, C, static_cast<Tri*>(tsum));
+  hipLaunchKernelGGL(scan_ssum_kernel, dim3((int)cdiv(tiles, kScanGroup)), dim3(256), 0, st, static_cast<const Tri*>(tsum), tiles, static_cast<Tri*>(ssum));
+  return true;
+}
+
 // The per-key counters live in a header at a FIXED place of the caller's workspace (independent of the batch size and
 // shared by both pull variants): they are the only state that must be zero on entry, and every step leaves them zero.
 int64_t pull_header_bytes(const kge_model_desc* md) { return a256((int64_t)md->num_entities * 4) + a256((int64_t)md->num_relations * 4) + 256; }
@@ -252,7 +291,7 @@ int64_t pull_workspace_bytes(const kge_model_desc* md, int64_t n) {
   const int64_t NK = (int64_t)md->num_entities + md->num_relations;
   const int C = pull_chunk();
   const int64_t max_extra = 3 * n / C + 1;
-  return a256(NK * 4) * 3 + 256 + a256(max_extra * 8) + a256(3 * n * 16) + a256(3 * n * 4) + a256(n * 4) + a256(2 * max_extra * md->d_e * 4) + 1024;
+  return a256(NK * 4) * 3 + 256 + a256(max_extra * 8) + a256(3 * n * 16) + a256(3 * n * 4) + a256(n * 4) + a256(2 * max_extra * md->d_e * 4) + scan_sums_bytes(NK) + 1024;
 }
 
 static void carve_pull(void* hdr, void* ws, const kge_model_desc* md, int64_t n, PullPlan* p) {
@@ -271,6 +310,8 @@ static void carve_pull(void* hdr, void* ws, const kge_model_desc* md, int64_t n,
   p->ranks = (int32_t*)take(3 * n * 4);
   p->coef = (float*)take(n * 4);
   p->slab = (float*)take(2 * max_extra * md->d_e * 4);
+  p->tsum = take(cdiv(NK, kScanTile) * (int64_t)sizeof(Tri));
+  p->ssum = take(cdiv(cdiv(NK, kScanTile), kScanGroup) * (int64_t)sizeof(Tri));
   p->max_extra = (int)max_extra;
   p->chunk = C;
 }
@@ -329,7 +370,9 @@ int pull_prepare(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, co
   const int igrid = (int)cdiv(n, kIdxBlockTriples);
   ProfScope prof(KGE_PROF_INDEX, st);  // index build (ids only)
   hipLaunchKernelGGL(hist_kernel, dim3(igrid), dim3(256), 0, st, pos, m_pos, neg, m_neg, N, md->num_relations, p.cnt, p.ranks);
-  hipLaunchKernelGGL(scan_mb_kernel, dim3((int)cdiv(NK, kScanTile)), dim3(256), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals, p.emap, p.max_extra);
+  const bool big = scan_sums_launch(p.cnt, NK, p.chunk, p.tsum, p.ssum, st);
+  hipLaunchKernelGGL(scan_mb_kernel, dim3((int)cdiv(NK, kScanTile)), dim3(256), 0, st, p.cnt, NK, p.chunk, p.off, p.eoff, p.poff, p.totals, p.emap, p.max_extra,
+                     big ? static_cast<const Tri*>(p.tsum) : nullptr, big ? static_cast<const Tri*>(p.ssum) : nullptr);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }
@@ -418,7 +461,9 @@ int pull_finish_launch(const kge_model_desc* md, float* gE, float* gR, const Pul
 
 // ---- entry points for pull2.hip: the same scan / pull / finish kernels over the N entity keys only
 void pull2_entity_plan(const PullPlan& e, int N, hipStream_t st) {
-  hipLaunchKernelGGL(scan_mb_kernel, dim3((int)cdiv(N, kScanTile)), dim3(256), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals, e.emap, e.max_extra);
+  const bool big = scan_sums_launch(e.cnt, N, e.chunk, e.tsum, e.ssum, st);
+  hipLaunchKernelGGL(scan_mb_kernel, dim3((int)cdiv(N, kScanTile)), dim3(256), 0, st, e.cnt, N, e.chunk, e.off, e.eoff, e.poff, e.totals, e.emap, e.max_extra,
+                     big ? static_cast<const Tri*>(e.tsum) : nullptr, big ? static_cast<const Tri*>(e.ssum) : nullptr);
 }
 
 // (the finish of the entity keys is fused into pull2.hip's rel_finish_kernel)

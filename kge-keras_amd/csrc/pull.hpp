@@ -65,6 +65,8 @@ struct PullPlan {
   int32_t* eoff;    // [NK]   first extra-chunk unit of the key
   int32_t* poff;    // [NK]   first slab slot of a multi-chunk key
   int32_t* totals;  // [4]    {extra units, slab slots}
+  void* tsum;       // [tiles] / [tiles / 1024] Tri: sums of the counters per tile of 1024 keys and per group of 1024 tiles (scan of a
+  void* ssum;       //          large table: scan_sums_launch); may be null where the table never has more than kScanDirect tiles
   int2* emap;       // [max_extra] (key, chunk) of extra units
   int4* entries;    // [3n]   {a | kind<<31, b, coef bits, t}
   float* coef;      // [n]
@@ -110,16 +112,26 @@ struct Tri { int a, b, c; };
 __device__ __forceinline__ Tri tri_add(Tri x, Tri y) { return Tri{x.a + y.a, x.b + y.b, x.c + y.c}; }
 __device__ __forceinline__ Tri tri_of(int n, int C) { const int nch = (n + C - 1) / C; return Tri{n, nch > 1 ? nch - 1 : 0, nch > 1 ? nch : 0}; }
 constexpr int kScanTile = 1024;
+// Summing everything in front of a tile is quadratic in the number of tiles: fine for the tables of the BASELINE configs (15 - 121
+// tiles), not for the tables 288 GB of HBM hold (10 M entities = 9 766 tiles: 45 ms per plan, measured).  Past kScanDirect tiles two
+// small launches run first -- the sum of every tile (tsum) and of every group of kScanGroup tiles (ssum) -- and a workgroup then adds
+// the group sums in front of its group and the tile sums in front of it inside the group: at most ntiles / 1024 + 1024 loads.
+constexpr int kScanDirect = 128, kScanGroup = 1024;
 // 256 threads; `red` holds 8 Tri.  The workgroup of tile `tile` writes off / eoff / poff of its keys and their emap entries; the
-// workgroup of the last tile writes totals = {extra units, slab slots, list entries}.
+// workgroup of the last tile writes totals = {extra units, slab slots, list entries}.  tsum / ssum: null = sum the counters directly.
 __device__ __forceinline__ void scan_tile_body(const int32_t* __restrict__ cnt, int NK, int C, int tile, int32_t* __restrict__ off,
                                                int32_t* __restrict__ eoff, int32_t* __restrict__ poff, int32_t* __restrict__ totals,
-                                               int2* __restrict__ emap, int max_extra, Tri* red) {
+                                               int2* __restrict__ emap, int max_extra, Tri* red, const Tri* __restrict__ tsum = nullptr,
+                                               const Tri* __restrict__ ssum = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int base = tile * kScanTile;
   // (1) everything in front of the tile
   Tri pre{0, 0, 0};
-  {
+  if (tsum) {
+    const int g = tile / kScanGroup;
+    for (int i = tid; i < g; i += 256) pre = tri_add(pre, ssum[i]);
+    for (int i = g * kScanGroup + tid; i < tile; i += 256) pre = tri_add(pre, tsum[i]);
+  } else {
     int k = tid;
     for (; k + 7 * 256 < base; k += 8 * 256) {  // eight independent loads in flight
       int c8[8];
@@ -198,6 +210,9 @@ int batch_plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_pos
                      const int32_t* cand_cnt, int pos_lanes, int64_t n_pos_cand, int64_t n_neg_cand, void* plan, int parts, uint32_t* err,
                      hipStream_t st);
 struct StepAdvance;  // kge_internal.hpp
+// pull.hip: tile and group sums of NK counters in front of the scan (no-op up to kScanDirect tiles); returns true when they were made
+bool scan_sums_launch(const int32_t* cnt, int NK, int C, void* tsum, void* ssum, hipStream_t st);
+int64_t scan_sums_bytes(int64_t NK);  // room for tsum + ssum (256-aligned halves: tsum first)
 int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR, void* plan,
                         int64_t m_pos, int64_t m_neg, float* loss_partials, int* n_partials, float* loss_out, void* ws, uint64_t seed,
                         hipStream_t st, const StepAdvance& adv, OptFinish* finish, const StepTail* tail = nullptr, int grad_parts = 3);

@@ -211,10 +211,11 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const int32_t* __restric
                                                          int32_t* __restrict__ totals, int2* __restrict__ emap, int max_extra, int etiles,
                                                          const int32_t* __restrict__ rcnt, int R, int32_t* __restrict__ roff,
                                                          int32_t* __restrict__ ruoff, int32_t* __restrict__ rtotal,
-                                                         int2* __restrict__ rumap, int max_units) {
+                                                         int2* __restrict__ rumap, int max_units, const Tri* __restrict__ tsum,
+                                                         const Tri* __restrict__ ssum) {
   __shared__ Tri red[8];
   __shared__ int wa[4], wb[4];
-  if ((int)blockIdx.x < etiles) scan_tile_body(ecnt, N, C, blockIdx.x, off, eoff, poff, totals, emap, max_extra, red);
+  if ((int)blockIdx.x < etiles) scan_tile_body(ecnt, N, C, blockIdx.x, off, eoff, poff, totals, emap, max_extra, red, tsum, ssum);
   else rel_plan_body(rcnt, R, roff, ruoff, rtotal, rumap, max_units, wa, wb);
 }
 
@@ -460,7 +461,7 @@ static Sizes sizes_of(const kge_model_desc* md, int64_t n) {
 static int64_t counters_bytes(const Sizes& z) { return b256(z.N * 4) + b256(z.R * 4); }
 static int64_t plan_bytes(const Sizes& z) {
   return b256(z.R * 4) * 2 + 256 + b256(z.max_units * 8) + b256(z.n * 4) + b256(z.n * 16) +                 // relation side
-         b256(z.N * 4) * 3 + 256 + b256(z.max_extra * 8) + b256(2 * z.n * 4) + b256(2 * z.n * 16) +          // entity side (incl. list entries)
+         b256(z.N * 4) * 3 + 256 + b256(z.max_extra * 8) + b256(2 * z.n * 4) + b256(2 * z.n * 16) + scan_sums_bytes(z.N) +  // entity side (incl. list entries)
          b256(z.cap * 8) + b256(z.cap * 4) + 256 + b256(z.cap * 4) + b256(z.n * 4) * 2 + b256((z.n / 256 + 1) * 4) + b256(z.n * 16) + 512;
 }
 static int64_t scratch_bytes(const Sizes& z, int d_e) {
@@ -505,6 +506,8 @@ static void carve_plan(void* counters, void* region, const kge_model_desc* md, i
   p->ent.emap = (int2*)take(z.max_extra * 8);
   p->erank = (int32_t*)take(2 * n * 4);
   p->ent.entries = (int4*)take(2 * n * 16);
+  p->ent.tsum = take(cdiv(z.N, kScanTile) * (int64_t)sizeof(Tri));
+  p->ent.ssum = take(cdiv(cdiv(z.N, kScanTile), kScanGroup) * (int64_t)sizeof(Tri));
   p->ent.ranks = p->erank;
   p->ent.max_extra = (int)z.max_extra;
   p->ent.chunk = z.C;
@@ -611,9 +614,12 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
   if (parts & 6) {
     ProfScope prof(KGE_PROF_INDEX, st);
     const int etiles = (int)cdiv(N, kScanTile);
-    if ((parts & 6) == 6)  // offsets of the entity lists and of the relation lists in one launch
+    if ((parts & 6) == 6) {  // offsets of the entity lists and of the relation lists in one launch (a large table: tile sums first)
+      const bool big = scan_sums_launch(p.ent.cnt, N, p.ent.chunk, p.ent.tsum, p.ent.ssum, st);
       hipLaunchKernelGGL(plan_scan_kernel, dim3(etiles + 1), dim3(256), 0, st, p.ent.cnt, N, p.ent.chunk, p.ent.off, p.ent.eoff, p.ent.poff, p.ent.totals,
-                         p.ent.emap, p.ent.max_extra, etiles, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
+                         p.ent.emap, p.ent.max_extra, etiles, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units,
+                         big ? static_cast<const Tri*>(p.ent.tsum) : nullptr, big ? static_cast<const Tri*>(p.ent.ssum) : nullptr);
+    }
     else if (parts & 2) pull2_entity_plan(p.ent, N, st);
     else hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
     if (parts & 4) hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);

@@ -43,6 +43,32 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
   const int len = min(a.C, c - chunk * a.C);
   const float* self = a.E + (int64_t)key * d_e;
 
+  // A row no triple of the batch touches: only the optimizer's streams (Keras updates every row of the table, models.py:87-112 with the
+  // default 'adam' of tests.py:86), all of the row's loads issued at once -- on a table far larger than the batch (most rows untouched)
+  // this is what the launch spends its time on, and the general path below would chain three memory round trips per wave (list bounds
+  // -> own row -> moments).  Same arithmetic as the general path with a zero gradient row.
+  if (c == 0) {
+    if (a.kind < 0) return;  // (gradient tables are all-zero between steps: a row nobody touched stays so)
+    float* wout0 = a.E_out + (int64_t)key * d_e;
+    float* mrow0 = a.mE + (int64_t)key * d_e;
+    float* vrow0 = a.vE + (int64_t)key * d_e;
+    const float lr0 = a.lr_state ? a.lr_state[0] : a.lr;
+#pragma unroll
+    for (int k = 0; k < NPER; ++k) {
+      const int i = sub + k * NSUB;
+      const int ch = lane + (i % NV) * G;
+      if (i < NACC && ch < nchunk) {
+        const int at = (i / NV) * h + ch * 4;
+        float4 w = L::ld(self + at), m = L::zero(), v = L::zero();
+        if (a.kind == KGE_OPT_ADAM_TF) { m = L::ld(mrow0 + at); v = L::ld(vrow0 + at); }
+        tail_upd(a.kind, lr0, a.b1, a.b2, a.eps, w, L::zero(), m, v);
+        L::st(wout0 + at, w);
+        if (a.kind == KGE_OPT_ADAM_TF) { L::st(mrow0 + at, m); L::st(vrow0 + at, v); }
+      }
+    }
+    return;
+  }
+
   // own row -> LDS, accumulator layout: slot i*G + lane holds float4 chunk lane + (i % NV)*G of half i / NV
 #pragma unroll
   for (int k = 0; k < NPER; ++k) {

@@ -100,3 +100,37 @@ def test_rank_counts_on_a_table_past_2_31_elements():
         got = cnt[side * nq:(side + 1) * nq]
         assert clear.mean() > 0.8 and np.array_equal(got[clear], ref[clear]) and np.all(np.abs(got - ref) <= 2)
     mdl._raise_on_flag()
+
+
+@pytest.mark.parametrize("path", ["step", "planned", "pairwise"])
+def test_list_offsets_of_a_table_of_many_tiles(path):
+    """The scan of the per-entity list lengths of a 2.2 M entity table (2 149 tiles of 1024 keys in 3 groups: tile sums and group sums in
+    front of the scan, pull.hpp) with hub entities -- lists of several chunks, i.e. all three scanned quantities non-trivial -- in
+    different tiles and groups: two steps against the oracle on the touched rows.  `pairwise`: the generic-list variant (pull.hip,
+    NK = N + R keys) through a pairwise loss."""
+    from kge_keras_amd import models as M
+    n_ent, d, n_rel = 2_200_000, 8, 5
+    rs = np.random.RandomState(9)
+    loss = "pairwize_hinge" if path == "pairwise" else "pointwize_logistic"
+    mdl = M.DistMult(e_dim=d, r_dim=d, num_entities=n_ent, num_relations=n_rel, dp=0.0, seed=2, loss_function=loss)
+    mdl.E.mul_(300.0)
+    mdl.compile("adam")
+    hubs = np.array([5, 1024 * 700 + 3, 1024 * 1100 + 9, 1024 * 2100 + 1, n_ent - 1])  # first tile, groups 0 / 1 / 2, last row
+    hot = np.unique(np.concatenate([rs.randint(0, n_ent, 400), hubs])).astype(np.int64)
+    Ec, m = _compact(mdl, hot)
+    Ro = mdl.Rel.cpu().numpy().astype(np.float64)
+    oo = O.AdamTF()
+
+    def batch(n):
+        ent = lambda: np.where(rs.rand(n) < 0.5, hubs[rs.randint(0, len(hubs), n)], hot[rs.randint(0, len(hot), n)])  # noqa: E731
+        return np.stack([ent(), rs.randint(0, n_rel, n), ent()], 1).astype(np.int32)
+    for step in range(2):
+        n_neg = 600 if path == "pairwise" else 4000
+        pos, neg = batch(64 if path != "pairwise" else n_neg), batch(n_neg)
+        data = mdl.plan_batch([pos, neg]) if path == "planned" else [pos, neg]
+        L = float(mdl.train_step(data)["loss"].item())
+        Lo = O.train_step("DistMult", Ec, Ro, oo, _remap(pos, m), _remap(neg, m), loss, 1.0, 1)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), step
+        np.testing.assert_allclose(mdl.E.index_select(0, torch.from_numpy(hot).cuda()).cpu().numpy(), Ec, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    mdl._raise_on_flag()
