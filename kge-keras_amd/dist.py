@@ -113,14 +113,15 @@ def make_rccl_comm(group=None):
     class UniqueId(C.Structure):  # ncclUniqueId: passed BY VALUE to ncclCommInitRank
         _fields_ = [("internal", C.c_char * 128)]
     uid = UniqueId()
-    if rank == 0:
-        rc = rccl.ncclGetUniqueId(C.byref(uid))
-        if rc != 0:
-            raise RuntimeError(f"ncclGetUniqueId failed ({rc})")
-    if ws > 1:
-        box = [bytes(uid) if rank == 0 else None]
+    rc0 = rccl.ncclGetUniqueId(C.byref(uid)) if rank == 0 else 0
+    if ws > 1:  # (rank 0 broadcasts also when it failed, so that every rank leaves together instead of waiting for the id)
+        box = [(bytes(uid) if rc0 == 0 else None) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
+        if box[0] is None:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
         C.memmove(C.byref(uid), box[0], 128)
+    elif rc0 != 0:
+        raise RuntimeError(f"ncclGetUniqueId failed ({rc0})")
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     rc = rccl.ncclCommInitRank(C.byref(comm), ws, uid, rank)
