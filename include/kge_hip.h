@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 7
+#define KGE_ABI_VERSION 8
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -43,6 +43,11 @@ typedef enum { KGE_DISTMULT = 0, KGE_TRANSE = 1, KGE_COMPLEX = 2, KGE_HOLE = 3, 
                KGE_ROTATE = 5 /* models.py:421-459 exactly as written: entity rows [re | im] of 2d floats, relation rows d phases;
                                * score = gamma - S if gamma > 0 else S, S = sum_k (re_s cos p - im_s sin p - re_o) + (re_s sin p + im_s cos p - im_o)
                                * (the signed sum: `norm` is never applied there).  d_e == 2 * d_r.  Training runs on the push path. */
+               ,
+               KGE_HAKE = 6   /* models.py:362-400 exactly as written: entity rows [phase | modulus] (d_e = 2h), relation rows
+                               * [phase | modulus | bias] (d_r = 3h); the modulus part of the score is ONE norm over all rows of a call
+                               * (tf.norm without an axis), so it has entry points of its own that take the rows of a call as a
+                               * segment: kge_hake_score, kge_hake_train_grads (+ kge_opt_apply).  The generic entry points refuse it. */
 } kge_model;
 
 /* KGEkeras.utils.loss_function_lookup names (utils.py:321-330). */
@@ -210,6 +215,30 @@ int kge_lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32
                         int32_t L, int32_t lit_rows, const float* theta_l, float* gradE, float* gradRel, float* gtheta_l, const int32_t* pos,
                         int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
                         int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* ---- HAKE (models.py:362-400; kge_model_desc.model = KGE_HAKE, gamma in the descriptor).  score_t = gamma - (phase_weight * sum_k
+ *      |sin((phase_s + phase_p - phase_o) / 2)| + mod_weight * sqrt(sum over ALL rows of the call of M^2)) with phase = row / (embedding_range
+ *      / pi), M = mod_s (mod_p + bias) - |mod_o| (1 - bias), bias = clip(bias_p, <= 1) raised to -|mod_p| -- the second term is tf.norm
+ *      WITHOUT an axis: one scalar over the whole tensor handed to the call.
+ *      kge_hake_score: rows [i * chunk, (i + 1) * chunk) are scored as one call each (chunk = 32: model.predict with Keras' default
+ *      batch size, utils.py:211,231; chunk <= 0 or >= n: all n rows in one call = model(inputs)); or, seg_off != NULL, the n_seg calls
+ *      [seg_off[i], seg_off[i+1]) of a device array of n_seg + 1 ascending offsets (the predict batches of many candidate lists in one
+ *      launch; workspace kge_hake_workspace_bytes(n, -n_seg)).  kge_hake_rank_counts: counts[q] = #{rows of [q_off[q], q_off[q+1]) scoring
+ *      above the first row of the range} -- the reference's rank of a candidate list whose row 0 is the target (utils.py:165-196,211-215)
+ *      is 1 + that; n_q <= 2^31 - 1 queries, < 2^24 rows each.
+ *      kge_hake_train_grads: the gradient half of the default Keras train step of the two-input wrapper (tests.py:63-89): the model is
+ *      called once on pos and once on neg (one norm per side), loss by ld, gradients of the three gathered rows added into gradE / gradRel
+ *      (float atomics; zero on entry like everywhere); kge_opt_apply completes the step.  Dropout by md->dropout / seed as in
+ *      kge_train_grads.  At sqrt(sum M^2) = 0 TensorFlow's gradient is NaN; zero here.  Workspace: kge_hake_workspace_bytes(n, chunk)
+ *      (chunk = 0 for training, n = m_pos + m_neg). */
+typedef struct { float phase_weight, mod_weight, embedding_range; } kge_hake_params;
+int64_t kge_hake_workspace_bytes(int64_t n, int64_t chunk);
+int kge_hake_score(const kge_model_desc* md, const kge_hake_params* hp, const float* E, const float* Rel, const int32_t* triples, int64_t n,
+                   int64_t chunk, const int64_t* seg_off, int64_t n_seg, float* out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                   kge_stream_t stream);
+int kge_hake_rank_counts(const float* scores, int64_t n, const int64_t* q_off, int64_t n_q, int32_t* counts, kge_stream_t stream);
+int kge_hake_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const kge_hake_params* hp, const float* E, const float* Rel,
+                         float* gradE, float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                         float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
 /* Seeds the device-resident step state: od->step_dev := {od->step - 1, lr_t(od->step), 0} (see kge_opt_desc). */
 int kge_opt_state_init(const kge_opt_desc* od, kge_stream_t stream);
 /* Keras optimizer update of one flat fp32 vector (w -= ..., g re-zeroed); od->mE / od->vE are its Adam slots. */

@@ -18,7 +18,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 KGE_OK, KGE_EINVAL, KGE_ESHAPE, KGE_EHIP, KGE_EWORKSPACE, KGE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4, "RotatE": 5}
+MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4, "RotatE": 5, "HAKE": 6}
 LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, "pairwize_logistic": 3,
             "pointwize_square_loss": 4, "pairwize_square_loss": 5, "pointwize_cross_entropy": 6}
 OPT_IDS = {"sgd": 0, "adam": 1}
@@ -43,6 +43,10 @@ class OptDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int64), ("mE", C.c_void_p), ("vE", C.c_void_p), ("mRel", C.c_void_p), ("vRel", C.c_void_p),
                 ("step_dev", C.c_void_p)]
+
+
+class HakeParams(C.Structure):
+    _fields_ = [("phase_weight", C.c_float), ("mod_weight", C.c_float), ("embedding_range", C.c_float)]
 
 
 class PipelineDesc(C.Structure):
@@ -84,6 +88,10 @@ SIGNATURES = {
     "kge_hole_spec_basis": (C.c_int, [_I32, _P, _P, _P]),
     "kge_hole_spec_forward": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "kge_hole_spec_adjoint": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P]),
+    "kge_hake_workspace_bytes": (_I64, [_I64, _I64]),
+    "kge_hake_score": (C.c_int, [_MD, C.POINTER(HakeParams), _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _P, _P]),
+    "kge_hake_rank_counts": (C.c_int, [_P, _I64, _P, _I64, _P, _P]),
+    "kge_hake_train_grads": (C.c_int, [_MD, _LD, C.POINTER(HakeParams), _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
     "kge_opt_state_init": (C.c_int, [_OD, _P]),
     "kge_opt_apply_vector": (C.c_int, [_OD, _P, _P, _I64, _F, _P]),
     "kge_rank_sweep_q_workspace_bytes": (_I64, [_I64, _I32]),

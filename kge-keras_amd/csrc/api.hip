@@ -31,12 +31,14 @@ static inline void clear_stale_error() { (void)hipGetLastError(); }
 int check_model(const kge_model_desc* md, const char* who) {
   clear_stale_error();
   if (!md) return fail(KGE_EINVAL, "%s: model descriptor is null", who);
-  if (md->model < KGE_DISTMULT || md->model > KGE_ROTATE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
+  if (md->model < KGE_DISTMULT || md->model > KGE_HAKE) return fail(KGE_EINVAL, "%s: unknown model %d", who, md->model);
   if (md->num_entities <= 0 || md->num_relations <= 0 || md->d_e <= 0 || md->d_r <= 0)
     return fail(KGE_EINVAL, "%s: non-positive table shape (%d,%d) (%d,%d)", who, md->num_entities, md->d_e, md->num_relations, md->d_r);
   // s*p*o, s+p-o and the ComplEx products broadcast row-against-row: TensorFlow rejects unequal widths
   if (md->model == KGE_ROTATE) {  // rotation phases: one per complex component (models.py:428-429: e_dim doubled, r_dim not)
     if (md->d_e != 2 * md->d_r) return fail(KGE_ESHAPE, "%s: RotatE needs e_dim %d == 2 * r_dim %d (tf.split halves against the phase row)", who, md->d_e, md->d_r);
+  } else if (md->model == KGE_HAKE) {  // [phase | modulus] against [phase | modulus | bias] (models.py:371-372,387-389)
+    if ((md->d_e & 1) || 3 * (md->d_e / 2) != md->d_r) return fail(KGE_ESHAPE, "%s: HAKE needs e_dim %d = 2h and r_dim %d = 3h", who, md->d_e, md->d_r);
   } else if (md->d_e != md->d_r) return fail(KGE_ESHAPE, "%s: e_dim %d and r_dim %d do not broadcast", who, md->d_e, md->d_r);
   if (md->model == KGE_COMPLEX && (md->d_e & 1)) return fail(KGE_ESHAPE, "%s: ComplEx rows must split in two halves (tf.split), width %d", who, md->d_e);
   if (md->model == KGE_TRANSE && md->norm != 1 && md->norm != 2 && md->norm != 3 && md->norm != 5)
@@ -204,6 +206,13 @@ int sampler_stream_draw(void*, int64_t, void*, void*, const int32_t*, const int3
                         int32_t*, int32_t*, int32_t*, int32_t*, uint32_t*, hipStream_t);
 int64_t sampler_plan_bytes();
 
+// hake.hip
+int64_t hake_workspace_bytes(int64_t, int64_t);
+int hake_score(const kge_model_desc*, const kge_hake_params*, const float*, const float*, const int32_t*, int64_t, int64_t, const int64_t*, int64_t, float*, void*,
+               int64_t, uint32_t*, hipStream_t);
+int hake_rank_counts(const float*, int64_t, const int64_t*, int64_t, int32_t*, hipStream_t);
+int hake_train_grads(const kge_model_desc*, const kge_loss_desc*, const kge_hake_params*, const float*, const float*, float*, float*, const int32_t*, int64_t,
+                     const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
 }  // namespace kge
 
 using namespace kge;
@@ -450,6 +459,7 @@ int kge_rank_counts(const kge_model_desc* md, const float* E, const float* Rel, 
   if (n_queries < 0 || n_filt < 0) return fail(KGE_EINVAL, "kge_rank_counts: negative size");
   if (n_queries == 0) return KGE_OK;
   if (side < 0 || side > 2) return fail(KGE_EINVAL, "kge_rank_counts: side must be 0 (tail), 1 (head) or 2 (both: tail queries, then head queries)");
+  if (md->model == KGE_HAKE) return fail(KGE_EUNSUPPORTED, "kge_rank_counts: a HAKE score depends on the rows it is predicted with (chunks of 32 in the reference's validate): rank through kge_hake_score");
   if (!E || !Rel || (!E_cand && cand_rows > 0) || !triples || !counts || !workspace || !err_flag || (n_filt && (!filt_query || !filt_ids)))
     return fail(KGE_EINVAL, "kge_rank_counts: null pointer");
   if (cand_offset < 0 || cand_rows < 0 || (int64_t)cand_offset + cand_rows > 0x7FFFFFFFll)
@@ -594,6 +604,45 @@ static int check_conve(const kge_model_desc* md, const char* who) {
   if (md->model != KGE_CONVE) return fail(KGE_EINVAL, "%s: model %d is not ConvE", who, md->model);
   if (!(md->hidden_dropout >= 0.f && md->hidden_dropout < 1.f)) return fail(KGE_EINVAL, "%s: hidden dropout rate %f outside [0,1)", who, md->hidden_dropout);
   return KGE_OK;
+}
+
+// ---- HAKE (hake.hip)
+static int check_hake(const kge_model_desc* md, const kge_hake_params* hp, const char* who) {
+  if (int rc = check_model(md, who)) return rc;
+  if (md->model != KGE_HAKE) return fail(KGE_EINVAL, "%s: model %d is not HAKE", who, md->model);
+  if (!hp || !(hp->embedding_range > 0.f)) return fail(KGE_EINVAL, "%s: kge_hake_params with embedding_range > 0 needed", who);
+  return KGE_OK;
+}
+
+int64_t kge_hake_workspace_bytes(int64_t n, int64_t chunk) {
+  if (n < 0) return fail(KGE_EINVAL, "kge_hake_workspace_bytes: negative size");
+  return hake_workspace_bytes(n, chunk > n ? n : chunk);  // (0: the two sides of a training batch; < 0: -chunk segments by offsets)
+}
+
+int kge_hake_score(const kge_model_desc* md, const kge_hake_params* hp, const float* E, const float* Rel, const int32_t* triples, int64_t n,
+                   int64_t chunk, const int64_t* seg_off, int64_t n_seg, float* out, void* workspace, int64_t workspace_bytes, uint32_t* err_flag,
+                   kge_stream_t stream) {
+  if (int rc = check_hake(md, hp, "kge_hake_score")) return rc;
+  if (n == 0) return KGE_OK;
+  if (n < 0 || n > 0x7FFFFFFFll || !E || !Rel || !triples || !out || !workspace || !err_flag) return fail(KGE_EINVAL, "kge_hake_score: bad arguments");
+  if (seg_off && (n_seg <= 0 || n_seg > 0x7FFFFFFFll)) return fail(KGE_EINVAL, "kge_hake_score: %lld segments", (long long)n_seg);
+  return hake_score(md, hp, E, Rel, triples, n, chunk, seg_off, n_seg, out, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_hake_rank_counts(const float* scores, int64_t n, const int64_t* q_off, int64_t n_q, int32_t* counts, kge_stream_t stream) {
+  if (n_q == 0) return KGE_OK;
+  if (n < 0 || n_q < 0 || n_q > 0x7FFFFFFFll || !scores || !q_off || !counts) return fail(KGE_EINVAL, "kge_hake_rank_counts: bad arguments");
+  return hake_rank_counts(scores, n, q_off, n_q, counts, static_cast<hipStream_t>(stream));
+}
+
+int kge_hake_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const kge_hake_params* hp, const float* E, const float* Rel,
+                         float* gradE, float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                         float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_hake(md, hp, "kge_hake_train_grads")) return rc;
+  if (int rc = check_train("kge_hake_train_grads", md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, err_flag)) return rc;
+  if (!workspace) return fail(KGE_EINVAL, "kge_hake_train_grads: null workspace");
+  return hake_train_grads(md, ld, hp, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, scores_out, seed, workspace, workspace_bytes, err_flag,
+                          static_cast<hipStream_t>(stream));
 }
 
 int kge_conve_sizes(const kge_model_desc* md, int64_t* n_theta, int64_t* n_stats) {

@@ -8,7 +8,7 @@ from .sampler import NumpyStream, PythonStream, build_batch
 from .utils import loss_function_lookup
 
 models = {'DistMult': _models.DistMult, 'TransE': _models.TransE, 'HolE': _models.HolE, 'ComplEx': _models.ComplEx,
-          'ConvE': _models.ConvE, 'pRotatE': _models.pRotatE, 'RotatE': _models.RotatE}  # tests.py:18-27, restricted to the path's model families
+          'ConvE': _models.ConvE, 'pRotatE': _models.pRotatE, 'RotatE': _models.RotatE, 'HAKE': _models.HAKE}  # tests.py:18-27, restricted to the path's model families
 
 
 class DataGenerator:

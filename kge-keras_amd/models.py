@@ -838,6 +838,188 @@ class RotatE(EmbeddingModel):
         return md
 
 
+class HAKE(EmbeddingModel):
+    """models.py:362-400, exactly as written: entity rows [phase | modulus] (e_dim doubled), relation rows [phase | modulus | bias]
+    (r_dim tripled); score = gamma - (phase_weight * sum_k |sin((phase_s + phase_p - phase_o) / 2)| + mod_weight * r) where r is
+    tf.norm(..., ord=2) WITHOUT an axis (:398): one scalar over every row of the tensor handed to that call of the model.  A
+    triple's score therefore depends on the rows it is scored with, and this class reproduces the three ways the reference calls
+    the model: `model(x)` -- all rows one call; `model.predict(x)` -- Keras' batches of 32 rows (utils.py:211,231), so `validate`
+    ranks candidate lists whose scores carry a per-32-row offset; the train step -- one call on the positives, one on the
+    negatives (tests.py:77-78).  Own entry points in the library (kge_hake_*): forward rows + per-call norms, the loss kernels, the
+    gradient rows by float atomics, then the dense optimizer sweep (kge_opt_apply); no batch plans, no matrix-core sweep."""
+    MODEL = "HAKE"
+
+    def __init__(self, epsilon=2, gamma=12, phase_weight=0.5, mod_weight=1, name='HAKE', **kwargs):
+        kwargs['e_dim'] = 2 * kwargs['e_dim']  # KeyError if absent, like models.py:371-372
+        kwargs['r_dim'] = 3 * kwargs['r_dim']
+        super().__init__(name=name, **kwargs)
+        if self._lit is not None:
+            raise NotImplementedError("the literal input path is not built for HAKE")
+        self.gamma = gamma
+        self.epsilon = epsilon
+        self.phase_weight = phase_weight
+        self.mod_weight = mod_weight
+        self.pi = np.pi
+        self.embedding_range = (self.gamma + self.epsilon) / self.e_dim / 2
+        self._hws = None
+
+    def _hake(self):
+        return _lib.HakeParams(float(self.phase_weight), float(self.mod_weight), float(self.embedding_range))
+
+    def _hake_ws(self, n, chunk):
+        need = check(lib.kge_hake_workspace_bytes(n, chunk))
+        if self._hws is None or self._hws.numel() < need:
+            self._hws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+        return self._hws
+
+    def _score(self, t, chunk, seg_off=None, md=None, E=None, Rel=None):
+        n = t.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        md, hp = md or self._model_desc(False), self._hake()
+        n_seg = 0 if seg_off is None else seg_off.numel() - 1
+        ws = self._hake_ws(n, -n_seg if n_seg else chunk)
+        check(lib.kge_hake_score(C.byref(md), C.byref(hp), (self.E if E is None else E).data_ptr(), (self.Rel if Rel is None else Rel).data_ptr(),
+                                 t.data_ptr(), n, chunk, seg_off.data_ptr() if n_seg else None, n_seg, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 self._err.data_ptr(), _lib.stream_ptr()))
+        return out
+
+    def call(self, inputs, training=False):
+        """model(inputs): every row of `inputs` in ONE call -- one modulus norm over all of them (models.py:398)."""
+        return self._score(as_triples(inputs, self.device, self.num_entities, self.num_relations), 0)
+
+    __call__ = call
+
+    def func(self, s, p, o, training=False):
+        """Score already-gathered rows (models.py:383-400) as one call: rows staged as temporary tables, same kernels."""
+        s = torch.as_tensor(s, dtype=torch.float32, device=self.device).reshape(-1, self.e_dim)
+        p = torch.as_tensor(p, dtype=torch.float32, device=self.device).reshape(-1, self.r_dim)
+        o = torch.as_tensor(o, dtype=torch.float32, device=self.device).reshape(-1, self.e_dim)
+        n = s.shape[0]
+        idx = torch.arange(n, dtype=torch.int32, device=self.device)
+        md = self._model_desc(False)
+        md.num_entities, md.num_relations = 2 * n, n
+        return self._score(torch.stack([idx, idx, idx + n], 1).contiguous(), 0, md=md, E=torch.cat([s, o], 0).contiguous(), Rel=p.contiguous())
+
+    def predict(self, x, batch_size=32, verbose=0, **_):
+        """keras Model.predict (utils.py:211,231): the model is called on consecutive batches of `batch_size` rows (32 unless the
+        caller says otherwise), each with its own modulus norm; numpy (n,) scores."""
+        out = self._score(as_triples(x, self.device, self.num_entities, self.num_relations), int(batch_size) if batch_size else 32).cpu().numpy()
+        self._raise_on_flag()
+        return out
+
+    # ------------------------------------------------------------------ training
+    def plan_supported(self):
+        return False
+
+    def _grads(self, pos, neg, md, ld, scores_out, seed):
+        ws = self._hake_ws(pos.shape[0] + neg.shape[0], 0)
+        hp = self._hake()
+        check(lib.kge_hake_train_grads(C.byref(md), C.byref(ld), C.byref(hp), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                       self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0], self._loss.data_ptr(),
+                                       scores_out.data_ptr() if scores_out is not None else None, seed, ws.data_ptr(), ws.numel(),
+                                       self._err.data_ptr(), _lib.stream_ptr()))
+
+    def train_grads(self, data, scores_out=None, parts=3):
+        if isinstance(data, BatchPlan) or parts != 3:
+            raise ValueError("HAKE trains batch by batch: no batch plans")
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
+        self._seed += 1
+        self._grads(pos, neg, md, ld, scores_out, self._seed)
+        return {"loss": self._loss[0]}
+
+    def train_step(self, data, scores_out=None):
+        """Default Keras train_step of the two-input wrapper (tests.py:63-89): one call of the model per side, loss, gradients,
+        optimizer update (+ the l3 regulariser's dense gradient inside the sweep)."""
+        if isinstance(data, tuple) and len(data) == 2 and (data[1] is None or isinstance(data[0], (list, tuple))):
+            data = data[0]
+        self.train_grads(data, scores_out)
+        self.apply_grads(1.0)
+        return {"loss": self._loss[0]}
+
+    def batch_loss(self, data):
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        if self.optimizer is None:
+            self.compile('sgd')
+        md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
+        md.dropout = 0.0
+        self._grads(pos, neg, md, ld, None, 0)
+        loss = self._loss[0].clone()
+        self._gall.zero_()
+        if self.regularization:
+            loss = loss + float(self.regularization) * self.E.abs().pow(3).sum()
+        return loss
+
+    # ------------------------------------------------------------------ ranking (utils.py:165-264)
+    def rank_counts(self, *a, **kw):
+        raise NotImplementedError("a HAKE score depends on the rows it is predicted with: rank() scores the reference's candidate lists")
+
+    rank_counts_shard = rank_counts
+
+    def _rank_side(self, part, N, fq, fi, side):
+        """Ranks of one side of a chunk of test triples, by the reference's own route: the candidate list of every query (target
+        first, then the kept entities ascending: utils.py:165-196) is predicted in batches of 32 rows and the target's score is
+        compared within the list (utils.py:211-215).  All lists of the chunk go through ONE scoring launch, with the predict
+        batches as segments."""
+        nq = len(part)
+        tcol, ccol = (2, 0) if side == 0 else (0, 2)
+        keep = np.ones((nq, N), dtype=bool)
+        keep[np.arange(nq), part[:, tcol]] = False
+        if len(fq):
+            keep[fq, fi] = False
+        qi, ids = np.nonzero(keep)  # (ascending ids within a query)
+        n_q = 1 + keep.sum(1).astype(np.int64)
+        q_off = np.zeros(nq + 1, dtype=np.int64)
+        np.cumsum(n_q, out=q_off[1:])
+        n = int(q_off[-1])
+        cand = np.empty(n, dtype=np.int32)
+        owner = np.empty(n, dtype=np.int64)
+        cand[q_off[:-1]] = part[:, tcol]
+        owner[q_off[:-1]] = np.arange(nq)
+        rest = np.ones(n, dtype=bool)
+        rest[q_off[:-1]] = False
+        cand[rest], owner[rest] = ids, qi
+        rows = np.empty((n, 3), dtype=np.int32)
+        rows[:, 1] = part[owner, 1]
+        rows[:, ccol] = part[owner, ccol]
+        rows[:, tcol] = cand
+        seg = np.concatenate([np.arange(q_off[i], q_off[i + 1], 32) for i in range(nq)] + [q_off[-1:]]).astype(np.int64)
+        t = torch.from_numpy(rows).to(self.device)
+        sc = self._score(t, 32, torch.from_numpy(seg).to(self.device))
+        cnt = torch.empty(nq, dtype=torch.int32, device=self.device)
+        qo = torch.from_numpy(q_off).to(self.device)
+        check(lib.kge_hake_rank_counts(sc.data_ptr(), n, qo.data_ptr(), nq, cnt.data_ptr(), _lib.stream_ptr()))
+        return 1 + cnt.cpu().numpy().astype(np.int64)
+
+    def rank_triples(self, test, num_entities, filt, chunk=256):
+        from .utils import filter_coo
+        test = np.ascontiguousarray(np.asarray(test, dtype=np.int32).reshape(-1, 3))
+        N = int(num_entities)
+        chunk = max(1, min(chunk, (1 << 26) // max(1, N)))  # candidate rows of a chunk: at most 64 M
+        tails, heads = np.empty(len(test), dtype=np.int64), np.empty(len(test), dtype=np.int64)
+        for a in range(0, len(test), chunk):
+            part = test[a:a + chunk]
+            tails[a:a + chunk] = self._rank_side(part, N, *filter_coo(part, 0, filt, N), 0)
+            heads[a:a + chunk] = self._rank_side(part, N, *filter_coo(part, 1, filt, N), 1)
+        self._raise_on_flag()
+        return tails, heads
+
+    def rank(self, test_data, num_entities, filter_t, filter_h, chunk=256):
+        test = np.asarray([tuple(int(v) for v in t) for t in test_data], dtype=np.int32).reshape(-1, 3)
+        N = int(num_entities)
+        chunk = max(1, min(chunk, (1 << 26) // max(1, N)))
+        tails, heads = np.empty(len(test), dtype=np.int64), np.empty(len(test), dtype=np.int64)
+        for a in range(0, len(test), chunk):
+            part = test[a:a + chunk]
+            lst = [tuple(int(v) for v in t) for t in part]
+            tails[a:a + chunk] = self._rank_side(part, N, *self._filter_coo(lst, N, filter_t, 0), 0)
+            heads[a:a + chunk] = self._rank_side(part, N, *self._filter_coo(lst, N, filter_h, 1), 1)
+        self._raise_on_flag()
+        return tails, heads
+
+
 class HolE(EmbeddingModel):
     """models.py:224-237: score = sum_k p_k * ccorr(s, o)_k.
 

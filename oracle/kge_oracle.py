@@ -33,6 +33,8 @@ def table_dims(model, e_dim, r_dim):
         return 2 * e_dim, 2 * r_dim
     if model == "RotatE":  # models.py:428-429: the entity rows are doubled, the relation rows (phases) are not
         return 2 * e_dim, r_dim
+    if model == "HAKE":  # models.py:371-372: entity rows [phase | modulus], relation rows [phase | modulus | bias]
+        return 2 * e_dim, 3 * r_dim
     return e_dim, r_dim
 
 
@@ -106,8 +108,41 @@ def func_rotate(s, p, o, gamma=12):
     return gamma - sc if gamma > 0 else sc
 
 
+def hake_params(e_dim_doubled, gamma=12, epsilon=2, phase_weight=0.5, mod_weight=1.0):
+    """models.py:364-381: (phase_weight, mod_weight, embedding_range) with embedding_range = (gamma + epsilon) / e_dim / 2 on the
+    doubled e_dim -- what the `norm` slot of score_rows / train_step carries for model == "HAKE"."""
+    return (phase_weight, mod_weight, (gamma + epsilon) / e_dim_doubled / 2)
+
+
+def _hake_parts(s, p, o, prm):
+    pw, mw, rng = prm
+    h = s.shape[-1] // 2
+    sc = np.pi / rng  # phase / (embedding_range / pi), models.py:391-393
+    phs, ms = s[..., :h] * sc, s[..., h:]
+    pho, mo = o[..., :h] * sc, o[..., h:]
+    php, mp, bp = p[..., :h] * sc, p[..., h:2 * h], p[..., 2 * h:]
+    b1 = np.minimum(bp, 1.0)                       # K.clip(bias_p, -inf, 1)            models.py:395
+    cond = b1 < -np.abs(mp)
+    b = np.where(cond, -np.abs(mp), b1)            # tf.where(bias < -|mod_p|, -|mod_p|, bias)   models.py:396
+    M = ms * (mp + b) - np.abs(mo) * (1 - b)
+    y = (phs + php - pho) / 2
+    return pw, mw, sc, h, ms, mo, mp, bp, b, cond, M, y
+
+
+def func_hake(s, p, o, prm, gamma=12):
+    """models.py:383-400, exactly as written: the phase part is a per-row L1 norm (axis=-1), the modulus part is tf.norm(..., ord=2)
+    WITHOUT an axis -- [TF] one vector norm over the entire tensor -- i.e. ONE scalar over all rows handed to this call (the whole
+    training batch side, or one predict chunk of 32 rows).  The score of a row therefore depends on the rows it is scored with."""
+    pw, mw, _sc, _h, _ms, _mo, _mp, _bp, _b, _cond, M, y = _hake_parts(s, p, o, prm)
+    r_score = mw * np.sqrt(np.sum(M * M))
+    p_score = pw * np.sum(np.abs(np.sin(y)), axis=-1)
+    return gamma - (p_score + r_score)
+
+
 def score_rows(model, s, p, o, norm=1, gamma=12):
-    """For model == "pRotatE" the `norm` slot carries the modulus product of models.py:476."""
+    """For model == "pRotatE" the `norm` slot carries the modulus product of models.py:476; for "HAKE" hake_params()."""
+    if model == "HAKE":
+        return func_hake(s, p, o, norm, gamma)
     if model == "pRotatE":
         return func_protate(s, p, o, norm, gamma)
     if model == "RotatE":
@@ -123,17 +158,32 @@ def score_rows(model, s, p, o, norm=1, gamma=12):
     raise KeyError(model)
 
 
-def call(model, E, Rel, triples, norm=1, gamma=12, dtype=np.float64):
+def call(model, E, Rel, triples, norm=1, gamma=12, dtype=np.float64, chunk=None):
     """EmbeddingModel.call (models.py:134-162) with dropout inactive (predict / dp=0):
-    unstack ids (:140) -> gather E[s], Rel[p], E[o] (:144-150) -> func (:160)."""
+    unstack ids (:140) -> gather E[s], Rel[p], E[o] (:144-150) -> func (:160).  chunk: model.predict scores its input in batches of
+    32 rows ([TF] Keras' default predict batch size) -- one `call` per batch, which matters for HAKE alone (its score depends on the
+    rows of the call); None = all rows in one call."""
     t = np.asarray(triples).reshape(-1, 3).astype(np.int64)
     E = np.asarray(E, dtype=dtype)
     Rel = np.asarray(Rel, dtype=dtype)
+    if chunk and model == "HAKE":
+        return np.concatenate([score_rows(model, E[c[:, 0]], Rel[c[:, 1]], E[c[:, 2]], norm, gamma) for c in (t[a:a + chunk] for a in range(0, len(t), chunk))])
     return score_rows(model, E[t[:, 0]], Rel[t[:, 1]], E[t[:, 2]], norm, gamma)
 
 
 def score_row_grads(model, s, p, o, g, norm=1, gamma=12):
     """d(sum_i g_i * score_i)/d(s,p,o) -- what autodiff hands to the three Embedding gathers [TF]."""
+    if model == "HAKE":  # one scalar norm over all rows: every row's modulus gradient carries the SUM of the g's
+        pw, mw, sc, h, ms, mo, mp, bp, b, cond, M, y = _hake_parts(s, p, o, norm)
+        dph = -pw * g[:, None] * 0.5 * np.sign(np.sin(y)) * np.cos(y) * sc
+        r = np.sqrt(np.sum(M * M))
+        dM = (-mw * np.sum(g) / r) * M if r > 0 else np.zeros_like(M)  # ([TF] 0/0 = NaN at r == 0; the kernels return 0 there)
+        db = dM * (ms + np.abs(mo))
+        dms = dM * (mp + b)
+        dmo = -dM * np.sign(mo) * (1 - b)
+        dmp = dM * ms + np.where(cond, -np.sign(mp) * db, 0.0)
+        dbp = np.where(cond | (bp > 1.0), 0.0, db)  # [TF] clip_by_value passes the gradient on [min, max]; where() to the taken branch
+        return np.concatenate([dph, dms], 1), np.concatenate([dph, dmp, dbp], 1), np.concatenate([-dph, dmo], 1)
     g = g[:, None]
     if model == "pRotatE":  # autodiff through atan2(sin x, cos x) is the identity; d|u|/du = sign(u) [TF sign(0) = 0]
         ph = lambda x: np.arctan2(np.sin(x), np.cos(x))  # noqa: E731

@@ -318,3 +318,38 @@ def test_protate_known_answers():
     assert O.func_protate(s, p, o, 2.0, 12)[0] == pytest.approx(12 - 2.0 * (1.0 + 0.5))
     assert O.func_protate(s, p, o, 2.0, 0)[0] == pytest.approx(2.0 * 1.5)
     assert O.func_protate(s + 2 * np.pi, p - 4 * np.pi, o + 6 * np.pi, 2.0, 12)[0] == pytest.approx(12 - 3.0)  # wrap invariance
+
+
+def test_hake_restatement_vs_torch_autograd_and_known_answer():
+    """HAKE exactly as written (models.py:362-400): phase part an L1 norm per row, modulus part ONE tf.norm over the whole tensor handed
+    to the call -- scores and the gradients of sum(g * score) against torch autograd (clamp / where / abs branches included), a
+    hand-computed value, and the batch dependence itself: a row scored alone != the same row scored in a batch."""
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(0)
+    m, h = 17, 6
+    s, o = rs.uniform(-1, 1, (m, 2 * h)), rs.uniform(-1, 1, (m, 2 * h))
+    p = rs.uniform(-1.5, 1.5, (m, 3 * h))
+    p[:, 2 * h:] *= 2  # biases beyond 1 and below -|mod_p|
+    prm = O.hake_params(2 * h, 12, 2, 0.5, 1.0)
+    g = rs.uniform(-1, 1, m)
+    sc = O.score_rows("HAKE", s, p, o, prm, 12)
+    ds, dp, do = O.score_row_grads("HAKE", s, p, o, g, prm, 12)
+    S, P, Ob = [torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (s, p, o)]
+    pw, mw, rng = prm
+    scale = rng / np.pi
+    phs, ms = S[:, :h] / scale, S[:, h:]
+    pho, mo = Ob[:, :h] / scale, Ob[:, h:]
+    php, mp, bp = P[:, :h] / scale, P[:, h:2 * h], P[:, 2 * h:]
+    b = torch.clamp(bp, max=1.0)
+    b = torch.where(b < -mp.abs(), -mp.abs(), b)
+    out = 12 - (pw * torch.sin((phs + php - pho) / 2).abs().sum(-1) + mw * torch.linalg.vector_norm(ms * (mp + b) - mo.abs() * (1 - b)))
+    assert np.allclose(out.detach().numpy(), sc, atol=1e-12)
+    (out * torch.tensor(g)).sum().backward()
+    for a, t in ((ds, S.grad), (dp, P.grad), (do, Ob.grad)):
+        assert np.allclose(a, t.numpy(), atol=1e-10)
+    # known answer (h = 1, one row): phases 0 -> p_score 0; M = 2*(3 + 0.5) - |-4|*(1 - 0.5) = 5 -> score = 12 - 5 = 7
+    one = O.func_hake(np.array([[0.0, 2.0]]), np.array([[0.0, 3.0, 0.5]]), np.array([[0.0, -4.0]]), (0.5, 1.0, 1.0), 12)
+    assert one == pytest.approx([7.0])
+    # batch dependence: the modulus norm is taken over all rows of the call
+    assert not np.allclose(O.score_rows("HAKE", s[:1], p[:1], o[:1], prm, 12), sc[:1])
+    assert np.allclose(O.call("HAKE", s, p, np.stack([np.arange(m)] * 3, 1) * 0 + np.array([[0, 0, 0]]), prm, 12)[:1], O.score_rows("HAKE", s[:1].repeat(m, 0), p[:1].repeat(m, 0), s[:1].repeat(m, 0), prm, 12)[:1])
