@@ -14,14 +14,14 @@ w = bench.workload("DistMult", 0)
 model = bench.make_model(w)
 pipe, dsamp = bench.make_pipeline(torch, model, w, 0, 6000)
 pipe.start()
-pipe.run(300)
+pipe.run(300, join=False)
 torch.cuda.synchronize()
-for mask in (15, 13, 12, 15):  # (never a mask with plan but without step: an unconsumed plan leaves its counters set and the next build would rank out of range)
+for mask in (15, 13, 12, 14, 15):  # (never a mask with plan but without step: an unconsumed plan leaves its counters set and the next build would rank out of range)
     os.environ["KGE_PIPE_STAGES"] = str(mask)
-    pipe.run(50)
+    pipe.run(50, join=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipe.run(500)
+    pipe.run(500, join=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"stages {mask:2d}: {dt / 500 * 1e3:.4f} ms per step", flush=True)

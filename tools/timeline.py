@@ -1,5 +1,5 @@
-"""Kernel timeline of the concurrent pipeline from a rocprofv3 kernel trace: python tools/timeline.py <kernel_trace.csv> [first_step] [n_steps]
-For n consecutive training steps (a step = from one fwd_rel_kernel start to the next) prints every kernel with its start offset,
+"""Kernel timeline of the concurrent pipeline from a rocprofv3 kernel trace: python tools/timeline.py <kernel_trace.csv> [first_step] [n_steps] [anchor]
+For n consecutive training steps (a step = from one start of the anchor kernel, default fwd_rel_kernel, to the next) prints every kernel with its start offset,
 duration and queue, then per queue the busy time and the idle gaps inside the window."""
 import collections
 import csv
@@ -7,7 +7,8 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "fwd_rel_kernel" in r["Kernel_Name"]]
+anchor = sys.argv[4] if len(sys.argv) > 4 else "fwd_rel_kernel"
+idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 t0, t1 = int(rows[idx[k]]["Start_Timestamp"]), int(rows[idx[k + n]]["Start_Timestamp"])
