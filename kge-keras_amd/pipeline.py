@@ -15,10 +15,13 @@ changes from step to step lives on the device: the generator states, the batch c
 Without dropout and without a hook between the halves of a step the whole loop is native (csrc/pipeline.cpp): kge_pipeline_run(n)
 issues n steps from C, kernel by kernel on four streams -- one ctypes call per `run`, no per-step Python; the step runs between twin
 tables (kge_train_step_swap: two launches), the draw and plan streams are confined to half of the compute units, and the loop is
-issued from a stream of this object's own (see _on_native).  The Python loop below remains for dropout (a per-step mask seed:
-kernel-by-kernel launches), for data-parallel training (`between`: the gradient all-reduce sits between the halves of the step)
-and for `serial` profiling runs; it replays S and P from hipGraphs captured once per buffer parity where it can (one graph holding
-all stages as branches does not overlap them on ROCm 7.2; separate graphs on separate streams do).
+issued from a stream of this object's own (see _on_native).  With an RCCL communicator (`comm`) the native loop runs the
+data-parallel step instead: gradient half, all-reduce of the flat gradient buffer on the communicator (the entity table's share beside
+the relation half), optimizer half.  The Python loop below remains for a `between` hook (data-parallel training over
+torch.distributed: the all-reduce sits between the halves of the step), for `serial` profiling runs and for epochs taken over from
+the native driver; it replays S and P from hipGraphs captured once per buffer parity where it can (one graph holding all stages as
+branches does not overlap them on ROCm 7.2; separate graphs on separate streams do).  (Dropout is no obstacle to the native loop: it
+launches kernel by kernel and hands every step its mask seed.)
 """
 import os
 import time
@@ -346,7 +349,8 @@ class TrainPipeline:
         _lib.check(_lib.lib.kge_pipeline_state(self._h, st4))
         if int(st4[2]):
             raise RuntimeError("TrainPipeline: the native driver left the current tables in the twins (a failed run); the epoch cannot be carried on")
-        assert int(st4[1]) == self.t, (int(st4[1]), self.t)
+        if int(st4[1]) != self.t:
+            raise RuntimeError(f"TrainPipeline: the native driver issued {int(st4[1])} steps of this epoch, this object counted {self.t}")
         self._np, self._taken_over = int(st4[0]), True
         self._native_active = False
         main = torch.cuda.current_stream()
