@@ -19,7 +19,7 @@ namespace kge {
 
 constexpr float kBnEps = 1e-3f, kBnMom = 0.99f;
 
-struct CvShape { int d, w, h, H, W, Ho, Wo, C, F, KH, KW; };
+struct CvShape { int d, w, h, H, W, Ho, Wo, C, F, KH, KW; uint32_t mWo, mW; };  // mWo, mW = ceil(2^32 / Wo), ceil(2^32 / W) (cv_div)
 // Conv2D(conv_filters, (conv_size_w, conv_size_h)) of models.py:254: a (KH, KW) kernel over the (2w rows, h columns) image, 'valid',
 // stride 1.  kge_model_desc.conv_kh / conv_kw == 0 stand for the reference default 3.
 static CvShape cv_shape(const kge_model_desc* md) {
@@ -31,6 +31,8 @@ static CvShape cv_shape(const kge_model_desc* md) {
   s.KW = md->conv_kw > 0 ? md->conv_kw : 3;
   s.C = md->conv_filters;
   s.d = d; s.w = w; s.h = d / w; s.H = 2 * w; s.W = s.h; s.Ho = s.H - s.KH + 1; s.Wo = s.W - s.KW + 1; s.F = s.Ho * s.Wo * s.C;
+  s.mWo = s.Wo > 1 ? (uint32_t)((0x100000000ull + s.Wo - 1) / s.Wo) : 0u;
+  s.mW = s.W > 1 ? (uint32_t)((0x100000000ull + s.W - 1) / s.W) : 0u;
   return s;
 }
 // the register-tiled kernels below are written for the reference defaults (8 filters of 3x3); every other shape takes the cvg_* kernels
@@ -46,74 +48,146 @@ static CvOff cv_off(const CvShape& s) {
   return o;
 }
 
+// x / dv for 0 <= x < 2^16, 1 <= dv < 2^16 with magic = ceil(2^32 / dv) (0 for dv == 1): the positions of an image, per lane and triple
+__device__ __forceinline__ int cv_div(int x, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)x, magic) : x; }
+
 // ------------------------------------------------------------------------------------------------ forward kernels
-// One wave per triple: the 2w x h image of (s ; p) is staged in LDS, every lane computes the C channels of positions
-// lane, lane+64, ...  Y[i][(pos)*C + c].  TRAIN: per-block partial sums of y and y^2 per channel.
-template <bool TRAIN, bool DROP, int C>
-__global__ __launch_bounds__(256) void cv_conv_fwd(const float* __restrict__ E, const float* __restrict__ Rel,
-                                                    const int32_t* __restrict__ tri, int64_t m, int N, int R, CvShape sh,
-                                                    const float* __restrict__ theta, float* __restrict__ Y,
-                                                    float* __restrict__ psum, uint32_t* __restrict__ err, uint64_t seed,
-                                                    int64_t row_offset, uint32_t thr, float dscale) {
+// One wave per triple: the 2w x h image of (s ; p) is staged in LDS, every lane computes the C channels of positions lane, lane+64, ...
+// The default shape (8 filters of 3x3) never stores the convolution's output: 2 592 floats per triple would be written once and read three
+// times (batch-norm apply, its backward sums, the convolution's backward) -- 2.1 GB per array of the bench shape each time -- while
+// recomputing them from the 400-float image in LDS costs 72 FMAs per position (cv_conv_at: one FMA order everywhere, so the recomputed
+// values are bit-identical wherever they are formed).  Other shapes: the cvg_* kernels further down, which store it.
+template <int C> struct CvKern { float k[9][C]; float b[C]; };
+template <int C>
+__device__ __forceinline__ void cv_kern_load(const float* __restrict__ theta, CvKern<C>& K) {
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int c = 0; c < C; ++c) K.k[a][c] = theta[a * C + c];
+#pragma unroll
+  for (int c = 0; c < C; ++c) K.b[c] = theta[9 * C + c];
+}
+// the 3x3 window at (r, q) and the C channel values of that position
+template <int C>
+__device__ __forceinline__ void cv_conv_at(const float* img, int W, int r, int q, const CvKern<C>& K, float (&xv)[9], float (&acc)[C]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) xv[a * 3 + b] = img[(r + a) * W + q + b];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = K.b[c];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = fmaf(xv[a], K.k[a][c], acc[c]);
+}
+// image of (s ; p) of triple i into this wave's LDS slice; false (and the error flag, if given) for ids outside the tables
+template <bool DROP>
+__device__ __forceinline__ bool cv_stage(float* img, const float* __restrict__ E, const float* __restrict__ Rel, const int32_t* __restrict__ tri,
+                                         int64_t i, int N, int R, int d, uint32_t* err, uint64_t seed, int64_t row_offset, uint32_t thr, float dscale,
+                                         int lane) {
+  const int s = tri[3 * i], p = tri[3 * i + 1], o = tri[3 * i + 2];
+  const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+  if (err && !ok && lane == 0) atomicOr(err, 1u);
+  const float* es = E + (int64_t)(ok ? s : 0) * d;
+  const float* rp = Rel + (int64_t)(ok ? p : 0) * d;
+  DropKey ks{0, 0}, kp{0, 0};
+  if (DROP) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
+  for (int k = lane; k < d; k += 64) {
+    float a = es[k], b = rp[k];
+    if (DROP) { a *= drop_mul(ks, k, thr, dscale); b *= drop_mul(kp, k, thr, dscale); }
+    img[k] = ok ? a : 0.f;       // rows 0..w-1   = s reshaped (w, h)
+    img[d + k] = ok ? b : 0.f;   // rows w..2w-1  = p reshaped (w, h)
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return ok;
+}
+
+// pass 1 of a training call: per-block partial sums of y and y^2 per channel, nothing else written
+template <bool DROP, int C>
+__global__ __launch_bounds__(256) void cv_conv_stats(const float* __restrict__ E, const float* __restrict__ Rel, const int32_t* __restrict__ tri,
+                                                      int64_t m, int N, int R, CvShape sh, const float* __restrict__ theta,
+                                                      float* __restrict__ psum, uint32_t* __restrict__ err, uint64_t seed, int64_t row_offset,
+                                                      uint32_t thr, float dscale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[4][2 * C];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* img = lds + wave * (sh.H * sh.W);
-  float kk[9][C], bcv[C];
-#pragma unroll
-  for (int a = 0; a < 9; ++a)
-#pragma unroll
-    for (int c = 0; c < C; ++c) kk[a][c] = theta[a * C + c];
-#pragma unroll
-  for (int c = 0; c < C; ++c) bcv[c] = theta[9 * C + c];
+  CvKern<C> K;
+  cv_kern_load<C>(theta, K);
   float s1[C], s2[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
   for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
-    const int s = tri[3 * i], p = tri[3 * i + 1], o = tri[3 * i + 2];
-    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
-    if (!ok && lane == 0) atomicOr(err, 1u);
-    const float* es = E + (int64_t)(ok ? s : 0) * sh.d;
-    const float* rp = Rel + (int64_t)(ok ? p : 0) * sh.d;
-    DropKey ks{0, 0}, kp{0, 0};
-    if (DROP) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
-    for (int k = lane; k < sh.d; k += 64) {
-      float a = es[k], b = rp[k];
-      if (DROP) { a *= drop_mul(ks, k, thr, dscale); b *= drop_mul(kp, k, thr, dscale); }
-      img[k] = ok ? a : 0.f;             // rows 0..w-1   = s reshaped (w, h)
-      img[sh.d + k] = ok ? b : 0.f;      // rows w..2w-1  = p reshaped (w, h)
-    }
-    __builtin_amdgcn_wave_barrier();
-    float* yrow = Y + i * (int64_t)sh.F;
+    cv_stage<DROP>(img, E, Rel, tri, i, N, R, sh.d, err, seed, row_offset, thr, dscale, lane);
     for (int pos = lane; pos < sh.Ho * sh.Wo; pos += 64) {
-      const int r = pos / sh.Wo, q = pos - r * sh.Wo;
-      float acc[C];
+      const int r = cv_div(pos, sh.mWo), q = pos - r * sh.Wo;
+      float xv[9], acc[C];
+      cv_conv_at<C>(img, sh.W, r, q, K, xv, acc);
 #pragma unroll
-      for (int c = 0; c < C; ++c) acc[c] = bcv[c];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const float xv = img[(r + a) * sh.W + q + b];
-#pragma unroll
-          for (int c = 0; c < C; ++c) acc[c] = fmaf(xv, kk[a * 3 + b][c], acc[c]);
-        }
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        yrow[pos * C + c] = acc[c];
-        if (TRAIN) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
-      }
+      for (int c = 0; c < C; ++c) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (TRAIN) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) { s1[c] = group_sum<64>(s1[c]); s2[c] = group_sum<64>(s2[c]); }
-    if (lane == 0)
+  for (int c = 0; c < C; ++c) { s1[c] = group_sum<64>(s1[c]); s2[c] = group_sum<64>(s2[c]); }
+  if (lane == 0)
 #pragma unroll
-      for (int c = 0; c < C; ++c) { red[wave][c] = s1[c]; red[wave][C + c] = s2[c]; }
-    __syncthreads();
-    if (threadIdx.x < 2 * C) psum[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    for (int c = 0; c < C; ++c) { red[wave][c] = s1[c]; red[wave][C + c] = s2[c]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) psum[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// pass 2 (the only pass in inference mode): A = Drop(ReLU(g1 * (y - mu) * inv + b1)) with y recomputed.  A wave's 64 positions x 8
+// channels are turned in LDS so that every store instruction covers 1 KB in a row (lane-per-position stores leave half-filled lines
+// behind each instruction: 1.08 ms per 204 800-row call against 0.46 ms).
+template <bool DROPE, bool DROPH, int C>
+__global__ __launch_bounds__(256) void cv_conv_act(const float* __restrict__ E, const float* __restrict__ Rel, const int32_t* __restrict__ tri,
+                                                    int64_t m, int N, int R, CvShape sh, const float* __restrict__ theta,
+                                                    const float* __restrict__ theta_g1, const float* __restrict__ theta_b1,
+                                                    const float* __restrict__ stat, float* __restrict__ A, uint32_t* __restrict__ err,
+                                                    uint64_t seed, int64_t row_offset, uint32_t thr_e, float ds_e, uint32_t thr_h, float ds_h) {
+  static_assert(C == 8, "two float4 per position");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ __attribute__((aligned(16))) float4 turn[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* img = lds + wave * (sh.H * sh.W);
+  CvKern<C> K;
+  cv_kern_load<C>(theta, K);
+  float sc[C], mu[C], be[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { sc[c] = theta_g1[c] * stat[C + c]; mu[c] = stat[c]; be[c] = theta_b1[c]; }
+  const int npos = sh.Ho * sh.Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
+    cv_stage<DROPE>(img, E, Rel, tri, i, N, R, sh.d, err, seed, row_offset, thr_e, ds_e, lane);
+    DropKey kh{0, 0};
+    if (DROPH) kh = drop_key(seed, row_offset + i, 3);
+    float4* arow4 = reinterpret_cast<float4*>(A + i * (int64_t)sh.F);
+    for (int p0 = 0; p0 < npos; p0 += 64) {
+      const int pos = p0 + lane;
+      if (pos < npos) {
+        const int r = cv_div(pos, sh.mWo), q = pos - r * sh.Wo;
+        float xv[9], acc[C];
+        cv_conv_at<C>(img, sh.W, r, q, K, xv, acc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float a = fmaf(sc[c], acc[c] - mu[c], be[c]);
+          a = a > 0.f ? a : 0.f;
+          if (DROPH) a *= drop_mul(kh, (uint32_t)(pos * C + c), thr_h, ds_h);
+          acc[c] = a;
+        }
+        turn[wave][2 * lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        turn[wave][2 * lane + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int n4 = 2 * min(64, npos - p0);  // float4 of this round
+      if (lane < n4) arow4[2 * p0 + lane] = turn[wave][lane];
+      if (lane + 64 < n4) arow4[2 * p0 + 64 + lane] = turn[wave][64 + lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -155,34 +229,6 @@ __global__ __launch_bounds__(256) void cv_bn_finalize(const float* __restrict__ 
   if (threadIdx.x == 0) {
     callstat[c] = mean;
     callstat[nch + c] = 1.f / sqrtf(var + kBnEps);
-  }
-}
-
-// A = Drop(ReLU(g1 * (Y - mu) * inv + b1)), elementwise over m*F (channel = index % C).
-template <bool DROP, int C>
-__global__ __launch_bounds__(256) void cv_bn1_apply(const float* __restrict__ Y, float* __restrict__ A, int64_t m, int F,
-                                                     const float* __restrict__ theta_g1, const float* __restrict__ theta_b1,
-                                                     const float* __restrict__ stat, uint64_t seed, int64_t row_offset, uint32_t thr,
-                                                     float dscale) {
-  const int64_t total4 = m * (int64_t)F / 4;  // F % 4 == 0 because C % 4 == 0
-  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
-    const float4 y = reinterpret_cast<const float4*>(Y)[i4];
-    const int64_t idx = i4 * 4;
-    const int c0 = (int)(idx % C);
-    float v[4] = {y.x, y.y, y.z, y.w};
-    const int64_t row = idx / F;
-    const int e0 = (int)(idx - row * F);
-    DropKey k{0, 0};
-    if (DROP) k = drop_key(seed, row_offset + row, 3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c0 + j;
-      float a = fmaf(theta_g1[c] * stat[C + c], v[j] - stat[c], theta_b1[c]);
-      a = a > 0.f ? a : 0.f;
-      if (DROP) a *= drop_mul(k, (uint32_t)(e0 + j), thr, dscale);
-      v[j] = a;
-    }
-    reinterpret_cast<float4*>(A)[i4] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -296,103 +342,125 @@ __global__ __launch_bounds__(256) void cv_bn2_bwd_apply(float* __restrict__ Z, c
   }
 }
 
-// dy1 = dA * (A > 0 ? hscale : 0) written over dA; per-block partial channel sums of dy1 and dy1*xhat1.  Each block: a
-// slab of 4096 float4; thread's channel group is fixed because 256*4 % C == 0.
-template <int C>
-__global__ __launch_bounds__(256) void cv_bn1_bwd_stats(float* __restrict__ dA, const float* __restrict__ A, const float* __restrict__ Y,
-                                                         int64_t total4, const float* __restrict__ stat, float hscale,
-                                                         float* __restrict__ psum) {
-  __shared__ float red[256][8];
-  const int64_t b0 = (int64_t)blockIdx.x * 4096;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  const int c0 = (int)((threadIdx.x * 4) % C);
-  for (int64_t i4 = b0 + threadIdx.x; i4 < min(total4, b0 + 4096); i4 += 256) {
-    float4 da = reinterpret_cast<float4*>(dA)[i4];
-    const float4 a = reinterpret_cast<const float4*>(A)[i4];
-    const float4 y = reinterpret_cast<const float4*>(Y)[i4];
-    float dv[4] = {da.x, da.y, da.z, da.w};
-    const float av[4] = {a.x, a.y, a.z, a.w}, yv[4] = {y.x, y.y, y.z, y.w};
+// ---- backward of the default shape with y recomputed (see cv_conv_stats): dy1 = dA * (A > 0 ? hscale : 0) is formed on the fly in both
+// kernels -- A > 0 <=> the pre-activation is positive and the element was kept by the hidden dropout -- and never written.
+// per-block partial channel sums of dy1 and dy1 * xhat1, reading dA alone
+template <bool DROPE, bool DROPH, int C>
+__global__ __launch_bounds__(256) void cv_bn1_bwd_rc(const float* __restrict__ E, const float* __restrict__ Rel, const int32_t* __restrict__ tri,
+                                                      int64_t m, int N, int R, CvShape sh, const float* __restrict__ theta,
+                                                      const float* __restrict__ theta_g1, const float* __restrict__ theta_b1,
+                                                      const float* __restrict__ stat, const float* __restrict__ dA, float* __restrict__ psum,
+                                                      uint64_t seed, int64_t row_offset, uint32_t thr_e, float ds_e, uint32_t thr_h, float ds_h) {
+  static_assert(C == 8, "two float4 per position");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4][2 * C];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* img = lds + wave * (sh.H * sh.W);
+  CvKern<C> K;
+  cv_kern_load<C>(theta, K);
+  float sc[C], mu[C], be[C], inv[C];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c0 + j;
-      const float dy = av[j] > 0.f ? dv[j] * hscale : 0.f;
-      dv[j] = dy;
-      s1[j] += dy;
-      s2[j] = fmaf(dy, (yv[j] - stat[c]) * stat[C + c], s2[j]);
+  for (int c = 0; c < C; ++c) { inv[c] = stat[C + c]; sc[c] = theta_g1[c] * inv[c]; mu[c] = stat[c]; be[c] = theta_b1[c]; }
+  float s1[C], s2[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  const float hscale = DROPH ? ds_h : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
+    cv_stage<DROPE>(img, E, Rel, tri, i, N, R, sh.d, nullptr, seed, row_offset, thr_e, ds_e, lane);
+    DropKey kh{0, 0};
+    if (DROPH) kh = drop_key(seed, row_offset + i, 3);
+    const float* da = dA + i * (int64_t)sh.F;
+    for (int pos = lane; pos < sh.Ho * sh.Wo; pos += 64) {
+      // (lane-per-position loads: turning the row in LDS as cv_conv_act does for its stores measured slower here, 0.80 against 0.67 ms)
+      const float4 d0 = reinterpret_cast<const float4*>(da + pos * C)[0], d1 = reinterpret_cast<const float4*>(da + pos * C)[1];
+      const float dv[C] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      const int r = cv_div(pos, sh.mWo), q = pos - r * sh.Wo;
+      float xv[9], acc[C];
+      cv_conv_at<C>(img, sh.W, r, q, K, xv, acc);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        bool keep = fmaf(sc[c], acc[c] - mu[c], be[c]) > 0.f;
+        if (DROPH) keep = keep && drop_mul(kh, (uint32_t)(pos * C + c), thr_h, ds_h) != 0.f;
+        const float dy = keep ? dv[c] * hscale : 0.f;
+        s1[c] += dy;
+        s2[c] = fmaf(dy, (acc[c] - mu[c]) * inv[c], s2[c]);
+      }
     }
-    reinterpret_cast<float4*>(dA)[i4] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][4 + j] = s2[j]; }
+  for (int c = 0; c < C; ++c) { s1[c] = group_sum<64>(s1[c]); s2[c] = group_sum<64>(s2[c]); }
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < C; ++c) { red[wave][c] = s1[c]; red[wave][C + c] = s2[c]; }
   __syncthreads();
-  if (threadIdx.x < 2 * C) {  // channel c (or C + c): sum over the threads whose float4 covers it
-    const int c = threadIdx.x % C, which = threadIdx.x / C;
-    float acc = 0.f;
-    for (int t = (c / 4); t < 256; t += C / 4) acc += red[t][which * 4 + (c & 3)];
-    psum[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = acc;
-  }
+  if (threadIdx.x < 2 * C) psum[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// One wave per triple: dY = inv1 * (g1*dy1 - mean - xhat1*mean2) on the fly (dy1 in dA); dK partial sums; dX -> dS, dP rows.
-template <bool DROP, int C>
-__global__ __launch_bounds__(256) void cv_conv_bwd(const float* __restrict__ E, const float* __restrict__ Rel,
-                                                    const int32_t* __restrict__ tri, int64_t m, int N, int R, CvShape sh,
-                                                    const float* __restrict__ theta, const float* __restrict__ stat,
-                                                    const float* __restrict__ bst, const float* __restrict__ dA,
-                                                    const float* __restrict__ Y, float* __restrict__ dS, float* __restrict__ dP,
-                                                    float* __restrict__ pk, uint64_t seed, int64_t row_offset, uint32_t thr,
-                                                    float dscale) {
+// One wave per triple: dY = inv1 * (g1*dy1 - mean - xhat1*mean2) from dA and the recomputed y, kept in LDS; dK partial sums in the same
+// pass over the positions (the window is in registers already); dX gathered per pixel from up to nine positions -> dS, dP rows.
+// (Tried and dropped: the position's nine contributions added into a 2w x h image with ds_add_f32 instead of the dY slice -- LDS float
+// atomics serialise their lanes: 3.54 ms per 204 800-row call against 2.46 ms; the dA row staged through LDS in whole-line loads: 2.64 ms.)
+template <bool DROPE, bool DROPH, int C>
+__global__ __launch_bounds__(256) void cv_conv_bwd_rc(const float* __restrict__ E, const float* __restrict__ Rel, const int32_t* __restrict__ tri,
+                                                       int64_t m, int N, int R, CvShape sh, const float* __restrict__ theta,
+                                                       const float* __restrict__ theta_g1, const float* __restrict__ theta_b1,
+                                                       const float* __restrict__ stat, const float* __restrict__ bst, const float* __restrict__ dA,
+                                                       float* __restrict__ dS, float* __restrict__ dP, float* __restrict__ pk, uint64_t seed,
+                                                       int64_t row_offset, uint32_t thr_e, float ds_e, uint32_t thr_h, float ds_h) {
+  static_assert(C == 8, "two float4 per position");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[4][9 * C];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int npos = sh.Ho * sh.Wo;
   float* img = lds + wave * (sh.H * sh.W + npos * C);
   float* dy = img + sh.H * sh.W;  // [npos][C]
+  CvKern<C> K;
+  cv_kern_load<C>(theta, K);
+  float sc[C], mu[C], be[C], inv[C], g1[C], m1[C], m2[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    inv[c] = stat[C + c]; g1[c] = theta_g1[c]; sc[c] = g1[c] * inv[c]; mu[c] = stat[c]; be[c] = theta_b1[c]; m1[c] = bst[c]; m2[c] = bst[C + c];
+  }
   float dk[9][C];
 #pragma unroll
   for (int a = 0; a < 9; ++a)
 #pragma unroll
     for (int c = 0; c < C; ++c) dk[a][c] = 0.f;
+  const float hscale = DROPH ? ds_h : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < m; i += (int64_t)gridDim.x * 4) {
-    const int s = tri[3 * i], p = tri[3 * i + 1], o = tri[3 * i + 2];
-    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
-    const float* es = E + (int64_t)(ok ? s : 0) * sh.d;
-    const float* rp = Rel + (int64_t)(ok ? p : 0) * sh.d;
-    DropKey ks{0, 0}, kp{0, 0};
-    if (DROP) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
-    for (int k = lane; k < sh.d; k += 64) {
-      float a = es[k], b = rp[k];
-      if (DROP) { a *= drop_mul(ks, k, thr, dscale); b *= drop_mul(kp, k, thr, dscale); }
-      img[k] = ok ? a : 0.f;
-      img[sh.d + k] = ok ? b : 0.f;
-    }
+    const bool ok = cv_stage<DROPE>(img, E, Rel, tri, i, N, R, sh.d, nullptr, seed, row_offset, thr_e, ds_e, lane);
+    DropKey ks{0, 0}, kp{0, 0}, kh{0, 0};
+    if (DROPE) { ks = drop_key(seed, row_offset + i, 0); kp = drop_key(seed, row_offset + i, 1); }
+    if (DROPH) kh = drop_key(seed, row_offset + i, 3);
     const float* da = dA + i * (int64_t)sh.F;
-    const float* yr = Y + i * (int64_t)sh.F;
-    for (int e = lane; e < sh.F; e += 64) {
-      const int c = e % C;
-      const float inv = stat[C + c];
-      const float xh = (yr[e] - stat[c]) * inv;
-      dy[e] = ok ? inv * (theta[10 * C + c] * da[e] - bst[c] - xh * bst[C + c]) : 0.f;  // theta[10C..11C) = g1
-    }
-    __builtin_amdgcn_wave_barrier();
-    // dK[a][b][c] += sum_pos X[r+a][q+b] * dY[pos][c]
     for (int pos = lane; pos < npos; pos += 64) {
-      const int r = pos / sh.Wo, q = pos - r * sh.Wo;
-      float dv[C];
+      const float4 d0 = reinterpret_cast<const float4*>(da + pos * C)[0], d1 = reinterpret_cast<const float4*>(da + pos * C)[1];
+      const float dv0[C] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      const int r = cv_div(pos, sh.mWo), q = pos - r * sh.Wo;
+      float xv[9], acc[C], dv[C];
+      cv_conv_at<C>(img, sh.W, r, q, K, xv, acc);
 #pragma unroll
-      for (int c = 0; c < C; ++c) dv[c] = dy[pos * C + c];
+      for (int c = 0; c < C; ++c) {
+        bool keep = fmaf(sc[c], acc[c] - mu[c], be[c]) > 0.f;
+        if (DROPH) keep = keep && drop_mul(kh, (uint32_t)(pos * C + c), thr_h, ds_h) != 0.f;
+        const float dy1 = keep ? dv0[c] * hscale : 0.f;
+        const float xh = (acc[c] - mu[c]) * inv[c];
+        dv[c] = ok ? inv[c] * (g1[c] * dy1 - m1[c] - xh * m2[c]) : 0.f;
+      }
+      reinterpret_cast<float4*>(dy + pos * C)[0] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+      reinterpret_cast<float4*>(dy + pos * C)[1] = make_float4(dv[4], dv[5], dv[6], dv[7]);
+      // dK[a][b][c] += X[r+a][q+b] * dY[pos][c]
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+      for (int a = 0; a < 9; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const float xv = img[(r + a) * sh.W + q + b];
-#pragma unroll
-          for (int c = 0; c < C; ++c) dk[a * 3 + b][c] = fmaf(xv, dv[c], dk[a * 3 + b][c]);
-        }
+        for (int c = 0; c < C; ++c) dk[a][c] = fmaf(xv[a], dv[c], dk[a][c]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // dX[u][v] = sum_{a,b,c} dY[u-a][v-b][c] * K[a][b][c]  (positions inside the valid output only)
     for (int k = lane; k < 2 * sh.d; k += 64) {
-      const int u = k / sh.W, v = k - u * sh.W;
+      const int u = cv_div(k, sh.mW), v = k - u * sh.W;
       float acc = 0.f;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -402,16 +470,18 @@ __global__ __launch_bounds__(256) void cv_conv_bwd(const float* __restrict__ E, 
         for (int b = 0; b < 3; ++b) {
           const int q = v - b;
           if (q < 0 || q >= sh.Wo) continue;
+          const float4 y0 = reinterpret_cast<const float4*>(dy + (r * sh.Wo + q) * C)[0], y1 = reinterpret_cast<const float4*>(dy + (r * sh.Wo + q) * C)[1];
+          const float yv[C] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
 #pragma unroll
-          for (int c = 0; c < C; ++c) acc = fmaf(dy[(r * sh.Wo + q) * C + c], theta[(a * 3 + b) * C + c], acc);
+          for (int c = 0; c < C; ++c) acc = fmaf(yv[c], K.k[a * 3 + b][c], acc);
         }
       }
       if (k < sh.d) {
-        if (DROP) acc *= drop_mul(ks, k, thr, dscale);
+        if (DROPE) acc *= drop_mul(ks, k, thr_e, ds_e);
         dS[i * sh.d + k] = acc;
       } else {
         const int kk2 = k - sh.d;
-        if (DROP) acc *= drop_mul(kp, kk2, thr, dscale);
+        if (DROPE) acc *= drop_mul(kp, kk2, thr_e, ds_e);
         dP[i * sh.d + kk2] = acc;
       }
     }
@@ -764,7 +834,8 @@ int64_t conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m
   const CvShape s = cv_shape(md);
   const int64_t n = m_pos + m_neg, mm = std::max(m_pos, m_neg);
   int64_t b = 0;
-  for (int64_t m : {m_pos, m_neg}) b += 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4);
+  const int nf = cv_fast(s) ? 1 : 2;  // A, and Y where the convolution's output is stored (the general kernels)
+  for (int64_t m : {m_pos, m_neg}) b += nf * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4);
   b += c256(mm * s.F * 4) + 3 * c256(n * s.d * 4) + c256(cv_psum_floats(s, mm) * 4) + c256(2 * (s.d + s.C) * 4) + 2 * c256(n * 4);
   b += pull_header_bytes(md) + pull_workspace_bytes(md, n) + c256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096;
   return b;
@@ -778,7 +849,7 @@ static void cv_carve(void* ws, const kge_model_desc* md, int64_t m_pos, int64_t 
   w->pull_hdr = take(pull_header_bytes(md));  // fixed place: zero on entry, left zero
   const int64_t ms[2] = {m_pos, m_neg};
   for (int c = 0; c < 2; ++c) {
-    w->call[c].Y = (float*)take(ms[c] * s.F * 4);
+    w->call[c].Y = cv_fast(s) ? nullptr : (float*)take(ms[c] * s.F * 4);
     w->call[c].A = (float*)take(ms[c] * s.F * 4);
     w->call[c].Z = (float*)take(ms[c] * s.d * 4);
     w->call[c].X = (float*)take(ms[c] * s.d * 4);
@@ -827,24 +898,25 @@ static int cv_forward(const kge_model_desc* md, const float* E, const float* Rel
   const float ds_e = 1.f / (1.f - md->dropout), ds_h = 1.f / (1.f - md->hidden_dropout);
   const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
   const size_t smem = (size_t)4 * s.H * s.W * sizeof(float);
-#define KGE_CONV(TR, DR) hipLaunchKernelGGL((cv_conv_fwd<TR, DR, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, \
-                                            md->num_relations, s, theta, b.Y, psum, err, seed, row_offset, thr_e, ds_e)
   int nb_stat1 = nb_conv;
-  if (fast) {
-    if (training) { if (drop_e) KGE_CONV(true, true); else KGE_CONV(true, false); }
-    else KGE_CONV(false, false);
+  if (fast) {  // (the convolution's output is not stored: pass 1 files its channel sums, pass 2 -- below -- recomputes it)
+    if (training) {
+      if (drop_e) hipLaunchKernelGGL((cv_conv_stats<true, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, psum, err, seed, row_offset, thr_e, ds_e);
+      else hipLaunchKernelGGL((cv_conv_stats<false, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, psum, err, seed, row_offset, thr_e, ds_e);
+    }
   } else {
     if (drop_e) hipLaunchKernelGGL((cvg_conv_fwd<true>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.Y, err, seed, row_offset, thr_e, ds_e);
     else hipLaunchKernelGGL((cvg_conv_fwd<false>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.Y, err, seed, row_offset, thr_e, ds_e);
     nb_stat1 = (int)cdiv(m, 16);
     if (training) hipLaunchKernelGGL((cvg_chan_sums<0>), dim3(nb_stat1), dim3(256), 0, st, b.Y, nullptr, nullptr, m, s.F, C, nullptr, 1.f, psum);
   }
-#undef KGE_CONV
   hipLaunchKernelGGL(cv_bn_finalize, dim3(C), dim3(256), 0, st, psum, nb_stat1, C, (double)m * s.Ho * s.Wo, 1, b.stat1, stats, stats + C, training ? 0 : 1);
   if (fast) {
-    const int nb_el = (int)std::min<int64_t>(cdiv(m * s.F / 4, 256), 8192);
-    if (drop_h) hipLaunchKernelGGL((cv_bn1_apply<true, 8>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
-    else hipLaunchKernelGGL((cv_bn1_apply<false, 8>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
+#define KGE_ACT(DE, DH) hipLaunchKernelGGL((cv_conv_act<DE, DH, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, \
+                                           s, theta, theta + o.g1, theta + o.b1, b.stat1, b.A, err, seed, row_offset, thr_e, ds_e, thr_h, ds_h)
+    if (drop_e) { if (drop_h) KGE_ACT(true, true); else KGE_ACT(true, false); }
+    else { if (drop_h) KGE_ACT(false, true); else KGE_ACT(false, false); }
+#undef KGE_ACT
   } else {
     const int nb_el = (int)std::min<int64_t>(cdiv(m * s.F, 256), 8192);
     if (drop_h) hipLaunchKernelGGL((cvg_bn1_apply<true>), dim3(nb_el), dim3(256), 0, st, b.Y, b.A, m, s.F, C, theta + o.g1, theta + o.b1, b.stat1, seed, row_offset, thr_h, ds_h);
@@ -905,22 +977,28 @@ static int cv_backward(const kge_model_desc* md, const float* E, const float* Re
   KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, s.d, s.F, (rocblas_int)m, &one, b.Z, s.d, b.A, s.F, &one, gtheta + o.Wd, s.d));
   const int64_t total4 = m * (int64_t)s.F / 4;
   int nb_bn1 = (int)cdiv(total4, 4096);
+  const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
+  const uint32_t thr_h = drop_thr(md->hidden_dropout);
   if (fast) {
-    hipLaunchKernelGGL((cv_bn1_bwd_stats<8>), dim3(nb_bn1), dim3(256), 0, st, w.dA, b.A, b.Y, total4, b.stat1, ds_h, w.psum);
+    const size_t smem1 = (size_t)4 * s.H * s.W * sizeof(float);
+    nb_bn1 = nb_conv;
+#define KGE_BN1(DE, DH) hipLaunchKernelGGL((cv_bn1_bwd_rc<DE, DH, 8>), dim3(nb_conv), dim3(256), smem1, st, E, Rel, tri, m, md->num_entities, md->num_relations, \
+                                           s, theta, theta + o.g1, theta + o.b1, b.stat1, w.dA, w.psum, seed, row_offset, thr_e, ds_e, thr_h, ds_h)
+    if (drop_e) { if (drop_h) KGE_BN1(true, true); else KGE_BN1(true, false); }
+    else { if (drop_h) KGE_BN1(false, true); else KGE_BN1(false, false); }
+#undef KGE_BN1
   } else {
     nb_bn1 = (int)cdiv(m, 16);
     hipLaunchKernelGGL((cvg_chan_sums<1>), dim3(nb_bn1), dim3(256), 0, st, w.dA, b.A, b.Y, m, s.F, C, b.stat1, ds_h, w.psum);
   }
   hipLaunchKernelGGL(cv_bn_bwd_finalize, dim3(C), dim3(256), 0, st, w.psum, nb_bn1, C, (double)m * s.Ho * s.Wo, theta + o.g1, bst1, gtheta + o.g1, gtheta + o.b1);
-  const int nb_conv = (int)std::min<int64_t>(cdiv(m, 4), 2048);
   if (fast) {
     const size_t smem = (size_t)4 * (s.H * s.W + s.Ho * s.Wo * C) * sizeof(float);
-    if (drop_e)
-      hipLaunchKernelGGL((cv_conv_bwd<true, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
-                         bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
-    else
-      hipLaunchKernelGGL((cv_conv_bwd<false, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, s, theta, b.stat1,
-                         bst1, w.dA, b.Y, dS, dP, w.psum, seed, row_offset, thr_e, ds_e);
+#define KGE_CBW(DE, DH) hipLaunchKernelGGL((cv_conv_bwd_rc<DE, DH, 8>), dim3(nb_conv), dim3(256), smem, st, E, Rel, tri, m, md->num_entities, md->num_relations, \
+                                           s, theta, theta + o.g1, theta + o.b1, b.stat1, bst1, w.dA, dS, dP, w.psum, seed, row_offset, thr_e, ds_e, thr_h, ds_h)
+    if (drop_e) { if (drop_h) KGE_CBW(true, true); else KGE_CBW(true, false); }
+    else { if (drop_h) KGE_CBW(false, true); else KGE_CBW(false, false); }
+#undef KGE_CBW
   } else {
     const size_t smem = (size_t)4 * (s.H * s.W + s.F + nk) * sizeof(float);
     if (drop_e)
@@ -943,12 +1021,12 @@ int conve_infer(const kge_model_desc* md, const float* E, const float* Rel, cons
   const CvShape s = cv_shape(md);
   const int64_t CH = 32768;  // rows per pass: bounds the activation buffers
   const int64_t m = std::min(n, CH);
-  const int64_t need = 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 1024;
+  const int64_t need = (cv_fast(s) ? 1 : 2) * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 1024;
   if (wbytes < need) return fail(KGE_EWORKSPACE, "ConvE inference: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)need);
   char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   auto take = [&](int64_t bytes) { char* r = q; q += c256(bytes); return r; };
   CvBuf b;
-  b.Y = (float*)take(m * s.F * 4); b.A = (float*)take(m * s.F * 4); b.Z = (float*)take(m * s.d * 4);
+  b.Y = cv_fast(s) ? nullptr : (float*)take(m * s.F * 4); b.A = (float*)take(m * s.F * 4); b.Z = (float*)take(m * s.d * 4);
   float* Xtmp = (float*)take(m * s.d * 4);
   b.stat1 = (float*)take(2 * s.C * 4); b.stat2 = (float*)take(2 * s.d * 4);
   float* psum = (float*)take(cv_psum_floats(s, m) * 4);
@@ -984,7 +1062,7 @@ int cv_rowsum_launch(const kge_model_desc* md, float* gE, float* gR, const PullP
 int64_t conve_infer_workspace_bytes(const kge_model_desc* md, int64_t n) {
   const CvShape s = cv_shape(md);
   const int64_t m = std::min<int64_t>(n, 32768);
-  return 2 * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 2048;
+  return (cv_fast(s) ? 1 : 2) * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 2048;
 }
 
 int conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta, float* stats,
