@@ -23,6 +23,8 @@ def _make(kind, seed=11):
         return M.DistMult(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, seed=seed, loss_function="pointwize_logistic"), N, R, rs
     if kind == "ConvE":
         return M.ConvE(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, hidden_dp=0.0, seed=seed, loss_function="pointwize_logistic"), N, R, rs
+    if kind == "HAKE":
+        return M.HAKE(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, seed=seed, loss_function="pointwize_logistic"), N, R, rs
     if kind == "RotatE":
         return M.RotatE(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, seed=seed, loss_function="pointwize_logistic"), N, R, rs
     lit = np.random.RandomState(3).rand(N, 5).astype(np.float32)
@@ -30,7 +32,7 @@ def _make(kind, seed=11):
                       loss_function="pairwize_hinge"), N, R, rs
 
 
-@pytest.mark.parametrize("kind", ["DistMult", "ConvE", "literal", "RotatE"])
+@pytest.mark.parametrize("kind", ["DistMult", "ConvE", "literal", "RotatE", "HAKE"])
 def test_save_load_round_trip(kind, tmp_path):
     a, N, R, rs = _make(kind)
     a.compile("adam")
