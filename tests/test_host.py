@@ -55,6 +55,18 @@ def test_argument_errors_without_gpu():
     md = _lib.ModelDesc(0, 10, 3, 8, 8, 1, 0.0, 0.0, 0, 0.0)
     assert _lib.lib.kge_score(ctypes.byref(md), 1, 1, 1, 0, 1, 1, None) == 0  # empty input is a no-op
     assert _lib.lib.kge_score(ctypes.byref(md), None, 1, 1, 4, 1, 1, None) == _lib.KGE_EINVAL
+    # HAKE (models.py:362-400): rows [phase | modulus] against [phase | modulus | bias]; entry points of its own
+    hp = _lib.HakeParams(0.5, 1.0, 0.1)
+    md = _lib.ModelDesc(_lib.MODEL_IDS["HAKE"], 10, 3, 8, 8, 1, 12.0, 0.0, 0, 0.0)  # r_dim must be 3 * e_dim / 2
+    assert _lib.lib.kge_hake_score(ctypes.byref(md), ctypes.byref(hp), 1, 1, 1, 4, 0, None, 0, 1, 1, 1 << 20, 1, None) == _lib.KGE_ESHAPE
+    md = _lib.ModelDesc(_lib.MODEL_IDS["HAKE"], 10, 3, 8, 12, 1, 12.0, 0.0, 0, 0.0)
+    assert _lib.lib.kge_hake_score(ctypes.byref(md), ctypes.byref(hp), 1, 1, 1, 0, 0, None, 0, 1, 1, 1 << 20, 1, None) == 0  # empty: a no-op
+    assert _lib.lib.kge_hake_score(ctypes.byref(md), None, 1, 1, 1, 4, 0, None, 0, 1, 1, 1 << 20, 1, None) == _lib.KGE_EINVAL
+    assert _lib.lib.kge_score(ctypes.byref(md), 1, 1, 1, 4, 1, 1, None) == _lib.KGE_EUNSUPPORTED and b"kge_score" in _lib.lib.kge_last_error()
+    assert _lib.lib.kge_rank_counts(ctypes.byref(md), 1, 1, None, 0, 10, 1, 4, 0, None, None, 0, 1, 0, None, 1, 1 << 20, 1, None) == _lib.KGE_EUNSUPPORTED
+    md.model = 0
+    assert _lib.lib.kge_hake_score(ctypes.byref(md), ctypes.byref(hp), 1, 1, 1, 4, 0, None, 0, 1, 1, 1 << 20, 1, None) in (_lib.KGE_EINVAL, _lib.KGE_ESHAPE)
+    assert _lib.lib.kge_hake_workspace_bytes(1000, 0) >= _lib.lib.kge_hake_workspace_bytes(1000, 1000) > 0
 
 
 # ------------------------------------------------------------------ samplers vs reference-generated vectors
