@@ -26,11 +26,11 @@ __device__ __forceinline__ int hole_dpad(int d) { return (d + 3) & ~3; }
 __host__ __device__ __forceinline__ int hole_lds_floats(int d) { return ((d + 3) & ~3) + ((2 * d + 16 + 3) & ~3); }
 
 // Stage one row into the broadcast slot (optionally reversed: u_i = row[(d - i) mod d]) with an optional dropout mask.
-template <bool DROP>
+template <bool DROP, int NL = 64>
 __device__ __forceinline__ void stage_u(float* u, const float* __restrict__ row, int d, bool reverse, int lane, DropKey key,
                                         uint32_t thr, float dscale) {
   const int dp = hole_dpad(d);
-  for (int i = lane; i < dp; i += 64) {
+  for (int i = lane; i < dp; i += NL) {
     float v = 0.f;
     if (i < d) {
       const int src = reverse ? (i == 0 ? 0 : d - i) : i;
@@ -42,10 +42,10 @@ __device__ __forceinline__ void stage_u(float* u, const float* __restrict__ row,
 }
 
 // Stage one row twice back to back (w2[j] = row[j mod d]) plus zero padding.
-template <bool DROP>
+template <bool DROP, int NL = 64>
 __device__ __forceinline__ void stage_w2(float* w2, const float* __restrict__ row, int d, int lane, DropKey key, uint32_t thr,
                                          float dscale) {
-  for (int i = lane; i < d; i += 64) {
+  for (int i = lane; i < d; i += NL) {
     float v = row[i];
     if (DROP) v *= drop_mul(key, (uint32_t)i, thr, dscale);
     w2[i] = v;
@@ -79,6 +79,41 @@ __device__ __forceinline__ void ccorr4(const float* __restrict__ u, const float*
   out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
 }
 
+// The same primitive with EIGHT outputs per lane (k0 = 8 * lane of a 32-lane half-wave, d <= 256): per 4 values of i one broadcast
+// ds_read_b128 of u and one ds_read_b128 of the window feed 32 FMAs instead of 16 -- ccorr4 keeps the LDS pipe of a CU ~75 % busy (four
+// SIMDs x two b128 reads per 16 FMAs), so the two halves of a wave each take a problem of their own (two triples, two list entries) and
+// the FMAs, not the reads, set the pace.  Every output's sum runs over i in ascending order, as in ccorr4: the values are bit-identical.
+constexpr int kHolePairD = 256;
+__device__ __forceinline__ void ccorr8(const float* __restrict__ u, const float* __restrict__ w2, int d, int k0, float out[8]) {
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+  if (k0 < d) {
+    float4 w0 = *reinterpret_cast<const float4*>(w2 + k0), w1 = *reinterpret_cast<const float4*>(w2 + k0 + 4);
+    const int d4 = d & ~3;
+    for (int i = 0; i < d4; i += 4) {
+      const float4 uu = *reinterpret_cast<const float4*>(u + i);
+      const float4 nx = *reinterpret_cast<const float4*>(w2 + k0 + i + 8);
+      const float e[11] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, nx.x, nx.y, nx.z};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[j] = fmaf(uu.x, e[j], a[j]);
+        a[j] = fmaf(uu.y, e[j + 1], a[j]);
+        a[j] = fmaf(uu.z, e[j + 2], a[j]);
+        a[j] = fmaf(uu.w, e[j + 3], a[j]);
+      }
+      w0 = w1; w1 = nx;
+    }
+    for (int i = d4; i < d; ++i) {  // d % 4 tail
+      const float ui = u[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = fmaf(ui, w2[k0 + i + j], a[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = a[j];
+}
+
 
 // Forward.  LOSS >= 0: pointwise loss fused; LOSS < 0: scores only (predict, pairwise two-phase path).
 // Dynamic LDS: 4 waves x hole_lds_floats(d) floats.
@@ -97,6 +132,53 @@ __global__ __launch_bounds__(256) void hole_fwd_kernel(const float* __restrict__
   const int64_t n = m_pos + m_neg;
   const float inv_pos = 1.f / (float)(m_pos > 0 ? m_pos : 1), inv_neg = 1.f / (float)(m_neg > 0 ? m_neg : 1);
   float lsum = 0.f;
+  if (d <= kHolePairD) {  // two triples per wave, one per half (ccorr8); LDS: two slices per wave
+    const int hw = lane >> 5, hl = lane & 31;
+    float* u2 = lds + (wave * 2 + hw) * hole_lds_floats(d);
+    float* w22 = u2 + hole_dpad(d);
+    for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * 2; t0 < n; t0 += (int64_t)gridDim.x * 8) {
+      const int64_t t = t0 + hw;
+      const bool live = t < n;
+      const bool is_pos = t < m_pos;
+      const int32_t* tr = live ? (is_pos ? pos + 3 * t : neg + 3 * (t - m_pos)) : pos;
+      const int s = live ? tr[0] : 0, p = live ? tr[1] : 0, o = live ? tr[2] : 0;
+      const bool ok = live && (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+      float part = 0.f;
+      DropKey ks{0, 0}, kp{0, 0}, ko{0, 0};
+      if (DROP) { ks = drop_key(seed, t, 0); kp = drop_key(seed, t, 1); ko = drop_key(seed, t, 2); }
+      if (ok) {
+        stage_u<DROP, 32>(u2, E + (int64_t)s * d, d, false, hl, ks, thr, dscale);
+        stage_w2<DROP, 32>(w22, E + (int64_t)o * d, d, hl, ko, thr, dscale);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (ok) {
+        const float* rp = Rel + (int64_t)p * d;
+        const int k0 = 8 * hl;
+        float x[8];
+        ccorr8(u2, w22, d, k0, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0 + j < d) {
+            float pv = rp[k0 + j];
+            if (DROP) pv *= drop_mul(kp, (uint32_t)(k0 + j), thr, dscale);
+            part = fmaf(pv, x[j], part);
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float score0 = group_sum<32>(part);
+      if (hl == 0 && live) {
+        float score = score0;
+        if (!ok) { score = __builtin_nanf(""); atomicOr(err, 1u); }
+        if (scores) scores[t] = score;
+        if (LOSS >= 0) {
+          float g = 0.f, l = 0.f;
+          if (ok) pointwise_term<LOSS>(score, is_pos, margin, is_pos ? inv_pos : inv_neg, g, l);
+          lsum += l;
+          coef[t] = g;
+        }
+      }
+    }
+  } else
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n; t += (int64_t)gridDim.x * 4) {
     const bool is_pos = t < m_pos;
     const int32_t* tr = is_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
@@ -170,6 +252,57 @@ __global__ __launch_bounds__(256) void hole_pull_kernel(const float* __restrict_
   const int start = off[key] + chunk * C;
   const int len = min(C, c - chunk * C);
   const bool is_rel = key >= N;
+  if (d <= kHolePairD) {  // two list entries per round, one per half-wave (ccorr8); the halves' sums meet at the end
+    const int hw = lane >> 5, hl = lane & 31, k0 = 8 * hl;
+    float* u2 = lds + (wave * 2 + hw) * hole_lds_floats(d);
+    float* w22 = u2 + hole_dpad(d);
+    float a8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a8[j] = 0.f;
+    for (int i = 0; i < len; i += 2) {
+      const bool live = i + hw < len;
+      const int4 e = entries[start + (live ? i + hw : i)];
+      const float cf = __int_as_float(e.z);
+      const bool act = live && cf != 0.f;
+      const int kind1 = is_rel ? 0 : ((unsigned)e.x >> 31);
+      const float *ur, *wr;
+      int ru, rw, rd;
+      bool rev = false;
+      if (is_rel) { ur = E + (int64_t)e.x * d; wr = E + (int64_t)e.y * d; ru = 0; rw = 2; rd = 1; }
+      else if (!kind1) { ur = Rel + (int64_t)(e.x & 0x7fffffff) * d; wr = E + (int64_t)e.y * d; ru = 1; rw = 2; rd = 0; }
+      else { ur = E + (int64_t)e.y * d; wr = Rel + (int64_t)(e.x & 0x7fffffff) * d; ru = 0; rw = 1; rd = 2; rev = true; }
+      DropKey ku{0, 0}, kw{0, 0}, kd{0, 0};
+      if (DROP) { ku = drop_key(seed, e.w, ru); kw = drop_key(seed, e.w, rw); kd = drop_key(seed, e.w, rd); }
+      if (act) {
+        stage_u<DROP, 32>(u2, ur, d, rev, hl, ku, thr, dscale);
+        stage_w2<DROP, 32>(w22, wr, d, hl, kw, thr, dscale);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (act) {
+        float x[8];
+        ccorr8(u2, w22, d, k0, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = cf * x[j];
+          if (DROP && k0 + j < d) v *= drop_mul(kd, (uint32_t)(k0 + j), thr, dscale);
+          a8[j] += v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a8[j] += __shfl_xor(a8[j], 32, 64);
+    float* dst2;
+    bool add2;
+    if (nch == 1) { dst2 = (is_rel ? gR + (int64_t)(key - N) * d : gE + (int64_t)key * d); add2 = true; }
+    else { dst2 = slab + (int64_t)(poff[key] + chunk) * d; add2 = false; }
+    if (hw == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < d) dst2[k0 + j] = add2 ? dst2[k0 + j] + a8[j] : a8[j];
+    }
+    return;
+  }
   constexpr int NP = kHoleMaxD / 256;  // passes of 256 outputs
   float acc[NP][4];
 #pragma unroll
@@ -265,7 +398,7 @@ static int hole_check(const kge_model_desc* md, const char* who) {
   return KGE_OK;
 }
 
-static size_t hole_smem(int d) { return (size_t)4 * hole_lds_floats(d) * sizeof(float); }
+static size_t hole_smem(int d) { return (size_t)(d <= kHolePairD ? 8 : 4) * hole_lds_floats(d) * sizeof(float); }  // (two slices per wave for the paired path)
 
 int hole_forward(const kge_model_desc* md, int loss, float margin, const float* E, const float* Rel, const int32_t* pos,
                  int64_t m_pos, const int32_t* neg, int64_t m_neg, float* coef, float* scores, float* loss_partials,
