@@ -724,13 +724,7 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
       nct_ = ct + 1;
       if (nct_ == nct) { nct_ = 0; nqt_ = qt + 1; }
     }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x16 acc[2][2];  // (no zero fill: the first four MFMAs of the unit take a zero C operand -- 64 vector moves per wave and unit less)
     for (int kc = 0; kc < nchunk; ++kc) {
       // every wave's DMA loads of image p have landed (issued in the first three groups of the previous chunk); everyone is done
       // reading image p ^ 1
@@ -757,6 +751,12 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
   acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][1].comp, acc[0][1], 0, 0, 0);             \
   acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][0].comp, acc[1][0], 0, 0, 0);             \
   acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][1].comp, acc[1][1], 0, 0, 0);
+#define KGE_STEP0(BUF, comp)                                                                                      \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][0].comp, zero16, 0, 0, 0);               \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][1].comp, zero16, 0, 0, 0);               \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][0].comp, zero16, 0, 0, 0);               \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][1].comp, zero16, 0, 0, 0);
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       KGE_FRAG(0, 0)
 #pragma unroll
       for (int j = 0; j < G; ++j) {
@@ -768,12 +768,16 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
         if (j == 0) { KGE5_OFF(0) KGE5_OFF(1) KGE5_OFF(2) KGE5_LD(0, p ^ 1) KGE5_LD(1, p ^ 1) KGE5_LD(2, p ^ 1) }
         if (j == 1) { KGE5_OFF(3) KGE5_OFF(4) KGE5_OFF(5) KGE5_LD(3, p ^ 1) KGE5_LD(4, p ^ 1) KGE5_LD(5, p ^ 1) }
         if (j == 2) { KGE5_OFF(6) KGE5_OFF(7) KGE5_OFF(8) KGE5_LD(6, p ^ 1) KGE5_LD(7, p ^ 1) KGE5_LD(8, p ^ 1) }
-        if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
+        if (j == 0) {
+          if (kc == 0) { KGE_STEP0(0, x) } else { KGE_STEP(0, x) }
+          KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w)
+        } else if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
         else { KGE_STEP(1, x) KGE_STEP(1, y) KGE_STEP(1, z) KGE_STEP(1, w) }
         KGE5_PIPE()
       }
       __builtin_amdgcn_sched_barrier(0);
 #undef KGE_STEP
+#undef KGE_STEP0
 #undef KGE_FRAG
       p ^= 1;
     }
