@@ -716,10 +716,6 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
     KGE5_LD(0, 0) KGE5_LD(1, 0) KGE5_LD(2, 0) KGE5_LD(3, 0) KGE5_LD(4, 0) KGE5_LD(5, 0) KGE5_LD(6, 0) KGE5_LD(7, 0) KGE5_LD(8, 0)
   }
   int p = 0;  // image the running chunk is read from
-  // the targets of this lane's 32 accumulator rows, held in registers while the range stays inside one query tile (read from tg_s in
-  // the epilogue of the first unit behind a tile change: a barrier lies between the store and that read)
-  float tgr[2][16];
-  bool tg_stale = true;
   for (int64_t u = u_begin; u < u_end; ++u) {
     // coordinates of the next unit of this workgroup's range (after the last one: this unit again, its values are dropped)
     const bool has_next = u + 1 < u_end;
@@ -797,19 +793,12 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
       const float D = __fmaf_rn(-2.f, dot, en);
       return EPI == 1 ? D < tgv : D > tgv;
     };
-    if (tg_stale) {  // uniform
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tgr[rt][r] = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-      tg_stale = false;
-    }
     if (c0 + kTile <= cand_rows) {  // uniform: every candidate column of the tile exists
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float tgv = tgr[rt][r];
+          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
           cnt[rt][r] += (hit(acc[rt][0][r], en0, tgv) ? 1 : 0) + (hit(acc[rt][1][r], en1, tgv) ? 1 : 0);
         }
     } else {
@@ -818,7 +807,7 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float tgv = tgr[rt][r];
+          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
           cnt[rt][r] += ((v0 && hit(acc[rt][0][r], en0, tgv)) ? 1 : 0) + ((v1 && hit(acc[rt][1][r], en1, tgv)) ? 1 : 0);
         }
     }
@@ -831,7 +820,6 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
           if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
           cnt[rt][r] = 0;
         }
-      tg_stale = true;
       __syncthreads();
       if (tid < kQT5) {
         if (q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
