@@ -401,6 +401,34 @@ def test_dropout_training_parity(model, kw, loss, grad_mode):
     np.testing.assert_allclose(mdl.predict(t), O.call(model, Eo, Ro, t, kw.get("norm", 1), kw.get("gamma", 12)), atol=2 * TOL)
 
 
+@pytest.mark.parametrize("d", [3, 30, 200, 256, 260])
+@pytest.mark.parametrize("dp", [0.0, 0.3])
+def test_hole_direct_kernels_over_row_widths(d, dp):
+    """The O(d^2) HolE kernels (csrc/hole.hip: what dropout steps run on): rows up to 256 floats take two problems per wave, eight
+    outputs per lane (ccorr8) -- widths that are not multiples of four or eight, the boundary itself -- wider rows one problem per wave
+    in passes of 256 outputs; destination lists of odd and even length, a row nobody touches."""
+    from kge_keras_amd import models as M
+    N, R, m = 23, 4, 77
+    rs = np.random.RandomState(d)
+    E0 = rs.uniform(-0.5, 0.5, (N, d)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, d)).astype(np.float32)
+    mdl = M.HolE(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=dp, init_entities=E0, init_relations=R0, loss_function="pointwize_logistic",
+                 seed=3, spectral=False)
+    mdl.compile("adam")
+    Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
+    oo = O.AdamTF()
+    for step in range(2):
+        pos, neg = _triples(rs, m, N - 1, R), _triples(rs, m + 4, N - 1, R)  # (entity N-1 stays untouched)
+        sc = torch.empty(2 * m + 4, dtype=torch.float32, device="cuda")
+        L = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+        Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, 1, 12, dropout=dp, seed=mdl._seed)
+        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    t = _triples(rs, 9, N, R)
+    np.testing.assert_allclose(mdl.predict(t), O.call("HolE", Eo, Ro, t, 1, 12), atol=2 * TOL)
+
+
 def test_dropout_default_rate_trains(datasets):
     """The reference's default dp=0.2 (models.py:22) through fit()."""
     from kge_keras_amd.harness import DataGenerator, build_model
