@@ -378,7 +378,12 @@ SideStream* side_stream();  // api.hip: lazily created helper stream (nullptr wh
 // and loss), reserved for batches small enough for an O(m_f * m_t) loss to be usable at all
 constexpr int kPairChunks = 16;
 constexpr int64_t kPairMaxRows = 131072;
-static int64_t pair_floats(int64_t n) { return n <= kPairMaxRows ? 3 * kPairChunks * align_up(n, 64) : 0; }
+// pairsort.hip: pairwize_hinge's all-pairs mean from the two sorted score vectors (no pairs formed); its scratch is carved from the same
+// place, so every batch size has what that path needs and batches up to kPairMaxRows also the chunk planes of the all-pairs kernels
+int64_t pair_sort_floats(int64_t n);
+int pairwise_hinge_sorted(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float margin, float* g_t, float* g_f, float* loss_partials,
+                          int* nb, float* scratch, int64_t scratch_floats, hipStream_t st);
+static int64_t pair_floats(int64_t n) { return std::max<int64_t>(n <= kPairMaxRows ? 3 * kPairChunks * align_up(n, 64) : 0, pair_sort_floats(n)); }
 static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 64 + 2 * align_up(n, 64) + pair_floats(n); }
 
 int64_t train_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
@@ -509,13 +514,22 @@ static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int6
   *nb = gf;
   ProfScope prof(KGE_PROF_PAIRWISE, st);
   if (ns == 1 || m_t == 1) {
+    // the hinge's all-pairs mean is a function of the order of the scores: past ~1e8 pairs two sorts and a binary search per row are
+    // cheaper than the pairs themselves (KGE_PAIR_SORT=0 / 1: never / always)
+    const char* sort_env = getenv("KGE_PAIR_SORT");  // (read per call: tests switch it)
+    const int sort_mode = sort_env ? atoi(sort_env) : -1;
+    if (LOSS == KGE_PAIRWIZE_HINGE && pair && sort_mode != 0 && (sort_mode == 1 || (double)m_t * (double)m_f >= 134217728.0)) {
+      const int rc = pairwise_hinge_sorted(ts, m_t, fs, m_f, margin, g_t, g_f, partials, nb, pair, pair_floats(m_t + m_f), st);
+      if (rc != 1) return rc;  // (1: the library calls want more temporary storage than the scratch holds -- the all-pairs kernels run)
+    }
+    const bool planes = pair && m_t + m_f <= kPairMaxRows;  // (larger batches: the scratch is the sort path's, one chunk per row here)
     // column chunks of at least 1024 scores, at most kPairChunks of them (scratch: pair = [chunks][m_f] g | [chunks][m_f] loss | [chunks][m_t] g)
     auto chunks = [](int64_t n_other) { return (int)std::max<int64_t>(1, std::min<int64_t>(kPairChunks, n_other / 1024)); };
-    const int cf = pair ? chunks(m_t) : 1, ct = pair ? chunks(m_f) : 1;
+    const int cf = planes ? chunks(m_t) : 1, ct = planes ? chunks(m_f) : 1;
     const int64_t stride = align_up(m_t + m_f, 64);
-    float* pf = pair && cf > 1 ? pair : nullptr;
+    float* pf = planes && cf > 1 ? pair : nullptr;
     float* lf = pf ? pair + kPairChunks * stride : nullptr;
-    float* pt = pair && ct > 1 ? pair + 2 * kPairChunks * stride : nullptr;
+    float* pt = planes && ct > 1 ? pair + 2 * kPairChunks * stride : nullptr;
     const int64_t lenf = align_up(cdiv(m_t, cf), 256), lent = align_up(cdiv(m_f, ct), 256);
     const float inv = 1.f / ((float)m_f * (float)m_t);
     hipLaunchKernelGGL((pairwise_allpairs_kernel<LOSS, 0>), dim3(gf, pf ? (int)cdiv(m_t, lenf) : 1), dim3(256), 0, st, ts, m_t, fs, m_f, margin, g_t, g_f, partials, pf, lf, lenf);

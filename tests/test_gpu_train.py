@@ -429,6 +429,44 @@ def test_hole_direct_kernels_over_row_widths(d, dp):
     np.testing.assert_allclose(mdl.predict(t), O.call("HolE", Eo, Ro, t, 1, 12), atol=2 * TOL)
 
 
+@pytest.mark.parametrize("m_t,m_f", [(1, 7), (300, 300), (5000, 4097), (1, 3000), (2048, 20480)])
+@pytest.mark.parametrize("margin", [1.0, 0.25])
+def test_pairwise_hinge_from_sorted_scores_equals_all_pairs(m_t, m_f, margin, monkeypatch):
+    """csrc/pairsort.hip: the all-pairs mean of pairwize_hinge (utils.py:300-305 with the harness's negative_samples = 1) from the two
+    sorted score vectors -- counts and a running sum instead of m_f * m_t pairs -- against the all-pairs kernels and the oracle.
+    Scores on a quarter grid, so that many pairs sit exactly on the hinge's corner (relu'(0) = 0: strict comparisons on both sides),
+    plus a NaN on either side (rows with bad ids: no part in the loss, zero gradient)."""
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(m_t + m_f)
+    t = (np.round(rs.uniform(-3, 3, m_t) * 4) / 4).astype(np.float32)
+    f = (np.round(rs.uniform(-3, 3, m_f) * 4) / 4).astype(np.float32)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("KGE_PAIR_SORT", mode)
+        L, gt, gf = M.loss_value("pairwize_hinge", t, f, margin, 1, return_grads=True)
+        out[mode] = (float(L.item()), gt.cpu().numpy(), gf.cpu().numpy())
+    Lo, gto, gfo = O.loss_value_and_grads("pairwize_hinge", t.astype(np.float64), f.astype(np.float64), margin, 1)
+    for mode in ("0", "1"):
+        L, gt, gf = out[mode]
+        assert L == pytest.approx(float(Lo), rel=1e-5, abs=1e-6), mode
+        np.testing.assert_allclose(gt, gto, rtol=1e-5, atol=1e-9, err_msg=mode)
+        np.testing.assert_allclose(gf, gfo, rtol=1e-5, atol=1e-9, err_msg=mode)
+    if m_t > 1 and m_f > 1:  # NaN rows
+        t2, f2 = t.copy(), f.copy()
+        t2[0] = np.nan
+        f2[-1] = np.nan
+        monkeypatch.setenv("KGE_PAIR_SORT", "1")
+        L, gt, gf = M.loss_value("pairwize_hinge", t2, f2, margin, 1, return_grads=True)
+        gt, gf = gt.cpu().numpy(), gf.cpu().numpy()
+        keep_t, keep_f = t2[1:].astype(np.float64), f2[:-1].astype(np.float64)
+        Lk, gtk, gfk = O.loss_value_and_grads("pairwize_hinge", keep_t, keep_f, margin, 1)
+        scale = (len(keep_t) * len(keep_f)) / (m_t * m_f)  # the mean still divides by all m_f * m_t entries
+        assert gt[0] == 0.0 and gf[-1] == 0.0
+        assert float(L.item()) == pytest.approx(float(Lk) * scale, rel=1e-5, abs=1e-6)
+        np.testing.assert_allclose(gt[1:], gtk * scale, rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(gf[:-1], gfk * scale, rtol=1e-5, atol=1e-9)
+
+
 def test_dropout_default_rate_trains(datasets):
     """The reference's default dp=0.2 (models.py:22) through fit()."""
     from kge_keras_amd.harness import DataGenerator, build_model
