@@ -108,6 +108,42 @@ size_t ps_temp_bytes(int64_t m_t, int64_t m_f, hipStream_t st) {
   return std::max(b1, std::max(b2, b3)) + 256;
 }
 
+// pairwize_square_loss (utils.py:314-319), all pairs: -(f_j - t_i)^2 separates -- four sums decide everything:
+//   L = -(m_t sum f^2 - 2 sum f sum t + m_f sum t^2) / (m_f m_t),  dL/dt_i = 2 (sum f - m_f t_i) / (m_f m_t),  dL/df_j = -2 (m_t f_j - sum t) / (m_f m_t)
+__global__ __launch_bounds__(256) void ps_square_sums_kernel(const float* __restrict__ ts, int64_t m_t, const float* __restrict__ fs, int64_t m_f,
+                                                              double* __restrict__ part /* [grid][4] */) {
+  __shared__ double red[4][256];
+  double st = 0.0, st2 = 0.0, sf = 0.0, sf2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m_t + m_f; i += (int64_t)gridDim.x * 256) {
+    if (i < m_t) { const double t = ts[i]; st += t; st2 += t * t; }
+    else { const double f = fs[i - m_t]; sf += f; sf2 += f * f; }
+  }
+  red[0][threadIdx.x] = st; red[1][threadIdx.x] = st2; red[2][threadIdx.x] = sf; red[3][threadIdx.x] = sf2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) part[(int64_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void ps_square_apply_kernel(const float* __restrict__ ts, int64_t m_t, const float* __restrict__ fs, int64_t m_f,
+                                                               const double* __restrict__ part, int nparts, float* __restrict__ g_t, float* __restrict__ g_f,
+                                                               float* __restrict__ loss_partials) {
+  double s[4] = {0.0, 0.0, 0.0, 0.0};  // every thread adds the partials in the same order
+  for (int b = 0; b < nparts; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] += part[(int64_t)b * 4 + q];
+  const double inv = 1.0 / ((double)m_f * (double)m_t);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m_t + m_f; i += (int64_t)gridDim.x * 256) {
+    if (i < m_t) g_t[i] = (float)(2.0 * (s[2] - (double)m_f * (double)ts[i]) * inv);
+    else g_f[i - m_t] = (float)(-2.0 * ((double)m_t * (double)fs[i - m_t] - s[0]) * inv);
+  }
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = blockIdx.x == 0 ? (float)(-((double)m_t * s[3] - 2.0 * s[2] * s[0] + (double)m_f * s[1]) * inv) : 0.f;
+}
+
 }  // namespace
 
 // floats of scratch that cover any batch of n = m_t + m_f rows (the temporary storage of the library calls is checked at run time)
@@ -132,6 +168,22 @@ int pairwise_hinge_sorted(const float* ts, int64_t m_t, const float* fs, int64_t
   const int grid = (int)std::min<int64_t>(cdiv(n, 256), kPsMaxBlocks);
   *nb = grid;
   hipLaunchKernelGGL(ps_search_kernel, dim3(grid), dim3(256), 0, st, ts, m_t, fs, m_f, margin, L.a_s, L.f_s, L.fpre, g_t, g_f, loss_partials);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// pairwize_square_loss with the all-pairs broadcast from four sums (see ps_square_sums_kernel).  KGE_OK; 1: no scratch.
+int pairwise_square_sums(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* g_t, float* g_f, float* loss_partials, int* nb,
+                         float* scratch, int64_t scratch_floats, hipStream_t st) {
+  constexpr int kParts = 64;
+  if (!scratch || scratch_floats < 2 * 4 * kParts + 64) return 1;
+  double* part = reinterpret_cast<double*>(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  const int64_t n = m_t + m_f;
+  const int parts = (int)std::min<int64_t>(cdiv(n, 256), kParts);
+  hipLaunchKernelGGL(ps_square_sums_kernel, dim3(parts), dim3(256), 0, st, ts, m_t, fs, m_f, part);
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256), kPsMaxBlocks);
+  *nb = grid;
+  hipLaunchKernelGGL(ps_square_apply_kernel, dim3(grid), dim3(256), 0, st, ts, m_t, fs, m_f, part, parts, g_t, g_f, loss_partials);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

@@ -383,6 +383,8 @@ constexpr int64_t kPairMaxRows = 131072;
 int64_t pair_sort_floats(int64_t n);
 int pairwise_hinge_sorted(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float margin, float* g_t, float* g_f, float* loss_partials,
                           int* nb, float* scratch, int64_t scratch_floats, hipStream_t st);
+int pairwise_square_sums(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* g_t, float* g_f, float* loss_partials, int* nb,
+                         float* scratch, int64_t scratch_floats, hipStream_t st);
 static int64_t pair_floats(int64_t n) { return std::max<int64_t>(n <= kPairMaxRows ? 3 * kPairChunks * align_up(n, 64) : 0, pair_sort_floats(n)); }
 static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 64 + 2 * align_up(n, 64) + pair_floats(n); }
 
@@ -521,6 +523,11 @@ static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int6
     if (LOSS == KGE_PAIRWIZE_HINGE && pair && sort_mode != 0 && (sort_mode == 1 || (double)m_t * (double)m_f >= 134217728.0)) {
       const int rc = pairwise_hinge_sorted(ts, m_t, fs, m_f, margin, g_t, g_f, partials, nb, pair, pair_floats(m_t + m_f), st);
       if (rc != 1) return rc;  // (1: the library calls want more temporary storage than the scratch holds -- the all-pairs kernels run)
+    }
+    // ... and the square loss separates into four sums (same switch)
+    if (LOSS == KGE_PAIRWIZE_SQUARE && pair && sort_mode != 0 && (sort_mode == 1 || (double)m_t * (double)m_f >= 4194304.0)) {
+      const int rc = pairwise_square_sums(ts, m_t, fs, m_f, g_t, g_f, partials, nb, pair, pair_floats(m_t + m_f), st);
+      if (rc != 1) return rc;
     }
     const bool planes = pair && m_t + m_f <= kPairMaxRows;  // (larger batches: the scratch is the sort path's, one chunk per row here)
     // column chunks of at least 1024 scores, at most kPairChunks of them (scratch: pair = [chunks][m_f] g | [chunks][m_f] loss | [chunks][m_t] g)

@@ -467,6 +467,22 @@ def test_pairwise_hinge_from_sorted_scores_equals_all_pairs(m_t, m_f, margin, mo
         np.testing.assert_allclose(gf[:-1], gfk * scale, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("m_t,m_f", [(1, 7), (300, 300), (5000, 4097), (1, 3000)])
+def test_pairwise_square_from_sums_equals_all_pairs(m_t, m_f, monkeypatch):
+    """csrc/pairsort.hip: -(f_j - t_i)^2 over all pairs (utils.py:314-319 with negative_samples = 1) separates into four sums; against
+    the all-pairs kernels and the oracle."""
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(m_t * 7 + m_f)
+    t, f = rs.uniform(-3, 3, m_t).astype(np.float32), rs.uniform(-2, 4, m_f).astype(np.float32)
+    Lo, gto, gfo = O.loss_value_and_grads("pairwize_square_loss", t.astype(np.float64), f.astype(np.float64), 1.0, 1)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("KGE_PAIR_SORT", mode)
+        L, gt, gf = M.loss_value("pairwize_square_loss", t, f, 1.0, 1, return_grads=True)
+        assert float(L.item()) == pytest.approx(float(Lo), rel=2e-5), mode
+        np.testing.assert_allclose(gt.cpu().numpy(), gto, rtol=2e-4, atol=1e-7, err_msg=mode)
+        np.testing.assert_allclose(gf.cpu().numpy(), gfo, rtol=2e-4, atol=1e-7, err_msg=mode)
+
+
 def test_dropout_default_rate_trains(datasets):
     """The reference's default dp=0.2 (models.py:22) through fit()."""
     from kge_keras_amd.harness import DataGenerator, build_model
