@@ -8,7 +8,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 
 def _tri(rs, n, N, R):
@@ -131,7 +131,7 @@ def test_val_loss_goes_through_the_literal_transform():
     Hd = {k: np.asarray(v, dtype=np.float64).copy() for k, v in H.items()}
     ref = O.literal_train_step("DistMult", Hd, "tanh", E0.astype(np.float64), R0.astype(np.float64), lit.astype(np.float64), O.AdamTF(), pos, neg,
                                "pairwize_hinge", 0.5, 1)[0]
-    assert got == pytest.approx(ref, abs=TOL, rel=1e-4)
+    assert got == pytest.approx(ref, rel=TOL_L, abs=TOL_LA)
     bare = O.dense_grads("DistMult", E0.astype(np.float64), R0.astype(np.float64), pos, neg, "pairwize_hinge", 0.5)[0]
     assert abs(bare - ref) > 1e-3  # the two models really differ
     assert np.array_equal(mdl.E.cpu().numpy(), E0) and float(mdl._gall.abs().max()) == 0.0 and float(mdl._lit["gtheta"].abs().max()) == 0.0

@@ -11,7 +11,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
 LOSSES = ["pointwize_hinge", "pointwize_logistic", "pointwize_square_loss", "pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"]
 
 
@@ -86,9 +86,9 @@ def test_hake_train_step_parity(loss, opt):
         sp, sn = O.call("HAKE", Eo, Ro, pos, prm, 12), O.call("HAKE", Eo, Ro, neg, prm, 12)  # one norm per side (tests.py:77-78)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step("HAKE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, prm, 12)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
 
 
@@ -102,15 +102,15 @@ def test_hake_dropout_regulariser_and_unequal_sides():
         pos, neg = _triples(rs, 120, N, R), _triples(rs, 200, N, R)
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("HAKE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, prm, 12, regularization=1e-3, dropout=0.3, seed=mdl._seed)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     # val_loss: no dropout, no update
     before = mdl.E.clone()
     pos, neg = _triples(rs, 50, N, R), _triples(rs, 50, N, R)
     Lv = float(mdl.batch_loss([pos, neg]).item())
     Lr, *_ = O.dense_grads("HAKE", Eo, Ro, pos, neg, "pointwize_logistic", 1, 1, prm, 12, 1e-3, 0.0, 0)
-    assert Lv == pytest.approx(float(Lr), abs=TOL, rel=1e-5)
+    assert Lv == pytest.approx(float(Lr), rel=TOL_L, abs=TOL_LA)
     assert torch.equal(before, mdl.E) and float(mdl._gall.abs().max()) == 0.0
 
 

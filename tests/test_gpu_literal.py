@@ -7,7 +7,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 
 def _mk(model, N, R, d, L, act, seed=0, **kw):
@@ -61,12 +61,12 @@ def test_literal_train_step_parity(model, kw, loss, act, dp):
         Lr, sp, sn = O.literal_train_step(model, Ho, act, Eo, Ro, Lo, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12),
                                           dropout=dp, seed=mdl._seed)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
-        assert L_ == pytest.approx(Lr, abs=TOL, rel=1e-4), (step, L_, Lr)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L_ == pytest.approx(Lr, rel=TOL_L, abs=TOL_LA), (step, L_, Lr)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
         W, b = mdl.get_literal_dense()
-        np.testing.assert_allclose(W, Ho["W"], atol=TOL)
-        np.testing.assert_allclose(b, Ho["b"], atol=TOL)
+        np.testing.assert_allclose(W, Ho["W"], atol=TOL_W)
+        np.testing.assert_allclose(b, Ho["b"], atol=TOL_W)
 
 
 @pytest.mark.parametrize("model,kw", [("pRotatE", {}), ("pRotatE", dict(gamma=0)), ("TransE", dict(norm=3.5, gamma=12)), ("TransE", dict(norm=1.5, gamma=0))])
@@ -88,12 +88,12 @@ def test_literal_under_protate_and_general_p_norm(model, kw, dp):
         L_ = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
         Lr, sp, sn = O.literal_train_step(model, Ho, "tanh", Eo, Ro, Lo, oo, pos, neg, "pointwize_logistic", 0.5, 1, norm, gamma, dropout=dp, seed=mdl._seed)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
-        assert L_ == pytest.approx(Lr, abs=TOL, rel=1e-4), (step, L_, Lr)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L_ == pytest.approx(Lr, rel=TOL_L, abs=TOL_LA), (step, L_, Lr)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
         W, b = mdl.get_literal_dense()
-        np.testing.assert_allclose(W, Ho["W"], atol=TOL)
-        np.testing.assert_allclose(b, Ho["b"], atol=TOL)
+        np.testing.assert_allclose(W, Ho["W"], atol=TOL_W)
+        np.testing.assert_allclose(b, Ho["b"], atol=TOL_W)
     t = _tri(rs, 100, N, R)
     s_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 0], "tanh")
     o_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 2], "tanh")
@@ -113,11 +113,11 @@ def test_literal_weight_gradient_split_contraction():
         pos, neg = _tri(rs, 2100, N, R), _tri(rs, 2055, N, R)
         L_ = float(mdl.train_step([pos, neg])["loss"].item())
         Lr, _, _ = O.literal_train_step("DistMult", Ho, "tanh", Eo, Ro, Lo, oo, pos, neg, "pointwize_logistic", 0.5, 1)
-        assert L_ == pytest.approx(Lr, abs=TOL, rel=1e-4), step
+        assert L_ == pytest.approx(Lr, rel=TOL_L, abs=TOL_LA), step
         W, b = mdl.get_literal_dense()
-        np.testing.assert_allclose(W, Ho["W"], atol=TOL)
-        np.testing.assert_allclose(b, Ho["b"], atol=TOL)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        np.testing.assert_allclose(W, Ho["W"], atol=TOL_W)
+        np.testing.assert_allclose(b, Ho["b"], atol=TOL_W)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
 
 
 def test_reference_script_configuration(datasets):

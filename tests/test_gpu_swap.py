@@ -9,7 +9,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 CASES = [("DistMult", {}, 200), ("DistMult", {}, 24), ("TransE", dict(norm=1, gamma=12), 40), ("TransE", dict(norm=2, gamma=12), 200),
          ("ComplEx", {}, 100), ("ComplEx", {}, 8), ("DistMult", {}, 256), ("ComplEx", {}, 200), ("pRotatE", {}, 100), ("pRotatE", {}, 24)]
@@ -61,11 +61,11 @@ def test_swap_step_equals_planned_step_and_oracle(model, kw, d, opt):
         Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_hinge", 2.0, 1, a.modulus if model == "pRotatE" else kw.get("norm", 1), kw.get("gamma", 12))
         tot += La
-        assert La == pytest.approx(Lb, rel=1e-6, abs=1e-7) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), step
+        assert La == pytest.approx(Lb, rel=1e-6, abs=1e-7) and La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
         np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-6)
         np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=2e-6)
-        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
     assert int(sa[0].item()) == int(sb[0].item()) == 3
     fa, fb = sa.view(torch.float32).cpu().numpy(), sb.view(torch.float32).cpu().numpy()
     assert fa[2] == fb[2]                                  # learning rate of the next update
@@ -231,11 +231,11 @@ def test_swap_step_random_shapes(case):
         Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
         info = (case, model, d, N, R, n_pos, n_neg, loss, opt, skew, step)
-        assert La == pytest.approx(Lb, rel=2e-6, abs=1e-6) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), info
+        assert La == pytest.approx(Lb, rel=2e-6, abs=1e-6) and La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), info
         np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=5e-6, err_msg=str(info))
         np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=5e-6, err_msg=str(info))
-        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL, err_msg=str(info))
-        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL, err_msg=str(info))
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W, err_msg=str(info))
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W, err_msg=str(info))
     a._raise_on_flag()
 
 
@@ -271,11 +271,11 @@ def test_swap_step_with_dropout(model, kw, d):
         assert a._seed == b._seed
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, a.modulus if model == "pRotatE" else kw.get("norm", 1),
                           kw.get("gamma", 12), dropout=dp, seed=a._seed)
-        assert La == pytest.approx(Lb, rel=2e-6, abs=1e-6) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), step
+        assert La == pytest.approx(Lb, rel=2e-6, abs=1e-6) and La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
         np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=5e-6)
         np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=5e-6)
-        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
     # gradient halves under dropout == the whole == the oracle's gradients with the same masks
     plan = c.plan_batch([pos, neg])
     c.train_grads(plan, parts=1)

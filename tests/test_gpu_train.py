@@ -10,7 +10,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 
 @pytest.fixture(params=["pull", "push"], autouse=True)
@@ -118,9 +118,9 @@ def test_train_step_parity(model, kw, loss, opt):
         sn = O.call(model, Eo, Ro, neg, kw.get("norm", 1), kw.get("gamma", 12))
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12))
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0  # accumulators re-zeroed
 
 
@@ -149,9 +149,9 @@ def test_cross_entropy_train_step(model, kw, opt):
         pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_cross_entropy", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 def test_train_gradients_exact_semantics():
@@ -183,8 +183,8 @@ def test_l3_regulariser():
         pos, neg = _triples(rs, 100, 30, 4), _triples(rs, 100, 30, 4)
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1.0, regularization=0.01)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
 
 
 def test_nations_harness_fit_matches_oracle(datasets):
@@ -212,11 +212,11 @@ def test_nations_harness_fit_matches_oracle(datasets):
             # the oracle consumes the same global streams: rewind to where the generator started this batch
             L = float(mdl.train_step([pos, neg])["loss"].item())
             Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, loss, 1.0, 1)
-            assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (loss, b)
+            assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (loss, b)
             np.random.set_state(np_state)
             random.setstate(py_state)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
         del idx, trl
 
 
@@ -250,9 +250,9 @@ def test_full_size_fb15k237_step(model, kw):
     L = float(mdl.train_step([pos, neg])["loss"].item())
     Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
     Lo = O.train_step(model, Eo, Ro, O.AdamTF(), pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
-    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
-    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     # size-independent property: the update is a function of the multiset of rows, not of their order
     mdl2 = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0,
                              loss_function="pointwize_logistic", **kw)
@@ -290,9 +290,9 @@ def test_duplicate_row_folding(model, kw, loss):
                 sn = O.call(model, Eo, Ro, neg, kw.get("norm", 1), kw.get("gamma", 12))
                 np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
                 Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12))
-                assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (mode, step)
-                np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-                np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+                assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (mode, step)
+                np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+                np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
                 out.append(L)
             res[mode] = (out, mdl.E.cpu().numpy())
             # ids outside the tables
@@ -349,10 +349,10 @@ def test_batch_plan_step_equals_plain_step(model, kw, dp, grad_mode):
                 La = float(a.train_step(plan)["loss"].item())
                 Lb = float(b.train_step([pos, neg])["loss"].item())
                 Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, b._seed)
-                assert La == pytest.approx(Lb, rel=1e-5, abs=1e-6) and La == pytest.approx(Lo, abs=TOL, rel=1e-5), (fold_mode, step)
+                assert La == pytest.approx(Lb, rel=1e-5, abs=1e-6) and La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (fold_mode, step)
                 np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-5)
-                np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
-                np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+                np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
+                np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
             # the gradient half alone (data-parallel split) + ids outside the tables raise through the plan too
             g = a.train_grads(a.plan_batch([pos, neg]))
             assert np.isfinite(float(g["loss"].item())) and float(a._gE.abs().max()) > 0
@@ -393,9 +393,9 @@ def test_dropout_training_parity(model, kw, loss, grad_mode):
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12),
                           dropout=0.3, seed=mdl._seed)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     # predict is dropout-free (keras Dropout is the identity outside fit)
     t = _triples(rs, 50, N, R)
     np.testing.assert_allclose(mdl.predict(t), O.call(model, Eo, Ro, t, kw.get("norm", 1), kw.get("gamma", 12)), atol=2 * TOL)
@@ -422,9 +422,9 @@ def test_hole_direct_kernels_over_row_widths(d, dp):
         sc = torch.empty(2 * m + 4, dtype=torch.float32, device="cuda")
         L = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
         Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, 1, 12, dropout=dp, seed=mdl._seed)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     t = _triples(rs, 9, N, R)
     np.testing.assert_allclose(mdl.predict(t), O.call("HolE", Eo, Ro, t, 1, 12), atol=2 * TOL)
 
@@ -509,9 +509,9 @@ def test_changing_batch_size_and_loss_on_one_model():
         pos, neg = _triples(rs, m, N, R), _triples(rs, m + 3, N, R)  # len(pos) != len(neg) is legal for the reference's losses
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, loss, 0.5, 1)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (m, loss)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (m, loss)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 @pytest.mark.parametrize("name", LOSSES + ["pointwize_cross_entropy"])
@@ -523,7 +523,7 @@ def test_loss_functions_callable(name):
     t, f = rs.uniform(-2, 2, 700), rs.uniform(-2, 2, 300)
     L = float(loss_function_lookup(name)(t, f, 0.7, 1).item())
     Lo, gto, gfo = O.loss_value_and_grads(name, t, f, 0.7, 1)
-    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+    assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
     _, gt, gf = loss_value(name, t, f, 0.7, 1, return_grads=True)
     np.testing.assert_allclose(gt.cpu().numpy(), gto, atol=1e-6, rtol=1e-4)
     np.testing.assert_allclose(gf.cpu().numpy(), gfo, atol=1e-6, rtol=1e-4)
@@ -539,12 +539,12 @@ def test_loss_functions_callable(name):
         # column-aligned broadcast, reduced: negative_samples == len(true)
         L = float(loss_function_lookup(name)(t[:60], f, 0.7, 60).item())
         Lo, gto, gfo = O.loss_value_and_grads(name, t[:60], f, 0.7, 60)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
         _, gt, gf = loss_value(name, t[:60], f, 0.7, 60, return_grads=True)
         np.testing.assert_allclose(gt.cpu().numpy(), gto, atol=1e-6, rtol=1e-4)
         np.testing.assert_allclose(gf.cpu().numpy(), gfo, atol=1e-6, rtol=1e-4)
     else:  # the pointwize losses ignore reduce_mean (utils.py:288-298)
-        assert float(loss_function_lookup(name)(t, f, 0.7, 1, reduce_mean=False).item()) == pytest.approx(Lo, abs=TOL, rel=1e-5)
+        assert float(loss_function_lookup(name)(t, f, 0.7, 1, reduce_mean=False).item()) == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
     with pytest.raises(KeyError):
         loss_function_lookup("nope")
 
@@ -563,9 +563,9 @@ def test_pairwise_column_aligned_train_step(model):
             pos, neg = _triples(rs, mt, N, R), _triples(rs, mt * rows, N, R)
             L = float(mdl.train_step([pos, neg])["loss"].item())
             Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, mt)
-            assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), loss
-            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+            assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), loss
+            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 @pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})])
@@ -594,16 +594,16 @@ def test_heavy_tailed_batch(model, kw, dp, grad_mode):
         pos, neg = draw(m), draw(m)
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, mdl._seed)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), step
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     if grad_mode == "pull":  # the same through a plan built ahead
         pos, neg = draw(m), draw(m)
         L = float(mdl.train_step(mdl.plan_batch([pos, neg]))["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, mdl._seed)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 @pytest.mark.parametrize("loss", ["pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"])
@@ -617,7 +617,7 @@ def test_pairwise_allpairs_at_script_scale(loss):
     t, f = rs.uniform(-2, 2, 5000), rs.uniform(-2, 2, 3100)
     L = float(loss_function_lookup(loss)(t, f, 0.7, 1).item())
     Lo, gto, gfo = O.loss_value_and_grads(loss, t, f, 0.7, 1)
-    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
+    assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
     _, gt, gf = loss_value(loss, t, f, 0.7, 1, return_grads=True)
     np.testing.assert_allclose(gt.cpu().numpy(), gto, atol=1e-7, rtol=1e-4)
     np.testing.assert_allclose(gf.cpu().numpy(), gfo, atol=1e-7, rtol=1e-4)
@@ -628,9 +628,9 @@ def test_pairwise_allpairs_at_script_scale(loss):
     pos, neg = _triples(rs, m, N, R), _triples(rs, m + 300, N, R)
     Ls = float(mdl.train_step([pos, neg])["loss"].item())
     Lso = O.train_step("DistMult", Eo, Ro, O.AdamTF(), pos, neg, loss, 0.5, 1)
-    assert Ls == pytest.approx(Lso, abs=TOL, rel=1e-5)
-    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    assert Ls == pytest.approx(Lso, rel=TOL_L, abs=TOL_LA)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 def test_wn18rr_complex400_train_step(datasets):
@@ -648,9 +648,9 @@ def test_wn18rr_complex400_train_step(datasets):
     L = float(mdl.train_step([pos, neg])["loss"].item())
     Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
     Lo = O.train_step("ComplEx", Eo, Ro, O.AdamTF(), pos, neg, "pointwize_logistic", 1.0)
-    assert L == pytest.approx(Lo, abs=TOL, rel=1e-5)
-    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+    assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 def test_edge_cases_single_row_and_skewed_batches():
@@ -665,9 +665,9 @@ def test_edge_cases_single_row_and_skewed_batches():
                          (np.tile(np.array([[4, 2, 4]]), (1500, 1)), np.tile(np.array([[4, 2, 5]]), (700, 1)))):
             L = float(mdl.train_step([pos, neg])["loss"].item())
             Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
-            assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (model, len(pos))
-            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=2 * TOL)
-            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=2 * TOL)
+            assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (model, len(pos))
+            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 @pytest.mark.parametrize("d", [31, 200, 6, 2])
@@ -690,10 +690,10 @@ def test_hole_spectral_step(d, loss):
         sp, sn = O.call("HolE", Eo, Ro, pos, 1, 12), O.call("HolE", Eo, Ro, neg, 1, 12)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, 1, 12)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5) and Lr == pytest.approx(Lo, abs=TOL, rel=1e-5)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
-        np.testing.assert_allclose(ref.E.cpu().numpy(), Eo, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA) and Lr == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        np.testing.assert_allclose(ref.E.cpu().numpy(), Eo, atol=TOL_W)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
     inner = mdl._spec["inner"]
     assert float(inner._gE.abs().max()) == 0.0 and float(inner._gR.abs().max()) == 0.0  # spectral accumulators re-zeroed
@@ -759,9 +759,9 @@ def test_protate_train_step_parity(loss, opt, gamma):
         sp, sn = O.call("pRotatE", Eo, Ro, pos, mdl.modulus, gamma), O.call("pRotatE", Eo, Ro, neg, mdl.modulus, gamma)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step("pRotatE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, mdl.modulus, gamma)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
 
 
@@ -779,9 +779,9 @@ def test_protate_large_planned_and_dropout():
         pos[: m // 2] = pos[m // 2: 2 * (m // 2)]  # duplicates
         La = float(a.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("pRotatE", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1, 1, a.modulus, 12)
-        assert La == pytest.approx(Lo, abs=TOL, rel=1e-5)
-        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
         if b.plan_supported():
             Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
             assert Lb == pytest.approx(La, abs=1e-5, rel=1e-5)
@@ -816,9 +816,9 @@ def test_hole_spectral_with_l3_regulariser():
         pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, 1, 12, regularization=0.01)
-        assert L == pytest.approx(Lo, abs=TOL, rel=1e-5), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+        assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
 
 
 @pytest.mark.parametrize("norm,gamma", [(3, 12), (1.5, 12), (4, 0)])
@@ -838,9 +838,9 @@ def test_transe_general_p_norm(norm, gamma):
             pos, neg = _triples(rs, m, N, R), _triples(rs, m, N, R)
             L = float(mdl.train_step([pos, neg])["loss"].item())
             Lo = O.train_step("TransE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, norm, gamma)
-            assert L == pytest.approx(Lo, abs=TOL, rel=1e-4), (loss, step)
-            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL)
-            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL)
+            assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (loss, step)
+            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
     test = list(dict.fromkeys(tuple(int(v) for v in x) for x in _triples(rs, 40, N, R)))
     filt = [tuple(int(v) for v in x) for x in _triples(rs, 200, N, R)]
     filt = [x for x in filt if x not in set(test)]

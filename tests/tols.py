@@ -1,0 +1,13 @@
+"""Tolerances of the GPU parity tests (HIP path through the C ABI vs the oracle on identical inputs).
+
+TOL    1e-4 absolute on fp32 SCORES: the tolerance BASELINE.json's north_star states ("within 1e-4 fp32 on scores").
+TOL_W  1e-6 absolute on the PARAMETER TABLES after k optimizer steps.  A whole Adam update is <= lr = 1e-3 per element and an SGD
+       update lr * g; an error in lr_t, an eps placed inside the root, a dropped duplicate on a low-count row or a wrong bias
+       correction moves an element by 1e-5 .. 1e-3, which 1e-4 would let through.  What fp32 itself costs against the fp64 oracle is
+       a few 1e-8 (table values of 0.02 .. 0.5 carry an ulp of 2e-9 .. 6e-8; bench.py's check of the benched path reads 4e-9).
+TOL_L  1e-6 relative on LOSS values (sums of up to 4e5 fp32 terms in a fixed tree order), with an absolute floor of 1e-7.
+Looser constants in individual tests carry their reason next to them."""
+TOL = 1e-4
+TOL_W = 1e-6
+TOL_L = 1e-6
+TOL_LA = 1e-7
