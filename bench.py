@@ -113,7 +113,7 @@ def make_model(w, dp=DP_BENCH):
     return model
 
 
-def make_pipeline(torch, model, w, rank, total_steps, graphs=True, between=None, between_halves=None, comm=None, world=1):
+def make_pipeline(torch, model, w, rank, total_steps, graphs=True, between=None, between_halves=None, comm=None, world=1, row_shard=None):
     """The benched object: TrainPipeline over the device sampler seeded like the host generator of make_batches()."""
     from kge_keras_amd.pipeline import TrainPipeline
     from kge_keras_amd.sampler import NumpyStream, PythonStream, DeviceSampler
@@ -122,7 +122,7 @@ def make_pipeline(torch, model, w, rank, total_steps, graphs=True, between=None,
     train_dev, perm_dev = torch.from_numpy(w["train"]).cuda(), torch.from_numpy(perm).cuda()
     dsamp = DeviceSampler(nps, PythonStream(rank))
     pipe = TrainPipeline(model, train_dev, CFG["n_train"], CFG["B"], CFG["ns"], CFG["N"], dsamp, graphs=graphs, between=between, between_halves=between_halves,
-                         comm=comm, world=world)
+                         comm=comm, world=world, row_shard=row_shard)
     nb_epoch = CFG["n_train"] // CFG["B"]
     pipe.load_epoch(perm_dev, [i % nb_epoch for i in range(total_steps)])
     return pipe, dsamp
@@ -537,6 +537,11 @@ def main():
     ap.add_argument("--model", default="DistMult", choices=["DistMult", "TransE"],
                     help="DistMult: the BASELINE configs[1] workload (the contract line).  TransE: configs[2] (L2, gamma 12) through the same "
                          "pipeline, for comparison only (no CPU baseline; config.workload names it)")
+    ap.add_argument("--train", default="replicas", choices=["replicas", "rows"],
+                    help="N > 1, the training half.  replicas (default): data-parallel replicas, every rank its own batch, dense gradient all-reduce "
+                         "(weak scaling: value = N batches' rows / time).  rows: the tables row-sharded, OWNER COMPUTES (dist.RowShardTrainer): every rank "
+                         "draws the SAME batch, updates its own entity / relation rows with its share of the Adam moments, then the updated rows are "
+                         "all-gathered -- the reference's one-batch-per-step semantics at N GPUs (strong scaling: value = one batch's rows / time)")
     ap.add_argument("--leg", default="all", choices=["all", "hbm"], help="hbm: only the HBM leg (the benched pipeline on the table past the Infinity Cache), "
                     "kernel by kernel on one stream -- the command whose `rocprofv3 --kernel-trace --stats` summary is committed as profiles/*_hbm_kernel_stats.csv")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip roofline_hbm (the same pipeline on a table that does not fit the Infinity Cache)")
@@ -585,11 +590,13 @@ def main():
     if dist_on:
         dist.barrier()
 
-    w = workload(args.model, rank)
+    rows_mode = dist_on and args.train == "rows"
+    data_rank = 0 if rows_mode else rank  # (owner-computes: every rank holds the same triples and draws the same batches from the same seeds)
+    w = workload(args.model, data_rank)
     E0, R0 = w["E0"], w["R0"]
     model = make_model(w)
     n_pool = 8
-    hb = host_batches(w, rank, n_pool)
+    hb = host_batches(w, data_rank, n_pool)
     dev = [(torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda()) for p, n in hb]
     m = CFG["B"] * CFG["ns"]
     per_step = 2 * m
@@ -610,6 +617,7 @@ def main():
         # (--dp-overlap auto: with the nccl / RCCL backend only -- gloo runs an async collective on CUDA tensors through the host at
         # 90 ms per step in the two-rank rehearsal, against 3.3 ms for the single all-reduce)
         overlap = args.dp_overlap == "on" or (args.dp_overlap == "auto" and args.backend == "nccl")
+        row_trainer = D.RowShardTrainer(model) if rows_mode else None
         pending = []
 
         def between_halves():
@@ -622,9 +630,9 @@ def main():
             else:
                 dist.all_reduce(model._gall, op=dist.ReduceOp.SUM)
             return 1.0 / world
-        between = between_fn if dist_on else None
+        between = between_fn if dist_on and not rows_mode else None
         # the data-parallel step inside the native driver (kge_pipeline_desc.comm): an RCCL communicator of the library's own
-        if dist_on and (args.dp_native == "on" or (args.dp_native == "auto" and args.backend == "nccl")):
+        if dist_on and not rows_mode and (args.dp_native == "on" or (args.dp_native == "auto" and args.backend == "nccl")):
             try:
                 comm, comm_destroy = D.make_rccl_comm()
             except Exception as e:  # (e.g. the gloo rehearsal with two ranks on one GPU: RCCL refuses duplicate devices)
@@ -640,8 +648,9 @@ def main():
         if comm is not None:
             between = None
         total = args.warmup + args.settle + 3 * args.steps + 8
-        pipe, dsamp = make_pipeline(torch, model, w, rank, total, graphs=True, between=between, between_halves=between_halves if dist_on and overlap and comm is None else None,
-                                    comm=comm, world=world)
+        pipe, dsamp = make_pipeline(torch, model, w, data_rank, total, graphs=True, between=between,
+                                    between_halves=between_halves if dist_on and overlap and comm is None and not rows_mode else None,
+                                    comm=comm, world=world, row_shard=row_trainer)
         if args.serial:
             pipe.use_graphs, pipe.serial = False, True
         pipe.start()
@@ -794,7 +803,10 @@ def main():
     _lib.lib.kge_prof_enable(0)
     if not args.probe:
         model._raise_on_flag()
-    loss = float(model._loss.item()) / (world if dist_on else 1)  # summed over ranks by the flat all-reduce
+    if rows_mode:
+        loss = float(row_trainer.loss.item())  # (partial losses summed by the exchange: the loss of the ONE batch)
+    else:
+        loss = float(model._loss.item()) / (world if dist_on else 1)  # summed over ranks by the flat all-reduce
     s_ms, s_n = _lib.prof_read("sampler")
     i_ms, i_n = _lib.prof_read("index")
     assert args.probe or int(dsamp.err.item()) == 0, "device sampler: rejection margin ran short"
@@ -834,18 +846,19 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        value = per_step * world * args.steps / dt
+        work_ranks = 1 if rows_mode else world  # (rows: all ranks work on ONE batch per step)
+        value = per_step * work_ranks * args.steps / dt
         # pull path: two gather kernels (fwd_rel_kernel: A_FWD + the relation-gradient row per triple; pull_kernel: the two entity
         # gradient rows per triple); push path: one fused kernel carrying A_TRAIN.
         kernels = {}
         variant = 1 if os.environ.get("KGE_PULL_VARIANT", "2") == "1" else 2
-        twin = pipe is not None and getattr(pipe, "_twins", None) is not None  # the step between twin tables (kge_train_step_swap)
+        twin = pipe is not None and (getattr(pipe, "_twins", None) is not None or rows_mode)  # the step between twin tables (kge_train_step_swap[_window])
         # Bytes a launch has to fetch from beyond the L2s, on the rows really processed (the 190 KB relation table is L2 resident and
         # is NOT counted; SURVEY 8(d)'s 4816 B per triple would also count three gradient rows, which this step keeps in registers):
         #   forward role   two entity rows per row                                  8 d   B per row
         #   entity role    one entity row per list entry, two entries per row       8 d   B per row
         #                  optimizer on every entity row: read w, m, v; write w, m, v 24 N d B per launch
-        adam_e = 24 * CFG["N"] * CFG["d"]
+        adam_e = 24 * CFG["N"] * CFG["d"] // work_ranks  # (rows mode: a rank streams the moments and rows of its window only)
         if twin and k_n and not f_n:
             kernels["step1_kernel (relation-grouped forward + per-entity-row gather, own scores, gradient row, optimizer: one launch)"] = (
                 k_ms / k_n * 1e-3, rows_launch * 16 * CFG["d"] + adam_e)
@@ -880,19 +893,20 @@ def main():
         res = {
             "metric": METRIC, "value": value, "unit": "scored triples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"FB15k-237 {args.model if args.model == 'DistMult' else 'TransE-L2 (gamma 12)'} d=200, B=2048, 100 negatives (409600 scored triples/step), pointwize_hinge + Adam(TF semantics), "
                                    f"dp={DP_BENCH:g} (the reference's default is 0.2: value_dp02); oversample_data draws with replacement, so {int(round(rows_launch))} of the 409600 rows of a step are distinct "
                                    "and the step folds the duplicates (same sums as TensorFlow's IndexedSlices accumulation): value counts all 409600, value_distinct the distinct ones",
                        "dp": DP_BENCH, "distinct_rows_per_step": rows_launch,
                        "N": CFG["N"], "R": CFG["R"], "d": CFG["d"], "B": CFG["B"], "ns": CFG["ns"],
-                       "parallelism": f"dp{world}" if dist_on else "single",
+                       "parallelism": (f"rows{world} (tables row-sharded, owner computes: same batch on every rank, updated rows all-gathered; "
+                                       f"{row_trainer.tables.exchanged_bytes()} B received per rank and step)" if rows_mode else f"dp{world}") if dist_on else "single",
                        "sampler": ("bit-exact MT19937 HIP sampler inside the timed region (generator words ahead in rings, batches drawn two steps ahead on their own stream)" if args.sampler == "device"
                                    else "bit-exact MT19937 batches pre-built on host, resident in HBM"),
                        "final_loss": loss},
             # value counts every row of both oversampled arrays (what the reference's step scores); the step folds duplicate rows, so
             # the gather kernels touch rows_per_launch distinct rows: value_distinct is the rate on those
-            "value_distinct": rows_launch * world * args.steps / dt,
+            "value_distinct": rows_launch * work_ranks * args.steps / dt,
             "value_ranks_per_sec": ev["ranks_per_sec"] if ev else None,
             "settle_steps": settle,  # 0: the K timed steps follow the W warm-up steps directly
             **({"value_first_steps": per_step * world * args.steps / dt_first, "ms_per_step_first_steps": dt_first / args.steps * 1e3} if settle > 0 else {}),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 8
+#define KGE_ABI_VERSION 9
 
 typedef void* kge_stream_t; /* hipStream_t */
 
@@ -319,6 +319,27 @@ int kge_train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const
                         float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
                         uint64_t seed, void* workspace, int64_t workspace_bytes, int32_t parts, kge_stream_t stream);
 
+/* The same step as one rank's share of an OWNER-COMPUTES step over row-sharded tables ("row-sharded tables ... each GPU runs
+ * Adam on its rows + all-gather of updated rows"; north star: "the entity table row-shards across the 8 GPUs").  Every rank holds the
+ * SAME batch -- the samplers are bit-exact functions of their seeds, so every rank draws it itself, no communication -- and the same
+ * input tables; rank r calls this with its window and then the ranks all-gather the window rows of E_out / Rel_out and sum their
+ * *loss_out.  The N-rank tables then equal the one-GPU tables of kge_train_step_swap on that batch (tests.py:55-61: ONE batch per
+ * step -- a data-parallel replica step trains on `ranks` batches instead), the two-launch step is kept, the exchange is half of a
+ * gradient all-reduce's bytes, and a rank streams 1/ranks of the optimizer's moments.
+ *   entity rows  [ent_lo, ent_hi): gradient from the row's list, optimizer -> E_out rows, moment rows of the window.  Moments are
+ *                addressed by GLOBAL row id: a rank that stores only its window's moment rows passes od->mE / od->vE offset by
+ *                -ent_lo * d_e floats (likewise mRel / vRel by -rel_lo * d_r);
+ *   relation rows [rel_lo, rel_hi): the relation-grouped forward runs on the units of these relations only -> partial rows ->
+ *                optimizer -> Rel_out rows; *loss_out = the loss terms of the batch rows whose relation is in the window (their sum over
+ *                disjoint windows covering [0, R) is the batch loss, up to fp32 summation order); the step state advances by one update
+ *                and adds this partial loss to its sum.
+ * Rows of E_out / Rel_out outside the window are NOT written.  The plan is consumed (all its counters left zero, also those of rows
+ * outside the window): every rank builds its own plan of the batch.  No dropout (masks are per batch row: fine, but not built). */
+typedef struct { int32_t ent_lo, ent_hi, rel_lo, rel_hi; } kge_row_window;
+int kge_train_step_swap_window(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in,
+                               float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
+                               uint64_t seed, void* workspace, int64_t workspace_bytes, const kge_row_window* win, kge_stream_t stream);
+
 /* ---- the reference's loss functions as callables on two score vectors (utils.py:288-319, reduce_mean=True):
  *      *loss_out = loss(true, false, margin, negative_samples); d_true / d_false (optional, may be NULL) receive the
  *      derivatives.  Workspace: kge_train_step_workspace_bytes(NULL-free md of any shape, ld, m_true, m_false) suffices;
@@ -342,6 +363,13 @@ int kge_set_grad_mode(int mode);
  * distinct rows and weights each by its multiplicity (same sums up to fp32 order).  0 = off, 1 (default) = batches of at
  * least 4096 rows, 2 = always. */
 int kge_set_dedup_mode(int mode);
+
+/* The harness's all-pairs broadcast of the pairwize losses (utils.py:300-319 called with negative_samples = 1, tests.py:81): past
+ * 2^27 pairs pairwize_hinge is evaluated from the two SORTED score vectors (counts + a running double sum, no pair formed), past
+ * 2^22 pairs pairwize_square_loss from four sums; below, the all-pairs kernels run.  The forms agree to fp32 rounding, not bit for
+ * bit (summation order changes with the algorithm, hence with the batch size).  -1 (default) = by pair count as above, 0 = always the
+ * all-pairs kernels, 1 = always the sorted / four-sums forms; the environment variable KGE_PAIR_SORT sets the initial value. */
+int kge_set_pair_sort_mode(int mode);
 
 /* ---- in-library kernel timing (bench.py's roofline leg): when enabled, every launcher brackets its dominant
  *      kernel with hipEvents recorded on the launch stream.  kge_prof_read synchronises those events, returns the

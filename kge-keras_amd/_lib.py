@@ -16,6 +16,11 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
         "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
 lib = C.CDLL(LIB_PATH)
+ABI_VERSION = 9  # KGE_ABI_VERSION of include/kge_hip.h this binding was written against (struct layouts, argument lists, the 24-byte step state)
+lib.kge_abi_version.restype = C.c_int
+if lib.kge_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} reports ABI version {lib.kge_abi_version()}, this binding needs {ABI_VERSION}: rebuild the library "
+                      f"(`make -C {os.path.join(_HERE, 'csrc')}`) -- a stale build would mis-read descriptors silently.")
 
 KGE_OK, KGE_EINVAL, KGE_ESHAPE, KGE_EHIP, KGE_EWORKSPACE, KGE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4, "RotatE": 5, "HAKE": 6}
@@ -43,6 +48,11 @@ class OptDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int64), ("mE", C.c_void_p), ("vE", C.c_void_p), ("mRel", C.c_void_p), ("vRel", C.c_void_p),
                 ("step_dev", C.c_void_p)]
+
+
+class RowWindow(C.Structure):
+    """kge_row_window: the rows of both tables one rank of an owner-computes step updates."""
+    _fields_ = [("ent_lo", C.c_int32), ("ent_hi", C.c_int32), ("rel_lo", C.c_int32), ("rel_hi", C.c_int32)]
 
 
 class HakeParams(C.Structure):
@@ -108,9 +118,11 @@ SIGNATURES = {
     "kge_train_grads_planned_parts": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
     "kge_train_step_swap_supported": (C.c_int, [_MD, _LD, _OD]),
     "kge_train_step_swap": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
+    "kge_train_step_swap_window": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_set_dedup_mode": (C.c_int, [C.c_int]),
+    "kge_set_pair_sort_mode": (C.c_int, [C.c_int]),
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),
     "kge_score": (C.c_int, [_MD, _P, _P, _P, _I64, _P, _P, _P]),

@@ -161,9 +161,10 @@ bool grad_halves_supported(const kge_model_desc*);
 int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, float*, float*, float*, float*, float, float*, void*,
               int64_t, hipStream_t, bool advanced = false, const OptFinish* finish = nullptr);
 
+void set_pair_sort_mode(int mode);  // train.hip
 bool step_swap_supported(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*);
 int train_step_swap(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, const float*, const float*, float*, float*, void*, int64_t,
-                    int64_t, float*, uint64_t, void*, int64_t, int, hipStream_t);
+                    int64_t, float*, uint64_t, void*, int64_t, int, hipStream_t, const kge_row_window* win = nullptr);
 
 int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
 int loss_pairs(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, int64_t, hipStream_t);
@@ -445,6 +446,25 @@ int kge_train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const
                          static_cast<hipStream_t>(stream));
 }
 
+int kge_train_step_swap_window(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in,
+                               float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
+                               uint64_t seed, void* workspace, int64_t workspace_bytes, const kge_row_window* win, kge_stream_t stream) {
+  if (!od || !win) return fail(KGE_EINVAL, "kge_train_step_swap_window: null descriptor");
+  if (int rc = check_plan("kge_train_step_swap_window", md, ld, m_pos, m_neg)) return rc;
+  if (!E_in || !Rel_in || !E_out || !Rel_out || !plan || !loss_out) return fail(KGE_EINVAL, "kge_train_step_swap_window: null pointer");
+  if (E_in == E_out || Rel_in == Rel_out) return fail(KGE_EINVAL, "kge_train_step_swap_window: input and output tables must be distinct buffers");
+  if (win->ent_lo < 0 || win->ent_hi < win->ent_lo || win->ent_hi > md->num_entities || win->rel_lo < 0 || win->rel_hi < win->rel_lo ||
+      win->rel_hi > md->num_relations)
+    return fail(KGE_EINVAL, "kge_train_step_swap_window: window [%d, %d) x [%d, %d) outside the tables (%d, %d)", win->ent_lo, win->ent_hi, win->rel_lo,
+                win->rel_hi, md->num_entities, md->num_relations);
+  if (md->dropout > 0.f || !step_swap_supported(md, ld, od))
+    return fail(KGE_EUNSUPPORTED, "kge_train_step_swap_window: needs what kge_train_step_swap needs, and no dropout");
+  if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
+    return fail(KGE_EWORKSPACE, "kge_train_step_swap_window: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
+  return train_step_swap(md, ld, od, E_in, Rel_in, E_out, Rel_out, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, 3,
+                         static_cast<hipStream_t>(stream), win);
+}
+
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries) {
   if (check_model(md, "kge_rank_workspace_bytes")) return KGE_EINVAL;
   if (n_queries < 0) return fail(KGE_EINVAL, "negative query count");
@@ -583,6 +603,12 @@ int kge_loss_value(const kge_loss_desc* ld, const float* true_scores, int64_t m_
   if (m_true <= 0 || m_false <= 0) return fail(KGE_EINVAL, "kge_loss_value: empty score vector (reduce_mean of nothing)");
   return loss_value(ld, true_scores, m_true, false_scores, m_false, loss_out, d_true, d_false, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
+}
+
+int kge_set_pair_sort_mode(int mode) {
+  if (mode < -1 || mode > 1) return fail(KGE_EINVAL, "kge_set_pair_sort_mode: mode %d (-1 = by pair count, 0 = all-pairs kernels, 1 = sorted scores / four sums)", mode);
+  set_pair_sort_mode(mode);
+  return KGE_OK;
 }
 
 int kge_set_dedup_mode(int mode) {

@@ -30,7 +30,14 @@ struct FwdRelArgs {
   const int32_t* rcnt; const int32_t* roff; const int32_t* rtotal; const int2* rumap; const int4* rentries;
   float* coef; float* scores; float* rslab;
   uint64_t seed; uint32_t thr; float dscale;
+  int rel_lo = 0, rel_hi = 0x7fffffff;  // relation window of an owner-computes step (kge_train_step_swap_window): units of other relations are skipped
 };
+
+__device__ __forceinline__ bool rel_in_window(const FwdRelArgs& a, int unit) {
+  if (a.rel_lo == 0 && a.rel_hi == 0x7fffffff) return true;
+  const int p = a.rumap[unit].x;
+  return p >= a.rel_lo && p < a.rel_hi;
+}
 
 // One wave per (relation, chunk).  64/G sub-groups of G lanes take different triples; lane l of a sub-group owns float4
 // chunks l, l+G, ... (NV of them) of the row (of each half row for ComplEx).  Adds the unit's loss terms to lsum (lane 0 of every
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(256) void fwd_rel_kernel(FwdRelArgs a, float* __res
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
   float lsum = 0.f;
   int len, c;
-  if (unit < a.rtotal[0]) fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP>(a, unit, 0, lsum, &len, &c);
+  if (unit < a.rtotal[0] && rel_in_window(a, unit)) fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP>(a, unit, 0, lsum, &len, &c);
   const float b = block_sum(lsum, red);
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
 }

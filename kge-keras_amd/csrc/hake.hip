@@ -187,10 +187,13 @@ __global__ __launch_bounds__(256) void hake_grad_kernel(HakeArgs a, const float*
 
 static int64_t h256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-// P | Q | scores | g (n floats each) | r norms (one per segment) | G (2) | the loss kernels' workspace
+// P | Q | scores | g (n floats each) | r norms (one per segment) | G (2) | chunk == 0 (a training batch of n = m_pos + m_neg rows) only:
+// the loss kernels' workspace for those n rows.  The scoring entry point runs no loss: kge_hake_score is called with up to 64 M
+// candidate rows per chunk by HAKE.rank / rank_triples, where the loss scratch (pairwise sort planes: ~56 B per row) would be 7 GB.
 int64_t hake_workspace_bytes(int64_t n, int64_t chunk) {
   const int64_t nseg = chunk > 0 ? cdiv(n, chunk) : std::max<int64_t>(2, -chunk);  // (chunk < 0: -chunk segments given by offsets)
-  return 4 * h256(n * 4) + h256(nseg * 4) + 256 + h256(train_workspace_bytes(nullptr, n, n)) + 512;
+  const int64_t loss_ws = chunk == 0 ? h256(train_workspace_bytes(nullptr, n, 0)) : 0;  // (the loss workspace depends on m_pos + m_neg only)
+  return 4 * h256(n * 4) + h256(nseg * 4) + 256 + loss_ws + 512;
 }
 
 static HakeArgs hake_args(const kge_model_desc* md, const kge_hake_params* hp, const float* E, const float* Rel, const int32_t* pos, int64_t m_pos,

@@ -56,7 +56,15 @@ struct StepTail {
   int32_t* rcnt;               // [R] zeroed here
   int R, d_r;
   int parts;                   // 1 = entity half, 2 = relation half (forward + relation rows + loss + step state), 3 = both
+  // Owner-computes window (kge_train_step_swap_window; SURVEY 8(e): tables row-sharded, every rank holds the same batch): this call
+  // updates entity rows [ent_lo, ent_hi) and relation rows [rel_lo, rel_hi) only -- the rest of E_out / Rel_out is some other rank's
+  // to write -- and its loss is the sum over the rows of ITS relations.  Default: everything ([0, N), [0, R)).  ecnt: the plan's
+  // entity counters, cleared by the closing launch when the window leaves rows out (nobody else would).
+  int ent_lo, ent_hi, rel_lo, rel_hi;
+  int32_t* ecnt;
+  int N;
 };
+inline void step_tail_whole(StepTail& t, int N, int R) { t.ent_lo = 0; t.ent_hi = N; t.rel_lo = 0; t.rel_hi = R; t.ecnt = nullptr; t.N = N; }
 
 struct PullPlan {
   int32_t* cnt;     // [NK]   contributions per key (key = entity id, or N + relation id)

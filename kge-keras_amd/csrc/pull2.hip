@@ -649,9 +649,12 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
   const bool self = tail != nullptr;
   // both halves in one call: the forward and the entity half share ONE launch (step1.hip; KGE_STEP1=0: launch by launch, for A/B timing)
   static const bool one_launch = [] { const char* v = getenv("KGE_STEP1"); return !v || atoi(v) != 0; }();
+  const bool windowed = self && (tail->ent_lo != 0 || tail->ent_hi != md->num_entities || tail->rel_lo != 0 || tail->rel_hi != R);
+  if (windowed && !(tail->parts == 3 && one_launch)) return fail(KGE_EUNSUPPORTED, "a row window needs the whole step in one call (parts = 3) on the one-launch path (KGE_STEP1 unset)");
   if (self && tail->parts == 3 && one_launch) {
     StepTail t = *tail;
     t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
+    t.ecnt = p.ent.cnt; t.N = md->num_entities;
     const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
                         nullptr, p.rslab, seed, drop ? drop_thr(md->dropout) : 0u, drop ? 1.f / (1.f - md->dropout) : 1.f};
     return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, st);

@@ -8,6 +8,7 @@ namespace kge {
 struct SelfArgs {
   const float* E; const float* Rel;
   int N, d_e, nchunk;
+  int row_lo, row_n;  // destination rows [row_lo, row_lo + row_n) are this launch's (an owner-computes window; the whole table: 0, N)
   float inv_pos, inv_neg, gamma, modulus, margin;
   const int32_t* off; const int32_t* poff; const int32_t* totals; const int2* emap; const int4* entries;
   float* slab; int32_t* cnt; int C;
@@ -29,12 +30,13 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
   const int lane64 = threadIdx.x & 63, lane = lane64 & (G - 1), sub = lane64 / G;
   const int N = a.N, d_e = a.d_e, nchunk = a.nchunk, h = d_e >> 1;
   int key, chunk;
-  if (unit < N) { key = unit; chunk = 0; }
+  if (unit < a.row_n) { key = a.row_lo + unit; chunk = 0; }
   else {
-    const int x = unit - N;
+    const int x = unit - a.row_n;
     if (x >= a.totals[0]) return;
     const int2 kc = a.emap[x];
     key = kc.x; chunk = kc.y;
+    if ((unsigned)(key - a.row_lo) >= (unsigned)a.row_n) return;  // a hub row of another window
   }
   // (the counter of a hub row is the ticket its chunk waves count down, so the length comes from the list starts)
   const int c = (key + 1 < N ? a.off[key + 1] : a.totals[2]) - a.off[key];

@@ -15,12 +15,23 @@ namespace kge {
 // The relation rows of the step: workgroup r < R sums the forward's partial rows of relation r and applies the optimizer
 // (tail_relation_row); the last workgroup reduces the forward's loss partials (fixed order) and moves the step state on.
 __global__ __launch_bounds__(256) void rel_tail_kernel(StepTail t, const float* __restrict__ Rel, LossFinish lf) {
+  if ((int)blockIdx.x > t.R) {  // (window steps only) the plan's entity counters outside the window: no wave of the entity half met them
+    const int i = ((int)blockIdx.x - t.R - 1) * 1024 + threadIdx.x * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u < t.N && (i + u < t.ent_lo || i + u >= t.ent_hi)) t.ecnt[i + u] = 0;
+    return;
+  }
   if ((int)blockIdx.x == t.R) {
     __shared__ float red[16];
     float s = 0.f;
     for (int i = threadIdx.x; i < lf.n; i += 256) s += lf.partials[i];
     const float b = block_sum(s, red);
     if (threadIdx.x == 0) { lf.loss_out[0] = b; step_advance(lf.adv, b); }
+    return;
+  }
+  if ((int)blockIdx.x < t.rel_lo || (int)blockIdx.x >= t.rel_hi) {  // another rank's relation row: only the plan's counter is left zero
+    if (threadIdx.x == 0) t.rcnt[blockIdx.x] = 0;
     return;
   }
   tail_relation_row(t, Rel, blockIdx.x);
@@ -59,6 +70,7 @@ void self_args_of(const kge_model_desc* md, const kge_loss_desc* ld, const float
   a.seed = 0; a.thr = drop_thr(md->dropout); a.dscale = 1.f / (1.f - md->dropout);  // (the caller sets the step's seed)
   a.kind = tail.kind; a.lr = lr_t; a.lr_state = nullptr; a.lr_keep = nullptr; a.b1 = tail.b1; a.b2 = tail.b2; a.eps = tail.eps;
   a.E_out = tail.E_out; a.mE = tail.mE; a.vE = tail.vE;
+  a.row_lo = tail.ent_lo; a.row_n = tail.ent_hi - tail.ent_lo;
 }
 
 // Entity half: every entity row of E_out, moments in place, entity counters of the plan left zero.  lr_t by value.
@@ -72,7 +84,7 @@ int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, co
   a.seed = seed;
   a.lr_state = tail.lr_state;  // (a whole step launch by launch: this launch comes first and keeps lr_t for the closing one)
   a.lr_keep = tail.lr_state ? tail.lr_slot : nullptr;
-  const int grid = (int)cdiv(a.N + e.max_extra, 4);
+  const int grid = (int)cdiv(a.row_n + e.max_extra, 4);
   const int nv = (int)cdiv(sh.nchunk, 16);
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
@@ -92,6 +104,7 @@ int pull2_entity_self_step(const kge_model_desc* md, const kge_loss_desc* ld, co
 int pull2_entity_self_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, int64_t m_pos, int64_t m_neg,
                             const PullPlan& e, float* gE, uint64_t seed, hipStream_t st) {
   StepTail t{};
+  step_tail_whole(t, md->num_entities, md->num_relations);
   t.kind = -1;
   t.E_out = gE; t.mE = gE; t.vE = gE;  // (moments unused)
   return pull2_entity_self_step(md, ld, E, Rel, m_pos, m_neg, e, t, 0.f, seed, st);
@@ -101,7 +114,8 @@ int pull2_entity_self_grads(const kge_model_desc* md, const kge_loss_desc* ld, c
 // loss reduced, step state moved on.
 int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st) {
   ProfScope prof(KGE_PROF_OPT, st);
-  hipLaunchKernelGGL(rel_tail_kernel, dim3(t.R + 1), dim3(256), 0, st, t, Rel, lf);
+  const bool windowed = t.ecnt && (t.ent_lo > 0 || t.ent_hi < t.N);
+  hipLaunchKernelGGL(rel_tail_kernel, dim3(t.R + 1 + (windowed ? (int)cdiv(t.N, 1024) : 0)), dim3(256), 0, st, t, Rel, lf);
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
 }

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, 
   const int unit = blockIdx.x * 4 + wave;
   float lsum = 0.f;
   int len, c;
-  if (unit < fa.rtotal[0]) fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP, G>(fa, unit, R, lsum, &len, &c);
+  if (unit < fa.rtotal[0] && rel_in_window(fa, unit)) fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP, G>(fa, unit, R, lsum, &len, &c);
   const float b = block_sum(lsum, red);
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
 }
@@ -64,15 +64,17 @@ void self_args_of(const kge_model_desc* md, const kge_loss_desc* ld, const float
                   const StepTail& tail, float lr_t, int nchunk, SelfArgs* out);  // pullself.hip
 
 // fa: the forward's arguments as pull2.hip fills them (coef / scores may be null); tail.{roff, rtotal, ruoff, rslab, rcnt, R, d_r} set.
-int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRelArgs& fa, int rel_blocks, const PullPlan& e, const StepTail& tail,
+int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRelArgs& fa_in, int rel_blocks, const PullPlan& e, const StepTail& tail,
                  float* loss_partials, float* loss_out, const StepAdvance& adv, hipStream_t st) {
   if (!pull_step_supported(md)) return fail(KGE_EUNSUPPORTED, "step between twin tables: row width not covered");
+  FwdRelArgs fa = fa_in;
+  if (tail.rel_lo != 0 || tail.rel_hi != tail.R) { fa.rel_lo = tail.rel_lo; fa.rel_hi = tail.rel_hi; }
   SelfArgs sa;
   self_args_of(md, ld, fa.E, fa.Rel, fa.m_pos, fa.m_neg, e, tail, tail.lr_t, fa.nchunk, &sa);
   sa.seed = fa.seed;
   sa.lr_state = tail.lr_state;
   sa.lr_keep = tail.lr_state ? tail.lr_slot : nullptr;
-  const int grid = rel_blocks + (int)cdiv(sa.N + e.max_extra, 4);
+  const int grid = rel_blocks + (int)cdiv(sa.row_n + e.max_extra, 4);  // (row_n: the rows of the step's entity window; all of them by default)
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
     if (md->model == KGE_DISTMULT) launch_step1<KGE_DISTMULT, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);

@@ -508,6 +508,17 @@ static int pairwise_shape(const kge_loss_desc* ld, int64_t m_t, int64_t m_f) {
   return KGE_OK;
 }
 
+// KGE_PAIR_SORT (0 / 1: never / always take the sorted / four-sums forms; unset: by pair count) -- read once; kge_set_pair_sort_mode
+// (tests, A/B timing) overrides it.  Note: past the thresholds below the pairwise losses change ALGORITHM, hence summation order, with
+// the batch size: all-pairs kernels below 2^27 pairs (hinge) / 2^22 pairs (square), sorted scores + running double sum / four sums
+// above -- results agree to fp32 rounding across the switch, not bit for bit.
+static int g_pair_sort_mode = -2;
+static int pair_sort_mode() {
+  if (g_pair_sort_mode == -2) { const char* v = getenv("KGE_PAIR_SORT"); g_pair_sort_mode = v ? atoi(v) : -1; }
+  return g_pair_sort_mode;
+}
+void set_pair_sort_mode(int mode) { g_pair_sort_mode = mode < -1 ? -1 : mode; }
+
 template <int LOSS>
 static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int64_t m_f, int64_t ns, float margin, float* g_t, float* g_f,
                              float* partials, float* pair, hipStream_t st, int* nb) {
@@ -518,8 +529,7 @@ static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int6
   if (ns == 1 || m_t == 1) {
     // the hinge's all-pairs mean is a function of the order of the scores: past ~1e8 pairs two sorts and a binary search per row are
     // cheaper than the pairs themselves (KGE_PAIR_SORT=0 / 1: never / always)
-    const char* sort_env = getenv("KGE_PAIR_SORT");  // (read per call: tests switch it)
-    const int sort_mode = sort_env ? atoi(sort_env) : -1;
+    const int sort_mode = pair_sort_mode();
     if (LOSS == KGE_PAIRWIZE_HINGE && pair && sort_mode != 0 && (sort_mode == 1 || (double)m_t * (double)m_f >= 134217728.0)) {
       const int rc = pairwise_hinge_sorted(ts, m_t, fs, m_f, margin, g_t, g_f, partials, nb, pair, pair_floats(m_t + m_f), st);
       if (rc != 1) return rc;  // (1: the library calls want more temporary storage than the scratch holds -- the all-pairs kernels run)
@@ -786,12 +796,14 @@ bool step_swap_supported(const kge_model_desc* md, const kge_loss_desc* ld, cons
 }
 int train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in, float* E_out,
                     float* Rel_out, void* plan, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace, int64_t wbytes,
-                    int parts, hipStream_t st) {
+                    int parts, hipStream_t st, const kge_row_window* win) {
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   int nb = 0;
   StepAdvance adv{od->step_dev, ws.lr_slot, od->kind, od->lr, od->beta1, od->beta2};
   StepTail t{};
+  step_tail_whole(t, md->num_entities, md->num_relations);
+  if (win) { t.ent_lo = win->ent_lo; t.ent_hi = win->ent_hi; t.rel_lo = win->rel_lo; t.rel_hi = win->rel_hi; }
   t.kind = od->kind;
   t.E_out = E_out; t.mE = od->mE; t.vE = od->vE;
   t.Rel_out = Rel_out; t.mR = od->mRel; t.vR = od->vRel;

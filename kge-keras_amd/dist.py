@@ -4,6 +4,11 @@
 * training  : triples are independent units -> data-parallel replicas.  The one exchange per step is the
               all-reduce of the dense gradient tables between kge_train_grads and kge_opt_apply; every rank
               then applies the identical update (tables stay bit-identical across ranks).
+              `RowShardedTables` / `row_sharded_step` is the other split SURVEY 8(e) names -- row-sharded tables, OWNER COMPUTES: every
+              rank draws the SAME batch (the samplers are bit-exact functions of their seeds: no communication), updates only the
+              entity rows and relation rows of its own window (gradient from the row's list + optimizer, moments sharded), then the
+              ranks all-gather the updated window rows and sum their partial losses.  One batch per step like the reference
+              (tests.py:55-61), N-rank tables == one-GPU tables, half the bytes of a gradient all-reduce.
 * evaluation: the entity table is row-sharded at rest.  Schedule (i) (`sharded_eval`): the shards are all-gathered
               into a full table on every GPU (YAGO3-10: 98.5 MB, one collective per evaluation, not per query), the
               queries are split across ranks and the integer ranks are all-gathered back.  Schedule (ii)
@@ -99,6 +104,133 @@ def dp_train_step(grads_fn, apply_fn, grad_tensors, loss_tensor=None, group=None
     apply_fn(1.0 / ws)
 
 
+class RowShardedTables:
+    """Both parameter tables of an owner-computes training run as TWIN buffers padded to `world` equal row shards (so that the exchange
+    of the updated rows is one in-place all-gather per table): a step reads the current pair and writes the other one
+    (kge_train_step_swap_window), the exchange completes it, the pairs swap.  Rank r owns entity rows [r * per_e, (r + 1) * per_e) and
+    relation rows [r * per_r, (r + 1) * per_r), clipped to the tables (= shard_range)."""
+
+    def __init__(self, E, Rel, group=None):
+        self.group = group
+        self.rank, self.ws = world(group)
+        self.N, self.R = int(E.shape[0]), int(Rel.shape[0])
+        self.per_e, self.per_r = (self.N + self.ws - 1) // self.ws, (self.R + self.ws - 1) // self.ws
+        mk = lambda t, per: [torch.zeros((per * self.ws, t.shape[1]), dtype=t.dtype, device=t.device) for _ in range(2)]  # noqa: E731
+        self.bufE, self.bufR = mk(E, self.per_e), mk(Rel, self.per_r)
+        self.bufE[0][:self.N].copy_(E)
+        self.bufR[0][:self.R].copy_(Rel)
+        self.cur = 0
+        self.ent = shard_range(self.N, self.rank, self.ws)
+        self.rel = shard_range(self.R, self.rank, self.ws)
+
+    @property
+    def E(self):
+        return self.bufE[self.cur][:self.N]
+
+    @property
+    def Rel(self):
+        return self.bufR[self.cur][:self.R]
+
+    @property
+    def E_out(self):
+        return self.bufE[self.cur ^ 1][:self.N]
+
+    @property
+    def Rel_out(self):
+        return self.bufR[self.cur ^ 1][:self.R]
+
+    def exchange(self, loss=None):
+        """The window rows every rank wrote into the out buffers -> complete tables on every rank (one all-gather per table, equal
+        padded shards, in place); `loss` (this rank's partial loss, a tensor) is summed over the ranks in place; the pairs swap."""
+        if self.ws > 1:
+            for buf, per in ((self.bufE[self.cur ^ 1], self.per_e), (self.bufR[self.cur ^ 1], self.per_r)):
+                mine = buf[self.rank * per:(self.rank + 1) * per]
+                if dist.get_backend(self.group) != "nccl":
+                    mine = mine.clone()  # (gloo stages through the host and is not specified for an input inside the output)
+                dist.all_gather_into_tensor(buf, mine, group=self.group)
+            if loss is not None:
+                dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+        self.cur ^= 1
+        return loss
+
+    def exchanged_bytes(self):
+        """Bytes one rank receives per step."""
+        return 4 * ((self.ws - 1) * (self.per_e * self.bufE[0].shape[1] + self.per_r * self.bufR[0].shape[1]))
+
+
+def row_sharded_step(tables, window_step, loss=None):
+    """One owner-computes step: window_step(E_in, Rel_in, E_out, Rel_out, (ent_lo, ent_hi), (rel_lo, rel_hi)) updates this rank's rows
+    of the out tables from the in tables (the HIP step kge_train_step_swap_window in production; injected, so that the same
+    orchestration runs on CPU tensors under gloo) and leaves this rank's partial loss in `loss`; then the exchange."""
+    window_step(tables.E, tables.Rel, tables.E_out, tables.Rel_out, tables.ent, tables.rel)
+    return tables.exchange(loss)
+
+
+class RowShardTrainer:
+    """Owner-computes training of an EmbeddingModel over a process group (one process per GPU): the model's tables move into the padded
+    twin buffers of a RowShardedTables, this rank keeps the Adam moments of ITS rows only (1 / world of the optimizer's state and
+    streams), and step(plan) = kge_train_step_swap_window on the rank's window + the exchange.  Every rank must feed the SAME batches
+    (same sampler seeds on every rank).  After every step model.E / model.Rel are the complete, current tables on every rank --
+    equal to what one GPU computes with kge_train_step_swap on that batch (up to fp32 summation order of the loss only: the rows
+    themselves are computed by the same waves in the same order)."""
+
+    def __init__(self, model, group=None):
+        from . import _lib
+        self._lib, self.model = _lib, model
+        if model.optimizer is None:
+            raise RuntimeError("compile the model first")
+        if float(getattr(model, "dp", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("row-sharded training is built for models without dropout")
+        self.tables = t = RowShardedTables(model.E, model.Rel, group)
+        self._install()
+        (lo, hi), (rlo, rhi) = t.ent, t.rel
+        de, dr = int(model.E.shape[1]), int(model.Rel.shape[1])
+        self.slots = None
+        if model.optimizer.kind == "adam":  # this rank's share of the moments: rows [lo, hi) / [rlo, rhi), addressed by global row id
+            mk = lambda rows, w: torch.zeros((max(1, rows), w), dtype=torch.float32, device=model.device)  # noqa: E731
+            self.slots = (mk(hi - lo, de), mk(hi - lo, de), mk(rhi - rlo, dr), mk(rhi - rlo, dr))
+            self._slot_ptrs = [self.slots[0].data_ptr() - 4 * lo * de, self.slots[1].data_ptr() - 4 * lo * de,
+                               self.slots[2].data_ptr() - 4 * rlo * dr, self.slots[3].data_ptr() - 4 * rlo * dr]
+        else:
+            self._slot_ptrs = [None] * 4
+        self.win = _lib.RowWindow(lo, hi, rlo, rhi)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=model.device)
+        self._ws = None
+        self._own_state = None
+
+    def _install(self):
+        self.model.entity_embedding.weights = self.tables.E
+        self.model.relational_embedding.weights = self.tables.Rel
+
+    def step(self, plan):
+        """One step on the batch `plan` was built from (a models.BatchPlan; consumed).  Returns the batch loss (0-d device tensor,
+        summed over the ranks' partial losses)."""
+        _lib, mo, t = self._lib, self.model, self.tables
+        C, lib = _lib.C, _lib.lib
+        md, ld = mo._model_desc(True), mo._loss_desc()
+        need = _lib.check(lib.kge_train_step_workspace_bytes(C.byref(md), C.byref(ld), plan.m_pos, plan.m_neg))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.zeros(int(need), dtype=torch.uint8, device=mo.device)  # zero-filled once (kge_hip.h)
+        o = mo.optimizer
+        sd = getattr(mo, "_step_dev", None)
+        if sd is None:  # (outside a TrainPipeline: a step state of this trainer's own)
+            if self._own_state is None:
+                self._own_state = torch.zeros(_lib.STEP_STATE_WORDS, dtype=torch.int64, device=mo.device)
+                od0 = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, int(o.iterations) + 1, None, None, None, None,
+                                   self._own_state.data_ptr())
+                _lib.check(lib.kge_opt_state_init(C.byref(od0), _lib.stream_ptr()))
+            sd = self._own_state
+        o.iterations += 1
+        od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, max(1, o.iterations), *self._slot_ptrs, sd.data_ptr())
+        _lib.check(lib.kge_train_step_swap_window(C.byref(md), C.byref(ld), C.byref(od), t.E.data_ptr(), t.Rel.data_ptr(), t.E_out.data_ptr(),
+                                                  t.Rel_out.data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), plan.m_pos, plan.m_neg,
+                                                  self.loss.data_ptr(), 0, self._ws.data_ptr(), self._ws.numel(), C.byref(self.win),
+                                                  _lib.stream_ptr()))
+        t.exchange(self.loss)
+        self._install()
+        return self.loss[0]
+
+
 def make_rccl_comm(group=None):
     """An RCCL communicator of this process group's ranks, made through RCCL's own C API (torch.distributed does not hand its
     communicators out): rank 0 draws the ncclUniqueId, the group broadcasts its 128 bytes (any backend), every rank joins with
@@ -108,7 +240,30 @@ def make_rccl_comm(group=None):
     import ctypes as C
     rank, ws = world(group)
     path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln), "librccl.so.1")
-    rccl = C.CDLL(path)  # (the copy PyTorch-ROCm mapped, as the library's own run-time lookup does)
+    rccl, why = None, None
+    try:
+        rccl = C.CDLL(path)  # (the copy PyTorch-ROCm mapped, as the library's own run-time lookup does)
+    except OSError as e:
+        why = f"RCCL not loadable ({e})"
+    if ws > 1:
+        # Pre-flight over the EXISTING process group, before any rank enters ncclCommInitRank: that call is itself collective, so a rank
+        # that raises inside it (RCCL refuses two ranks on one device) would leave its peers blocked there.  Every rank reports
+        # (host, device identity, RCCL loaded); all ranks or none go on.
+        import socket
+        ident = None
+        if torch.cuda.is_available():
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            ident = str(getattr(pr, "uuid", None) or (getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None), torch.cuda.current_device()))
+        seen = [None] * ws
+        dist.all_gather_object(seen, (socket.gethostname(), ident, why), group=group)
+        bad = [f"rank {r}: {w}" for r, (_h, _i, w) in enumerate(seen) if w]
+        devs = [(h, i) for h, i, _w in seen]
+        if len(set(devs)) < ws:
+            bad.append(f"ranks share a device ({devs}): RCCL refuses duplicate devices in one communicator")
+        if bad:
+            raise RuntimeError("make_rccl_comm: " + "; ".join(bad))
+    elif why:
+        raise RuntimeError("make_rccl_comm: " + why)
 
     class UniqueId(C.Structure):  # ncclUniqueId: passed BY VALUE to ncclCommInitRank
         _fields_ = [("internal", C.c_char * 128)]

@@ -877,7 +877,7 @@ class HAKE(EmbeddingModel):
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         md, hp = md or self._model_desc(False), self._hake()
         n_seg = 0 if seg_off is None else seg_off.numel() - 1
-        ws = self._hake_ws(n, -n_seg if n_seg else chunk)
+        ws = self._hake_ws(n, -n_seg if n_seg else (chunk if 0 < chunk < n else n))  # (scoring: no loss scratch; chunk 0 sizes a training batch)
         check(lib.kge_hake_score(C.byref(md), C.byref(hp), (self.E if E is None else E).data_ptr(), (self.Rel if Rel is None else Rel).data_ptr(),
                                  t.data_ptr(), n, chunk, seg_off.data_ptr() if n_seg else None, n_seg, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                  self._err.data_ptr(), _lib.stream_ptr()))

@@ -32,7 +32,8 @@ from . import _lib
 
 
 class TrainPipeline:
-    def __init__(self, model, kg, n_rows, batch_size, ns, num_e, sampler, graphs=True, between=None, between_halves=None, comm=None, world=1):
+    def __init__(self, model, kg, n_rows, batch_size, ns, num_e, sampler, graphs=True, between=None, between_halves=None, comm=None, world=1,
+                 row_shard=None):
         """kg: (n,3) int32 device rows; n_rows: length of the epoch permutation; sampler: DeviceSampler whose states are loaded.
         `between`: optional callable run between the gradient half and the optimizer half of every step (the data-parallel
         all-reduce); the optimizer half then stays outside the graphs.
@@ -41,6 +42,11 @@ class TrainPipeline:
         table's share beside the relation half, optimizer half with scale 1 / world); excludes `between`."""
         if comm is not None and between is not None:
             raise ValueError("TrainPipeline: either an RCCL communicator (native data-parallel steps) or a `between` hook, not both")
+        # row_shard: a dist.RowShardTrainer -- owner-computes steps over row-sharded tables: every rank feeds this pipeline the SAME
+        # batches (same sampler seeds), the step stage is the trainer's windowed step + its exchange (collectives: never captured)
+        if row_shard is not None and (comm is not None or between is not None):
+            raise ValueError("TrainPipeline: row_shard excludes comm / between (those are the data-parallel replica step)")
+        self.row_shard = row_shard
         self.comm, self.world = comm, int(world)
         if not model.pipeline_supported():
             # (HolE's frequency-domain step takes plans too, but is a composite of library calls, not one captured step)
@@ -56,7 +62,9 @@ class TrainPipeline:
         # collective, optimizer half) is launched kernel by kernel, so that no collective ever sits inside a captured graph
         self.use_graphs = bool(graphs) and float(getattr(model, "dp", 0.0) or 0.0) == 0.0
         self.native_wanted = bool(graphs)  # the native driver launches kernel by kernel: dropout (a seed per step) is no obstacle
-        self.graph_stages = ("S", "P", "T") if between is None else ("S", "P")
+        # (a collective never sits inside a captured graph: with a `between` hook OR an RCCL communicator the step stage -- gradient half,
+        #  all-reduce, optimizer half -- is launched kernel by kernel; only the draw and plan stages are replayed)
+        self.graph_stages = ("S", "P", "T") if between is None and comm is None and row_shard is None else ("S", "P")
         m = self.B * self.ns
         # the batch before oversampling + how often each row was picked: the sampler's by-product the plans are built from when
         # there is no dropout (with dropout every oversampled row has its own mask and the plan takes the arrays as they are)
@@ -127,7 +135,9 @@ class TrainPipeline:
         build(4)
 
     def _stage_T(self, slot):
-        if self.comm is not None:  # (the Python loop's form of the native data-parallel step: serial / profiling runs)
+        if self.row_shard is not None:
+            self.row_shard.step(self.plans[slot])
+        elif self.comm is not None:  # (the Python loop's form of the native data-parallel step: serial / profiling runs)
             self.model.train_grads(self.plans[slot])
             g = self.model._gall
             _lib.check(_lib.lib.kge_allreduce_f32(self.comm if isinstance(self.comm, int) else self.comm.value, g.data_ptr(), g.numel(), _lib.stream_ptr()))
@@ -238,7 +248,7 @@ class TrainPipeline:
 
     # ------------------------------------------------------------------ native driver (csrc/pipeline.cpp)
     def native_ok(self):
-        return self.native_wanted and self.between is None and not self.serial
+        return self.native_wanted and self.between is None and self.row_shard is None and not self.serial
 
     def _on_native(self, fn, join=True):
         """Run fn with the native driver's own stream current, ordered after the caller's stream and (join) joined back into it.  The
@@ -408,7 +418,8 @@ class TrainPipeline:
         """Prologue: batches 0 and 1 on their way.  Switches the optimizer to the device step state."""
         mo = self.model
         main = torch.cuda.current_stream()
-        mo._ensure_train_state(self.B * self.ns, self.B * self.ns)
+        if self.row_shard is None:  # (a row-shard trainer keeps its own workspace and only this rank's share of the moments)
+            mo._ensure_train_state(self.B * self.ns, self.B * self.ns)
         for pl in self.plans:  # counters of a plan that was built but never consumed (an epoch cut short) would poison the next build
             pl.buf.zero_()
         self._np, self._taken_over = 2, False
@@ -416,7 +427,7 @@ class TrainPipeline:
             mo._step_dev = self.step_dev
             # twin tables (kge_train_step_swap: lr_t of every update comes from the device step state, so the step may also be one
             # of this object's captured stages); with dropout the three-launch step is the faster one
-            if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0 and self.comm is None:
+            if os.environ.get("KGE_PIPE_SWAP", "1") != "0" and float(getattr(mo, "dp", 0.0) or 0.0) == 0.0 and self.comm is None and self.row_shard is None:
                 if self._twins is None or self._twins[0].shape != mo.E.shape or self._twins[1].shape != mo.Rel.shape:
                     self._twins = (torch.empty_like(mo.E), torch.empty_like(mo.Rel))
                 mo._step_twins = self._twins
@@ -471,7 +482,10 @@ class TrainPipeline:
         if getattr(mo, "_step_dev", None) is not None:
             mo.optimizer.iterations = int(self.step_dev[0].item())
             mo._step_dev = mo._step_twins = None
-            return self.step_dev.view(torch.float64)[2].clone()  # running sum kept by the library (kge_opt_desc.step_dev), a double
+            tot = self.step_dev.view(torch.float64)[2].clone()  # running sum kept by the library (kge_opt_desc.step_dev), a double
+            if self.row_shard is not None and self.row_shard.tables.ws > 1:  # (every rank's state summed ITS partial losses)
+                torch.distributed.all_reduce(tot, group=self.row_shard.tables.group)
+            return tot
         return self.loss_sum
 
     def run_epoch(self, index, order):

@@ -188,6 +188,62 @@ def test_data_parallel_step_equals_big_batch():
     assert out[0][2] == pytest.approx(L, rel=1e-12)
 
 
+def _row_batches():
+    rs = np.random.RandomState(7)
+    N, R, d, m = 37, 5, 6, 96  # neither table divides by the world size: the last shards are short
+    E = rs.uniform(-0.5, 0.5, (N, d))
+    Rl = rs.uniform(-0.5, 0.5, (R, d))
+    tri = lambda: np.stack([rs.randint(0, N - 3, m), rs.randint(0, R, m), rs.randint(0, N - 3, m)], 1)  # noqa: E731  (entities N-3.. untouched)
+    return N, R, d, E, Rl, [(tri(), tri()) for _ in range(3)]
+
+
+def _row_worker(rank, world):
+    """Owner-computes steps (dist.RowShardedTables / row_sharded_step): EVERY rank holds the same batch; it updates the entity rows and
+    relation rows of its window only (gradient rows + Adam with this rank's share of the moments, restated with the oracle), then
+    the window rows are all-gathered and the partial losses summed."""
+    from kge_keras_amd import dist as D
+    N, R, d, E, Rl, batches = _row_batches()
+    tables = D.RowShardedTables(torch.from_numpy(E.copy()), torch.from_numpy(Rl.copy()))
+    assert tables.ent == D.shard_range(N, rank, world) and tables.rel == D.shard_range(R, rank, world)
+    opt = O.AdamTF()  # slots hold this rank's window rows only
+    loss = torch.zeros(1, dtype=torch.float64)
+    losses = []
+    for pos, neg in batches:
+        def window_step(E_in, R_in, E_out, R_out, ent, rel):
+            Ein, Rin = E_in.numpy(), R_in.numpy()
+            _L, sp, sn, gE, gR = O.dense_grads("DistMult", Ein, Rin, pos, neg, "pointwize_logistic", 1.0)
+            opt.begin_step()
+            (lo, hi), (rlo, rhi) = ent, rel
+            we, wr = Ein[lo:hi].copy(), Rin[rlo:rhi].copy()
+            opt.apply("E", we, gE[lo:hi])
+            opt.apply("R", wr, gR[rlo:rhi])
+            E_out[lo:hi] = torch.from_numpy(we)
+            R_out[rlo:rhi] = torch.from_numpy(wr)
+            # this rank's partial loss: the terms of the batch rows whose relation lies in its window (utils.py:291-292, both means)
+            tp = np.log(1e-6 + 1 + np.exp(-sp)) / len(sp)
+            tn = np.log(1e-6 + 1 + np.exp(sn)) / len(sn)
+            inp, inn = (pos[:, 1] >= rlo) & (pos[:, 1] < rhi), (neg[:, 1] >= rlo) & (neg[:, 1] < rhi)
+            loss[0] = tp[inp].sum() + tn[inn].sum()
+        D.row_sharded_step(tables, window_step, loss)
+        losses.append(float(loss[0]))
+    assert tables.exchanged_bytes() == 4 * (world - 1) * (tables.per_e * d + tables.per_r * d)
+    return tables.E.numpy().copy(), tables.Rel.numpy().copy(), losses
+
+
+def test_row_sharded_owner_computes_step_equals_one_process():
+    """Three owner-computes steps on two ranks == three ordinary steps of one process on the same batches: tables identical on both
+    ranks and equal to the unsharded oracle (the update of a row depends on its own gradient and moments only), losses equal."""
+    out = _spawn(_row_worker)
+    N, R, d, E, Rl, batches = _row_batches()
+    opt = O.AdamTF()
+    Ls = [O.train_step("DistMult", E, Rl, opt, pos, neg, "pointwize_logistic", 1.0) for pos, neg in batches]
+    for r in range(2):
+        np.testing.assert_allclose(out[r][0], E, atol=1e-15)
+        np.testing.assert_allclose(out[r][1], Rl, atol=1e-15)
+        np.testing.assert_allclose(out[r][2], Ls, rtol=1e-12)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_shard_helpers_single_process():
     from kge_keras_amd import dist as D
     assert D.shard_range(123182, 7, 8) == (107786, 123182) and D.shard_range(123182, 0, 8) == (0, 15398)

@@ -285,3 +285,125 @@ def test_swap_step_with_dropout(model, kw, d):
     np.testing.assert_allclose(c._gE.cpu().numpy(), gEo, atol=1e-5)
     np.testing.assert_allclose(c._gR.cpu().numpy(), gRo, atol=1e-5)
     assert float(c._loss[0].item()) == pytest.approx(Lg, rel=1e-5)
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+@pytest.mark.parametrize("model,kw,d,n_win", [("DistMult", {}, 200, 2), ("DistMult", {}, 24, 3), ("TransE", dict(norm=2, gamma=12), 64, 2),
+                                              ("ComplEx", {}, 40, 4), ("pRotatE", {}, 24, 2)])
+def test_row_windows_on_one_device_equal_the_unsharded_step(model, kw, d, n_win, opt):
+    """kge_train_step_swap_window: the owner-computes step of SURVEY 8(e) rehearsed on ONE device.  `n_win` "ranks" -- each with its own plan
+    of the SAME batch, its own step state and ONLY ITS WINDOW'S Adam moment rows (base pointers offset by -lo rows) -- write their
+    entity rows and relation rows into shared out tables; together these must equal what kge_train_step_swap leaves on one GPU
+    (<= 1e-6: the list order inside a row comes from each plan build's atomics), the partial losses must add up to the batch loss,
+    every plan's counters must be left zero (a later build with parts | 8 still trains right), and rows outside a window must not be
+    written by that window's call.  Hub entity (chunk waves + ticket inside one window), untouched entities, a dominant relation,
+    windows that do not divide the tables; three steps, tables alternating."""
+    from kge_keras_amd import _lib, models as M
+    from kge_keras_amd import dist as D
+    C, lib = _lib.C, _lib.lib
+    N, R = 301, 7
+    rs = np.random.RandomState(13)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    mk = lambda: getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0,  # noqa: E731
+                                   loss_function="pointwize_logistic", margin=1.0, **kw)
+    n_pos, n_neg = 64, 1500
+    ref = mk()
+    ref.compile(opt)
+    ref._ensure_train_state(n_pos, n_neg)
+    _state(ref)
+    ref._step_twins = (torch.empty_like(ref.E), torch.empty_like(ref.Rel))
+    # the "ranks"
+    ranks = []
+    for r in range(n_win):
+        m = mk()
+        m.compile(opt)
+        (lo, hi), (rlo, rhi) = D.shard_range(N, r, n_win), D.shard_range(R, r, n_win)
+        sd = torch.zeros(_lib.STEP_STATE_WORDS, dtype=torch.int64, device="cuda")
+        o = m.optimizer
+        od0 = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, 1, None, None, None, None, sd.data_ptr())
+        _lib.check(lib.kge_opt_state_init(C.byref(od0), _lib.stream_ptr()))
+        slots = [torch.zeros((max(1, hi - lo), de), device="cuda"), torch.zeros((max(1, hi - lo), de), device="cuda"),
+                 torch.zeros((max(1, rhi - rlo), dr), device="cuda"), torch.zeros((max(1, rhi - rlo), dr), device="cuda")]
+        ptrs = [slots[0].data_ptr() - 4 * lo * de, slots[1].data_ptr() - 4 * lo * de, slots[2].data_ptr() - 4 * rlo * dr, slots[3].data_ptr() - 4 * rlo * dr]
+        md, ld = m._model_desc(True), m._loss_desc()
+        ws = torch.zeros(int(_lib.check(lib.kge_train_step_workspace_bytes(C.byref(md), C.byref(ld), n_pos, n_neg))), dtype=torch.uint8, device="cuda")
+        ranks.append(dict(m=m, win=_lib.RowWindow(lo, hi, rlo, rhi), sd=sd, slots=slots, ptrs=ptrs if opt == "adam" else [None] * 4, ws=ws,
+                          loss=torch.zeros(1, device="cuda"), plan=None))
+    cur = (torch.from_numpy(E0).cuda(), torch.from_numpy(R0).cuda())
+    nxt = (torch.full_like(cur[0], 7.0), torch.full_like(cur[1], 7.0))  # (7: never a table value -- rows nobody wrote would show)
+    for step in range(3):
+        ent = lambda n: np.where(rs.rand(n) < 0.3, 7, rs.randint(0, N - 40, n))  # hub: entity 7; entities N-40.. never touched
+        rel = lambda n: np.where(rs.rand(n) < 0.6, 2, rs.randint(0, R, n))
+        pos = np.stack([ent(n_pos), rel(n_pos), ent(n_pos)], 1).astype(np.int32)
+        neg = np.stack([ent(n_neg), rel(n_neg), ent(n_neg)], 1).astype(np.int32)
+        L_ref = float(ref.train_step(ref.plan_batch([pos, neg]))["loss"].item())
+        tot = 0.0
+        for k, rk in enumerate(ranks):
+            m = rk["m"]
+            rk["plan"] = m.plan_batch([pos, neg], out=rk["plan"], parts=7 | (8 if step else 0))  # (8: counters known to be zero after a window step)
+            md, ld = m._model_desc(True), m._loss_desc()
+            o = m.optimizer
+            od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, step + 1, *rk["ptrs"], rk["sd"].data_ptr())
+            before = nxt[0].clone()
+            _lib.check(lib.kge_train_step_swap_window(C.byref(md), C.byref(ld), C.byref(od), cur[0].data_ptr(), cur[1].data_ptr(), nxt[0].data_ptr(),
+                                                      nxt[1].data_ptr(), rk["plan"].buf.data_ptr(), rk["plan"].buf.numel(), n_pos, n_neg,
+                                                      rk["loss"].data_ptr(), 0, rk["ws"].data_ptr(), rk["ws"].numel(), C.byref(rk["win"]), _lib.stream_ptr()))
+            tot += float(rk["loss"][0].item())
+            w = rk["win"]
+            outside = torch.ones(N, dtype=torch.bool, device="cuda")
+            outside[w.ent_lo:w.ent_hi] = False
+            assert torch.equal(nxt[0][outside], before[outside]), (step, k)  # rows of other windows untouched by this call
+            assert int(rk["sd"][0].item()) == step + 1
+        assert tot == pytest.approx(L_ref, rel=2e-6), step
+        np.testing.assert_allclose(nxt[0].cpu().numpy(), ref.E.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(nxt[1].cpu().numpy(), ref.Rel.cpu().numpy(), atol=1e-6)
+        if opt == "adam":  # the moment shards, stitched together, are the unsharded moments
+            for j in range(4):
+                whole = torch.cat([rk["slots"][j][:((rk["win"].ent_hi - rk["win"].ent_lo) if j < 2 else (rk["win"].rel_hi - rk["win"].rel_lo))] for rk in ranks])
+                np.testing.assert_allclose(whole.cpu().numpy(), ref.optimizer.slots[j].cpu().numpy(), atol=1e-7)
+        cur, nxt = nxt, cur
+        nxt[0].fill_(7.0)
+        nxt[1].fill_(7.0)
+    ref._raise_on_flag()
+    # bad windows are refused
+    bad = _lib.RowWindow(5, N + 1, 0, R)
+    rk = ranks[0]
+    md, ld = rk["m"]._model_desc(True), rk["m"]._loss_desc()
+    o = rk["m"].optimizer
+    od = _lib.OptDesc(_lib.OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, 4, *rk["ptrs"], rk["sd"].data_ptr())
+    assert lib.kge_train_step_swap_window(C.byref(md), C.byref(ld), C.byref(od), cur[0].data_ptr(), cur[1].data_ptr(), nxt[0].data_ptr(), nxt[1].data_ptr(),
+                                          rk["plan"].buf.data_ptr(), rk["plan"].buf.numel(), n_pos, n_neg, rk["loss"].data_ptr(), 0, rk["ws"].data_ptr(),
+                                          rk["ws"].numel(), C.byref(bad), _lib.stream_ptr()) == -1
+
+
+def test_row_shard_trainer_world_of_one_equals_twin_step():
+    """dist.RowShardTrainer without a process group (one rank: the window is the whole table, the exchange a swap of the twin
+    buffers): three steps equal the ordinary twin-table step, model.E / model.Rel follow the current buffers."""
+    from kge_keras_amd import models as M
+    from kge_keras_amd import dist as D
+    N, R, d = 90, 5, 32
+    rs = np.random.RandomState(2)
+    E0 = rs.uniform(-0.5, 0.5, (N, d)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, d)).astype(np.float32)
+    a, b = (M.DistMult(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0, loss_function="pointwize_hinge", margin=1.0)
+            for _ in range(2))
+    for m in (a, b):
+        m.compile("adam")
+    a._ensure_train_state(40, 400)
+    _state(a)
+    a._step_twins = (torch.empty_like(a.E), torch.empty_like(a.Rel))
+    tr = D.RowShardTrainer(b)
+    Eo, Ro, oo = E0.astype(np.float64), R0.astype(np.float64), O.make_optimizer("adam")
+    for step in range(3):
+        pos = np.stack([rs.randint(0, N, 40), rs.randint(0, R, 40), rs.randint(0, N, 40)], 1).astype(np.int32)
+        neg = np.stack([rs.randint(0, N, 400), rs.randint(0, R, 400), rs.randint(0, N, 400)], 1).astype(np.int32)
+        La = float(a.train_step(a.plan_batch([pos, neg]))["loss"].item())
+        Lb = float(tr.step(b.plan_batch([pos, neg])).item())
+        Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1.0)
+        assert La == pytest.approx(Lb, rel=1e-6) and Lb == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
+        np.testing.assert_allclose(b.E.cpu().numpy(), a.E.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(b.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(b.Rel.cpu().numpy(), Ro, atol=TOL_W)
+    assert b.predict(pos).shape == (40,)

@@ -429,6 +429,18 @@ def test_hole_direct_kernels_over_row_widths(d, dp):
     np.testing.assert_allclose(mdl.predict(t), O.call("HolE", Eo, Ro, t, 1, 12), atol=2 * TOL)
 
 
+def _pair_sort(mode):
+    """kge_set_pair_sort_mode: "0" all-pairs kernels, "1" sorted scores / four sums, None: by pair count (the default)."""
+    from kge_keras_amd import _lib
+    _lib.check(_lib.lib.kge_set_pair_sort_mode(-1 if mode is None else int(mode)))
+
+
+@pytest.fixture(autouse=True)
+def _pair_sort_default():
+    yield
+    _pair_sort(None)
+
+
 @pytest.mark.parametrize("m_t,m_f", [(1, 7), (300, 300), (5000, 4097), (1, 3000), (2048, 20480)])
 @pytest.mark.parametrize("margin", [1.0, 0.25])
 def test_pairwise_hinge_from_sorted_scores_equals_all_pairs(m_t, m_f, margin, monkeypatch):
@@ -442,7 +454,7 @@ def test_pairwise_hinge_from_sorted_scores_equals_all_pairs(m_t, m_f, margin, mo
     f = (np.round(rs.uniform(-3, 3, m_f) * 4) / 4).astype(np.float32)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("KGE_PAIR_SORT", mode)
+        _pair_sort(mode)
         L, gt, gf = M.loss_value("pairwize_hinge", t, f, margin, 1, return_grads=True)
         out[mode] = (float(L.item()), gt.cpu().numpy(), gf.cpu().numpy())
     Lo, gto, gfo = O.loss_value_and_grads("pairwize_hinge", t.astype(np.float64), f.astype(np.float64), margin, 1)
@@ -455,7 +467,7 @@ def test_pairwise_hinge_from_sorted_scores_equals_all_pairs(m_t, m_f, margin, mo
         t2, f2 = t.copy(), f.copy()
         t2[0] = np.nan
         f2[-1] = np.nan
-        monkeypatch.setenv("KGE_PAIR_SORT", "1")
+        _pair_sort("1")
         L, gt, gf = M.loss_value("pairwize_hinge", t2, f2, margin, 1, return_grads=True)
         gt, gf = gt.cpu().numpy(), gf.cpu().numpy()
         keep_t, keep_f = t2[1:].astype(np.float64), f2[:-1].astype(np.float64)
@@ -467,7 +479,7 @@ def test_pairwise_hinge_from_sorted_scores_equals_all_pairs(m_t, m_f, margin, mo
         np.testing.assert_allclose(gf[:-1], gfk * scale, rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("m_t,m_f", [(1, 7), (300, 300), (5000, 4097), (1, 3000)])
+@pytest.mark.parametrize("m_t,m_f", [(1, 7), (300, 300), (5000, 4097), (1, 3000), (2048, 20480)])
 def test_pairwise_square_from_sums_equals_all_pairs(m_t, m_f, monkeypatch):
     """csrc/pairsort.hip: -(f_j - t_i)^2 over all pairs (utils.py:314-319 with negative_samples = 1) separates into four sums; against
     the all-pairs kernels and the oracle."""
@@ -476,11 +488,22 @@ def test_pairwise_square_from_sums_equals_all_pairs(m_t, m_f, monkeypatch):
     t, f = rs.uniform(-3, 3, m_t).astype(np.float32), rs.uniform(-2, 4, m_f).astype(np.float32)
     Lo, gto, gfo = O.loss_value_and_grads("pairwize_square_loss", t.astype(np.float64), f.astype(np.float64), 1.0, 1)
     for mode in ("0", "1"):
-        monkeypatch.setenv("KGE_PAIR_SORT", mode)
+        _pair_sort(mode)
         L, gt, gf = M.loss_value("pairwize_square_loss", t, f, 1.0, 1, return_grads=True)
         assert float(L.item()) == pytest.approx(float(Lo), rel=2e-5), mode
         np.testing.assert_allclose(gt.cpu().numpy(), gto, rtol=2e-4, atol=1e-7, err_msg=mode)
         np.testing.assert_allclose(gf.cpu().numpy(), gfo, rtol=2e-4, atol=1e-7, err_msg=mode)
+    if m_t > 1 and m_f > 1:
+        # a NaN score (a row with ids outside the tables) on the `true` side: -(f - t)^2 has no corner to hide it behind -- in the reference
+        # the mean is NaN and so is every d/df_j; d/dt_i of the other rows stays finite.  Both forms must show the same pattern.
+        t2 = t.copy()
+        t2[0] = np.nan
+        for mode in ("0", "1"):
+            _pair_sort(mode)
+            L, gt, gf = M.loss_value("pairwize_square_loss", t2, f, 1.0, 1, return_grads=True)
+            gt, gf = gt.cpu().numpy(), gf.cpu().numpy()
+            assert np.isnan(float(L.item())) and np.isnan(gt[0]) and np.all(np.isnan(gf)), mode
+            np.testing.assert_allclose(gt[1:], gto[1:], rtol=2e-4, atol=1e-7, err_msg=mode)
 
 
 def test_dropout_default_rate_trains(datasets):
