@@ -334,7 +334,10 @@ class AdamTF:
         lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m = b1*m+(1-b1)*g;  v = b2*v+(1-b2)*g^2;  w -= lr_t*m/(sqrt(v)+eps)"""
 
     def __init__(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
-        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        # [TF] OptimizerV2 keeps its hyper-parameters as tensors of the VARIABLE's dtype (`_get_hyper(name, var_dtype)`, float32 for
+        # the embedding tables): beta_2 is 0.999 rounded to float32 (0.99900001287...), and 1 - beta_2^t feels that rounding at 1.3e-5
+        # relative for small t (lr_t at 6e-6).  The restatement therefore holds the float32-rounded values (as doubles).
+        self.lr, self.b1, self.b2, self.eps = (float(np.float32(x)) for x in (lr, b1, b2, eps))
         self.t = 0
         self.slots = {}
 
@@ -359,7 +362,7 @@ class SGDTF:
     """[TF] Keras SGD, lr=0.01, no momentum: w[ids] -= lr*g with duplicate ids accumulated."""
 
     def __init__(self, lr=0.01):
-        self.lr = lr
+        self.lr = float(np.float32(lr))  # (float32 hyper-parameter tensor, as in AdamTF)
         self.t = 0
 
     def begin_step(self):

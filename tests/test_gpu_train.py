@@ -10,7 +10,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, TOL_W_LONG, TOL_L_BIG  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 
 @pytest.fixture(params=["pull", "push"], autouse=True)
@@ -394,8 +394,8 @@ def test_dropout_training_parity(model, kw, loss, grad_mode):
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12),
                           dropout=0.3, seed=mdl._seed)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W_LONG)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W_LONG)
     # predict is dropout-free (keras Dropout is the identity outside fit)
     t = _triples(rs, 50, N, R)
     np.testing.assert_allclose(mdl.predict(t), O.call(model, Eo, Ro, t, kw.get("norm", 1), kw.get("gamma", 12)), atol=2 * TOL)
@@ -423,8 +423,8 @@ def test_hole_direct_kernels_over_row_widths(d, dp):
         L = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
         Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, 1, 12, dropout=dp, seed=mdl._seed)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W_LONG)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W_LONG)
     t = _triples(rs, 9, N, R)
     np.testing.assert_allclose(mdl.predict(t), O.call("HolE", Eo, Ro, t, 1, 12), atol=2 * TOL)
 
@@ -714,9 +714,9 @@ def test_hole_spectral_step(d, loss):
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, 1, 12)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA) and Lr == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
-        np.testing.assert_allclose(ref.E.cpu().numpy(), Eo, atol=TOL_W)
+        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W_LONG)
+        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W_LONG)
+        np.testing.assert_allclose(ref.E.cpu().numpy(), Eo, atol=TOL_W_LONG)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
     inner = mdl._spec["inner"]
     assert float(inner._gE.abs().max()) == 0.0 and float(inner._gR.abs().max()) == 0.0  # spectral accumulators re-zeroed

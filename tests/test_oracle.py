@@ -245,24 +245,29 @@ def test_dense_grads_and_adam_vs_torch(model, norm, gamma, loss):
 
 
 def test_adam_tf_formula():
-    # two steps by hand
+    # two steps by hand.  [TF] the hyper-parameters are float32 tensors (OptimizerV2._get_hyper(name, var_dtype)): 0.9, 0.999, 1e-3 and
+    # 1e-7 enter the formula rounded to float32
+    lr, b1, b2, eps = (float(np.float32(x)) for x in (1e-3, 0.9, 0.999, 1e-7))
     w = np.array([[1.0, -2.0]])
     g1 = np.array([[0.5, 0.0]])
     opt = O.AdamTF()
     opt.begin_step()
     opt.apply("w", w, g1)
-    m = 0.1 * g1
-    v = 0.001 * g1 ** 2
-    lr1 = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
-    exp = np.array([[1.0, -2.0]]) - lr1 * m / (np.sqrt(v) + 1e-7)
+    m = (1 - b1) * g1
+    v = (1 - b2) * g1 ** 2
+    lr1 = lr * np.sqrt(1 - b2) / (1 - b1)
+    exp = np.array([[1.0, -2.0]]) - lr1 * m / (np.sqrt(v) + eps)
     np.testing.assert_allclose(w, exp, rtol=1e-14)
+    # the closed form of step 1 (m / sqrt(v) = sqrt(1 - b2) / (1 - b1) ... ) with the decimal constants, to the precision float32 constants allow
+    np.testing.assert_allclose(w, np.array([[1.0, -2.0]]) - 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9) * (0.1 * g1) / (np.sqrt(0.001 * g1 ** 2) + 1e-7), rtol=1e-7)
     # untouched element still decays its moments on later steps (dense semantics)
     opt.begin_step()
     opt.apply("w", w, np.zeros_like(w))
-    m2 = 0.9 * m
-    v2 = 0.999 * v
-    lr2 = 1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
-    np.testing.assert_allclose(w, exp - lr2 * m2 / (np.sqrt(v2) + 1e-7), rtol=1e-14)
+    m2 = b1 * m
+    v2 = b2 * v
+    lr2 = lr * np.sqrt(1 - b2 ** 2) / (1 - b1 ** 2)
+    np.testing.assert_allclose(w, exp - lr2 * m2 / (np.sqrt(v2) + eps), rtol=1e-14)
+    assert opt.lr_t(2) == pytest.approx(1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2), rel=1e-5)  # (float32 beta_2: 6.6e-6 off the decimal form at t = 2)
 
 
 def test_glorot_limits():
