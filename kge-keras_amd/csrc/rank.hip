@@ -366,230 +366,22 @@ __global__ __launch_bounds__(256) void rank_sweep_kernel(const float* __restrict
   if (tid < kTile && q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
 }
 
-// Same sweep for rows of K % 4 == 0 floats on 16-byte boundaries (every table the models hand over), built so that the
-// matrix pipe is the only thing a wave waits for:
-//   * PERSISTENT and BALANCED: the grid is one workgroup per residency slot (2 per CU); the (query tile, candidate tile) units,
-//     query-major, are cut into gridDim.x equal contiguous ranges (+-1 unit), so there is no partially filled last round of
-//     workgroups (3680 workgroups over 512 slots lost ~10 % there) and the per-workgroup prologue is paid once.  A range that
-//     crosses into the next query tile flushes its counters (LDS -> one global atomic per query row) and reloads the targets.
-//     Workgroup b takes the logical range (b mod 8)*(grid/8) + b/8: workgroups are dealt round-robin to the 8 XCDs, so each
-//     XCD's L2 sees ~20 neighbouring query tiles and, across them, the same few candidate tiles at a time;
-//   * candidate tile / k chunk are nested loops, the four accumulators are zeroed and consumed once per tile and (VGPR-form
-//     MFMA, see the Makefile) never move (the flattened loop of the generic kernel makes the compiler carry them in VGPRs and
-//     copy 64 registers in and out of the accumulator file every chunk);
-//   * the staging slots of a thread (tile row, float4 column) are loop invariant; rows past the end are clamped to the last
-//     valid row instead of predicated (queries past nq never store, candidates past cand_rows are masked in the epilogue), so
-//     the prefetch of the next chunk is 10 address computations + 10 loads with no branch, issued one slot per group of 16
-//     MFMAs between scheduling barriers; the LDS fragments of group j+1 are read while group j multiplies;
-//   * the prefetch after the very last chunk re-reads the current unit's first chunk (no branch; the values are dropped).
-// The k order of every accumulation chain is the one documented at the top of the file (same LDS image, same reads).
-// EPI 0: count score_c = <q, e_c> > tgt.  EPI 1 / 2 (TransE-L2, rank_sumsq_kernel): count D_c = en[c] - 2 <q, e_c> < tgt / > tgt.
-template <int BK, bool TAIL, int EPI = 0>
-__global__ __launch_bounds__(256) void rank_sweep4_kernel(const float* __restrict__ Qv, const float* __restrict__ tgt,
-                                                           int nq, const float* __restrict__ Ec, int K, int Kpad,
-                                                           int cand_rows, int32_t* __restrict__ counts,
-                                                           const float* __restrict__ en_c = nullptr, int parts = 0) {
-  constexpr int LS = BK + 4;
-  constexpr int C4 = BK / 4;
-  constexpr int PF = kTile * C4 / 256;
-  static_assert(kTile * C4 % 256 == 0, "staging slots must divide evenly");
-  static_assert(PF == 4 || PF == 5, "staging code is written for 4 or 5 slots per thread");
-  __shared__ __attribute__((aligned(16))) float As[kTile * LS];
-  __shared__ __attribute__((aligned(16))) float Bs[kTile * LS];
-  __shared__ int cnt_s[kTile];
-  __shared__ float tg_s[kTile];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wq = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
-  const int nqt = (nq + kTile - 1) / kTile, nct = (cand_rows + kTile - 1) / kTile;
-  const int64_t total = (int64_t)nqt * nct;
-  const int nb = gridDim.x;
-  // workgroups are dealt round-robin to the 8 XCDs: logical block lb makes the 64 workgroups of an XCD neighbours in the unit order,
-  // i.e. one XCD works on one block of consecutive query tiles (its Q block stays in that XCD's L2)
-  const int lb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  // parts > 0 (nb == nqt * parts): every workgroup sweeps 1/parts of ONE query tile's candidate tiles, so all workgroups start at
-  // one of `parts` candidate phases and walk in step -- the workgroups of an XCD read the same few E tiles at the same time (one
-  // fabric read, the rest L2 hits).  parts == 0: equal contiguous cuts of the unit list (phases spread over all candidate tiles).
-  int64_t u_begin, u_end;
-  if (parts > 0) {
-    const int q_ = lb / parts, p_ = lb - q_ * parts;
-    u_begin = (int64_t)q_ * nct + (int64_t)nct * p_ / parts;
-    u_end = (int64_t)q_ * nct + (int64_t)nct * (p_ + 1) / parts;
-  } else {
-    u_begin = total * lb / nb;
-    u_end = total * (lb + 1) / nb;
-  }
-  if (u_begin >= u_end) return;
-  int qt = (int)(u_begin / nct), ct = (int)(u_begin - (int64_t)qt * nct);
-  int q0 = qt * kTile;
-
-  int cnt[2][16];  // one counter per accumulator row (both candidate halves of the wave tile add into it)
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cnt[rt][r] = 0;
-  if (tid < kTile) {
-    cnt_s[tid] = 0;
-    // rows past nq: a value nothing compares true against (NaN targets count nothing either)
-    tg_s[tid] = q0 + tid < nq ? tgt[q0 + tid] : (EPI == 1 ? -__builtin_inff() : __builtin_inff());
-  }
-
-  // loop-invariant staging slots; named scalars (PF is 4 or 5), slot 4 is compiled out when PF == 4
-  const int last_row = cand_rows - 1, last_q = nq - 1;
-  const int nchunk = Kpad / BK;
-#define KGE_SLOT(U)                                                                  \
-  const int r##U = (tid + U * 256) / C4, cB##U = ((tid + U * 256) - r##U * C4) * 4;  \
-  const int lo##U = r##U * LS + cB##U;                                               \
-  float4 pa##U, pb##U;
-  KGE_SLOT(0) KGE_SLOT(1) KGE_SLOT(2) KGE_SLOT(3) KGE_SLOT(4)
-#undef KGE_SLOT
-#define KGE_PF1(U, Q0, C0, K0)                                                                                     \
-  if (U < PF) {                                                                                                    \
-    const int qrow_ = min((Q0) + r##U, last_q);                                                                    \
-    pa##U = *reinterpret_cast<const float4*>(Qv + (int64_t)qrow_ * Kpad + (K0) + cB##U);                           \
-    const int row_ = min((C0) + r##U, last_row);                                                                   \
-    if (TAIL) { /* K % 4 == 0: a float4 is inside the row or entirely in the padding */                            \
-      const bool in_ = (K0) + cB##U < K;                                                                           \
-      const float4 v_ = *reinterpret_cast<const float4*>(Ec + (int64_t)row_ * K + (in_ ? (K0) + cB##U : 0));      \
-      pb##U = in_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
-    } else {                                                                                                       \
-      pb##U = *reinterpret_cast<const float4*>(Ec + (int64_t)row_ * K + (K0) + cB##U);                             \
-    }                                                                                                              \
-  }
-#define KGE_ST1(U)                                                   \
-  if (U < PF) {                                                      \
-    *reinterpret_cast<float4*>(As + lo##U) = pa##U;                  \
-    *reinterpret_cast<float4*>(Bs + lo##U) = pb##U;                  \
-  }
-  const float* a_rd = As + (wq * 64 + l31) * LS + 4 * half;
-  const float* b_rd = Bs + (wc * 64 + l31) * LS + 4 * half;
-
-  {
-    const int c0_ = ct * kTile;
-    KGE_PF1(0, q0, c0_, 0) KGE_PF1(1, q0, c0_, 0) KGE_PF1(2, q0, c0_, 0) KGE_PF1(3, q0, c0_, 0) KGE_PF1(4, q0, c0_, 0)
-  }
-  for (int64_t u = u_begin; u < u_end; ++u) {
-    // coordinates of the next unit of this workgroup's range (after the last one: this unit again, its values are dropped)
-    const bool has_next = u + 1 < u_end;
-    int nqt_ = qt, nct_ = ct;
-    if (has_next) {
-      nct_ = ct + 1;
-      if (nct_ == nct) { nct_ = 0; nqt_ = qt + 1; }
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    for (int kc = 0; kc < nchunk; ++kc) {
-      __syncthreads();  // everyone is done reading the previous chunk
-      KGE_ST1(0) KGE_ST1(1) KGE_ST1(2) KGE_ST1(3) KGE_ST1(4)
-      __syncthreads();
-      // next chunk: its loads are issued one staging slot per group of 16 MFMAs, between scheduling barriers, so the address
-      // arithmetic runs in the shadow of the matrix pipe and every load has at least one full group ahead of it
-      const bool wrap = kc + 1 == nchunk;
-      const int nq0 = wrap ? nqt_ * kTile : q0, nc0 = (wrap ? nct_ : ct) * kTile, nk0 = wrap ? 0 : (kc + 1) * BK;
-      float4 fa[2][2], fb[2][2];  // [buffer][row tile]: the fragments of group j+1 are read while group j multiplies
-#define KGE_FRAG(BUF, J)                                                                          \
-  _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                 \
-    fa[BUF][x] = *reinterpret_cast<const float4*>(a_rd + x * 32 * LS + 8 * (J));                  \
-    fb[BUF][x] = *reinterpret_cast<const float4*>(b_rd + x * 32 * LS + 8 * (J));                  \
-  }
-#define KGE_STEP(BUF, comp)                                                                                           \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][0].comp, acc[0][0], 0, 0, 0);             \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][1].comp, acc[0][1], 0, 0, 0);             \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][0].comp, acc[1][0], 0, 0, 0);             \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][1].comp, acc[1][1], 0, 0, 0);
-      KGE_FRAG(0, 0)
-#pragma unroll
-      for (int j = 0; j < BK / 8; ++j) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < BK / 8) {
-          if ((j & 1) == 0) { KGE_FRAG(1, j + 1) } else { KGE_FRAG(0, j + 1) }
-        }
-        if (j == 0) { KGE_PF1(0, nq0, nc0, nk0) }
-        if (j == 1) { KGE_PF1(1, nq0, nc0, nk0) }
-        if (j == 2) { KGE_PF1(2, nq0, nc0, nk0) }
-        if (j == 3) { KGE_PF1(3, nq0, nc0, nk0) }
-        if (j == 4) { KGE_PF1(4, nq0, nc0, nk0) }
-        __builtin_amdgcn_sched_barrier(0);
-        if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
-        else { KGE_STEP(1, x) KGE_STEP(1, y) KGE_STEP(1, z) KGE_STEP(1, w) }
-      }
-#undef KGE_STEP
-#undef KGE_FRAG
-    }
-    // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
-    const int c0 = ct * kTile;
-    float en0 = 0.f, en1 = 0.f;  // squared norms of this lane's two candidate columns (EPI != 0)
-    if (EPI != 0) {
-      en0 = en_c[min(c0 + wc * 64 + l31, last_row)];
-      en1 = en_c[min(c0 + wc * 64 + 32 + l31, last_row)];
-    }
-    auto hit = [&](float dot, float en, float tgv) {
-      if (EPI == 0) return dot > tgv;
-      const float D = __fmaf_rn(-2.f, dot, en);
-      return EPI == 1 ? D < tgv : D > tgv;
-    };
-    if (c0 + kTile <= cand_rows) {  // uniform: every candidate column of the tile exists
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-          cnt[rt][r] += (hit(acc[rt][0][r], en0, tgv) ? 1 : 0) + (hit(acc[rt][1][r], en1, tgv) ? 1 : 0);
-        }
-    } else {
-      const bool v0 = c0 + wc * 64 + l31 < cand_rows, v1 = c0 + wc * 64 + 32 + l31 < cand_rows;
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-          cnt[rt][r] += ((v0 && hit(acc[rt][0][r], en0, tgv)) ? 1 : 0) + ((v1 && hit(acc[rt][1][r], en1, tgv)) ? 1 : 0);
-        }
-    }
-    if (!has_next || nqt_ != qt) {  // uniform: the range leaves this query tile -> flush its counters
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (cnt[rt][r]) atomicAdd(&cnt_s[row], cnt[rt][r]);
-          cnt[rt][r] = 0;
-        }
-      __syncthreads();
-      if (tid < kTile) {
-        if (q0 + tid < nq && cnt_s[tid]) atomicAdd(&counts[q0 + tid], cnt_s[tid]);
-        if (has_next) {  // read again after the two barriers of the next chunk
-          const int nq0_ = nqt_ * kTile;
-          cnt_s[tid] = 0;
-          tg_s[tid] = nq0_ + tid < nq ? tgt[nq0_ + tid] : (EPI == 1 ? -__builtin_inff() : __builtin_inff());
-        }
-      }
-    }
-    qt = nqt_;
-    ct = nct_;
-    q0 = qt * kTile;
-  }
-#undef KGE_PF1
-#undef KGE_ST1
-}
-
-// The sweep on 256 x 128 block tiles: ONE 512-thread workgroup per CU (8 waves as 4 x 2 of 64 x 64, two per SIMD), the k chunks
-// double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without passing through registers).
-// What rank_sweep4_kernel loses (tools/mfma_probe.cpp: the pipe itself delivers 96-98 % of its peak to this MFMA stream, fragments
-// from LDS and barriers included; the sweep reached 65-78 %, ~1 500 idle pipe cycles per chunk of 5 120):
-//   * its single LDS image forces barrier -> 10 ds_write_b128 per thread -> barrier between any two chunks;
-//   * the address arithmetic, fragment reads and staging loads of a group of 16 MFMAs stand in front of the group as one burst of ~50
-//     instructions; the two waves of a SIMD run in step, so a burst in one is a burst in both and the pipe idles for its length.
-// Here chunk k+1 lands in the other image while the MFMAs of chunk k run (one barrier per chunk, no LDS store instruction at all: a
-// wave issues 9 DMA loads per chunk), a candidate tile feeds 256 query rows (25 % fewer bytes into LDS per flop), the addresses are a
-// wave-uniform base pointer + a 32-bit offset per lane (three vector instructions per DMA and chunk), and every non-MFMA instruction
-// of a group is interleaved with the group's MFMAs (sched_group_barrier).  Fragment reads, MFMA order and epilogue are
-// rank_sweep4_kernel's: the k order of every accumulation chain is the one documented at the top of the file, so the target / filter
-// kernels (chain_dot) still see bit-identical scores.
+// The matrix-core sweep for rows of K % 4 == 0 floats on 16-byte boundaries (every table the models hand over): 256 x 128 block tiles,
+// ONE 512-thread workgroup per CU (8 waves as 4 x 2 of 64 x 64, two per SIMD), PERSISTENT over a contiguous range of (query tile,
+// candidate tile) units, the k chunks double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without
+// passing through registers; no LDS store instruction at all: a wave issues 9 DMA loads per chunk, one barrier per chunk).  What the
+// pipe can deliver to this MFMA stream was measured first (tools/mfma_probe.cpp: 96-98 % of its peak, fragments from LDS and barriers
+// included); what a sweep loses is (a) instruction bursts in front of MFMA groups -- the two waves of a SIMD run in step, so a burst in
+// one is a burst in both and the pipe idles for its length -- and (b) per-unit work that nothing overlaps.  Hence:
+//   * the addresses of the DMA loads are a wave-uniform base pointer + a 32-bit offset per lane (three vector instructions per load
+//     and chunk), and every non-MFMA instruction of a group of MFMAs is interleaved with them (sched_group_barrier);
+//   * round 4: the LAST chunk of a unit runs TILE-MAJOR -- all of its k steps on accumulator tile (0,0), then (0,1), (1,0), (1,1) --
+//     so that the count-greater epilogue of a finished 32 x 32 tile (16 compares + 16 add-with-carry per lane) rides between the MFMAs
+//     of the next tile instead of standing behind the unit's last MFMA in both waves of every SIMD at once (four vector compares per
+//     MFMA slot, against a pipe that idled for the whole epilogue: ~2 000 of a K = 200 unit's 51 200 pipe cycles); only the epilogue of
+//     tile (1,1) is left behind the last MFMA.  A tile's own k order does not change -- an accumulator sees its chunk's k steps in the
+//     same ascending order whether the other tiles' steps sit between them or not -- so every accumulation chain is still the one
+//     documented at the top of the file and the target / filter kernels (chain_dot) see bit-identical scores.
 // LDS-DMA writes 64 lanes x 16 bytes = one contiguous KiB per instruction ("segment"); the images keep their padded rows (BK + 4
 // floats: conflict-free ds_read_b128 fragments), so lane l of segment g fills float4 number 64 g + l of the image -- row (64 g + l) /
 // (C4 + 1), column (64 g + l) % (C4 + 1) -- from wherever that float4 lives in global memory; the pad column repeats column 0 (never
@@ -617,7 +409,7 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
   __shared__ __attribute__((aligned(1024))) float As[2][kQT5 * LS];
   __shared__ __attribute__((aligned(1024))) float Bs[2][kTile * LS];
   __shared__ int cnt_s[kQT5];
-  __shared__ float tg_s[kQT5];
+  __shared__ __attribute__((aligned(16))) float tg_s[kQT5];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
   const int nqt = (nq + kQT5 - 1) / kQT5, nct = (cand_rows + kTile - 1) / kTile;
@@ -626,7 +418,7 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
   // workgroups are dealt round-robin to the 8 XCDs: logical block lb makes the workgroups of an XCD neighbours in the unit order
   const int lb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   int64_t u_begin, u_end;
-  if (parts > 0) {  // (see rank_sweep4_kernel: every workgroup sweeps 1/parts of ONE query tile's candidate tiles)
+  if (parts > 0) {  // phase-aligned cut: every workgroup sweeps 1/parts of ONE query tile's candidate tiles, all workgroups walking in step
     const int q_ = lb / parts, p_ = lb - q_ * parts;
     u_begin = (int64_t)q_ * nct + (int64_t)nct * p_ / parts;
     u_end = (int64_t)q_ * nct + (int64_t)nct * (p_ + 1) / parts;
@@ -655,7 +447,7 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
   // the row.  Rows past the tile's last valid row are clamped to that row (queries past nq never store their counters, candidates past
   // cand_rows are masked in the epilogue): of = min(rb, last valid row's offset + cb), two vector instructions per slot and chunk.
   const int last_row = cand_rows - 1, last_q = nq - 1;
-  const int nchunk = Kpad / BK;
+  const int nchunk = Kpad / BK;  // >= 2 (the launcher sends rows of a single chunk, K <= BK, to the generic kernel): chunk 0 opens the accumulators
 #define KGE5_SLOT(U)                                                                                     \
   const int sg##U = U < SA ? (wave + 8 * U) % SEG_A : (wave + 8 * (U - SA)) % SEG_B;                     \
   const int f##U = sg##U * 64 + lane;                                                                    \
@@ -693,13 +485,18 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
       KGE5_DMA_S(gB, of##U, lds_b + (unsigned)(((BUF) * (kTile * LS) + sg##U * 256) * 4));          \
     }                                                                                                    \
   }
-  // the instruction stream of one group: 16 x { one MFMA, at most one memory instruction (LDS read / DMA load), at most two ALU
-  // instructions } -- fragment reads, DMA loads and address arithmetic ride between the MFMAs instead of standing in front of them
-#define KGE5_PIPE()                                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                    \
+  // next chunk into the other image: three DMA loads (offset, then load) in each of the first three groups of a chunk
+#define KGE5_STAGE(J, BUF)                                                                                                   \
+  if ((J) == 0) { KGE5_OFF(0) KGE5_OFF(1) KGE5_OFF(2) KGE5_LD(0, BUF) KGE5_LD(1, BUF) KGE5_LD(2, BUF) }                        \
+  if ((J) == 1) { KGE5_OFF(3) KGE5_OFF(4) KGE5_OFF(5) KGE5_LD(3, BUF) KGE5_LD(4, BUF) KGE5_LD(5, BUF) }                        \
+  if ((J) == 2) { KGE5_OFF(6) KGE5_OFF(7) KGE5_OFF(8) KGE5_LD(6, BUF) KGE5_LD(7, BUF) KGE5_LD(8, BUF) }
+  // the instruction stream of one group: N x { one MFMA, at most one memory instruction (LDS read / DMA load), at most ALU vector /
+  // scalar instructions } -- fragment reads, DMA loads, address arithmetic and (last chunk) the epilogue ride between the MFMAs
+#define KGE5_PIPE(N, MEM, ALU)                                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < (N); ++i_) {                                                   \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
-    __builtin_amdgcn_sched_group_barrier(0x100 | 0x010, 1, 0);                                           \
-    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004, 2, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x100 | 0x010, (MEM), 0);                                       \
+    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004, (ALU), 0);                                       \
   }
   const int a_off = (wq * 64 + l31) * LS + 4 * half;
   const int b_off = (wc * 64 + l31) * LS + 4 * half;
@@ -715,6 +512,7 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
     KGE5_OFF(0) KGE5_OFF(1) KGE5_OFF(2) KGE5_OFF(3) KGE5_OFF(4) KGE5_OFF(5) KGE5_OFF(6) KGE5_OFF(7) KGE5_OFF(8)
     KGE5_LD(0, 0) KGE5_LD(1, 0) KGE5_LD(2, 0) KGE5_LD(3, 0) KGE5_LD(4, 0) KGE5_LD(5, 0) KGE5_LD(6, 0) KGE5_LD(7, 0) KGE5_LD(8, 0)
   }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int p = 0;  // image the running chunk is read from
   for (int64_t u = u_begin; u < u_end; ++u) {
     // coordinates of the next unit of this workgroup's range (after the last one: this unit again, its values are dropped)
@@ -724,22 +522,21 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
       nct_ = ct + 1;
       if (nct_ == nct) { nct_ = 0; nqt_ = qt + 1; }
     }
-    f32x16 acc[2][2];  // (no zero fill: the first four MFMAs of the unit take a zero C operand -- 64 vector moves per wave and unit less)
-    for (int kc = 0; kc < nchunk; ++kc) {
+    f32x16 acc[2][2];  // (no zero fill: the first MFMA of every accumulator takes a zero C operand -- 64 vector moves per wave and unit less)
+    // ---- chunks 0 .. nchunk - 2, group-major: a group = one float4 of k per operand row = 4 k-steps x 4 accumulator tiles
+    for (int kc = 0; kc + 1 < nchunk; ++kc) {
       // every wave's DMA loads of image p have landed (issued in the first three groups of the previous chunk); everyone is done
       // reading image p ^ 1
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const float* a_rd = &As[p][a_off];
       const float* b_rd = &Bs[p][b_off];
-      // the chunk staged next (the first chunk of the next unit behind the last chunk of this one)
-      const bool wrap = kc + 1 == nchunk;
-      const int nq0 = wrap ? nqt_ * kQT5 : q0, nc0 = (wrap ? nct_ : ct) * kTile, nk0 = wrap ? 0 : (kc + 1) * BK;
-      const float* gA = Qv + (int64_t)nq0 * Kpad + nk0;
-      const float* gB = Ec + (int64_t)nc0 * K + (TAIL ? 0 : nk0);
+      const int nk0 = (kc + 1) * BK;  // the chunk staged next: the next chunk of this unit
+      const float* gA = Qv + (int64_t)q0 * Kpad + nk0;
+      const float* gB = Ec + (int64_t)(ct * kTile) * K + (TAIL ? 0 : nk0);
       const int kB_ = nk0;
       (void)kB_;
-      const unsigned limA = (unsigned)min(last_q - nq0, kQT5 - 1) * (unsigned)Kpad * 4u, limB = (unsigned)min(last_row - nc0, kTile - 1) * (unsigned)K * 4u;
+      const unsigned limA = (unsigned)min(last_q - q0, kQT5 - 1) * (unsigned)Kpad * 4u, limB = (unsigned)min(last_row - ct * kTile, kTile - 1) * (unsigned)K * 4u;
       float4 fa[2][2], fb[2][2];  // [buffer][row tile]: the fragments of group j+1 are read while group j multiplies
 #define KGE_FRAG(BUF, J)                                                                          \
   _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                 \
@@ -756,7 +553,6 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
   acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][0].comp, fb[BUF][1].comp, zero16, 0, 0, 0);               \
   acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][0].comp, zero16, 0, 0, 0);               \
   acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[BUF][1].comp, fb[BUF][1].comp, zero16, 0, 0, 0);
-      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       KGE_FRAG(0, 0)
 #pragma unroll
       for (int j = 0; j < G; ++j) {
@@ -764,16 +560,13 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
         if (j + 1 < G) {
           if ((j & 1) == 0) { KGE_FRAG(1, j + 1) } else { KGE_FRAG(0, j + 1) }
         }
-        // next chunk into the other image: three DMA loads (offset, then load) in each of the first three groups
-        if (j == 0) { KGE5_OFF(0) KGE5_OFF(1) KGE5_OFF(2) KGE5_LD(0, p ^ 1) KGE5_LD(1, p ^ 1) KGE5_LD(2, p ^ 1) }
-        if (j == 1) { KGE5_OFF(3) KGE5_OFF(4) KGE5_OFF(5) KGE5_LD(3, p ^ 1) KGE5_LD(4, p ^ 1) KGE5_LD(5, p ^ 1) }
-        if (j == 2) { KGE5_OFF(6) KGE5_OFF(7) KGE5_OFF(8) KGE5_LD(6, p ^ 1) KGE5_LD(7, p ^ 1) KGE5_LD(8, p ^ 1) }
+        KGE5_STAGE(j, p ^ 1)
         if (j == 0) {
           if (kc == 0) { KGE_STEP0(0, x) } else { KGE_STEP(0, x) }
           KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w)
         } else if ((j & 1) == 0) { KGE_STEP(0, x) KGE_STEP(0, y) KGE_STEP(0, z) KGE_STEP(0, w) }
         else { KGE_STEP(1, x) KGE_STEP(1, y) KGE_STEP(1, z) KGE_STEP(1, w) }
-        KGE5_PIPE()
+        KGE5_PIPE(16, 1, 2)
       }
       __builtin_amdgcn_sched_barrier(0);
 #undef KGE_STEP
@@ -781,34 +574,103 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
 #undef KGE_FRAG
       p ^= 1;
     }
-    // fused count-greater epilogue: D[i][j], j = lane&31 (candidate), i = (r&3) + 8*(r>>2) + 4*half (query)
+    // ---- the unit's last chunk, tile-major, with the count-greater epilogue of tile t - 1 between the MFMAs of tile t.
+    // D[i][j] of a 32 x 32 tile: j = lane & 31 (candidate), i = (r & 3) + 8 * (r >> 2) + 4 * half (query), r = accumulator register.
     const int c0 = ct * kTile;
+    // (this lane's two candidate columns exist: false only in the table's last, partial tile -- its rows past the end are clamped copies
+    // of the last row and must not count)
+    const bool v0 = c0 + wc * 64 + l31 < cand_rows, v1 = c0 + wc * 64 + 32 + l31 < cand_rows;
     float en0 = 0.f, en1 = 0.f;  // squared norms of this lane's two candidate columns (EPI != 0)
     if (EPI != 0) {
       en0 = en_c[min(c0 + wc * 64 + l31, last_row)];
       en1 = en_c[min(c0 + wc * 64 + 32 + l31, last_row)];
     }
-    auto hit = [&](float dot, float en, float tgv) {
-      if (EPI == 0) return dot > tgv;
-      const float D = __fmaf_rn(-2.f, dot, en);
-      return EPI == 1 ? D < tgv : D > tgv;
-    };
-    if (c0 + kTile <= cand_rows) {  // uniform: every candidate column of the tile exists
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const float* a_rd = &As[p][a_off];
+      const float* b_rd = &Bs[p][b_off];
+      // the chunk staged next: the first chunk of the next unit
+      const int nq0 = nqt_ * kQT5, nc0 = nct_ * kTile;
+      const float* gA = Qv + (int64_t)nq0 * Kpad;
+      const float* gB = Ec + (int64_t)nc0 * K;
+      const int kB_ = 0;
+      (void)kB_;
+      const unsigned limA = (unsigned)min(last_q - nq0, kQT5 - 1) * (unsigned)Kpad * 4u, limB = (unsigned)min(last_row - nc0, kTile - 1) * (unsigned)K * 4u;
+      float4 ta[2], tb[2];   // [buffer]: the fragment pair of the tile's next group is read while this group multiplies
+      float4 tg4[4];         // targets of the row tile's 16 accumulator rows of this lane: tg4[q].{x,y,z,w} = rows 8 q + 4 half + {0..3}
+#define KGE_TFRAG(BUF, T, J)                                                                                  \
+  ta[BUF] = *reinterpret_cast<const float4*>(a_rd + ((T) >> 1) * 32 * LS + 8 * (J));                          \
+  tb[BUF] = *reinterpret_cast<const float4*>(b_rd + ((T) & 1) * 32 * LS + 8 * (J));
+#define KGE_TSTEP(T, BUF, comp) \
+  acc[(T) >> 1][(T) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[BUF].comp, tb[BUF].comp, acc[(T) >> 1][(T) & 1], 0, 0, 0);
+      // epilogue of accumulator row R of tile T (row tile T >> 1, candidate half T & 1): counter += (score > target), as a vector compare
+      // into VCC and an add-with-carry -- two vector instructions per score.  (Written out: from `cnt += hit ? 1 : 0` the compiler makes
+      // compare, wait state, select 0 / 1 into a fresh register, add.)  No column mask here: see the partial tile below.
+#define KGE_TEPI1(T, R)                                                                                       \
+  {                                                                                                           \
+    const float4 t4_ = tg4[(R) >> 2];                                                                         \
+    const float tgv = ((R) & 3) == 0 ? t4_.x : (((R) & 3) == 1 ? t4_.y : (((R) & 3) == 2 ? t4_.z : t4_.w));    \
+    float sc_ = acc[(T) >> 1][(T) & 1][R];                                                                    \
+    if (EPI != 0) sc_ = __fmaf_rn(-2.f, sc_, ((T) & 1) ? en1 : en0);                                          \
+    if (EPI == 1) asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(cnt[(T) >> 1][R]) : "v"(sc_), "v"(tgv) : "vcc"); \
+    else asm volatile("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(cnt[(T) >> 1][R]) : "v"(sc_), "v"(tgv) : "vcc");           \
+  }
+#define KGE_TEPI(T, R0, R1) _Pragma("unroll") for (int r = (R0); r < (R1); ++r) KGE_TEPI1(T, r)
+#define KGE_TTARGETS(RT)                                                                                      \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                               \
+    tg4[q] = *reinterpret_cast<const float4*>(&tg_s[wq * 64 + (RT) * 32 + 8 * q + 4 * half]);
+      KGE_TFRAG(0, 0, 0)
+      KGE_TTARGETS(0)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-          cnt[rt][r] += (hit(acc[rt][0][r], en0, tgv) ? 1 : 0) + (hit(acc[rt][1][r], en1, tgv) ? 1 : 0);
+        for (int j = 0; j < G; ++j) {
+          const int g = t * G + j;  // running group number: buffers alternate across the tile switch too
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + 1 < G) {
+            if ((g & 1) == 0) { KGE_TFRAG(1, t, j + 1) } else { KGE_TFRAG(0, t, j + 1) }
+          } else if (t + 1 < 4) {
+            if ((g & 1) == 0) { KGE_TFRAG(1, t + 1, 0) } else { KGE_TFRAG(0, t + 1, 0) }
+          }
+          if (t == 0) { KGE5_STAGE(j, p ^ 1) }
+          // the 16 accumulator rows of the finished tile t - 1 are dealt over this tile's G groups, one row behind each MFMA
+          // (row e0 + i behind the group's MFMA i; the inline assembly is not an instruction class sched_group_barrier could place)
+          const int e0 = j * 16 / G, e1 = (j + 1) * 16 / G;
+#define KGE_TE(I) if (t > 0 && e0 + (I) < e1) KGE_TEPI1(t > 0 ? t - 1 : 0, e0 + (I) < 16 ? e0 + (I) : 15)
+          if ((g & 1) == 0) { KGE_TSTEP(t, 0, x) KGE_TE(0) KGE_TSTEP(t, 0, y) KGE_TE(1) KGE_TSTEP(t, 0, z) KGE_TE(2) KGE_TSTEP(t, 0, w) KGE_TE(3) }
+          else { KGE_TSTEP(t, 1, x) KGE_TE(0) KGE_TSTEP(t, 1, y) KGE_TE(1) KGE_TSTEP(t, 1, z) KGE_TE(2) KGE_TSTEP(t, 1, w) KGE_TE(3) }
+#undef KGE_TE
         }
-    } else {
-      const bool v0 = c0 + wc * 64 + l31 < cand_rows, v1 = c0 + wc * 64 + 32 + l31 < cand_rows;
+        if (t == 2) {  // the epilogues still to come (tile 2 during tile 3, tile 3 at the end) are the wave's second row tile: its targets
+                       // (tile 1's epilogue, just issued between tile 2's MFMAs, was the last user of the first row tile's)
+          __builtin_amdgcn_sched_barrier(0);
+          KGE_TTARGETS(1)
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      KGE_TEPI(3, 0, 16)
+#undef KGE_TFRAG
+#undef KGE_TSTEP
+#undef KGE_TEPI
+#undef KGE_TTARGETS
+    }
+    p ^= 1;
+    if (c0 + kTile > cand_rows) {
+      // (uniform; the table's last candidate tile, one unit in nct) the tile's rows past the end were filled with clamped copies of the
+      // last row and the epilogue above counted them like any other column: the lanes that hold such columns take their hits back.  The
+      // accumulators are still live (the next unit's first MFMAs overwrite them).
+      auto hit = [&](float dot, float en, float tgv) {
+        if (EPI == 0) return dot > tgv;
+        const float D = __fmaf_rn(-2.f, dot, en);
+        return EPI == 1 ? D < tgv : D > tgv;
+      };
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float tgv = tg_s[wq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-          cnt[rt][r] += ((v0 && hit(acc[rt][0][r], en0, tgv)) ? 1 : 0) + ((v1 && hit(acc[rt][1][r], en1, tgv)) ? 1 : 0);
+          cnt[rt][r] -= ((!v0 && hit(acc[rt][0][r], en0, tgv)) ? 1 : 0) + ((!v1 && hit(acc[rt][1][r], en1, tgv)) ? 1 : 0);
         }
     }
     if (!has_next || nqt_ != qt) {  // uniform: the range leaves this query tile -> flush its counters
@@ -845,6 +707,7 @@ __global__ __launch_bounds__(512) void rank_sweep5_kernel(const float* __restric
 #undef KGE5_DMA_V
 #undef KGE5_OFF
 #undef KGE5_PIPE
+#undef KGE5_STAGE
 }
 
 // One thread per CSR entry (query pair_q[e], filtered global id filt_ids[e]); un-counts it if it was counted.
@@ -1071,19 +934,17 @@ static int pick_bk(int K) {
   return best;
 }
 
-static int sweep_variant() {  // KGE_RANK_SWEEP=1 selects the generic (predicated) kernel for aligned tables too
+static int pick_bk(int K);
+int rank_kpad(int K);
+// rows the 256 x 128 kernel takes: float4-aligned widths of at least two k chunks (its first chunk opens the accumulators, its last one
+// carries the epilogue); narrower rows (K <= 40: a sweep of no weight) take the generic kernel
+static bool sweep5_rows(int K) { return K % 4 == 0 && rank_kpad(K) / pick_bk(K) >= 2; }
+
+static int sweep_variant() {  // KGE_RANK_SWEEP=1 (A/B timing, tests) selects the generic (predicated) kernel for aligned tables too
   static const int v = [] { const char* e = getenv("KGE_RANK_SWEEP"); return e ? atoi(e) : 0; }();
   return v;
 }
 
-static int sweep_slots() {  // workgroups of the persistent sweep: two per CU (register and LDS budget of rank_sweep4_kernel)
-  static const int v = [] { const char* e = getenv("KGE_RANK_SLOTS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 2 * kCUs; }();
-  return v;
-}
-
-static bool sweep5_on() {  // KGE_RANK_SWEEP=4: the 128 x 128 kernel with two 256-thread workgroups per CU (A/B timing)
-  return sweep_variant() != 4;
-}
 static int sweep5_slots() {  // workgroups of rank_sweep5_kernel: one per CU (137 KB of LDS, 512 threads)
   static const int v = [] { const char* e = getenv("KGE_RANK_SLOTS5"); const int x = e ? atoi(e) : 0; return x > 0 ? x : kCUs; }();
   return v;
@@ -1094,57 +955,32 @@ static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float
   if (nq <= 0 || cand_rows <= 0) return;
   ProfScope prof_sweep(KGE_PROF_RANK_SWEEP, st);
 #define KGE_SWEEP(KERNEL, BKV, FLAG) hipLaunchKernelGGL((KERNEL<BKV, FLAG>), grid, dim3(256), 0, st, Qv, tgt, nq, Ec, K, Kpad, cand_rows, tpb, counts)
-  if (v4 && (sweep_variant() == 0 || sweep_variant() == 4) && nq < (int64_t)1 << 30) {
+  if (v4 && sweep5_rows(K) && sweep_variant() == 0 && nq < (int64_t)1 << 30) {
     const bool tail = Kpad != K;
-    if (sweep5_on()) {
-      // 256 x 128 tiles, one 512-thread workgroup per CU.  The phase-aligned cut is taken when it leaves at most 1/32 of the CUs
-      // without a workgroup (it cuts the fabric traffic, not the run time); otherwise equal contiguous cuts of the unit list.
-      const int64_t nqt = cdiv(nq, kQT5), nct = cdiv(cand_rows, kTile);
-      const int64_t units = nqt * nct;
-      const int slots = sweep5_slots();
-      int parts = 0;
-      {
-        static const bool align = [] { const char* e = getenv("KGE_RANK_ALIGN"); return !(e && atoi(e) == 0); }();
-        if (align && nqt <= slots && units > slots) {
-          const int64_t g = std::min<int64_t>(slots / nqt, nct);
-          if (g >= 1 && nqt * g * 32 >= (int64_t)slots * 31) parts = (int)g;
-        }
-      }
-      const dim3 pgrid((unsigned)(parts ? nqt * parts : std::min<int64_t>(units, slots)));
-#define KGE_SWEEP5(BKV, FLAG)                                                                                                                        \
-  do {                                                                                                                                               \
-    if (epi == 1) hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 1>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);      \
-    else if (epi == 2) hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 2>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts); \
-    else hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 0>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);               \
-  } while (0)
-      if (BK == 40) { if (tail) KGE_SWEEP5(40, true); else KGE_SWEEP5(40, false); }
-      else { if (tail) KGE_SWEEP5(32, true); else KGE_SWEEP5(32, false); }
-#undef KGE_SWEEP5
-      return;
-    }
-    const int64_t nqt = cdiv(nq, kTile), nct = cdiv(cand_rows, kTile);
+    // 256 x 128 tiles, one 512-thread workgroup per CU.  The phase-aligned cut is taken when it leaves at most 1/32 of the CUs
+    // without a workgroup (it cuts the fabric traffic, not the run time); otherwise equal contiguous cuts of the unit list.
+    const int64_t nqt = cdiv(nq, kQT5), nct = cdiv(cand_rows, kTile);
     const int64_t units = nqt * nct;
-    const int slots = sweep_slots();
-    // phase-aligned cut (KGE_RANK_ALIGN=0: equal cuts): `parts` workgroups per query tile with nqt * parts close to, and not above,
-    // the residency slots -- worth it when that leaves at most ~12 % of the slots empty
+    const int slots = sweep5_slots();
     int parts = 0;
     {
       static const bool align = [] { const char* e = getenv("KGE_RANK_ALIGN"); return !(e && atoi(e) == 0); }();
       if (align && nqt <= slots && units > slots) {
         const int64_t g = std::min<int64_t>(slots / nqt, nct);
-        if (g >= 1 && nqt * g * 8 >= (int64_t)slots * 7) parts = (int)g;
+        if (g >= 1 && nqt * g * 32 >= (int64_t)slots * 31) parts = (int)g;
       }
     }
     const dim3 pgrid((unsigned)(parts ? nqt * parts : std::min<int64_t>(units, slots)));
-#define KGE_SWEEP4(BKV, FLAG)                                                                                                                        \
-  do {                                                                                                                                               \
-    if (epi == 1) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 1>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);      \
-    else if (epi == 2) hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 2>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts); \
-    else hipLaunchKernelGGL((rank_sweep4_kernel<BKV, FLAG, 0>), pgrid, dim3(256), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);               \
-  } while (0)
-    if (BK == 40) { if (tail) KGE_SWEEP4(40, true); else KGE_SWEEP4(40, false); }
-    else { if (tail) KGE_SWEEP4(32, true); else KGE_SWEEP4(32, false); }
-#undef KGE_SWEEP4
+#define KGE_SWEEP5(BKV, FLAG)                                                                                                                        \
+do {                                                                                                                                               \
+  if (epi == 1) hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 1>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);      \
+  else if (epi == 2) hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 2>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts); \
+  else hipLaunchKernelGGL((rank_sweep5_kernel<BKV, FLAG, 0>), pgrid, dim3(512), 0, st, Qv, tgt, (int)nq, Ec, K, Kpad, cand_rows, counts, en_c, parts);               \
+} while (0)
+    if (BK == 40) { if (tail) KGE_SWEEP5(40, true); else KGE_SWEEP5(40, false); }
+    else { if (tail) KGE_SWEEP5(32, true); else KGE_SWEEP5(32, false); }
+#undef KGE_SWEEP5
+    return;
   } else {
     if (BK == 40) { if (v4) KGE_SWEEP(rank_sweep_kernel, 40, true); else KGE_SWEEP(rank_sweep_kernel, 40, false); }
     else { if (v4) KGE_SWEEP(rank_sweep_kernel, 32, true); else KGE_SWEEP(rank_sweep_kernel, 32, false); }
@@ -1229,7 +1065,7 @@ static int rank_counts_impl(const kge_model_desc* md, const float* E, const floa
   float* Qv = reinterpret_cast<float*>(p);
   float* tgt = tgt_out ? tgt_out : Qv + nq * Kpad;
   const bool cand_in_table0 = Ec == E + (int64_t)cand_offset * K && cand_offset + cand_rows <= md->num_entities;
-  const bool mfma_ok = (K % 4 == 0) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) && nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4);
+  const bool mfma_ok = sweep5_rows(K) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) && nq < (int64_t)1 << 30 && sweep_variant() == 0;
   const bool merged = md->model == KGE_TRANSE ? (md->norm == 2 && !tgt_out && rank_l2_mfma() && mfma_ok && cand_in_table0) : mfma_ok;
   if (side == 2 && !merged) {
     for (int h = 0; h < 2; ++h)
@@ -1242,8 +1078,8 @@ static int rank_counts_impl(const kge_model_desc* md, const float* E, const floa
   // (the per-row tables of the two forms below -- squared norms, (sin, cos) pairs -- are built from E and indexed by global id, so the
   // candidates must be rows of E itself; a row shard held apart from the query table takes the direct distance sweep)
   const bool cand_in_table = cand_in_table0;
-  if (md->model == KGE_TRANSE && md->norm == 2 && !tgt_out && rank_l2_mfma() && (K % 4 == 0) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) &&
-      nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4) && cand_in_table) {
+  if (md->model == KGE_TRANSE && md->norm == 2 && !tgt_out && rank_l2_mfma() && sweep5_rows(K) && (((uintptr_t)E | (uintptr_t)Ec) % 16 == 0) &&
+      nq < (int64_t)1 << 30 && sweep_variant() == 0 && cand_in_table) {
     float* en = tgt + align_up(nq, 64);  // behind the target values (the query block is sized for align_up(K, 32) >= rank_kpad(K) floats per row)
     Kpad = rank_kpad(K);
     hipLaunchKernelGGL(rank_sumsq_kernel, dim3((int)cdiv((int64_t)md->num_entities * 16, 256)), dim3(256), 0, st, E, md->num_entities, K, en);
@@ -1292,7 +1128,7 @@ static int rank_counts_impl(const kge_model_desc* md, const float* E, const floa
     KGE_HIP_TRY(hipGetLastError());
     return KGE_OK;
   }
-  if ((K % 4 == 0) && ((uintptr_t)E % 16 == 0) && nq < (int64_t)1 << 30 && (sweep_variant() == 0 || sweep_variant() == 4)) {
+  if ((K % 4 == 0) && ((uintptr_t)E % 16 == 0) && nq < (int64_t)1 << 30 && sweep_variant() == 0) {
     for (int h = 0; h < nside; ++h) {
       const int sd = side == 2 ? h : side;
       if (BK == 40) hipLaunchKernelGGL((rank_target4_kernel<40>), dim3((int)cdiv(nt, 64)), dim3(64), 0, st, Qv + h * nt * Kpad, E, triples, (int)nt, sd, md->num_entities, K, Kpad, tgt + h * nt, counts + h * nt, accumulate ? 0 : 1);
