@@ -116,6 +116,25 @@ int kge_device_props(int64_t props[4]);
 int kge_score(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n,
               float* out, uint32_t* err_flag, kge_stream_t stream);
 
+/* The same with the Dropout layer ACTIVE -- EmbeddingModel.call(inputs, training=True) (models.py:134-162: every lookup goes through
+ * self.dp, which Keras switches on under training=True): row i takes the masks of batch row row_offset + i of step `seed`, the masks
+ * the training kernels regenerate (a counter-based hash of (seed, batch row, role, element); kept entries scaled by 1 / (1 - rate),
+ * rate = md->dropout; rate 0 = kge_score).  TensorFlow's own mask stream is not reproducible; the oracle regenerates these. */
+int kge_score_training(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n, uint64_t seed,
+                       int64_t row_offset, float* out, uint32_t* err_flag, kge_stream_t stream);
+
+/* ---- forward-only loss of one [pos, neg] batch in INFERENCE mode: what Keras logs as val_loss when fit() is given validation_data
+ *      (tests.py:130-134) / Model.evaluate over the wrapper's add_loss (tests.py:77-84) -- scores of both arrays on the given tables,
+ *      loss_function(score, fscore, margin, negative_samples); no gradient lists, gradient rows or optimizer.  E may be the
+ *      transformed table of the literal path (kge_lit_transform).  *loss_out = the loss; running_sum (optional device double) += it,
+ *      so an epoch of validation batches is summed without a host read per batch.  kge_l3_value adds the l3_reg term
+ *      weight * sum |E|^3 (models.py:10-11,78-92) to *loss_inout -- once per evaluation, the tables do not move.
+ *      Workspace: kge_loss_workspace_bytes(m_pos, m_neg). */
+int kge_loss_only(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const int32_t* pos, int64_t m_pos,
+                  const int32_t* neg, int64_t m_neg, float* loss_out, double* running_sum, void* workspace, int64_t workspace_bytes,
+                  uint32_t* err_flag, kge_stream_t stream);
+int kge_l3_value(const float* E, int64_t n, float weight, float* loss_inout, void* workspace, int64_t workspace_bytes, kge_stream_t stream);
+
 /* ---- one training batch: the default Keras train_step over the two-input functional wrapper
  *      (tests.py:63-89,130-134): score(pos), score(neg) on the same tables, loss, sparse gradients of both
  *      tables with duplicates summed, optimizer update.  pos and neg are (m_pos,3)/(m_neg,3) as produced by
@@ -204,7 +223,7 @@ int kge_hole_spec_adjoint(float* Ghat, int64_t rows, int32_t d, const float* W, 
 /* ---- LiteralE-style input path (models.py:114-120,152-158; tests.py:113,125-126): s_hat = act(Dense([dp(E[s]) ; dp(Lit[s])])),
  *      o_hat likewise with the same Dense, score = func(s_hat, dp(Rel[p]), o_hat).  Lit is the frozen (lit_rows, L) literal table,
  *      theta_l = [W (d_e + L, d_e) row-major | b (d_e)], act = 0 linear, 1 relu, 2 sigmoid, 3 tanh, 4 softplus, 5 softsign, 6 elu,
- *      7 selu, 8 exponential.  kge_lit_transform builds the transformed entity table (rows, d_e) in inference mode: predict and
+ *      7 selu, 8 exponential, 9 softmax (over the layer's d_e outputs).  kge_lit_transform builds the transformed entity table (rows, d_e) in inference mode: predict and
  *      the 1-vs-all ranking then run the ordinary kernels on it.  kge_lit_train_grads is the gradient half of a train step
  *      (gradients into gradE / gradRel / gtheta_l, zero on entry); DistMult, TransE and ComplEx are built. */
 int64_t kge_lit_workspace_bytes(const kge_model_desc* md, int32_t L, int64_t m_pos, int64_t m_neg);

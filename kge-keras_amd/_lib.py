@@ -27,7 +27,7 @@ MODEL_IDS = {"DistMult": 0, "TransE": 1, "ComplEx": 2, "HolE": 3, "ConvE": 4, "R
 LOSS_IDS = {"pointwize_hinge": 0, "pointwize_logistic": 1, "pairwize_hinge": 2, "pairwize_logistic": 3,
             "pointwize_square_loss": 4, "pairwize_square_loss": 5, "pointwize_cross_entropy": 6}
 OPT_IDS = {"sgd": 0, "adam": 1}
-ACT_IDS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "softsign": 5, "elu": 6, "selu": 7, "exponential": 8}
+ACT_IDS = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "softsign": 5, "elu": 6, "selu": 7, "exponential": 8, "softmax": 9}
 MT_STATE_BYTES = 2504
 CAND_POS_LANES = 16  # KGE_CAND_POS_LANES
 STEP_STATE_WORDS = 3  # KGE_STEP_STATE_BYTES / 8: {int64 updates done, float lr_t of the next update + pad, double loss sum}
@@ -126,6 +126,9 @@ SIGNATURES = {
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),
     "kge_score": (C.c_int, [_MD, _P, _P, _P, _I64, _P, _P, _P]),
+    "kge_score_training": (C.c_int, [_MD, _P, _P, _P, _I64, _U64, _I64, _P, _P, _P]),
+    "kge_loss_only": (C.c_int, [_MD, _LD, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P]),
+    "kge_l3_value": (C.c_int, [_P, _I64, _F, _P, _P, _I64, _P]),
     "kge_train_step_workspace_bytes": (_I64, [_MD, _LD, _I64, _I64]),
     "kge_train_step": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
     "kge_train_grads": (C.c_int, [_MD, _LD, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),

@@ -162,6 +162,10 @@ int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, 
               int64_t, hipStream_t, bool advanced = false, const OptFinish* finish = nullptr);
 
 void set_pair_sort_mode(int mode);  // train.hip
+int loss_only(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, const int32_t*, int64_t, const int32_t*, int64_t, float*, double*,
+              void*, int64_t, uint32_t*, hipStream_t);
+int l3_value(const float*, int64_t, float, float*, void*, int64_t, hipStream_t);
+int score_dispatch_training(const kge_model_desc*, const float*, const float*, const int32_t*, int64_t, uint64_t, int64_t, float*, uint32_t*, hipStream_t);
 bool step_swap_supported(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*);
 int train_step_swap(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, const float*, const float*, float*, float*, void*, int64_t,
                     int64_t, float*, uint64_t, void*, int64_t, int, hipStream_t, const kge_row_window* win = nullptr);
@@ -271,6 +275,30 @@ int kge_score(const kge_model_desc* md, const float* E, const float* Rel, const 
   if (n == 0) return KGE_OK;
   if (!E || !Rel || !triples || !out || !err_flag) return fail(KGE_EINVAL, "kge_score: null pointer");
   return score_dispatch(md, E, Rel, triples, n, out, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_score_training(const kge_model_desc* md, const float* E, const float* Rel, const int32_t* triples, int64_t n, uint64_t seed,
+                       int64_t row_offset, float* out, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_model(md, "kge_score_training")) return rc;
+  if (n < 0 || row_offset < 0) return fail(KGE_EINVAL, "kge_score_training: n = %lld, row_offset = %lld", (long long)n, (long long)row_offset);
+  if (n == 0) return KGE_OK;
+  if (!E || !Rel || !triples || !out || !err_flag) return fail(KGE_EINVAL, "kge_score_training: null pointer");
+  return score_dispatch_training(md, E, Rel, triples, n, seed, row_offset, out, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_loss_only(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const int32_t* pos, int64_t m_pos,
+                  const int32_t* neg, int64_t m_neg, float* loss_out, double* running_sum, void* workspace, int64_t workspace_bytes,
+                  uint32_t* err_flag, kge_stream_t stream) {
+  clear_stale_error();
+  if (int rc = check_model(md, "kge_loss_only")) return rc;
+  if (!ld || !E || !Rel || !pos || !neg || !loss_out || !workspace || !err_flag) return fail(KGE_EINVAL, "kge_loss_only: null pointer");
+  if (m_pos <= 0 || m_neg <= 0) return fail(KGE_EINVAL, "kge_loss_only: empty batch side (reduce_mean of nothing)");
+  return loss_only(md, ld, E, Rel, pos, m_pos, neg, m_neg, loss_out, running_sum, workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_l3_value(const float* E, int64_t n, float weight, float* loss_inout, void* workspace, int64_t workspace_bytes, kge_stream_t stream) {
+  if (!E || n < 0 || !loss_inout || !workspace) return fail(KGE_EINVAL, "kge_l3_value: bad arguments");
+  return l3_value(E, n, weight, loss_inout, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int64_t kge_train_step_workspace_bytes(const kge_model_desc* md, const kge_loss_desc* ld, int64_t m_pos, int64_t m_neg) {

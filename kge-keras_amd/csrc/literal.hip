@@ -80,6 +80,37 @@ __global__ __launch_bounds__(256) void lit_act_fwd(float* __restrict__ Z, float*
   }
 }
 
+// act 9 = softmax over the Dense layer's e_dim outputs (keras.activations.softmax, axis -1): the one activation of the reference's
+// `literal_activation` choices that is not element-wise.  One wave per row: z = Z + b, h = exp(z - max z) / sum; Zb keeps h (the backward
+// needs h, not z).  Backward: dz_i = h_i (dh_i - sum_j dh_j h_j), in place on dH, then the same per-block column sums as lit_act_bwd.
+constexpr int kActSoftmax = 9;
+__global__ __launch_bounds__(256) void lit_softmax_fwd(float* __restrict__ Z, float* __restrict__ H, int64_t rows, int d, const float* __restrict__ b) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    float mx = -__builtin_inff();
+    for (int k = lane; k < d; k += 64) mx = fmaxf(mx, Z[r * d + k] + b[k]);
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int k = lane; k < d; k += 64) sum += expf(Z[r * d + k] + b[k] - mx);
+    sum = group_sum<64>(sum);
+    const float inv = 1.f / sum;
+    for (int k = lane; k < d; k += 64) {
+      const float h = expf(Z[r * d + k] + b[k] - mx) * inv;
+      H[r * d + k] = h;
+      Z[r * d + k] = h;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void lit_softmax_bwd_rows(float* __restrict__ dH, const float* __restrict__ Hs, int64_t rows, int d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    float dot = 0.f;
+    for (int k = lane; k < d; k += 64) dot += dH[r * d + k] * Hs[r * d + k];
+    dot = group_sum<64>(dot);
+    for (int k = lane; k < d; k += 64) dH[r * d + k] = Hs[r * d + k] * (dH[r * d + k] - dot);
+  }
+}
+
 constexpr int kLitHoleMax = 512;  // HolE rows in LDS: 4 waves x 3 rows x 512 floats = 24 KB
 
 // per triple: s_hat = H[t], o_hat = H[n+t], p' = Rel[p]*mask.  MODE 0: score.  MODE 1: row gradients dH[t], dH[n+t], dP[t] (masked).
@@ -266,7 +297,7 @@ static int lit_check(const kge_model_desc* md, int L, int act) {
   if (md->model == KGE_HOLE && md->d_e > kLitHoleMax)
     return fail(KGE_EUNSUPPORTED, "literal path under HolE: rows of at most %d floats (e_dim = %d)", kLitHoleMax, md->d_e);
   if (L <= 0) return fail(KGE_EINVAL, "literal path: literal width %d", L);
-  if (act < 0 || act > 8) return fail(KGE_EUNSUPPORTED, "literal path: activation id %d (softmax and custom callables are not built)", act);
+  if (act < 0 || act > kActSoftmax) return fail(KGE_EUNSUPPORTED, "literal path: activation id %d (custom callables are not built)", act);
   return KGE_OK;
 }
 
@@ -285,6 +316,9 @@ int lit_transform(const kge_model_desc* md, int act, const float* E, const float
   KGE_BLAS_TRY(rocblas_set_stream(h, st));
   const float one = 1.f, zero = 0.f;
   KGE_BLAS_TRY(rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, d, rows, K1, &one, theta, d, A, K1, &zero, out, d));
+  if (act == kActSoftmax)
+    hipLaunchKernelGGL(lit_softmax_fwd, dim3((int)std::min<int64_t>(cdiv(rows, 4), 8192)), dim3(256), 0, st, out, out, (int64_t)rows, d, theta + (int64_t)K1 * d);
+  else
   hipLaunchKernelGGL(lit_act_fwd, dim3((int)std::min<int64_t>(cdiv((int64_t)rows * d, 256), 8192)), dim3(256), 0, st, out, out, (int64_t)rows, d,
                      theta + (int64_t)K1 * d, act);
   KGE_HIP_TRY(hipGetLastError());
@@ -383,14 +417,17 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
     if (drop) hipLaunchKernelGGL((lit_gather<true>), dim3(gw), dim3(256), 0, st, E, Lit, pos, m_pos, neg, m_neg, md->num_entities, lit_rows_n, d, L, A, err, seed, thr, dscale);
     else hipLaunchKernelGGL((lit_gather<false>), dim3(gw), dim3(256), 0, st, E, Lit, pos, m_pos, neg, m_neg, md->num_entities, lit_rows_n, d, L, A, err, seed, thr, dscale);
     KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (rocblas_int)(2 * n), K1, &one, theta, d, A, K1, &zero, Zb, d));
-    hipLaunchKernelGGL(lit_act_fwd, dim3(gel), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d, act);
+    if (act == kActSoftmax) hipLaunchKernelGGL(lit_softmax_fwd, dim3((int)std::min<int64_t>(cdiv(2 * n, 4), 8192)), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d);
+    else hipLaunchKernelGGL(lit_act_fwd, dim3(gel), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d, act);
     launch_rows_model<0>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, nullptr, sc, nullptr, nullptr, seed);
   }
   if (int rc = loss_value(ld, sc, m_pos, sc + m_pos, m_neg, loss_out, g, g + m_pos, loss_ws, loss_ws_bytes, st)) return rc;
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
     launch_rows_model<1>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, g, nullptr, dH, dPb, seed);
-    hipLaunchKernelGGL(lit_act_bwd, dim3(nb_rows), dim3(256), 0, st, dH, Zb, 2 * n, d, act, psum);
+    // (softmax: rows first -- dz = h (dh - <dh, h>) -- then the column sums through the linear branch of lit_act_bwd)
+    if (act == kActSoftmax) hipLaunchKernelGGL(lit_softmax_bwd_rows, dim3((int)std::min<int64_t>(cdiv(2 * n, 4), 8192)), dim3(256), 0, st, dH, Zb, 2 * n, d);
+    hipLaunchKernelGGL(lit_act_bwd, dim3(nb_rows), dim3(256), 0, st, dH, Zb, 2 * n, d, act == kActSoftmax ? 0 : act, psum);
     hipLaunchKernelGGL(lit_colsum, dim3(d), dim3(256), 0, st, psum, nb_rows, d, gtheta + (int64_t)K1 * d);
     // dA(2n,K1) = dZ(2n,d) W^T ; dW(K1,d) += A^T dZ   (column-major views as in conve.hip)
     KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_transpose, rocblas_operation_none, K1, (rocblas_int)(2 * n), d, &one, theta, d, dH, d, &zero, dA, K1));

@@ -641,6 +641,43 @@ int loss_value(const kge_loss_desc* ld, const float* ts, int64_t m_t, const floa
   return KGE_OK;
 }
 
+// ---- forward-only loss of one [pos, neg] batch in inference mode (what Keras reports as val_loss: tests.py:130-134 passes
+// validation_data; Model.evaluate runs the wrapper's add_loss with the layers in inference mode): scores of both arrays (score.hip),
+// the loss on them, nothing else -- no gradient lists, no gradient rows, no optimizer.  running_sum (optional, device double):
+// += the loss, so that a caller sums an epoch of validation batches without reading any of them back.
+__global__ void loss_running_sum_kernel(const float* __restrict__ loss, double* __restrict__ sum) { sum[0] += (double)loss[0]; }
+
+int loss_only(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const int32_t* pos, int64_t m_pos,
+              const int32_t* neg, int64_t m_neg, float* loss_out, double* running_sum, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  Workspace ws;
+  if (int rc = carve(workspace, wbytes, nullptr, m_pos, m_neg, &ws)) return rc;
+  if (int rc = score_dispatch(md, E, Rel, pos, m_pos, ws.sbuf, err, st)) return rc;
+  if (int rc = score_dispatch(md, E, Rel, neg, m_neg, ws.sbuf + m_pos, err, st)) return rc;
+  if (int rc = loss_value(ld, ws.sbuf, m_pos, ws.sbuf + m_pos, m_neg, loss_out, nullptr, nullptr, workspace, wbytes, st)) return rc;
+  if (running_sum) hipLaunchKernelGGL(loss_running_sum_kernel, dim3(1), dim3(1), 0, st, loss_out, running_sum);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
+// w * sum |E|^3 over n table elements (l3_reg, models.py:10-11,78-92: part of every Keras loss value when regularization != 0), added
+// to *loss_inout; block partials summed in a fixed order.
+__global__ __launch_bounds__(256) void l3_partials_kernel(const float* __restrict__ E, int64_t n, float* __restrict__ partials) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float a = fabsf(E[i]); s += a * a * a; }
+  const float b = block_sum(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = b;
+}
+int l3_value(const float* E, int64_t n, float weight, float* loss_inout, void* workspace, int64_t wbytes, hipStream_t st) {
+  Workspace ws;
+  if (int rc = carve(workspace, wbytes, nullptr, 0, 0, &ws)) return rc;
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 1024), kMaxBlocks));
+  hipLaunchKernelGGL(l3_partials_kernel, dim3(nb), dim3(256), 0, st, E, n, ws.reg_partials);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws.reg_partials, nb, weight, 1, loss_inout);
+  KGE_HIP_TRY(hipGetLastError());
+  return KGE_OK;
+}
+
 int train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, float* gE, float* gR,
                 const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out,
                 uint64_t seed, void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st) {

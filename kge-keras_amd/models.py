@@ -253,10 +253,21 @@ class EmbeddingModel:
 
     # ------------------------------------------------------------------ forward (models.py:134-162)
     def call(self, inputs, training=False):
-        """(n,3) ids -> (n,) scores as a device tensor.  Dropout is only applied inside train_step."""
+        """(n,3) ids -> (n,) scores as a device tensor (models.py:134-162).  training=True: the Dropout layer on the three gathered rows
+        is active like under Keras (every call draws fresh masks: the counter-based masks of the training kernels, seeded by this
+        model's step counter, which the call advances); with the literal path the masks sit on the transformed rows' inputs as in
+        a train step, so that path scores through the gradient half and discards the gradients."""
         t = as_triples(inputs, self.device, self.num_entities, self.num_relations)
         n = t.shape[0]
         out = torch.empty(n, dtype=torch.float32, device=self.device)
+        if training and self.dp > 0.0:
+            if self._lit is not None:
+                raise NotImplementedError("call(training=True) with the literal input path: use train_step(..., scores_out=...)")
+            md = self._model_desc(True)
+            self._seed += 1
+            check(lib.kge_score_training(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), t.data_ptr(), n, self._seed, 0, out.data_ptr(),
+                                         self._err.data_ptr(), _lib.stream_ptr()))
+            return out
         md = self._model_desc(False)
         Et = self._eval_table()
         check(lib.kge_score(C.byref(md), Et.data_ptr(), self.Rel.data_ptr(), t.data_ptr(), n, out.data_ptr(),
@@ -266,7 +277,8 @@ class EmbeddingModel:
     __call__ = call
 
     def func(self, s, p, o, training=False):
-        """Score already-gathered rows (models.py:160): rows are staged as temporary tables and scored by the same kernel."""
+        """Score already-gathered rows (models.py:160): rows are staged as temporary tables and scored by the same kernel (training=True:
+        dropout on the three rows, as in call)."""
         s = torch.as_tensor(s, dtype=torch.float32, device=self.device).reshape(-1, self.e_dim)
         p = torch.as_tensor(p, dtype=torch.float32, device=self.device).reshape(-1, self.r_dim)
         o = torch.as_tensor(o, dtype=torch.float32, device=self.device).reshape(-1, self.e_dim)
@@ -274,9 +286,15 @@ class EmbeddingModel:
         Et = torch.cat([s, o], 0).contiguous()
         idx = torch.arange(n, dtype=torch.int32, device=self.device)
         t = torch.stack([idx, idx, idx + n], 1).contiguous()
-        md = self._model_desc(False)
+        drop = bool(training) and self.dp > 0.0
+        md = self._model_desc(drop)
         md.num_entities, md.num_relations = 2 * n, n
         out = torch.empty(n, dtype=torch.float32, device=self.device)
+        if drop:
+            self._seed += 1
+            check(lib.kge_score_training(C.byref(md), Et.data_ptr(), p.contiguous().data_ptr(), t.data_ptr(), n, self._seed, 0, out.data_ptr(),
+                                         self._err.data_ptr(), _lib.stream_ptr()))
+            return out
         check(lib.kge_score(C.byref(md), Et.data_ptr(), p.contiguous().data_ptr(), t.data_ptr(), n, out.data_ptr(),
                             self._err.data_ptr(), _lib.stream_ptr()))
         return out
@@ -513,46 +531,63 @@ class EmbeddingModel:
         return type("History", (), {"history": history, "model": self})()
 
     def evaluate(self, x, **_):
-        """Mean batch loss over a generator without updating the tables (keras Model.evaluate over add_loss)."""
-        tot, n = 0.0, 0
-        for i in range(len(x)):
+        """Mean batch loss over a generator without updating the tables (keras Model.evaluate over add_loss; what fit reports as
+        val_loss, tests.py:130-134).  Forward only (kge_loss_only); the batch losses are summed on the device -- one host read per
+        evaluation, not per batch; the inference-mode table of the literal path and the l3_reg term are formed once."""
+        n = len(x)
+        if n == 0:
+            return 0.0
+        acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        ctx = self._loss_only_context()
+        for i in range(n):
             X, _y = x[i]
-            tot += float(self.batch_loss(X).item())
-            n += 1
-        return tot / max(1, n)
+            self._batch_loss_into(X, ctx, acc)
+        tot = float(acc.item()) / n
+        if self.regularization:
+            tot += float(self._l3_term(ctx).item())
+        return tot
 
-    def batch_loss(self, data):
-        """Loss of one [pos, neg] batch in inference mode (no dropout), no update: what Keras reports as val_loss (the added loss
-        + the regularisation term).  The gradient half of a step runs -- through the literal transform when the model has one --
-        and its gradients are discarded by clearing the accumulators; no optimizer is involved."""
+    def _loss_only_context(self):
+        """What a run of forward-only losses shares: the inference-mode entity table (transformed once with the literal path)."""
+        return {"Et": self._eval_table()}
+
+    def _loss_ws(self, m_pos, m_neg):
+        need = check(lib.kge_loss_workspace_bytes(int(m_pos), int(m_neg)))
+        if getattr(self, "_lws", None) is None or self._lws.numel() < need:
+            self._lws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+        return self._lws
+
+    def _batch_loss_into(self, data, ctx, acc=None, out=None):
+        """Forward-only loss of one [pos, neg] batch (no regulariser) -> out (1 float, device); acc (1 double, device) += it."""
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
-        if self.optimizer is None:
-            self.compile('sgd')
-        md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
-        md.dropout = 0.0
-        md.hidden_dropout = 0.0
-        lt = self._lit
-        if lt is not None:  # models.py:152-158: the score is taken on act(Dense([E ; literals])) rows
-            need = check(lib.kge_lit_workspace_bytes(C.byref(md), lt["L"], pos.shape[0], neg.shape[0]))
-            if lt["ws"] is None or lt["ws"].numel() < need:
-                lt["ws"] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
-            check(lib.kge_lit_train_grads(C.byref(md), C.byref(ld), lt["act"], self.E.data_ptr(), self.Rel.data_ptr(), lt["table"].data_ptr(),
-                                          lt["L"], lt["table"].shape[0], lt["theta"].data_ptr(), self._gE.data_ptr(), self._gR.data_ptr(),
-                                          lt["gtheta"].data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0],
-                                          self._loss.data_ptr(), None, 0, lt["ws"].data_ptr(), lt["ws"].numel(), self._err.data_ptr(),
-                                          _lib.stream_ptr()))
-            lt["gtheta"].zero_()
-        else:
-            check(lib.kge_train_grads(C.byref(md), C.byref(ld), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
-                                      self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0],
-                                      self._loss.data_ptr(), None, 0, self._ws.data_ptr(), self._ws.numel(), self._err.data_ptr(),
-                                      _lib.stream_ptr()))
-        loss = self._loss[0].clone()
-        self._gall.zero_()  # gradient accumulators (and the loss word inside the same buffer) back to zero
-        if self.regularization:  # l3_reg on the whole entity table (models.py:10-11,78-92), part of every Keras loss value
-            loss = loss + float(self.regularization) * self.E.abs().pow(3).sum()
-        return loss
+        md, ld = self._model_desc(False), self._loss_desc()
+        ws = self._loss_ws(pos.shape[0], neg.shape[0])
+        if out is None:
+            out = getattr(self, "_vloss", None)
+            if out is None:
+                out = self._vloss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        check(lib.kge_loss_only(C.byref(md), C.byref(ld), ctx["Et"].data_ptr(), self.Rel.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(),
+                                neg.shape[0], out.data_ptr(), acc.data_ptr() if acc is not None else None, ws.data_ptr(), ws.numel(),
+                                self._err.data_ptr(), _lib.stream_ptr()))
+        return out
+
+    def _l3_term(self, ctx=None):
+        """regularization * sum |E|^3 over the whole entity table (models.py:10-11,78-92) as a 1-element device tensor."""
+        out = torch.zeros(1, dtype=torch.float32, device=self.device)
+        ws = self._loss_ws(1, 1)
+        check(lib.kge_l3_value(self.E.data_ptr(), self.E.numel(), float(self.regularization), out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return out
+
+    def batch_loss(self, data):
+        """Loss of one [pos, neg] batch in inference mode (no dropout), no update: what Keras reports as val_loss (the added loss + the
+        regularisation term).  Forward only: two score launches and the loss on them (kge_loss_only) -- through the literal transform
+        when the model has one; no gradient half runs and no optimizer is involved."""
+        ctx = self._loss_only_context()
+        loss = self._batch_loss_into(data, ctx, out=torch.zeros(1, dtype=torch.float32, device=self.device))
+        if self.regularization:
+            loss = loss + self._l3_term(ctx)
+        return loss[0]
 
     # ------------------------------------------------------------------ filtered 1-vs-all ranking (utils.py:165-264)
     @staticmethod
@@ -938,19 +973,27 @@ class HAKE(EmbeddingModel):
         self.apply_grads(1.0)
         return {"loss": self._loss[0]}
 
-    def batch_loss(self, data):
+    def _batch_loss_into(self, data, ctx, acc=None, out=None):
+        """Forward-only loss in inference mode: the wrapper calls the model once per side (tests.py:77-78), so every side is ONE segment of
+        the call-wide norm (kge_hake_score, chunk = all rows); the loss on the two score vectors by kge_loss_value."""
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
-        if self.optimizer is None:
-            self.compile('sgd')
-        md, ld = self._ensure_train_state(pos.shape[0], neg.shape[0])
-        md.dropout = 0.0
-        self._grads(pos, neg, md, ld, None, 0)
-        loss = self._loss[0].clone()
-        self._gall.zero_()
-        if self.regularization:
-            loss = loss + float(self.regularization) * self.E.abs().pow(3).sum()
-        return loss
+        sp, sn = self._score(pos, 0), self._score(neg, 0)
+        sc = torch.cat([sp, sn])
+        ld = self._loss_desc()
+        ws = self._loss_ws(pos.shape[0], neg.shape[0])
+        if out is None:
+            out = getattr(self, "_vloss", None)
+            if out is None:
+                out = self._vloss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        check(lib.kge_loss_value(C.byref(ld), sc.data_ptr(), pos.shape[0], sc[pos.shape[0]:].data_ptr(), neg.shape[0], out.data_ptr(), None, None,
+                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        if acc is not None:
+            acc += out.double()
+        return out
+
+    def _loss_only_context(self):
+        return {}
 
     # ------------------------------------------------------------------ ranking (utils.py:165-264)
     def rank_counts(self, *a, **kw):
@@ -1201,7 +1244,23 @@ class ConvE(EmbeddingModel):
     __call__ = call
 
     def func(self, s, p, o, training=False):
-        raise NotImplementedError("ConvE.func on pre-gathered rows: use call()/predict() on id triples")
+        """ConvE.func on already-gathered rows (models.py:264-275): the rows are staged as temporary tables ([s ; o], p) and scored by the
+        same kernels in inference mode (moving statistics, no dropout)."""
+        if training:
+            raise NotImplementedError("ConvE.func(training=True): batch statistics and dropout are built inside train_step only")
+        s = torch.as_tensor(s, dtype=torch.float32, device=self.device).reshape(-1, int(self.dim))
+        p = torch.as_tensor(p, dtype=torch.float32, device=self.device).reshape(-1, int(self.dim)).contiguous()
+        o = torch.as_tensor(o, dtype=torch.float32, device=self.device).reshape(-1, int(self.dim))
+        n = s.shape[0]
+        Et = torch.cat([s, o], 0).contiguous()
+        idx = torch.arange(n, dtype=torch.int32, device=self.device)
+        t = torch.stack([idx, idx, idx + n], 1).contiguous()
+        md = self._infer_ws(n)
+        md.num_entities, md.num_relations = 2 * n, n
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        check(lib.kge_conve_score(C.byref(md), Et.data_ptr(), p.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(), t.data_ptr(), n,
+                                  out.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        return out
 
     def hidden(self, triples):
         """x(s, p) of every row in inference mode, (n, dim) on the device; score(s, p, o) = <x, E[o]>."""
@@ -1248,8 +1307,27 @@ class ConvE(EmbeddingModel):
         check(lib.kge_opt_apply_vector(C.byref(odv), self.theta.data_ptr(), self._gtheta.data_ptr(), self.theta.numel(), 1.0, _lib.stream_ptr()))
         return {"loss": self._loss[0]}
 
-    def batch_loss(self, data):
-        raise NotImplementedError("ConvE: evaluation-only loss is not built (use predict / validate)")
+    def _batch_loss_into(self, data, ctx, acc=None, out=None):
+        """Forward-only loss of one batch in inference mode (models.py:239-275 with moving statistics and no dropout; tests.py:130-134
+        passes validation_data to fit): the scores of both arrays by kge_conve_score, the loss on them by kge_loss_value."""
+        pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
+        neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
+        sc = torch.empty(pos.shape[0] + neg.shape[0], dtype=torch.float32, device=self.device)
+        for t, o_ in ((pos, sc[:pos.shape[0]]), (neg, sc[pos.shape[0]:])):
+            md = self._infer_ws(t.shape[0])
+            check(lib.kge_conve_score(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(), t.data_ptr(),
+                                      t.shape[0], o_.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        ld = self._loss_desc()
+        ws = self._loss_ws(pos.shape[0], neg.shape[0])
+        if out is None:
+            out = getattr(self, "_vloss", None)
+            if out is None:
+                out = self._vloss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        check(lib.kge_loss_value(C.byref(ld), sc.data_ptr(), pos.shape[0], sc[pos.shape[0]:].data_ptr(), neg.shape[0], out.data_ptr(), None, None,
+                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        if acc is not None:
+            acc += out.double()
+        return out
 
     def rank_triples(self, test, num_entities, filt, chunk=8192):
         """Filtered ranks (utils.py:199-264).  Tails: queries x(s,p) against the entity table.  Heads: x depends on the

@@ -772,7 +772,7 @@ def conve_train_step(P, E, Rel, opt, pos, neg, loss="pointwize_hinge", margin=1,
 # [TF] Dense: x @ W + b with W Glorot-uniform ((e_dim + L), e_dim), b zeros; Keras activation strings.
 # Dropout multipliers: roles 0/1/2 = s/p/o rows as everywhere, 5/6 = the literal rows of s / o.
 # ----------------------------------------------------------------------------------------------
-ACTIVATIONS = ("linear", "relu", "sigmoid", "tanh", "softplus", "softsign", "elu", "selu", "exponential")
+ACTIVATIONS = ("linear", "relu", "sigmoid", "tanh", "softplus", "softsign", "elu", "selu", "exponential", "softmax")  # (softmax: row-wise, literal_transform)
 _SELU_A, _SELU_S = 1.6732632423543772, 1.0507009873554805
 
 
@@ -815,8 +815,20 @@ def literal_transform(H, E, Lit, ids, act, me=None, ml=None):
         a_e, a_l = a_e * me, a_l * ml
     A = np.concatenate([a_e, a_l], axis=1)
     Z = A @ H["W"] + H["b"]
+    if act == "softmax":  # [TF] keras.activations.softmax over the layer's outputs (axis -1): the one choice that is not element-wise
+        e = np.exp(Z - Z.max(axis=1, keepdims=True))
+        h = e / e.sum(axis=1, keepdims=True)
+        return h, dict(A=A, dh=None, h=h)
     h, dh = activation(act, Z)
     return h, dict(A=A, dh=dh)
+
+
+def literal_act_backward(cache, g):
+    """dL/dZ from dL/dh: g * act'(Z) element-wise, or the softmax Jacobian h (g - <g, h>) per row."""
+    if cache["dh"] is None:
+        h = cache["h"]
+        return h * (g - np.sum(g * h, axis=1, keepdims=True))
+    return g * cache["dh"]
 
 
 def literal_train_step(model, H, act, E, Rel, Lit, opt, pos, neg, loss="pointwize_hinge", margin=1, negative_samples=1, norm=1, gamma=12,
@@ -846,7 +858,7 @@ def literal_train_step(model, H, act, E, Rel, Lit, opt, pos, neg, loss="pointwiz
         ds, dp, do = score_row_grads(model, c["s"], c["p"], c["o"], g.astype(dt), norm, gamma)
         _scatter_add(gR, c["t"][:, 1], (dp * c["mp"]).astype(dt))
         for dh, cache, mask, col in ((ds, c["cs"], c["ms"], 0), (do, c["co"], c["mo"], 2)):
-            dZ = dh * cache["dh"]
+            dZ = literal_act_backward(cache, dh)
             gW += cache["A"].T @ dZ
             gb += dZ.sum(0)
             dA = dZ @ H["W"].T

@@ -46,7 +46,7 @@ def test_literal_predict_parity(act):
 
 @pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=1, gamma=12)), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {}),
                                       ("HolE", {})])
-@pytest.mark.parametrize("loss,act", [("pairwize_hinge", "tanh"), ("pointwize_logistic", "relu"), ("pointwize_hinge", "sigmoid")])
+@pytest.mark.parametrize("loss,act", [("pairwize_hinge", "tanh"), ("pointwize_logistic", "relu"), ("pointwize_hinge", "sigmoid"), ("pointwize_logistic", "softmax")])
 @pytest.mark.parametrize("dp", [0.0, 0.25])
 def test_literal_train_step_parity(model, kw, loss, act, dp):
     N, R, d, L, m = 30, 4, 16, 5, 200
