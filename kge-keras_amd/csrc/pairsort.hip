@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void ps_square_apply_kernel(const float* __res
 }  // namespace
 
 // floats of scratch that cover any batch of n = m_t + m_f rows (the temporary storage of the library calls is checked at run time)
-int64_t pair_sort_floats(int64_t n) { return 12 * align_up(n, 64) + 65536; }
+// (12 n: the sort path's keys, sorted keys and running sums; 20 n: the 16 + 16 sum planes, padded factors and workgroup sums of the one-pass
+// pairwize_logistic, pairlog.hip)
+int64_t pair_sort_floats(int64_t n) { return 20 * align_up(n, 64) + 65536; }
 
 // KGE_OK; 1 when the scratch does not cover this call (the caller keeps the all-pairs kernels).  *nb = loss partials written.
 int pairwise_hinge_sorted(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float margin, float* g_t, float* g_f, float* loss_partials,

@@ -385,6 +385,9 @@ int pairwise_hinge_sorted(const float* ts, int64_t m_t, const float* fs, int64_t
                           int* nb, float* scratch, int64_t scratch_floats, hipStream_t st);
 int pairwise_square_sums(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* g_t, float* g_f, float* loss_partials, int* nb,
                          float* scratch, int64_t scratch_floats, hipStream_t st);
+// pairlog.hip: pairwize_logistic's all-pairs mean in one tiled pass (every pair once, e^f and e^-t once per score)
+int pairwise_logistic_onepass(const float* ts, int64_t m_t, const float* fs, int64_t m_f, float* g_t, float* g_f, float* loss_partials, int* nb,
+                              float* scratch, int64_t scratch_floats, hipStream_t st);
 static int64_t pair_floats(int64_t n) { return std::max<int64_t>(n <= kPairMaxRows ? 3 * kPairChunks * align_up(n, 64) : 0, pair_sort_floats(n)); }
 static int64_t base_floats(int64_t n) { return 2 * kMaxBlocks + 64 + 2 * align_up(n, 64) + pair_floats(n); }
 
@@ -537,6 +540,11 @@ static int launch_pairwise_t(const float* ts, int64_t m_t, const float* fs, int6
     // ... and the square loss separates into four sums (same switch)
     if (LOSS == KGE_PAIRWIZE_SQUARE && pair && sort_mode != 0 && (sort_mode == 1 || (double)m_t * (double)m_f >= 4194304.0)) {
       const int rc = pairwise_square_sums(ts, m_t, fs, m_f, g_t, g_f, partials, nb, pair, pair_floats(m_t + m_f), st);
+      if (rc != 1) return rc;
+    }
+    // ... and the logistic loss, which no order or moment decides, takes every pair ONCE in a tiled pass (pairlog.hip) from 2^22 pairs on
+    if (LOSS == KGE_PAIRWIZE_LOGISTIC && pair && sort_mode != 0 && (sort_mode == 1 || (double)m_t * (double)m_f >= 4194304.0)) {
+      const int rc = pairwise_logistic_onepass(ts, m_t, fs, m_f, g_t, g_f, partials, nb, pair, pair_floats(m_t + m_f), st);
       if (rc != 1) return rc;
     }
     const bool planes = pair && m_t + m_f <= kPairMaxRows;  // (larger batches: the scratch is the sort path's, one chunk per row here)

@@ -111,7 +111,7 @@ def test_hake_dropout_regulariser_and_unequal_sides():
     Lv = float(mdl.batch_loss([pos, neg]).item())
     Lr, *_ = O.dense_grads("HAKE", Eo, Ro, pos, neg, "pointwize_logistic", 1, 1, prm, 12, 1e-3, 0.0, 0)
     assert Lv == pytest.approx(float(Lr), rel=TOL_L, abs=TOL_LA)
-    assert torch.equal(before, mdl.E) and float(mdl._gall.abs().max()) == 0.0
+    assert torch.equal(before, mdl.E) and float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0  # (forward only: nothing accumulated)
 
 
 def test_hake_validate_is_the_references_candidate_lists_predicted_32_rows_at_a_time():

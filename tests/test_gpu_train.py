@@ -877,3 +877,38 @@ def test_transe_general_p_norm(norm, gamma):
     from kge_keras_amd import models as M
     with pytest.raises(NotImplementedError):
         M.TransE(e_dim=8, r_dim=8, num_entities=5, num_relations=2, norm=np.inf).predict(np.array([[0, 0, 1]]))
+
+
+@pytest.mark.parametrize("m_t,m_f", [(1024, 1024), (2048, 3000), (5000, 4097), (2048, 20480), (20480, 20480)])
+def test_pairwise_logistic_one_pass_equals_all_pairs(m_t, m_f):
+    """csrc/pairlog.hip: the all-pairs mean of pairwize_logistic (utils.py:307-312 with the harness's negative_samples = 1) in one tiled
+    pass -- e^f and e^-t once per score, every pair evaluated once into its row sum AND its column sum -- against the all-pairs
+    kernels (one sweep per side) and the oracle; ragged sizes (padded workgroup ranges), scores beyond +-40 (the exact per-pair form
+    inside the same kernel), a NaN score (the mean is NaN in the reference too) and run-to-run bit-identity (no atomics)."""
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(m_t * 3 + m_f)
+    t, f = rs.uniform(-6, 9, m_t).astype(np.float32), rs.uniform(-8, 6, m_f).astype(np.float32)
+    Lo, gto, gfo = O.loss_value_and_grads("pairwize_logistic", t.astype(np.float64), f.astype(np.float64), 1.0, 1)
+    out = {}
+    for mode in ("0", "1"):
+        _pair_sort(mode)
+        L, gt, gf = M.loss_value("pairwize_logistic", t, f, 1.0, 1, return_grads=True)
+        out[mode] = (float(L.item()), gt.cpu().numpy(), gf.cpu().numpy())
+        assert out[mode][0] == pytest.approx(float(Lo), rel=2e-6), mode
+        np.testing.assert_allclose(out[mode][1], gto, rtol=2e-5, atol=1e-12, err_msg=mode)
+        np.testing.assert_allclose(out[mode][2], gfo, rtol=2e-5, atol=1e-12, err_msg=mode)
+    _pair_sort("1")
+    L2, gt2, gf2 = M.loss_value("pairwize_logistic", t, f, 1.0, 1, return_grads=True)
+    assert float(L2.item()) == out["1"][0] and np.array_equal(gt2.cpu().numpy(), out["1"][1]) and np.array_equal(gf2.cpu().numpy(), out["1"][2])
+    if m_t == 5000:
+        tb, fb = t.copy(), f.copy()
+        tb[7], fb[11] = -45.0, 42.0   # beyond +-40: the per-pair form e^(f - t) (up to e^87, still a float32) inside the same kernel
+        Lb, gtb, gfb = O.loss_value_and_grads("pairwize_logistic", tb.astype(np.float64), fb.astype(np.float64), 1.0, 1)
+        L, gt, gf = M.loss_value("pairwize_logistic", tb, fb, 1.0, 1, return_grads=True)
+        assert float(L.item()) == pytest.approx(float(Lb), rel=2e-6)
+        np.testing.assert_allclose(gt.cpu().numpy(), gtb, rtol=2e-5, atol=1e-12)
+        np.testing.assert_allclose(gf.cpu().numpy(), gfb, rtol=2e-5, atol=1e-12)
+        tn = t.copy()
+        tn[3] = np.nan
+        L, gt, gf = M.loss_value("pairwize_logistic", tn, f, 1.0, 1, return_grads=True)
+        assert np.isnan(float(L.item())) and np.all(np.isnan(gf.cpu().numpy())) and np.isnan(gt.cpu().numpy()[3])
