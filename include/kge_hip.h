@@ -383,6 +383,16 @@ int kge_set_grad_mode(int mode);
  * least 4096 rows, 2 = always. */
 int kge_set_dedup_mode(int mode);
 
+/* Run-to-run reproducibility of the planned training step ("only the former is run-to-run deterministic").  By default a row's
+ * place in its relation list and in its entity lists is the arrival order of integer atomics, so two runs from the same seeds add a
+ * row's gradient terms in different orders: equal to fp32 rounding, not bit for bit (like TensorFlow's unsorted segment sums).  With
+ * the mode on -- also by KGE_DETERMINISTIC=1 in the environment -- the place is the rank BY BATCH ROW (two stable sorts per plan, on
+ * the plan stage: off the step's critical path), duplicate folding by hash is off, and every sum of the planned pointwise step has ONE
+ * order: two seeded epochs are bit-identical.  Set it BEFORE sizing plan buffers (kge_batch_plan_bytes grows by the sort scratch).
+ * Not covered: the push path's float atomics, the sorted pairwize_hinge form (its running sum is a decoupled look-back scan). */
+int kge_set_deterministic(int on);
+int kge_get_deterministic(void);
+
 /* The harness's all-pairs broadcast of the pairwize losses (utils.py:300-319 called with negative_samples = 1, tests.py:81): past
  * 2^27 pairs pairwize_hinge is evaluated from the two SORTED score vectors (counts + a running double sum, no pair formed), past
  * 2^22 pairs pairwize_square_loss from four sums; below, the all-pairs kernels run.  The forms agree to fp32 rounding, not bit for

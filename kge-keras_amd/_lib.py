@@ -123,6 +123,8 @@ SIGNATURES = {
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_set_dedup_mode": (C.c_int, [C.c_int]),
     "kge_set_pair_sort_mode": (C.c_int, [C.c_int]),
+    "kge_set_deterministic": (C.c_int, [C.c_int]),
+    "kge_get_deterministic": (C.c_int, []),
     "kge_prof_enable": (C.c_int, [C.c_int]),
     "kge_prof_read": (C.c_int, [C.c_int, _P, _P]),
     "kge_score": (C.c_int, [_MD, _P, _P, _P, _I64, _P, _P, _P]),

@@ -11,18 +11,7 @@
 
 namespace kge {
 
-char* err_buf() {
-  static thread_local char buf[512] = {0};
-  return buf;
-}
-
-int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(err_buf(), 512, fmt, ap);
-  va_end(ap);
-  return code;
-}
+// (err_buf / fail / kge_last_error: errors.cpp -- host-only, shared with the sanitizer build of the host objects)
 
 // hipGetLastError() is per thread and sticky across callers: an error some other library left behind (PyTorch probing the
 // platform at start-up has been seen to leave "no ROCm-capable device") must not be reported as ours after the next launch.
@@ -162,6 +151,8 @@ int opt_apply(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, 
               int64_t, hipStream_t, bool advanced = false, const OptFinish* finish = nullptr);
 
 void set_pair_sort_mode(int mode);  // train.hip
+void set_deterministic_mode(int on);  // pull2.hip
+bool deterministic_mode();
 int loss_only(const kge_model_desc*, const kge_loss_desc*, const float*, const float*, const int32_t*, int64_t, const int32_t*, int64_t, float*, double*,
               void*, int64_t, uint32_t*, hipStream_t);
 int l3_value(const float*, int64_t, float, float*, void*, int64_t, hipStream_t);
@@ -224,7 +215,6 @@ using namespace kge;
 
 extern "C" {
 
-const char* kge_last_error(void) { return err_buf(); }
 int kge_abi_version(void) { return KGE_ABI_VERSION; }
 
 int kge_set_grad_mode(int mode) {
@@ -638,6 +628,12 @@ int kge_set_pair_sort_mode(int mode) {
   set_pair_sort_mode(mode);
   return KGE_OK;
 }
+
+int kge_set_deterministic(int on) {
+  set_deterministic_mode(on);
+  return KGE_OK;
+}
+int kge_get_deterministic(void) { return deterministic_mode() ? 1 : 0; }
 
 int kge_set_dedup_mode(int mode) {
   if (mode < 0 || mode > 2) return fail(KGE_EINVAL, "kge_set_dedup_mode: mode %d (0 = off, 1 = batches of 4096+ rows, 2 = always)", mode);

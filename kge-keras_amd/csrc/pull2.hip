@@ -24,6 +24,8 @@
 // TensorFlow's IndexedSlices accumulation up to fp32 summation order.  Off when dropout is on (every row has its own mask).
 #include <cstdlib>
 
+#include <hipcub/hipcub.hpp>
+
 #include "dropout.hpp"
 #include "kge_internal.hpp"
 #include "pull.hpp"
@@ -62,6 +64,7 @@ struct Plan2 {
   // entity side (same meaning as PullPlan, keys = entities only)
   PullPlan ent;
   int32_t* erank;   // [2][n]
+  char* det;        // deterministic mode: 12 n int32 of (key, item) pairs + the sort's temporary storage (null otherwise)
 };
 
 // Where the step's rows come from: the caller's (pos, neg) arrays, or the materialised rows {s, p, o, +-multiplicity} of the plan
@@ -428,9 +431,11 @@ static int64_t dedup_bytes(int64_t n) {
   return b256(cap * 8) + b256(cap * 4) + 256 + b256(cap * 4) + b256(n * 4) * 2 + b256((n / 256 + 1) * 4) + b256(n * 16) + b256(n * 4);
 }
 // Folding needs the packed key 2*((s*R + p)*N + o) + side + 1 to fit 64 bits, and pays off only on batches of some size.
+bool deterministic_mode();
 static bool dedup_applies(const kge_model_desc* md, int64_t n) {
   const int mode = dedup_mode();
   if (mode == 0 || md->dropout > 0.f || (mode == 1 && n < 4096)) return false;
+  if (deterministic_mode()) return false;  // (which thread's CAS installs a key, hence the folded rows' numbering, is a race)
   return (long double)md->num_entities * md->num_entities * md->num_relations * 2.0L + 2.0L < 1.8e19L;
 }
 
@@ -459,8 +464,9 @@ static Sizes sizes_of(const kge_model_desc* md, int64_t n) {
   return z;
 }
 static int64_t counters_bytes(const Sizes& z) { return b256(z.N * 4) + b256(z.R * 4); }
+static int64_t det_bytes(int64_t n);
 static int64_t plan_bytes(const Sizes& z) {
-  return b256(z.R * 4) * 2 + 256 + b256(z.max_units * 8) + b256(z.n * 4) + b256(z.n * 16) +                 // relation side
+  return det_bytes(z.n) + b256(z.R * 4) * 2 + 256 + b256(z.max_units * 8) + b256(z.n * 4) + b256(z.n * 16) +                 // relation side
          b256(z.N * 4) * 3 + 256 + b256(z.max_extra * 8) + b256(2 * z.n * 4) + b256(2 * z.n * 16) + scan_sums_bytes(z.N) +  // entity side (incl. list entries)
          b256(z.cap * 8) + b256(z.cap * 4) + 256 + b256(z.cap * 4) + b256(z.n * 4) * 2 + b256((z.n / 256 + 1) * 4) + b256(z.n * 16) + 512;
 }
@@ -511,6 +517,7 @@ static void carve_plan(void* counters, void* region, const kge_model_desc* md, i
   p->ent.ranks = p->erank;
   p->ent.max_extra = (int)z.max_extra;
   p->ent.chunk = z.C;
+  p->det = det_bytes(n) ? take(det_bytes(n) - 256) : nullptr;
 }
 
 static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Plan2* p) {
@@ -569,6 +576,81 @@ __global__ __launch_bounds__(256) void zero_words_kernel(int32_t* __restrict__ p
   if (i < n) p[i] = 0;
 }
 
+// ---- deterministic list order (kge_set_deterministic(1) / KGE_DETERMINISTIC=1).  By default a row's place in its relation list and in
+// its two entity lists is the arrival order of plan_hist_kernel's integer atomics (LDS within a workgroup, global across them), so two
+// runs from the same seeds add a row's gradient terms in different orders and agree to fp32 rounding only.  Here the place is the row's
+// RANK BY BATCH ROW among the rows of the same key: (key, item) pairs through a stable radix sort (hipCUB), rank = position - first
+// position of the key.  Slower (two sorts per plan: the plan stage runs beside the step, off its critical path) and bit-reproducible:
+// every list, hence every sum of the step, has one order.
+struct DetBufs { int32_t *ekey, *eitem, *ekey_s, *eitem_s, *rkey, *ritem, *rkey_s, *ritem_s; void* temp; size_t temp_bytes; };
+constexpr int32_t kDetNone = 0x7fffffff;  // key of a row that takes no part: sorts behind every real key
+
+template <int MODE>
+__global__ __launch_bounds__(256) void det_rows_kernel(HistSrc hs, int64_t n, int N, int R, int32_t* __restrict__ ekey, int32_t* __restrict__ eitem,
+                                                        int32_t* __restrict__ rkey, int32_t* __restrict__ ritem, int32_t* __restrict__ erank,
+                                                        int32_t* __restrict__ rrank, int4* __restrict__ uniq_out, int32_t* __restrict__ nu_out,
+                                                        uint32_t* __restrict__ err) {
+  const int64_t rows = MODE == 2 ? hs.n_all : src_rows(hs.src);
+  if (MODE != 0 && nu_out && blockIdx.x == 0 && threadIdx.x == 0) nu_out[0] = (int32_t)rows;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  int32_t ks = kDetNone, ko = kDetNone, kr = kDetNone, rr = -2;
+  if (t < rows) {
+    int s, p, o, w;
+    if (MODE == 2) {
+      w = 0;
+      if (t < hs.n_pos_cand) { for (int l = 0; l < hs.lanes; ++l) w += hs.cand_cnt[l * hs.n_pos_cand + t]; }
+      else w = -hs.cand_cnt[(int64_t)(hs.lanes - 1) * hs.n_pos_cand + t];
+      s = hs.cand_rows[3 * t]; p = hs.cand_rows[3 * t + 1]; o = hs.cand_rows[3 * t + 2];
+    } else {
+      src_load(hs.src, t, s, p, o, w);
+    }
+    const bool ok = (unsigned)s < (unsigned)N && (unsigned)p < (unsigned)R && (unsigned)o < (unsigned)N;
+    if (MODE == 2 && w != 0 && !ok) { atomicOr(err, 1u); w = 0; }
+    if (MODE != 0 && uniq_out) uniq_out[t] = make_int4(s, p, o, w);
+    if (w != 0 && !ok) rr = -1;
+    if (w != 0 && ok) { ks = s; ko = o; kr = p; }
+  }
+  ekey[t] = ks; eitem[t] = (int32_t)t;
+  ekey[n + t] = ko; eitem[n + t] = (int32_t)(n + t);
+  rkey[t] = kr; ritem[t] = (int32_t)t;
+  erank[t] = -1; erank[n + t] = -1;
+  rrank[t] = rr;
+}
+
+// sorted (key, item): rank of an item = its position - the first position of its key (binary search); the key's last item files the count
+__global__ __launch_bounds__(256) void det_rank_kernel(const int32_t* __restrict__ key_s, const int32_t* __restrict__ item_s, int64_t n,
+                                                        int32_t* __restrict__ rank_of_item, int32_t* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t k = key_s[i];
+  if (k == kDetNone) return;
+  int64_t lo = 0, hi = i;
+  while (lo < hi) {  // first index with key_s >= k
+    const int64_t mid = (lo + hi) >> 1;
+    if (key_s[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  rank_of_item[item_s[i]] = (int32_t)(i - lo);
+  if (i + 1 == n || key_s[i + 1] != k) cnt[k] = (int32_t)(i - lo + 1);
+}
+
+static int g_deterministic = -1;
+bool deterministic_mode() {
+  if (g_deterministic < 0) { const char* v = getenv("KGE_DETERMINISTIC"); g_deterministic = v && atoi(v) != 0 ? 1 : 0; }
+  return g_deterministic != 0;
+}
+void set_deterministic_mode(int on) { g_deterministic = on ? 1 : 0; }
+
+static size_t det_temp_bytes(int64_t n) {
+  size_t a = 0, b = 0;
+  const int32_t* k = nullptr;
+  int32_t* ko = nullptr;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, k, ko, k, ko, (int)(2 * n), 0, 31, (hipStream_t)0);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, k, ko, k, ko, (int)n, 0, 31, (hipStream_t)0);
+  return std::max(a, b) + 256;
+}
+static int64_t det_bytes(int64_t n) { return deterministic_mode() && 2 * n < 0x7fffffffll ? 12 * b256(n * 4) + (int64_t)b256((int64_t)det_temp_bytes(n)) + 256 : 0; }
+
 // ---- plan: everything that depends on the ids only.  `own_rows`: the plan must not refer to the caller's arrays afterwards
 // (kge_batch_plan_build), so rows that are not folded are copied.
 struct Counted { const int32_t* rows; const int32_t* cnt; int lanes; int64_t n_pos, n_all; };  // batch in folded form (rows == null: not given)
@@ -599,7 +681,29 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
     }
     ProfScope prof(KGE_PROF_INDEX, st);
     const int hgrid = (int)cdiv(cd.rows ? cd.n_all : n, kEntRows);
-    if (cd.rows) {
+    if (p.det) {  // deterministic list order: ranks by batch row through two stable sorts (see det_rows_kernel)
+      DetBufs db;
+      char* q = p.det;
+      auto tk = [&](int64_t cnt) { int32_t* r = (int32_t*)q; q += b256(cnt * 4); return r; };
+      db.ekey = tk(2 * n); db.eitem = tk(2 * n); db.ekey_s = tk(2 * n); db.eitem_s = tk(2 * n);
+      db.rkey = tk(n); db.ritem = tk(n); db.rkey_s = tk(n); db.ritem_s = tk(n);
+      db.temp = q; db.temp_bytes = det_temp_bytes(n);
+      const int dgrid = (int)cdiv(n, 256);
+      if (cd.rows) {
+        const HistSrc hs{src, cd.rows, cd.cnt, cd.lanes, cd.n_pos, cd.n_all};
+        hipLaunchKernelGGL((det_rows_kernel<2>), dim3(dgrid), dim3(256), 0, st, hs, n, N, R, db.ekey, db.eitem, db.rkey, db.ritem, p.erank, p.rrank, d.uniq, d.nu, err);
+      } else {
+        const HistSrc hs{Src{pos, m_pos, neg, m_neg, nullptr, nullptr}, nullptr, nullptr, 1, 0, 0};
+        hipLaunchKernelGGL((det_rows_kernel<1>), dim3(dgrid), dim3(256), 0, st, hs, n, N, R, db.ekey, db.eitem, db.rkey, db.ritem, p.erank, p.rrank, own_rows ? d.uniq : nullptr,
+                           own_rows ? d.nu : nullptr, err);
+      }
+      size_t tb = db.temp_bytes;
+      KGE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db.temp, tb, (const int32_t*)db.ekey, db.ekey_s, (const int32_t*)db.eitem, db.eitem_s, (int)(2 * n), 0, 31, st));
+      tb = db.temp_bytes;
+      KGE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db.temp, tb, (const int32_t*)db.rkey, db.rkey_s, (const int32_t*)db.ritem, db.ritem_s, (int)n, 0, 31, st));
+      hipLaunchKernelGGL(det_rank_kernel, dim3((int)cdiv(2 * n, 256)), dim3(256), 0, st, db.ekey_s, db.eitem_s, 2 * n, p.erank, p.ent.cnt);
+      hipLaunchKernelGGL(det_rank_kernel, dim3(dgrid), dim3(256), 0, st, db.rkey_s, db.ritem_s, n, p.rrank, p.rcnt);
+    } else if (cd.rows) {
       const HistSrc hs{src, cd.rows, cd.cnt, cd.lanes, cd.n_pos, cd.n_all};
       hipLaunchKernelGGL((plan_hist_kernel<2>), dim3(hgrid), dim3(256), 0, st, hs, n, N, R, p.ent.cnt, p.erank, p.rcnt, p.rrank, d.uniq, d.nu, err);
     } else if (fold) {

@@ -6,6 +6,7 @@ import hashlib
 import os
 import random
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -365,3 +366,24 @@ def test_native_loader_matches_load_kg_and_index_kg(golden, datasets, tmp_path):
         U.load_indexed(str(bad))
     with pytest.raises(FileNotFoundError):
         U.load_indexed(str(tmp_path / "nope.txt"))
+
+
+def test_host_objects_under_asan_ubsan():
+    """SURVEY 5 (sanitizers): sampler.cpp, frontend.cpp and mtjump.cpp -- raw pointer arithmetic on caller buffers -- built with
+    -fsanitize=address,undefined (`make -C kge-keras_amd/csrc asan`) and driven through every host entry point at its edges by
+    tests/host_asan_driver.py in a child process with the sanitizer runtime preloaded (CPU only: the build container, never the GPU box).
+    A sanitizer report aborts the child; the final line must be HOST-ASAN-OK."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ here")
+    csrc = os.path.join(ROOT, "kge-keras_amd", "csrc")
+    rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not rt or not os.path.exists(rt):
+        pytest.skip("no AddressSanitizer runtime here")
+    b = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout + b.stderr
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_asan_driver.py"), os.path.join(csrc, "libkge_host_asan.so")],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("HOST-ASAN-OK"), (r.stdout[-2000:], r.stderr[-4000:])
