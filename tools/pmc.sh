@@ -5,8 +5,8 @@
 tag=$1
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/pmc_${tag}_fetch -- python3 $root/bench.py --steps 5 --warmup 2 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval > $root/gpurun_out/pmc_${tag}_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/pmc_${tag}_write -- python3 $root/bench.py --steps 5 --warmup 2 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval > $root/gpurun_out/pmc_${tag}_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/pmc_${tag}_fetch -- python3 $root/bench.py --steps 5 --warmup 2 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval --no-hbm-leg --no-dp02 > $root/gpurun_out/pmc_${tag}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/pmc_${tag}_write -- python3 $root/bench.py --steps 5 --warmup 2 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval --no-hbm-leg --no-dp02 > $root/gpurun_out/pmc_${tag}_write.log 2>&1
 cd $root
 python3 - <<EOF
 import csv, glob, json, collections

@@ -3,7 +3,7 @@
 tag=$1; shift
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/bench.py --steps 100 --warmup 3 --no-cpu-baseline --no-sharded-eval --force-dist --dp-native on "$@" > $root/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -- python3 $root/bench.py --steps 100 --warmup 3 --no-cpu-baseline --no-sharded-eval --no-hbm-leg --no-dp02 --force-dist --dp-native on "$@" > $root/gpurun_out/prof_$tag.log 2>&1
 rc=$?
 cd $root
 tail -3 gpurun_out/prof_$tag.log
