@@ -158,12 +158,13 @@ def host_batches(w, rank, n_batches, folded=False):
     return out
 
 
-def check_benched_path(model_name="DistMult", steps=3, rank=0, fp64=False, tol=1e-6, tol_loss_rel=1e-6):
+def check_benched_path(model_name="DistMult", steps=3, rank=0, fp64=False, tol=2e-6, tol_loss_rel=1e-6):
     """Parity of the benched code path at the benched size: a fresh model driven by TrainPipeline (device sampler, counted
     plans, steps between twin tables) for `steps` steps on the bench workload.  (a) every batch the device drew == the host
     generator's, bit for bit (rows before oversampling and pick counts; tests.py:55-61, utils.py:114-147); (b) loss, entity
     table and relation table after every step against the oracle's C restatement (fp32; fp64=True: also the NumPy fp64 oracle):
-    tables within `tol` absolute (1e-6: a whole Adam update is 1e-3, so a wrong lr_t, eps placement or a dropped duplicate shows),
+    tables within `tol` absolute (2e-6 -- measured: DistMult 1e-7, TransE-L2 with its x / |x| 9.5e-7 --: a whole Adam update is 1e-3, so a wrong
+    lr_t, eps placement or a dropped duplicate shows),
     the loss within `tol_loss_rel` relative.  The oracle is the checker only.  Returns a dict for the bench line; raises
     AssertionError on a mismatch."""
     import torch
