@@ -67,15 +67,14 @@ void prof_end(int label, hipStream_t st) {
   g_prof.pending[label] = nullptr;
 }
 
-// ---- tuning knobs (env overrides are for experiments on the GPU box; defaults are what ships)
+// ---- tuning constants (what measured fastest; the environment switches of rounds 1-3 that selected the slower alternatives are gone:
+// profiles/r0*_experiments.txt keep their numbers) and the few switches that select a code PATH (tests and A/B timing use them)
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
   return v && *v ? std::atoi(v) : dflt;
 }
 
 int score_group_width(int nchunk) {
-  static const int forced = env_int("KGE_SCORE_G", 0);
-  if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
   int p2 = 1;
   while (p2 < nchunk) p2 <<= 1;
   int g = p2 / 4;
@@ -83,19 +82,15 @@ int score_group_width(int nchunk) {
 }
 
 int fwd_group_width(int nchunk) {
-  static const int forced = env_int("KGE_FWD_G", 0);
-  if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
   return score_group_width(nchunk);
 }
 
 int rank_blocks_target() {
-  static const int t = env_int("KGE_RANK_BLOCKS", 16 * kCUs);
-  return t < 1 ? 1 : t;
+  return 16 * kCUs;
 }
 
 int pull_chunk() {
-  static const int c = env_int("KGE_PULL_CHUNK", 128);
-  return c < 8 ? 8 : c;
+  return 128;  // list entries per chunk wave of a hub row
 }
 
 int pull_variant() {
@@ -130,8 +125,6 @@ SideStream* side_stream() {
 }
 
 int push_group_width(int width) {
-  static const int forced = env_int("KGE_PUSH_G", 0);
-  if (forced == 16 || forced == 32 || forced == 64) return forced;
   return width <= 16 ? 16 : (width <= 32 ? 32 : 64);
 }
 

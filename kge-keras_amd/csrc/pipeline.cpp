@@ -328,11 +328,8 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
       for (void* b : d.plan_more) { if (!b || avail == Pipeline::kMaxPlans) break; p->plan_buf[avail++] = b; }
     }
     p->np = p->graphs ? 2 : avail;
-    if (const char* e = std::getenv("KGE_PIPE_PLANS")) { const int x = std::atoi(e); if (x >= 2 && x <= avail && !p->graphs) p->np = x; }
     p->rec_every = std::max(1, p->np - 2);
-    if (const char* e = std::getenv("KGE_PIPE_REC_EVERY")) { const int x = std::atoi(e); if (x >= 1 && x <= p->rec_every) p->rec_every = x; }
   }
-  if (const char* e = std::getenv("KGE_PIPE_RING")) { if (std::atoi(e) == 0) p->ring = false; }
   // twin tables: the step closed by its pull launch (direct launches only: a captured step has its table pointers baked in)
   if ((d.E_twin != nullptr) != (d.Rel_twin != nullptr)) { delete p; return fail(KGE_EINVAL, "kge_pipeline_create: E_twin and Rel_twin go together"); }
   // (with dropout the twin step is available but measured slower than the three-launch step -- 0.46 against 0.39 ms per step at the
@@ -340,7 +337,7 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   p->swap = !d.comm && d.E_twin && !p->graphs && d.md.dropout == 0.f && kge_train_step_swap_supported(&d.md, &d.ld, &d.od) == 1;
   if (d.comm) p->graphs = false;  // (a collective never sits inside a captured graph)
   p->dp_halves = d.comm && kge_train_grads_halves_supported(&d.md, &d.ld) == 1;
-  if (const char* e = std::getenv("KGE_PIPE_DP_HALVES")) { if (std::atoi(e) == 0) p->dp_halves = false; }
+  if (const char* e = std::getenv("KGE_PIPE_DP_HALVES")) { if (std::atoi(e) == 0) p->dp_halves = false; }  // (tests run both forms)
   if (const char* e = std::getenv("KGE_PIPE_SWAP")) { if (std::atoi(e) == 0) p->swap = false; }
   if (p->graphs && prof_is_on()) {
     delete p;
@@ -354,11 +351,10 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   } while (0)
   {
     // the producer stages run below the training stream's priority: the step is the critical chain, everything else has a batch
-    // or more of slack (KGE_PIPE_PRIO=0: all streams at the default priority)
+    // or more of slack
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
-    const char* e = std::getenv("KGE_PIPE_PRIO");
-    const int prio = (e && std::atoi(e) == 0) ? 0 : lo;
+    const int prio = lo;
     // The producer streams are confined to half of the compute units -- in EVERY shader engine of every XCD: the queue's CU mask
     // numbers the units XCD-first, then shader engine, then unit (32 consecutive bits = unit i of all 8 x 4 engines), so "every other
     // group of 32 bits" keeps units 0, 2, 4, 6 of each engine.  The step's waves then find half of the units free of producer waves
@@ -367,14 +363,11 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
     // priority and is a BLOCKING stream: it synchronises with the legacy default stream, so this form needs the caller on a stream of
     // its own (kge_pipeline_create's `stream` != 0; pipeline.py drives the loop from one); on the default stream, and with
     // KGE_PIPE_CUMASK=0, the producers are plain low-priority streams over all units.
-    // KGE_PIPE_CUMASK=k / KGE_PIPE_CUGROUP=g / KGE_PIPE_CUKEEP=m: keep the first m of every k groups of g mask bits.
+    // (KGE_PIPE_CUMASK=0 switches the confinement off, k > 1 keeps one of every k groups of 32 mask bits.)
     const char* em = std::getenv("KGE_PIPE_CUMASK");
     const int stride = em ? std::atoi(em) : (stream ? 2 : 0);
     if (stride > 1) {
-      const char* eg = std::getenv("KGE_PIPE_CUGROUP");
-      const int group = eg ? std::max(1, std::atoi(eg)) : 32;
-      const char* ek = std::getenv("KGE_PIPE_CUKEEP");
-      const int keep = ek ? std::max(1, std::atoi(ek)) : 1;
+      const int group = 32, keep = 1;
       hipDeviceProp_t prop;
       int dev = 0;
       KGE_CREATE_TRY(hipGetDevice(&dev));  // (one process per GPU: the rank's own device)
@@ -382,10 +375,9 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
       const int ncu = prop.multiProcessorCount;
       std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
       for (int c = 0; c < ncu; ++c) if ((c / group) % stride < keep) mask[(size_t)c / 32] |= 1u << (c % 32);
-      // which producer streams are confined (KGE_PIPE_CUMASK_STREAMS: 1 generator rounds, 2 draw, 4 plan) [6: the rounds run thin and
-      // long, cost the step nothing where they are, and sit on the critical path of an epoch's first batches]
-      const char* es = std::getenv("KGE_PIPE_CUMASK_STREAMS");
-      const int which = es ? std::atoi(es) : 6;
+      // which producer streams are confined (1 generator rounds, 2 draw, 4 plan): draw and plan -- the rounds run thin and long, cost
+      // the step nothing where they are, and sit on the critical path of an epoch's first batches
+      const int which = 6;
       // CU-masked streams are made once per process and shared by all pipelines: a masked queue that is destroyed goes back to the
       // runtime's queue pool with its mask still set and is handed to the next stream that is created -- measured on ROCm 7.2: the
       // steps of a second pipeline ran at half speed after the first one had been destroyed (profiles/r02_experiments.txt)

@@ -301,12 +301,9 @@ static void launch_pull(int nchunk, int grid, hipStream_t st, const float* E, co
 #define KGE_PULL(GW, NVV) do { if (drop) KGE_PULL1(GW, NVV, true); else KGE_PULL1(GW, NVV, false); } while (0)
   // 16-lane sub-groups: four list entries of a row in flight per wave (measured at d=200: 114.6 us vs 149.7 us with one
   // 64-lane group on lists of ~56 entries, 49.0 vs 53.7 us on lists of ~18)
-  static const int exp_g = [] { const char* v = getenv("KGE_PULL_G"); return v ? atoi(v) : 0; }();  // experiments: sub-group width at 33..64 chunks
   if (nchunk <= 8) KGE_PULL(8, 1);
   else if (nchunk <= 16) KGE_PULL(16, 1);
   else if (nchunk <= 32) KGE_PULL(16, 2);
-  else if (nchunk <= 64 && exp_g == 8) KGE_PULL(8, 8);
-  else if (nchunk <= 64 && exp_g == 32) KGE_PULL(32, 2);
   else if (nchunk <= 64) KGE_PULL(16, 4);
   else if (nchunk <= 128) KGE_PULL(64, 2);
   else KGE_PULL(64, 4);

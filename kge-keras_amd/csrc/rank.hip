@@ -946,8 +946,7 @@ static int sweep_variant() {  // KGE_RANK_SWEEP=1 (A/B timing, tests) selects th
 }
 
 static int sweep5_slots() {  // workgroups of rank_sweep5_kernel: one per CU (137 KB of LDS, 512 threads)
-  static const int v = [] { const char* e = getenv("KGE_RANK_SLOTS5"); const int x = e ? atoi(e) : 0; return x > 0 ? x : kCUs; }();
-  return v;
+  return kCUs;
 }
 
 static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float* Qv, const float* tgt, int64_t nq, const float* Ec,
@@ -964,8 +963,7 @@ static void launch_sweep(int BK, bool v4, dim3 grid, hipStream_t st, const float
     const int slots = sweep5_slots();
     int parts = 0;
     {
-      static const bool align = [] { const char* e = getenv("KGE_RANK_ALIGN"); return !(e && atoi(e) == 0); }();
-      if (align && nqt <= slots && units > slots) {
+      if (nqt <= slots && units > slots) {
         const int64_t g = std::min<int64_t>(slots / nqt, nct);
         if (g >= 1 && nqt * g * 32 >= (int64_t)slots * 31) parts = (int)g;
       }

@@ -55,16 +55,14 @@ __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, 
 // or 32 lanes x NV = 2 -- the same instruction count per row, half the row-sized register arrays.  Measured at the FB15k-237 shape:
 // DistMult 65.7 us on 16 lanes (93 VGPRs, 5 waves per SIMD) against 67.2 us on 32 (59 VGPRs, 8 waves: the launch is bound by the
 // fabric, not by occupancy); TransE-L2 91.6 us (98 VGPRs, 4 waves) against 75.4 us.  So: DistMult 16 lanes, the others 32.
-// KGE_STEP_G=16 | 32 forces one (A/B timing).
 template <int MODEL, int NORM, int LOSS>
 static void launch_step1_nv(int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R, const StepTail& tt) {
-  static const int force_g = [] { const char* v = getenv("KGE_STEP_G"); return v ? atoi(v) : 0; }();
   const bool drop = fa.thr != 0u;
 #define KGE_S1(NVV, GW) do { if (drop) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, true>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R, tt); \
                              else hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, false>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R, tt); } while (0)
   if (nchunk <= 16) KGE_S1(1, 16);
   else if (nchunk <= 32) KGE_S1(2, 16);
-  else if (force_g == 16 || (force_g != 32 && MODEL == KGE_DISTMULT)) KGE_S1(4, 16);
+  else if (MODEL == KGE_DISTMULT) KGE_S1(4, 16);
   else KGE_S1(2, 32);
 #undef KGE_S1
 }

@@ -78,10 +78,9 @@ class TrainPipeline:
         from .models import BatchPlan
         # plans[0], plans[1]: one per buffer parity; plans[2]: the native driver's third buffer (kge_pipeline_desc.plan3), which the
         # Python loop also uses when it takes an epoch over from the driver (batch k sits in plans[k % self._np])
-        # (KGE_PIPE_PLAN_BUFFERS = 4..6: further buffers, with which the driver records "plan consumed" on the step stream behind every
-        # (buffers - 2)-th step only -- measured at the bench shape: 0.0999 ms per step with 3, 0.1005 with 4, 0.102 with 5, 0.104 with 6,
-        # so three it is: profiles/r03_experiments.txt)
-        n_plans = max(3, min(6, int(os.environ.get("KGE_PIPE_PLAN_BUFFERS", "3"))))
+        # (four to six buffers, with "plan consumed" recorded behind every (buffers - 2)-th step only, measured slower at the bench shape:
+        # 0.0999 ms per step with 3, 0.1005 with 4, 0.102 with 5, 0.104 with 6 -- profiles/r03_experiments.txt -- so three it is)
+        n_plans = 3
         self.plans = [BatchPlan(torch.zeros(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(n_plans)]
         self._np = 2
         self.index = torch.zeros(int(n_rows), dtype=torch.int64, device=self.dev)   # epoch permutation (tests.py:50-53)
