@@ -42,20 +42,7 @@ __device__ __forceinline__ bool rel_in_window(const FwdRelArgs& a, int unit) {
 // One wave per (relation, chunk).  64/G sub-groups of G lanes take different triples; lane l of a sub-group owns float4
 // chunks l, l+G, ... (NV of them) of the row (of each half row for ComplEx).  Adds the unit's loss terms to lsum (lane 0 of every
 // sub-group), writes the unit's partial relation-gradient row to rslab[unit].  Returns the relation; *len_out = rows of the unit, *c_out = rows of the relation.
-// SC1: the unit's partial row is stored write-through (global_store_dwordx4 ... sc1) -- what a consumer on another compute unit needs when
-// it picks the row up INSIDE the same launch (step1.hip: the relation's last unit wave sums the partial rows).
-using f32x4_t = __attribute__((ext_vector_type(4))) float;
-__device__ __forceinline__ void store4_sc1(float* p, float4 v) {
-  const f32x4_t x = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
-}
-__device__ __forceinline__ float4 load4_sc1(const float* p) {
-  f32x4_t x;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
-  return make_float4(x.x, x.y, x.z, x.w);
-}
-
-template <int MODEL, int NORM, int LOSS, int NV, bool DROP, int G = 16, bool SC1 = false>
+template <int MODEL, int NORM, int LOSS, int NV, bool DROP, int G = 16>
 __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R, float& lsum, int* len_out, int* c_out) {
   constexpr int NA = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   const float* __restrict__ E = a.E;
@@ -184,13 +171,8 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
     for (int j = 0; j < NV; ++j) {
       const int ch = lane + j * G;
       if (ch < nchunk) {
-        if (SC1) {
-          store4_sc1(dst + ch * 4, acc[j]);
-          if (MODEL == KGE_COMPLEX) store4_sc1(dst + h + ch * 4, acc[NV + j]);
-        } else {
-          *reinterpret_cast<float4*>(dst + ch * 4) = acc[j];
-          if (MODEL == KGE_COMPLEX) *reinterpret_cast<float4*>(dst + h + ch * 4) = acc[NV + j];
-        }
+        *reinterpret_cast<float4*>(dst + ch * 4) = acc[j];
+        if (MODEL == KGE_COMPLEX) *reinterpret_cast<float4*>(dst + h + ch * 4) = acc[NV + j];
       }
     }
   }

@@ -63,12 +63,8 @@ struct StepTail {
   int ent_lo, ent_hi, rel_lo, rel_hi;
   int32_t* ecnt;
   int N;
-  // The relation rows closed INSIDE the first launch (step1.hip): rdone[p] counts the finished unit waves of relation p (zero between
-  // steps: the wave that finishes the relation resets it); the closing launch then only has the relations without rows, the loss and
-  // the step state left.  null: the closing launch sums every relation's partial rows (rel_tail_kernel as before).
-  int32_t* rdone;
 };
-inline void step_tail_whole(StepTail& t, int N, int R) { t.ent_lo = 0; t.ent_hi = N; t.rel_lo = 0; t.rel_hi = R; t.ecnt = nullptr; t.N = N; t.rdone = nullptr; }
+inline void step_tail_whole(StepTail& t, int N, int R) { t.ent_lo = 0; t.ent_hi = N; t.rel_lo = 0; t.rel_hi = R; t.ecnt = nullptr; t.N = N; }
 
 struct PullPlan {
   int32_t* cnt;     // [NK]   contributions per key (key = entity id, or N + relation id)

@@ -60,7 +60,6 @@ struct Plan2 {
   int32_t* rrank;   // [n]  rank of triple t in its relation list (-1: invalid ids)
   int4* rentries;   // [n]  {s, o, t, 0}
   float* rslab;     // [max_units][d]
-  int32_t* rdone;   // [R] finished unit waves per relation (the relation rows closed inside step1_kernel); zero between steps
   int max_units;
   // entity side (same meaning as PullPlan, keys = entities only)
   PullPlan ent;
@@ -472,7 +471,7 @@ static int64_t plan_bytes(const Sizes& z) {
          b256(z.cap * 8) + b256(z.cap * 4) + 256 + b256(z.cap * 4) + b256(z.n * 4) * 2 + b256((z.n / 256 + 1) * 4) + b256(z.n * 16) + 512;
 }
 static int64_t scratch_bytes(const Sizes& z, int d_e) {
-  return b256(z.max_units * d_e * 4) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + b256(z.R * 4) + 512;
+  return b256(z.max_units * d_e * 4) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + 512;
 }
 
 int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n) {
@@ -529,7 +528,6 @@ static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Pla
   p->ent.coef = (float*)take(n * 4);
   p->ent.slab = (float*)take(2 * z.max_extra * md->d_e * 4);
   p->dd.uscore = (float*)take(n * 4);
-  p->rdone = (int32_t*)take(z.R * 4);  // (in the train workspace: zero-filled once at allocation, left zero by every step)
 }
 
 // kernels of pull.hip reused on the entity keys
@@ -761,8 +759,6 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     StepTail t = *tail;
     t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
     t.ecnt = p.ent.cnt; t.N = md->num_entities;
-    static const bool fused_tail = [] { const char* v = getenv("KGE_STEP_FUSED_TAIL"); return !v || atoi(v) != 0; }();  // (0: A/B timing)
-    t.rdone = fused_tail ? p.rdone : nullptr;
     const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
                         nullptr, p.rslab, seed, drop ? drop_thr(md->dropout) : 0u, drop ? 1.f / (1.f - md->dropout) : 1.f};
     return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, st);

@@ -105,48 +105,6 @@ __device__ __forceinline__ void tail_relation_row(const StepTail& t, const float
   }
 }
 
-// The same for ONE wave, inside the launch that produced the partial rows (step1.hip): the relation's last unit wave -- told by the value
-// its add to rdone[row] returned, behind its own write-through stores and s_waitcnt vmcnt(0) -- takes an agent-scope acquire, reads the
-// relation's nch partial rows with sc1 loads (other compute units, possibly other XCDs, stored them write-through), sums them in unit
-// order and applies the optimizer.  Deterministic: one wave, ascending unit order.
-__device__ __forceinline__ float4 load4_sc1_q(const float4* p) {
-  using v4 = __attribute__((ext_vector_type(4))) float;
-  v4 x;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x) : "v"(p) : "memory");
-  return make_float4(x.x, x.y, x.z, x.w);
-}
-__device__ __forceinline__ void tail_relation_row_wave(const StepTail& t, const float* __restrict__ Rel, int row, int nch, float lr) {
-  const int lane = threadIdx.x & 63;
-  const int d4 = t.d_r >> 2;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  for (int q0 = 0; q0 < d4; q0 += 64) {
-    const int q = q0 + lane;
-    if (q < d4) {
-      const float4* src = reinterpret_cast<const float4*>(t.rslab) + (int64_t)t.ruoff[row] * d4 + q;
-      const int64_t at = (int64_t)row * t.d_r + q * 4;
-      float4 w = *reinterpret_cast<const float4*>(Rel + at), m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
-      if (t.kind == KGE_OPT_ADAM_TF) { m = *reinterpret_cast<const float4*>(t.mR + at); v = *reinterpret_cast<const float4*>(t.vR + at); }
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-      int j = 0;
-      for (; j + 4 <= nch; j += 4) {  // four loads in flight, added in unit order
-        const float4 a = load4_sc1_q(src + (int64_t)j * d4), b = load4_sc1_q(src + (int64_t)(j + 1) * d4), c2 = load4_sc1_q(src + (int64_t)(j + 2) * d4),
-                     d = load4_sc1_q(src + (int64_t)(j + 3) * d4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        g = (((g + a) + b) + c2) + d;
-      }
-      for (; j < nch; ++j) {
-        const float4 a = load4_sc1_q(src + (int64_t)j * d4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        g = g + a;
-      }
-      tail_upd(t.kind, lr, t.b1, t.b2, t.eps, w, g, m, v);
-      *reinterpret_cast<float4*>(t.Rel_out + at) = w;
-      if (t.kind == KGE_OPT_ADAM_TF) { *reinterpret_cast<float4*>(t.mR + at) = m; *reinterpret_cast<float4*>(t.vR + at) = v; }
-    }
-  }
-  if (lane == 0) { t.rcnt[row] = 0; t.rdone[row] = 0; }
-}
-
 template <int MODEL, int NORM, int G, int NV, int VEC, bool DROP>
 __global__ __launch_bounds__(256) void pull_kernel(const float* __restrict__ E, const float* __restrict__ Rel,
                                                     float* __restrict__ gE, float* __restrict__ gR, int N, int NK, int d_e,

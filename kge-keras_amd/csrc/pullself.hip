@@ -34,11 +34,6 @@ __global__ __launch_bounds__(256) void rel_tail_kernel(StepTail t, const float* 
     if (threadIdx.x == 0) t.rcnt[blockIdx.x] = 0;
     return;
   }
-  if (t.rdone) {  // the first launch closed every relation that has rows; what is left here: the relations WITHOUT rows (Keras' Adam moves those too)
-    const int row = blockIdx.x;
-    const int c = (row + 1 < t.R ? t.roff[row + 1] : t.rtotal[1]) - t.roff[row];
-    if (c != 0) return;
-  }
   tail_relation_row(t, Rel, blockIdx.x);
 }
 

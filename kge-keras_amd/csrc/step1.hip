@@ -15,7 +15,7 @@
 namespace kge {
 
 template <int MODEL, int NORM, int LOSS, int NV, int G, bool DROP>
-__global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, float* __restrict__ loss_partials, int rel_blocks, int R, StepTail tt) {
+__global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, float* __restrict__ loss_partials, int rel_blocks, int R) {
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   __shared__ float4 selfrow[4][NACC * G];
   __shared__ float red[16];
@@ -29,24 +29,7 @@ __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, 
   const int unit = blockIdx.x * 4 + wave;
   float lsum = 0.f;
   int len, c;
-  if (unit < fa.rtotal[0] && rel_in_window(fa, unit)) {
-    if (tt.rdone) {
-      // Round 4: the relation's rows are closed inside this launch.  The partial row leaves write-through; behind s_waitcnt vmcnt(0) the
-      // wave counts itself done; the wave whose add completes the relation's units sums the partial rows and applies the optimizer
-      // (tail_relation_row_wave) while the entity half of the launch is still running -- rel_tail_kernel's ~10 us per step and one
-      // launch gap are gone from the step's chain.  No release fence anywhere (round 2's ticket version paid an L2 write-back per unit
-      // wave: 265 us): the stores are sc1, the one consumer per relation takes an agent-scope acquire and reads with sc1 loads.
-      const int p = fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP, G, true>(fa, unit, R, lsum, &len, &c);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int old = 0;
-      if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(tt.rdone + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      old = __builtin_amdgcn_readfirstlane(old);
-      const int nch = rel_units(c);
-      if (old + 1 == nch) tail_relation_row_wave(tt, fa.Rel, p, nch, sa.lr_state ? sa.lr_state[0] : sa.lr);
-    } else {
-      fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP, G>(fa, unit, R, lsum, &len, &c);
-    }
-  }
+  if (unit < fa.rtotal[0] && rel_in_window(fa, unit)) fwd_rel_unit<MODEL, NORM, LOSS, NV, DROP, G>(fa, unit, R, lsum, &len, &c);
   const float b = block_sum(lsum, red);
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = b;
 }
@@ -56,10 +39,10 @@ __global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, 
 // DistMult 65.7 us on 16 lanes (93 VGPRs, 5 waves per SIMD) against 67.2 us on 32 (59 VGPRs, 8 waves: the launch is bound by the
 // fabric, not by occupancy); TransE-L2 91.6 us (98 VGPRs, 4 waves) against 75.4 us.  So: DistMult 16 lanes, the others 32.
 template <int MODEL, int NORM, int LOSS>
-static void launch_step1_nv(int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R, const StepTail& tt) {
+static void launch_step1_nv(int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
   const bool drop = fa.thr != 0u;
-#define KGE_S1(NVV, GW) do { if (drop) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, true>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R, tt); \
-                             else hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, false>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R, tt); } while (0)
+#define KGE_S1(NVV, GW) do { if (drop) hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, true>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R); \
+                             else hipLaunchKernelGGL((step1_kernel<MODEL, NORM, LOSS, NVV, GW, false>), dim3(grid), dim3(256), 0, st, fa, sa, lp, rb, R); } while (0)
   if (nchunk <= 16) KGE_S1(1, 16);
   else if (nchunk <= 32) KGE_S1(2, 16);
   else if (MODEL == KGE_DISTMULT) KGE_S1(4, 16);
@@ -67,11 +50,11 @@ static void launch_step1_nv(int nchunk, int grid, hipStream_t st, const FwdRelAr
 #undef KGE_S1
 }
 template <int MODEL, int NORM>
-static void launch_step1(int loss, int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R, const StepTail& tt) {
-  if (loss == KGE_POINTWIZE_HINGE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_HINGE>(nchunk, grid, st, fa, sa, lp, rb, R, tt);
-  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nchunk, grid, st, fa, sa, lp, rb, R, tt);
-  else if (loss == KGE_POINTWIZE_SQUARE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nchunk, grid, st, fa, sa, lp, rb, R, tt);
-  else launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nchunk, grid, st, fa, sa, lp, rb, R, tt);
+static void launch_step1(int loss, int nchunk, int grid, hipStream_t st, const FwdRelArgs& fa, const SelfArgs& sa, float* lp, int rb, int R) {
+  if (loss == KGE_POINTWIZE_HINGE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_HINGE>(nchunk, grid, st, fa, sa, lp, rb, R);
+  else if (loss == KGE_POINTWIZE_LOGISTIC) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_LOGISTIC>(nchunk, grid, st, fa, sa, lp, rb, R);
+  else if (loss == KGE_POINTWIZE_SQUARE) launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_SQUARE>(nchunk, grid, st, fa, sa, lp, rb, R);
+  else launch_step1_nv<MODEL, NORM, KGE_POINTWIZE_CROSS_ENTROPY>(nchunk, grid, st, fa, sa, lp, rb, R);
 }
 
 int rel_tail_launch(const StepTail& t, const float* Rel, const LossFinish& lf, hipStream_t st);  // pullself.hip
@@ -92,11 +75,11 @@ int step1_launch(const kge_model_desc* md, const kge_loss_desc* ld, const FwdRel
   const int grid = rel_blocks + (int)cdiv(sa.row_n + e.max_extra, 4);  // (row_n: the rows of the step's entity window; all of them by default)
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
-    if (md->model == KGE_DISTMULT) launch_step1<KGE_DISTMULT, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R, tail);
-    else if (md->model == KGE_COMPLEX) launch_step1<KGE_COMPLEX, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R, tail);
-    else if (md->norm == 1) launch_step1<KGE_TRANSE, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R, tail);
-    else if (md->norm == 3) launch_step1<KGE_TRANSE, 3>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R, tail);
-    else launch_step1<KGE_TRANSE, 2>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R, tail);
+    if (md->model == KGE_DISTMULT) launch_step1<KGE_DISTMULT, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else if (md->model == KGE_COMPLEX) launch_step1<KGE_COMPLEX, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else if (md->norm == 1) launch_step1<KGE_TRANSE, 1>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else if (md->norm == 3) launch_step1<KGE_TRANSE, 3>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
+    else launch_step1<KGE_TRANSE, 2>(ld->loss, fa.nchunk, grid, st, fa, sa, loss_partials, rel_blocks, tail.R);
   }
   KGE_HIP_TRY(hipGetLastError());
   const LossFinish lf{loss_partials, rel_blocks, loss_out, adv};
