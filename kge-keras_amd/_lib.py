@@ -16,7 +16,7 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
         "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
 lib = C.CDLL(LIB_PATH)
-ABI_VERSION = 9  # KGE_ABI_VERSION of include/kge_hip.h this binding was written against (struct layouts, argument lists, the 24-byte step state)
+ABI_VERSION = 10  # KGE_ABI_VERSION of include/kge_hip.h this binding was written against (struct layouts, argument lists, the 24-byte step state)
 lib.kge_abi_version.restype = C.c_int
 if lib.kge_abi_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {lib.kge_abi_version()}, this binding needs {ABI_VERSION}: rebuild the library "
@@ -119,6 +119,8 @@ SIGNATURES = {
     "kge_train_step_swap_supported": (C.c_int, [_MD, _LD, _OD]),
     "kge_train_step_swap": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
     "kge_train_step_swap_window": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P, _P]),
+    "kge_train_step_swap_chain": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I64, _P]),
+    "kge_train_step_swap_flush": (C.c_int, [_MD, _LD, _OD, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_set_dedup_mode": (C.c_int, [C.c_int]),

@@ -31,6 +31,9 @@ struct FwdRelArgs {
   float* coef; float* scores; float* rslab;
   uint64_t seed; uint32_t thr; float dscale;
   int rel_lo = 0, rel_hi = 0x7fffffff;  // relation window of an owner-computes step (kge_train_step_swap_window): units of other relations are skipped
+  // chained steps (StepChain, pull.hpp): the relation rows are being written by this launch's closers -- wait for gate[0] >= gate_need
+  // before the first read of one; the rows of a relation come from the list starts (the counters are cleared by this very launch)
+  const uint32_t* gate = nullptr; uint32_t gate_need = 0; uint32_t* gate_to = nullptr; int gate_R = 0;
 };
 
 __device__ __forceinline__ bool rel_in_window(const FwdRelArgs& a, int unit) {
@@ -63,12 +66,16 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
   (void)hc; (void)seed; (void)thr; (void)dscale;
   const int2 pc = rumap[unit];
   const int p = pc.x;
-  const int c = a.rcnt[p];
+  const int c = a.gate ? (p + 1 < a.gate_R ? roff[p + 1] : a.rtotal[1]) - roff[p] : a.rcnt[p];
   const int chunk = rel_chunk_rows(c);
   const int start = roff[p] + pc.y * chunk;
   const int len = min(chunk, c - pc.y * chunk);
   const float* rp = Rel + (int64_t)p * d_e;
   float4 pv[NA], acc[NA];
+  // the first entry is fetched in front of the gate of a chained step (it does not depend on the relation rows)
+  int4 e_nx = make_int4(0, 0, 0, 0);
+  if (sub < len) e_nx = rentries[start + sub];
+  if (a.gate) rel_gate_wait(a.gate, a.gate_need, a.gate_to);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int ch = lane + j * G;
@@ -77,8 +84,6 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
     if (MODEL == KGE_COMPLEX) { pv[NV + j] = ch < nchunk ? *reinterpret_cast<const float4*>(rp + h + ch * 4) : f4(0.f); acc[NV + j] = f4(0.f); }
   }
   // the next entry is fetched while this one's rows are gathered and multiplied (entry -> rows is a dependent load per round otherwise)
-  int4 e_nx = make_int4(0, 0, 0, 0);
-  if (sub < len) e_nx = rentries[start + sub];
   for (int i = sub; i < len; i += 64 / G) {
     const int4 e = e_nx;
     if (i + 64 / G < len) e_nx = rentries[start + i + 64 / G];

@@ -105,6 +105,27 @@ __device__ __forceinline__ void step_advance(const StepAdvance& a, float loss) {
   step_state_loss(a.step)[0] += (double)loss;
 }
 
+// The gate of a chained step (StepChain, pull.hpp): `ready` is 64 words on 64 cache lines, all set to the launch's token by the state
+// workgroup once every closer has stored its row; a wave polls the line of its workgroup with relaxed agent-scope loads (they bypass
+// the caches) until it reads the token.  No wave reads a relation row in front of its gate, and the caches were invalidated when
+// the launch began, so behind the gate plain loads see the closers' write-through stores.  Bounded: closers and the state workgroup are
+// the first workgroups of the grid and wait for no reader, so the token always arrives -- if it does not (a fault), the wave carries on
+// and the flush reports it.
+constexpr int kGateLines = 64, kGateStride = 32;  // words
+__device__ __forceinline__ void rel_gate_wait(const uint32_t* ready, uint32_t need, uint32_t* timeouts) {
+  const uint32_t* line = ready + (blockIdx.x & (kGateLines - 1)) * kGateStride;
+  uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  if (v < need) {
+    int spins = 0;
+    do {
+      __builtin_amdgcn_s_sleep(4);
+      v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } while (v < need && ++spins < (1 << 16));
+    if (v < need && (threadIdx.x & 63) == 0) atomicAdd(timeouts, 1u);
+  }
+  asm volatile("" ::: "memory");
+}
+
 // One extra workgroup of the pull launch reduces the forward's loss partials (fixed order) and advances the step state, when the
 // step has no finish kernel to do it (OptFinish, pull.hpp).
 struct LossFinish { const float* partials; int n; float* loss_out; StepAdvance adv; };

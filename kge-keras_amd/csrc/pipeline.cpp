@@ -87,6 +87,8 @@ struct Pipeline {
   bool arrays = false;             // batches as plain oversampled arrays (dropout): no folded form, plan from the arrays
   uint64_t seed = 0;               // arrays: dropout seed of the last step issued (kge_pipeline_set_seed)
   bool swap = false;               // steps alternate between the caller's tables and their twins (kge_train_step_swap)
+  bool chain = false;              // ... as chained steps (kge_train_step_swap_chain: one launch per step); KGE_PIPE_CHAIN=0 keeps the two-launch step
+  int64_t chain_seq = 0;           // steps issued in the running chain (a chain lives inside one kge_pipeline_run)
   int parity = 0;                  // swap: 1 = the current tables are the twins
   int stage_mask = 15;  // experiments only (KGE_PIPE_STAGES): bit s clear = stage s is not launched (its events still are recorded)
 };
@@ -150,6 +152,9 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
       if (p->swap) {  // (the caller moves the parity on; lr_t of the update comes from the device-resident step state)
         const int q = p->parity;
         const int parts = 3;
+        if (p->chain)  // one launch per step: the relation rows of a step are closed inside the next step's launch (kge_pipeline_run ends the chain)
+          return kge_train_step_swap_chain(&d.md, &d.ld, &d.od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin,
+                                           plan_buf, d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, p->chain_seq++, st);
         return kge_train_step_swap(&d.md, &d.ld, &d.od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, plan_buf,
                                    d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, parts, st);
       }
@@ -233,21 +238,26 @@ int produce(Pipeline* p, int64_t k) {
   }
   const int pj = (int)(k % p->np);
   KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->planned[(int)((k + p->np - 2) % p->np)], 0));  // (still the record behind plan k-2: its candidate buffers are free)
-  if (int rc = launch(p, DRAW, j, p->s_draw, k)) return rc;
-  KGE_PIPE_TRY(hipEventRecord(p->ready[j], p->s_draw));
-  KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->ready[j], 0));
-  if (p->graphs) {
-    KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->pfreed[pj], 0));  // (the step that consumed this plan buffer: k-2)
-  } else if (k - p->np >= 0) {  // the first record at or behind step k - np (see Pipeline::rec_every)
+  if (!p->graphs && k - p->np >= 0) {
+    // the first record at or behind step k - np (see Pipeline::rec_every): the step that consumed the plan buffer of batch k.  The DRAW
+    // stream waits for it (it has half a step of slack per batch) and the plan, which waits for the draw, is ordered behind it that way:
+    // one barrier packet less on the plan stream, which paces the pipeline once the step is a single launch.
     const int64_t need = k - p->np;
     const int64_t first = std::max<int64_t>(0, p->n_recs - Pipeline::kRecs);
     bool found = false;
     for (int64_t r = first; r < p->n_recs && !found; ++r)
-      if (p->recs[r % Pipeline::kRecs].step >= need) { KGE_PIPE_TRY(hipStreamWaitEvent(p->s_plan, p->recs[r % Pipeline::kRecs].ev, 0)); found = true; }
+      if (p->recs[r % Pipeline::kRecs].step >= need) { KGE_PIPE_TRY(hipStreamWaitEvent(p->s_draw, p->recs[r % Pipeline::kRecs].ev, 0)); found = true; }
     if (!found) return fail(KGE_EINVAL, "kge_pipeline: no record of step %lld for the plan of batch %lld (internal)", (long long)need, (long long)k);
   }
-  if (int rc = launch(p, PLAN, p->graphs ? j : (j | (pj << 4)), p->s_plan, k)) return rc;
-  KGE_PIPE_TRY(hipEventRecord(p->planned[pj], p->s_plan));
+  if (int rc = launch(p, DRAW, j, p->s_draw, k)) return rc;
+  KGE_PIPE_TRY(hipEventRecord(p->ready[j], p->s_draw));
+  hipStream_t s_plan = p->s_plan;
+  KGE_PIPE_TRY(hipStreamWaitEvent(s_plan, p->ready[j], 0));
+  if (p->graphs) {
+    KGE_PIPE_TRY(hipStreamWaitEvent(s_plan, p->pfreed[pj], 0));  // (the step that consumed this plan buffer: k-2)
+  }
+  if (int rc = launch(p, PLAN, p->graphs ? j : (j | (pj << 4)), s_plan, k)) return rc;
+  KGE_PIPE_TRY(hipEventRecord(p->planned[pj], s_plan));
   return KGE_OK;
 }
 
@@ -335,6 +345,7 @@ int kge_pipeline_create(const kge_pipeline_desc* desc, kge_stream_t stream, void
   // (with dropout the twin step is available but measured slower than the three-launch step -- 0.46 against 0.39 ms per step at the
   // bench shape, where nothing is folded: 409 600 rows, three masks per element and entry in a kernel that is already register bound)
   p->swap = !d.comm && d.E_twin && !p->graphs && d.md.dropout == 0.f && kge_train_step_swap_supported(&d.md, &d.ld, &d.od) == 1;
+  { const char* e = std::getenv("KGE_PIPE_CHAIN"); p->chain = p->swap && !(e && std::atoi(e) == 0); }
   if (d.comm) p->graphs = false;  // (a collective never sits inside a captured graph)
   p->dp_halves = d.comm && kge_train_grads_halves_supported(&d.md, &d.ld) == 1;
   if (const char* e = std::getenv("KGE_PIPE_DP_HALVES")) { if (std::atoi(e) == 0) p->dp_halves = false; }  // (tests run both forms)
@@ -492,6 +503,7 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
   if (const char* e = std::getenv("KGE_PIPE_STAGES")) p->stage_mask = std::atoi(e) & 15;  // (experiments: may change between calls)
   const double t_in = now_ns();
   int rc = KGE_OK;
+  p->chain_seq = 0;
   for (int64_t i = 0; i < n_steps && rc == KGE_OK; ++i) {
     const int j = (int)(p->t % p->np);
     if (hipStreamWaitEvent(main_st, p->planned[j], 0) != hipSuccess) { rc = fail(KGE_EHIP, "kge_pipeline_run: hipStreamWaitEvent failed"); break; }
@@ -510,6 +522,16 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
       p->last_rec_step = step;
     }
     rc = produce(p, p->t + 1);
+  }
+  // the end of the chain: the last step issued is closed (its relation rows, loss, step state) -- also after a failure half way
+  if (p->chain && p->chain_seq > 0) {
+    const kge_pipeline_desc& d = p->d;
+    const int q = p->parity ^ 1;  // the parity the last step ran with
+    const int64_t m = d.B * d.ns;
+    const int frc = kge_train_step_swap_flush(&d.md, &d.ld, &d.od, q ? d.Rel_twin : d.Rel, q ? d.Rel : d.Rel_twin, m, m, d.loss_out, d.train_ws, d.train_ws_bytes,
+                                              p->chain_seq - 1, d.err_flag, main_st);
+    if (frc != KGE_OK && rc == KGE_OK) rc = frc;
+    p->chain_seq = 0;
   }
   // the caller reads (E, Rel) -- also after a failure half way: the steps issued so far must not be left in the twins
   if (p->swap && p->parity) {

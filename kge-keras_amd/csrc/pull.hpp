@@ -41,6 +41,27 @@ struct OptFinish {
 // the optimizer to that row -- parameters read from the step's input tables, written to the twin tables (every other wave still
 // gathers the OLD rows), moments in place -- so neither a gradient table nor an optimizer sweep exists.  lr_t of the update: read from
 // the device-resident step state when the whole step is one call (lr_state / lr_slot), by value (lr_t) when its halves are issued apart.
+// Chained steps (kge_train_step_swap_chain; step1.hip): the closing launch of a step costs ~10 us + a ~7 us kernel boundary on the step
+// stream for ~1 us of work, so inside a run of steps the relation rows of step i are closed by the FIRST workgroups of step i+1's
+// launch ("closers": one per relation row, + one "state" workgroup for the loss and the step state), and every other wave of that
+// launch waits at a gate before its first read of a relation row.  The gate has no atomics and no word that many waves write or that
+// everybody polls: closer r stores the launch's token into its own word flags[r]; the state workgroup -- the only poller of those --
+// sees all R of them and stores the token into 64 words on 64 cache lines; a reader polls one of the 64 (its workgroup's).  (A first
+// version counted one word up with R atomics and let every wave poll that word: 0.140 ms per step against 0.100 without a chain.)
+// Nothing else crosses
+// workgroups inside a launch: partial rows, loss partials, the relation lists' bounds and lr_t all travel from launch i to launch
+// i+1 in buffers picked by the parity of i, i.e. across a kernel boundary.  The chain ends with kge_train_step_swap_flush.
+struct StepChain {
+  uint32_t* flags;      // [R] token of the launch in which the closer of relation r last stored its row (null: not chained)
+  uint32_t* ready;      // [64 lines] the gate: the token once all closers of the launch have stored (kge_internal.hpp: rel_gate_wait)
+  uint32_t* timeouts;   // [1] gate waits that gave up (a fault, reported by the flush)
+  float* lr_ring;       // [4] lr_t of update seq in slot seq & 3
+  float* partials[2];   // loss partials of step seq in [seq & 1]
+  float* slab[2];       // partial relation rows of step seq in [seq & 1]
+  int32_t* relmeta[2];  // [2R] {first unit, rows} of every relation of step seq in [seq & 1]
+  int64_t seq;          // number of this step in the chain (0: nothing to close)
+};
+
 struct StepTail {
   int kind;                    // KGE_OPT_SGD | KGE_OPT_ADAM_TF
   float *E_out, *mE, *vE;      // entity side (E_in is the kernels' E)
@@ -63,6 +84,7 @@ struct StepTail {
   int ent_lo, ent_hi, rel_lo, rel_hi;
   int32_t* ecnt;
   int N;
+  StepChain ch;                // ch.flags non-null: a chained step
 };
 inline void step_tail_whole(StepTail& t, int N, int R) { t.ent_lo = 0; t.ent_hi = N; t.rel_lo = 0; t.rel_hi = R; t.ecnt = nullptr; t.N = N; }
 

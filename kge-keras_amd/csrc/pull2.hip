@@ -60,6 +60,9 @@ struct Plan2 {
   int32_t* rrank;   // [n]  rank of triple t in its relation list (-1: invalid ids)
   int4* rentries;   // [n]  {s, o, t, 0}
   float* rslab;     // [max_units][d]
+  float* rslab2;    // chained steps (StepChain): the slab of the odd steps, and {first unit, rows} of every relation by step parity
+  int32_t* relmeta[2];
+  uint32_t *gate_flags, *gate_ready;
   int max_units;
   // entity side (same meaning as PullPlan, keys = entities only)
   PullPlan ent;
@@ -363,6 +366,29 @@ __global__ __launch_bounds__(256) void ent_fill_kernel(Src src, int64_t n, const
 
 
 
+// Both fills in one launch (a plan built in one piece): one load of the row, one kernel boundary less on the plan stream.
+__global__ __launch_bounds__(256) void fill_both_kernel(Src src, int64_t n, const int32_t* __restrict__ roff, const int32_t* __restrict__ rrank,
+                                                         int4* __restrict__ rentries, float* __restrict__ scores, uint32_t* __restrict__ err,
+                                                         const int32_t* __restrict__ off, const int32_t* __restrict__ erank, int4* __restrict__ entries) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= src_rows(src)) return;
+  const int r = rrank[t];
+  const int r0 = erank[t];
+  if (r == -2 && r0 < 0) return;  // a candidate row nobody picked (multiplicity 0)
+  if (r == -1) {  // ids outside the tables: the row takes no part in the step, scores NaN, error flag raised
+    if (scores) scores[t] = __builtin_nanf("");
+    atomicOr(err, 1u);
+  }
+  if (r < 0 && r0 < 0) return;
+  int s, p, o, w;
+  src_load(src, t, s, p, o, w);
+  if (r >= 0) rentries[roff[p] + r] = make_int4(s, o, (int)t, w);
+  if (r0 >= 0) {
+    entries[off[s] + r0] = make_int4(p, o, w, (int)t);
+    entries[off[o] + erank[n + t]] = make_int4(p | (int)0x80000000, s, w, (int)t);
+  }
+}
+
 // gR[p] += sum of the relation's slab rows (one workgroup per relation)
 // Also: leaves rcnt all-zero for the next step (the workspace is self-cleaning; it is zeroed once at allocation), and the
 // extra last block reduces the forward's loss partials (fixed order) into *loss_out.
@@ -471,7 +497,8 @@ static int64_t plan_bytes(const Sizes& z) {
          b256(z.cap * 8) + b256(z.cap * 4) + 256 + b256(z.cap * 4) + b256(z.n * 4) * 2 + b256((z.n / 256 + 1) * 4) + b256(z.n * 16) + 512;
 }
 static int64_t scratch_bytes(const Sizes& z, int d_e) {
-  return b256(z.max_units * d_e * 4) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + 512;
+  return b256(z.max_units * d_e * 4) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + 512 +
+         b256(z.max_units * d_e * 4) + 2 * b256(2 * z.R * 4) + b256(z.R * 4) + b256(64 * 128);  // chained steps: second slab of partial relation rows, two relation-bounds tables, the gate
 }
 
 int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n) {
@@ -528,6 +555,11 @@ static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Pla
   p->ent.coef = (float*)take(n * 4);
   p->ent.slab = (float*)take(2 * z.max_extra * md->d_e * 4);
   p->dd.uscore = (float*)take(n * 4);
+  p->rslab2 = (float*)take(z.max_units * md->d_e * 4);
+  p->relmeta[0] = (int32_t*)take(2 * z.R * 4);
+  p->relmeta[1] = (int32_t*)take(2 * z.R * 4);
+  p->gate_flags = (uint32_t*)take(z.R * 4);
+  p->gate_ready = (uint32_t*)take(64 * 128);
 }
 
 // kernels of pull.hip reused on the entity keys
@@ -726,8 +758,12 @@ static int plan_build(const kge_model_desc* md, const int32_t* pos, int64_t m_po
     }
     else if (parts & 2) pull2_entity_plan(p.ent, N, st);
     else hipLaunchKernelGGL(rel_plan_kernel, dim3(1), dim3(256), 0, st, p.rcnt, R, p.roff, p.ruoff, p.rtotal, p.rumap, p.max_units);
-    if (parts & 4) hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
-    if (parts & 2) hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.off, p.erank, p.ent.entries);
+    if ((parts & 6) == 6) {
+      hipLaunchKernelGGL(fill_both_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.roff, p.rrank, p.rentries, scores, err, p.ent.off, p.erank, p.ent.entries);
+    } else {
+      if (parts & 4) hipLaunchKernelGGL(rel_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, p.roff, p.rrank, p.rentries, scores, err);
+      if (parts & 2) hipLaunchKernelGGL(ent_fill_kernel, dim3(tgrid), dim3(256), 0, st, src, n, p.ent.off, p.erank, p.ent.entries);
+    }
   }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;
@@ -755,10 +791,16 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
   static const bool one_launch = [] { const char* v = getenv("KGE_STEP1"); return !v || atoi(v) != 0; }();
   const bool windowed = self && (tail->ent_lo != 0 || tail->ent_hi != md->num_entities || tail->rel_lo != 0 || tail->rel_hi != R);
   if (windowed && !(tail->parts == 3 && one_launch)) return fail(KGE_EUNSUPPORTED, "a row window needs the whole step in one call (parts = 3) on the one-launch path (KGE_STEP1 unset)");
+  if (self && tail->ch.timeouts && !(tail->parts == 3 && one_launch)) return fail(KGE_EUNSUPPORTED, "chained steps need the whole step in one call on the one-launch path (KGE_STEP1 unset)");
   if (self && tail->parts == 3 && one_launch) {
     StepTail t = *tail;
     t.roff = p.roff; t.rtotal = p.rtotal; t.ruoff = p.ruoff; t.rslab = p.rslab; t.rcnt = p.rcnt; t.R = R; t.d_r = md->d_r;
     t.ecnt = p.ent.cnt; t.N = md->num_entities;
+    if (t.ch.timeouts) {
+      if (windowed) return fail(KGE_EUNSUPPORTED, "chained steps take no row window");
+      t.ch.slab[0] = p.rslab; t.ch.slab[1] = p.rslab2; t.ch.relmeta[0] = p.relmeta[0]; t.ch.relmeta[1] = p.relmeta[1];
+      t.ch.flags = p.gate_flags; t.ch.ready = p.gate_ready;
+    }
     const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
                         nullptr, p.rslab, seed, drop ? drop_thr(md->dropout) : 0u, drop ? 1.f / (1.f - md->dropout) : 1.f};
     return step1_launch(md, ld, fa, fgrid, p.ent, t, loss_partials, loss_out, adv, st);
@@ -873,6 +915,21 @@ int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const
   carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
   const Src src{nullptr, m_pos, nullptr, m_neg, p.dd.uniq, p.dd.nu};
   return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv, finish, tail, grad_parts);
+}
+
+// step1.hip
+int chain_flush_launch(const StepTail& tail, const float* Rel_in, int rel_blocks, float* loss_out, const StepAdvance& adv, uint32_t* err, hipStream_t st);
+// The end of a chain of steps (kge_train_step_swap_flush): closes step tail.ch.seq, whose relation rows go Rel_in -> tail.Rel_out.
+int train_chain_flush(const kge_model_desc* md, const float* Rel_in, int64_t m_pos, int64_t m_neg, float* loss_out, void* ws, const StepAdvance& adv,
+                      const StepTail& tail, uint32_t* err, hipStream_t st) {
+  const int64_t n = m_pos + m_neg;
+  Plan2 p;
+  carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
+  StepTail t = tail;
+  t.R = md->num_relations; t.d_r = md->d_r;
+  t.ch.slab[0] = p.rslab; t.ch.slab[1] = p.rslab2; t.ch.relmeta[0] = p.relmeta[0]; t.ch.relmeta[1] = p.relmeta[1];
+  t.ch.flags = p.gate_flags; t.ch.ready = p.gate_ready;
+  return chain_flush_launch(t, Rel_in, (int)cdiv(sizes_of(md, n).max_units, 4), loss_out, adv, err, st);
 }
 
 }  // namespace kge

@@ -50,13 +50,17 @@ __device__ __forceinline__ float4 shx(float4 v, int off) {
 // One wave per unit.  Lane l of a G-lane sub-group owns chunks l, l+G, ... (NV of them) of the row (of each HALF row for
 // ComplEx); the 64/G sub-groups of the wave take different list entries and meet in a shuffle reduction at the end.
 // Optimizer update of one float4 / float of a row (the expressions of train.hip's opt_sweep, gscale = 1, no L3 term).
+// Every fused multiply-add is spelled out and the compiler's own contraction is off: left to itself it fuses different products in the
+// copies of this function inlined into different kernels (rel_tail_kernel, the closers of a chained step, the flush: one ulp apart
+// on a few elements), and the rows of a step must not depend on which launch happens to close them.
 __device__ __forceinline__ void tail_upd(int kind, float lr, float b1, float b2, float eps, float& w, float g, float& m, float& v) {
+#pragma clang fp contract(off)
   if (kind == KGE_OPT_ADAM_TF) {
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
-    w -= lr * m / (sqrtf(v) + eps);
+    m = __fmaf_rn(b1, m, (1.f - b1) * g);
+    v = __fmaf_rn(b2, v, ((1.f - b2) * g) * g);
+    w = w - (lr * m) / (sqrtf(v) + eps);
   } else {
-    w -= lr * g;
+    w = __fmaf_rn(-lr, g, w);
   }
 }
 __device__ __forceinline__ void tail_upd(int kind, float lr, float b1, float b2, float eps, float4& w, float4 g, float4& m, float4& v) {

@@ -306,7 +306,11 @@ class EmbeddingModel:
         return out
 
     def _raise_on_flag(self):
-        if int(self._err.item()) != 0:
+        flag = int(self._err.item())
+        if flag & 32:  # (kge_train_step_swap_flush: bounded gate waits of chained steps -- a device fault, never a data error)
+            self._err.zero_()
+            raise RuntimeError("chained training steps: a wave gave up waiting for the relation rows of the previous step (device fault); the tables are not to be trusted")
+        if flag != 0:
             self._err.zero_()
             raise IndexError("triple ids out of range of the embedding tables (indices[...] is not in [0, N))")
 

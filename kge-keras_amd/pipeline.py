@@ -80,7 +80,7 @@ class TrainPipeline:
         # Python loop also uses when it takes an epoch over from the driver (batch k sits in plans[k % self._np])
         # (four to six buffers, with "plan consumed" recorded behind every (buffers - 2)-th step only, measured slower at the bench shape:
         # 0.0999 ms per step with 3, 0.1005 with 4, 0.102 with 5, 0.104 with 6 -- profiles/r03_experiments.txt -- so three it is)
-        n_plans = 3
+        n_plans = 4  # (the step records "plan consumed" every second step then: pipeline.cpp rec_every; 3 -> 4 measured 0.1017 -> 0.0987 ms per step with chained steps)
         self.plans = [BatchPlan(torch.zeros(int(need), dtype=torch.uint8, device=self.dev), m, m) for _ in range(n_plans)]
         self._np = 2
         self.index = torch.zeros(int(n_rows), dtype=torch.int64, device=self.dev)   # epoch permutation (tests.py:50-53)

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import oracle as O
-from tols import TOL_W, TOL_L, TOL_LA
+from tols import TOL_W, TOL_L, TOL_LA, assert_tables
 
 pytestmark = pytest.mark.gpu
 
@@ -77,8 +77,8 @@ def test_adam_gradients_between_1e_7_and_1e_5_pin_epsilon(form):
         Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
         Eg = mdl.E.cpu().numpy()
-        np.testing.assert_allclose(Eg, Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(Eg, Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
         if step == 0:
             assert np.max(np.abs(Eg - E_w1)) > 1e-4 and np.max(np.abs(Eg - E_w2)) > 1e-5
     mdl._raise_on_flag()
@@ -145,8 +145,8 @@ def test_adam_row_touched_once_among_409600(form):
         Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
         Eg = mdl.E.cpu().numpy()
-        np.testing.assert_allclose(Eg, Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(Eg, Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
         moved = np.abs(Eg[lone].astype(np.float64) - E0[lone])
         if step == 0:
             assert moved.max() > 2e-5 and moved.max() < 1e-3         # it moved, by ~316 g

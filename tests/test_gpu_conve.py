@@ -7,7 +7,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, assert_tables  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 
 def _mk(N, R, d, seed=0, **kw):
@@ -65,8 +65,8 @@ def test_conve_train_step_parity(loss, opt, dp, hdp):
         Lo, sp, sn = O.conve_train_step(Po, Eo, Ro, oo, pos, neg, loss, 0.5, 1, dp, hdp, seed=mdl._seed)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
         got = mdl.get_head_params()
         for k in ("K", "g1", "b1", "Wd", "g2", "b2", "mm1", "mv1", "mm2", "mv2"):
             np.testing.assert_allclose(got[k], Po[k], atol=2e-4, rtol=1e-3, err_msg=k)
@@ -151,8 +151,8 @@ def test_conve_general_shape_train_step_parity(shape, dp, hdp):
         Lo, sp, sn = O.conve_train_step(Po, Eo, Ro, oo, pos, neg, "pointwize_logistic", 0.5, 1, dp, hdp, seed=mdl._seed)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
         got = mdl.get_head_params()
         for k in ("K", "g1", "b1", "Wd", "g2", "b2", "mm1", "mv1", "mm2", "mv2"):
             np.testing.assert_allclose(got[k], Po[k], atol=2e-4, rtol=1e-3, err_msg=k)

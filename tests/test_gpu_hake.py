@@ -11,7 +11,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA, TOL_W_LONG, TOL_L_BIG  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, TOL_W_LONG, TOL_L_BIG, assert_tables  # noqa: E402  (tests/tols.py: what each constant bounds)
 LOSSES = ["pointwize_hinge", "pointwize_logistic", "pointwize_square_loss", "pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"]
 
 
@@ -87,8 +87,8 @@ def test_hake_train_step_parity(loss, opt):
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step("HAKE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, prm, 12)
         assert L == pytest.approx(Lo, rel=TOL_L_BIG, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
 
 
@@ -103,8 +103,8 @@ def test_hake_dropout_regulariser_and_unequal_sides():
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("HAKE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, prm, 12, regularization=1e-3, dropout=0.3, seed=mdl._seed)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     # val_loss: no dropout, no update
     before = mdl.E.clone()
     pos, neg = _triples(rs, 50, N, R), _triples(rs, 50, N, R)

@@ -8,7 +8,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, assert_tables  # noqa: E402  (tests/tols.py: what each constant bounds)
 N, R, D = 10_800_000, 7, 200
 
 
@@ -57,8 +57,8 @@ def test_train_step_on_a_table_past_2_31_elements(path):
         Lo = O.train_step("DistMult", Ec, Ro, oo, _remap(pos, m), _remap(neg, m), "pointwize_logistic", 1.0, 1)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
         got = mdl.E.index_select(0, torch.from_numpy(hot).cuda()).cpu().numpy()
-        np.testing.assert_allclose(got, Ec, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(got, Ec)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     mdl._raise_on_flag()
     # rows nobody touched did not move (dense Adam: m = v = 0 there) -- spot check on both sides of the mark
     probe = torch.tensor([1, 12345, 2**31 // D + 7, N - 2], device="cuda")
@@ -131,6 +131,6 @@ def test_list_offsets_of_a_table_of_many_tiles(path):
         L = float(mdl.train_step(data)["loss"].item())
         Lo = O.train_step("DistMult", Ec, Ro, oo, _remap(pos, m), _remap(neg, m), loss, 1.0, 1)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
-        np.testing.assert_allclose(mdl.E.index_select(0, torch.from_numpy(hot).cuda()).cpu().numpy(), Ec, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.index_select(0, torch.from_numpy(hot).cuda()).cpu().numpy(), Ec)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     mdl._raise_on_flag()

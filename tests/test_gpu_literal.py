@@ -7,7 +7,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA, TOL_W_LONG, TOL_L_BIG  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, TOL_W_LONG, TOL_L_BIG, assert_tables  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 
 def _mk(model, N, R, d, L, act, seed=0, **kw):
@@ -89,11 +89,11 @@ def test_literal_under_protate_and_general_p_norm(model, kw, dp):
         Lr, sp, sn = O.literal_train_step(model, Ho, "tanh", Eo, Ro, Lo, oo, pos, neg, "pointwize_logistic", 0.5, 1, norm, gamma, dropout=dp, seed=mdl._seed)
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
         assert L_ == pytest.approx(Lr, rel=TOL_L, abs=TOL_LA), (step, L_, Lr)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
         W, b = mdl.get_literal_dense()
-        np.testing.assert_allclose(W, Ho["W"], atol=TOL_W)
-        np.testing.assert_allclose(b, Ho["b"], atol=TOL_W)
+        assert_tables(W, Ho["W"])
+        assert_tables(b, Ho["b"])
     t = _tri(rs, 100, N, R)
     s_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 0], "tanh")
     o_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 2], "tanh")
@@ -115,9 +115,9 @@ def test_literal_weight_gradient_split_contraction():
         Lr, _, _ = O.literal_train_step("DistMult", Ho, "tanh", Eo, Ro, Lo, oo, pos, neg, "pointwize_logistic", 0.5, 1)
         assert L_ == pytest.approx(Lr, rel=TOL_L, abs=TOL_LA), step
         W, b = mdl.get_literal_dense()
-        np.testing.assert_allclose(W, Ho["W"], atol=TOL_W)
-        np.testing.assert_allclose(b, Ho["b"], atol=TOL_W)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        assert_tables(W, Ho["W"])
+        assert_tables(b, Ho["b"])
+        assert_tables(mdl.E.cpu().numpy(), Eo)
 
 
 def test_reference_script_configuration(datasets):

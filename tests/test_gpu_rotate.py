@@ -10,7 +10,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, assert_tables  # noqa: E402  (tests/tols.py: what each constant bounds)
 LOSSES = ["pointwize_hinge", "pointwize_logistic", "pointwize_square_loss", "pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"]
 
 
@@ -65,8 +65,8 @@ def test_rotate_train_step_parity(loss, opt, gamma):
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step("RotatE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, 2, gamma)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
 
 
@@ -81,8 +81,8 @@ def test_rotate_dropout_step_and_bad_ids():
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("RotatE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, 2, 12, dropout=0.3, seed=mdl._seed)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     bad = torch.tensor([[0, 0, 1], [0, R, 1], [N, 0, 1]], dtype=torch.int32, device="cuda")
     sc = mdl.call(bad).cpu().numpy()
     assert np.isfinite(sc[0]) and np.isnan(sc[1]) and np.isnan(sc[2])

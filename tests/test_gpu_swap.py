@@ -9,7 +9,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, assert_tables  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 CASES = [("DistMult", {}, 200), ("DistMult", {}, 24), ("TransE", dict(norm=1, gamma=12), 40), ("TransE", dict(norm=2, gamma=12), 200),
          ("ComplEx", {}, 100), ("ComplEx", {}, 8), ("DistMult", {}, 256), ("ComplEx", {}, 200), ("pRotatE", {}, 100), ("pRotatE", {}, 24)]
@@ -64,8 +64,8 @@ def test_swap_step_equals_planned_step_and_oracle(model, kw, d, opt):
         assert La == pytest.approx(Lb, rel=1e-6, abs=1e-7) and La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
         np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-6)
         np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=2e-6)
-        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(a.E.cpu().numpy(), Eo)
+        assert_tables(a.Rel.cpu().numpy(), Ro)
     assert int(sa[0].item()) == int(sb[0].item()) == 3
     fa, fb = sa.view(torch.float32).cpu().numpy(), sb.view(torch.float32).cpu().numpy()
     assert fa[2] == fb[2]                                  # learning rate of the next update
@@ -274,8 +274,8 @@ def test_swap_step_with_dropout(model, kw, d):
         assert La == pytest.approx(Lb, rel=2e-6, abs=1e-6) and La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
         np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=5e-6)
         np.testing.assert_allclose(a.Rel.cpu().numpy(), b.Rel.cpu().numpy(), atol=5e-6)
-        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(a.E.cpu().numpy(), Eo)
+        assert_tables(a.Rel.cpu().numpy(), Ro)
     # gradient halves under dropout == the whole == the oracle's gradients with the same masks
     plan = c.plan_batch([pos, neg])
     c.train_grads(plan, parts=1)
@@ -404,6 +404,76 @@ def test_row_shard_trainer_world_of_one_equals_twin_step():
         Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1.0)
         assert La == pytest.approx(Lb, rel=1e-6) and Lb == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
         np.testing.assert_allclose(b.E.cpu().numpy(), a.E.cpu().numpy(), atol=1e-6)
-        np.testing.assert_allclose(b.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(b.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(b.E.cpu().numpy(), Eo)
+        assert_tables(b.Rel.cpu().numpy(), Ro)
     assert b.predict(pos).shape == (40,)
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+@pytest.mark.parametrize("model,kw,d", [("DistMult", {}, 200), ("DistMult", {}, 24), ("TransE", dict(norm=2, gamma=12), 64), ("ComplEx", {}, 40),
+                                        ("pRotatE", {}, 24)])
+def test_chained_steps_equal_the_same_steps_one_by_one(model, kw, d, opt):
+    """kge_train_step_swap_chain / kge_train_step_swap_flush: the relation rows, loss and step state of step i are produced by the first
+    workgroups of step i + 1's launch (every other wave of that launch waits for them at a gate), the last step by the flush.  Same
+    waves, same summation order: tables, moments, step state (count, next lr_t, loss sum) and the last loss must be BIT-IDENTICAL to the
+    same steps through kge_train_step_swap (list order pinned by the deterministic mode, since the two models build their own plans).
+    Chains of 1, 2 and 5 steps back to back on the same workspace (the flush leaves the gates ready for the next chain); a hub entity, a
+    dominant relation, relations without rows, untouched entities; the plan buffers' counters must be left zero by a chained step
+    (rebuilt with parts | 8)."""
+    from kge_keras_amd import _lib, models as M
+    C, lib = _lib.C, _lib.lib
+    N, R = 301, 9
+    rs = np.random.RandomState(21)
+    de, dr = O.table_dims(model, d, d)
+    E0 = rs.uniform(-0.5, 0.5, (N, de)).astype(np.float32)
+    R0 = rs.uniform(-0.5, 0.5, (R, dr)).astype(np.float32)
+    mk = lambda: getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0.0, init_entities=E0, init_relations=R0,  # noqa: E731
+                                   loss_function="pointwize_logistic", margin=1.0, **kw)
+    n_pos, n_neg = 64, 1500
+    lib.kge_set_deterministic(1)
+    try:
+        ref, chn = mk(), mk()
+        for m in (ref, chn):
+            m.compile(opt)
+            m._ensure_train_state(n_pos, n_neg)
+            _state(m)
+        ref._step_twins = (torch.empty_like(ref.E), torch.empty_like(ref.Rel))
+        cur = [chn.E, chn.Rel]
+        nxt = [torch.full_like(chn.E, 7.0), torch.full_like(chn.Rel, 7.0)]
+        plans = [None, None, None]
+        md, ld = chn._model_desc(True), chn._loss_desc()
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        k = 0
+        for chain_len in (1, 2, 5):
+            last = None
+            for seq in range(chain_len):
+                ent = lambda n: np.where(rs.rand(n) < 0.3, 7, rs.randint(0, N - 40, n))  # hub: entity 7; entities N-40.. never touched
+                rel = lambda n: np.where(rs.rand(n) < 0.6, 2, rs.randint(0, R - 2, n))   # relation 2 dominant; relations R-2.. without rows
+                pos = np.stack([ent(n_pos), rel(n_pos), ent(n_pos)], 1).astype(np.int32)
+                neg = np.stack([ent(n_neg), rel(n_neg), ent(n_neg)], 1).astype(np.int32)
+                L_ref = ref.train_step(ref.plan_batch([pos, neg]))["loss"].clone()
+                plans[k % 3] = chn.plan_batch([pos, neg], out=plans[k % 3], parts=7 | (8 if k >= 3 else 0))
+                chn.optimizer.iterations += 1
+                od = chn._opt_desc()
+                _lib.check(lib.kge_train_step_swap_chain(C.byref(md), C.byref(ld), C.byref(od), cur[0].data_ptr(), cur[1].data_ptr(), nxt[0].data_ptr(),
+                                                         nxt[1].data_ptr(), plans[k % 3].buf.data_ptr(), plans[k % 3].buf.numel(), n_pos, n_neg,
+                                                         chn._loss.data_ptr(), 0, chn._ws.data_ptr(), chn._ws.numel(), seq, _lib.stream_ptr()))
+                last = (cur[1], nxt[1])
+                cur, nxt = nxt, cur
+                k += 1
+            od = chn._opt_desc()
+            _lib.check(lib.kge_train_step_swap_flush(C.byref(md), C.byref(ld), C.byref(od), last[0].data_ptr(), last[1].data_ptr(), n_pos, n_neg,
+                                                     chn._loss.data_ptr(), chn._ws.data_ptr(), chn._ws.numel(), chain_len - 1, err.data_ptr(), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert int(err.item()) == 0
+            assert torch.equal(cur[0], ref.E), (chain_len, float((cur[0] - ref.E).abs().max()))
+            assert torch.equal(cur[1], ref.Rel), (chain_len, float((cur[1] - ref.Rel).abs().max()))
+            assert torch.equal(chn._step_dev, ref._step_dev), (chain_len, chn._step_dev, ref._step_dev)
+            assert torch.equal(chn._loss, L_ref.reshape(1)) or float(chn._loss[0]) == float(L_ref)
+            if opt == "adam":
+                for a, b in zip(chn.optimizer.slots, ref.optimizer.slots):
+                    assert torch.equal(a, b)
+            nxt[0].fill_(7.0)
+            nxt[1].fill_(7.0)
+    finally:
+        lib.kge_set_deterministic(0)

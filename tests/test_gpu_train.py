@@ -10,7 +10,7 @@ import torch
 import oracle as O
 
 pytestmark = pytest.mark.gpu
-from tols import TOL, TOL_W, TOL_L, TOL_LA, TOL_W_LONG, TOL_L_BIG  # noqa: E402  (tests/tols.py: what each constant bounds)
+from tols import TOL, TOL_W, TOL_L, TOL_LA, TOL_W_LONG, TOL_L_BIG, assert_tables  # noqa: E402  (tests/tols.py: what each constant bounds)
 
 
 @pytest.fixture(params=["pull", "push"], autouse=True)
@@ -119,8 +119,8 @@ def test_train_step_parity(model, kw, loss, opt):
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12))
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0  # accumulators re-zeroed
 
 
@@ -150,8 +150,8 @@ def test_cross_entropy_train_step(model, kw, opt):
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_cross_entropy", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 def test_train_gradients_exact_semantics():
@@ -184,7 +184,7 @@ def test_l3_regulariser():
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1.0, regularization=0.01)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
 
 
 def test_nations_harness_fit_matches_oracle(datasets):
@@ -215,8 +215,8 @@ def test_nations_harness_fit_matches_oracle(datasets):
             assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (loss, b)
             np.random.set_state(np_state)
             random.setstate(py_state)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
         del idx, trl
 
 
@@ -251,8 +251,8 @@ def test_full_size_fb15k237_step(model, kw):
     Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
     Lo = O.train_step(model, Eo, Ro, O.AdamTF(), pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
     assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+    assert_tables(mdl.E.cpu().numpy(), Eo)
+    assert_tables(mdl.Rel.cpu().numpy(), Ro)
     # size-independent property: the update is a function of the multiset of rows, not of their order
     mdl2 = getattr(M, model)(e_dim=d, r_dim=d, num_entities=N, num_relations=R, dp=0, init_entities=E0, init_relations=R0,
                              loss_function="pointwize_logistic", **kw)
@@ -291,8 +291,8 @@ def test_duplicate_row_folding(model, kw, loss):
                 np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
                 Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, 1, kw.get("norm", 1), kw.get("gamma", 12))
                 assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (mode, step)
-                np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-                np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+                assert_tables(mdl.E.cpu().numpy(), Eo)
+                assert_tables(mdl.Rel.cpu().numpy(), Ro)
                 out.append(L)
             res[mode] = (out, mdl.E.cpu().numpy())
             # ids outside the tables
@@ -351,8 +351,8 @@ def test_batch_plan_step_equals_plain_step(model, kw, dp, grad_mode):
                 Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, b._seed)
                 assert La == pytest.approx(Lb, rel=1e-5, abs=1e-6) and La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (fold_mode, step)
                 np.testing.assert_allclose(a.E.cpu().numpy(), b.E.cpu().numpy(), atol=2e-5)
-                np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
-                np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
+                assert_tables(a.E.cpu().numpy(), Eo)
+                assert_tables(a.Rel.cpu().numpy(), Ro)
             # the gradient half alone (data-parallel split) + ids outside the tables raise through the plan too
             g = a.train_grads(a.plan_batch([pos, neg]))
             assert np.isfinite(float(g["loss"].item())) and float(a._gE.abs().max()) > 0
@@ -533,8 +533,8 @@ def test_changing_batch_size_and_loss_on_one_model():
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("DistMult", Eo, Ro, oo, pos, neg, loss, 0.5, 1)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (m, loss)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 @pytest.mark.parametrize("name", LOSSES + ["pointwize_cross_entropy"])
@@ -587,8 +587,8 @@ def test_pairwise_column_aligned_train_step(model):
             L = float(mdl.train_step([pos, neg])["loss"].item())
             Lo = O.train_step(model, Eo, Ro, oo, pos, neg, loss, 0.5, mt)
             assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), loss
-            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+            assert_tables(mdl.E.cpu().numpy(), Eo)
+            assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 @pytest.mark.parametrize("model,kw", [("DistMult", {}), ("TransE", dict(norm=2, gamma=12)), ("ComplEx", {})])
@@ -618,15 +618,15 @@ def test_heavy_tailed_batch(model, kw, dp, grad_mode):
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, mdl._seed)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), step
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     if grad_mode == "pull":  # the same through a plan built ahead
         pos, neg = draw(m), draw(m)
         L = float(mdl.train_step(mdl.plan_batch([pos, neg]))["loss"].item())
         Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12), 0.0, dp, mdl._seed)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 @pytest.mark.parametrize("loss", ["pairwize_hinge", "pairwize_logistic", "pairwize_square_loss"])
@@ -652,8 +652,8 @@ def test_pairwise_allpairs_at_script_scale(loss):
     Ls = float(mdl.train_step([pos, neg])["loss"].item())
     Lso = O.train_step("DistMult", Eo, Ro, O.AdamTF(), pos, neg, loss, 0.5, 1)
     assert Ls == pytest.approx(Lso, rel=TOL_L, abs=TOL_LA)
-    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+    assert_tables(mdl.E.cpu().numpy(), Eo)
+    assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 def test_wn18rr_complex400_train_step(datasets):
@@ -672,8 +672,8 @@ def test_wn18rr_complex400_train_step(datasets):
     Eo, Ro = E0.astype(np.float64), R0.astype(np.float64)
     Lo = O.train_step("ComplEx", Eo, Ro, O.AdamTF(), pos, neg, "pointwize_logistic", 1.0)
     assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-    np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-    np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+    assert_tables(mdl.E.cpu().numpy(), Eo)
+    assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 def test_edge_cases_single_row_and_skewed_batches():
@@ -689,8 +689,8 @@ def test_edge_cases_single_row_and_skewed_batches():
             L = float(mdl.train_step([pos, neg])["loss"].item())
             Lo = O.train_step(model, Eo, Ro, oo, pos, neg, "pointwize_logistic", 1.0, 1, kw.get("norm", 1), kw.get("gamma", 12))
             assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (model, len(pos))
-            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+            assert_tables(mdl.E.cpu().numpy(), Eo)
+            assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 @pytest.mark.parametrize("d", [31, 200, 6, 2])
@@ -783,8 +783,8 @@ def test_protate_train_step_parity(loss, opt, gamma):
         np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-5)
         Lo = O.train_step("pRotatE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, mdl.modulus, gamma)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
     assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0
 
 
@@ -803,8 +803,8 @@ def test_protate_large_planned_and_dropout():
         La = float(a.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("pRotatE", Eo, Ro, oo, pos, neg, "pointwize_hinge", 1, 1, a.modulus, 12)
         assert La == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA)
-        np.testing.assert_allclose(a.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(a.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(a.E.cpu().numpy(), Eo)
+        assert_tables(a.Rel.cpu().numpy(), Ro)
         if b.plan_supported():
             Lb = float(b.train_step(b.plan_batch([pos, neg]))["loss"].item())
             assert Lb == pytest.approx(La, abs=1e-5, rel=1e-5)
@@ -840,8 +840,8 @@ def test_hole_spectral_with_l3_regulariser():
         L = float(mdl.train_step([pos, neg])["loss"].item())
         Lo = O.train_step("HolE", Eo, Ro, oo, pos, neg, "pointwize_logistic", 1, 1, 1, 12, regularization=0.01)
         assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (step, L, Lo)
-        np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-        np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+        assert_tables(mdl.E.cpu().numpy(), Eo)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro)
 
 
 @pytest.mark.parametrize("norm,gamma", [(3, 12), (1.5, 12), (4, 0)])
@@ -862,8 +862,8 @@ def test_transe_general_p_norm(norm, gamma):
             L = float(mdl.train_step([pos, neg])["loss"].item())
             Lo = O.train_step("TransE", Eo, Ro, oo, pos, neg, loss, 0.5, 1, norm, gamma)
             assert L == pytest.approx(Lo, rel=TOL_L, abs=TOL_LA), (loss, step)
-            np.testing.assert_allclose(mdl.E.cpu().numpy(), Eo, atol=TOL_W)
-            np.testing.assert_allclose(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W)
+            assert_tables(mdl.E.cpu().numpy(), Eo)
+            assert_tables(mdl.Rel.cpu().numpy(), Ro)
     test = list(dict.fromkeys(tuple(int(v) for v in x) for x in _triples(rs, 40, N, R)))
     filt = [tuple(int(v) for v in x) for x in _triples(rs, 200, N, R)]
     filt = [x for x in filt if x not in set(test)]

@@ -12,10 +12,29 @@ TOL_W_LONG  5e-6 on the tables where a gradient element is a LONG fp32 sum or si
        1 / (1 - rate) before the same sums).  Still 20x below what the optimizer faults named above would do.
 TOL_L_BIG  5e-6 relative on losses of models whose scores are of magnitude ~10 (HAKE: gamma - distance, fp32 ulp 1e-6 on the score)
        under the pairwize losses, which act on score DIFFERENCES (measured 1.5e-6 .. 2.5e-6).
+assert_tables(actual, desired): every element within TOL_W, except that at most one element in a thousand (at least one) may sit up to
+       3 * TOL_W off.  Why: on an element whose gradient is below eps / sqrt(1 - beta_2) = 3e-6, Adam's update is LINEAR in the gradient
+       with slope lr sqrt(1 - beta_2) / eps = 316 (first updates), so the fp32 rounding of a gradient sum (1e-10 .. 3e-9, and the order
+       of the sum follows the arrival order of the plan's atomics, i.e. it changes from run to run) shows as 3e-8 .. 1e-6 on that
+       element.  Seen once: one element of 1 280 at 1.10e-6 in a run of the whole suite, the same test passing alone.  The faults the
+       1e-6 bound exists for (tests/test_gpu_adam.py) move whole rows by 1e-5 .. 1e-3 and still fail this check.
 Looser constants in individual tests carry their reason next to them."""
+import numpy as np
 TOL = 1e-4
 TOL_W = 1e-6
 TOL_L = 1e-6
 TOL_LA = 1e-7
 TOL_W_LONG = 5e-6
 TOL_L_BIG = 5e-6
+
+
+def assert_tables(actual, desired, atol=TOL_W, straggler_factor=3.0):
+    actual, desired = np.asarray(actual, dtype=np.float64), np.asarray(desired, dtype=np.float64)
+    assert actual.shape == desired.shape, (actual.shape, desired.shape)
+    err = np.abs(actual - desired)
+    assert not np.isnan(err).any(), "NaN in the tables"
+    over = err > atol
+    allowed = max(1, actual.size // 1000)
+    worst = float(err.max()) if err.size else 0.0
+    assert int(over.sum()) <= allowed and worst <= straggler_factor * atol, \
+        f"{int(over.sum())} of {actual.size} elements beyond {atol:g} (allowed {allowed} up to {straggler_factor * atol:g}); max abs error {worst:.3e}"
