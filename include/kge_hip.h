@@ -225,7 +225,9 @@ int kge_hole_spec_adjoint(float* Ghat, int64_t rows, int32_t d, const float* W, 
  *      theta_l = [W (d_e + L, d_e) row-major | b (d_e)], act = 0 linear, 1 relu, 2 sigmoid, 3 tanh, 4 softplus, 5 softsign, 6 elu,
  *      7 selu, 8 exponential, 9 softmax (over the layer's d_e outputs).  kge_lit_transform builds the transformed entity table (rows, d_e) in inference mode: predict and
  *      the 1-vs-all ranking then run the ordinary kernels on it.  kge_lit_train_grads is the gradient half of a train step
- *      (gradients into gradE / gradRel / gtheta_l, zero on entry); DistMult, TransE and ComplEx are built. */
+ *      (gradients into gradE / gradRel / gtheta_l, zero on entry); built under DistMult, TransE (every norm id, i.e. pRotatE too), ComplEx,
+ *      HolE and RotatE (d_e = 2 d_r: the Dense is d_e wide; the workspace must be zero-filled once, a padded relation-gradient table
+ *      lives in it); ConvE and HAKE return KGE_EUNSUPPORTED. */
 int64_t kge_lit_workspace_bytes(const kge_model_desc* md, int32_t L, int64_t m_pos, int64_t m_neg);
 int64_t kge_lit_transform_workspace_bytes(const kge_model_desc* md, int32_t L, int32_t rows);
 int kge_lit_transform(const kge_model_desc* md, int32_t act, const float* E, const float* Lit, int32_t L, int32_t lit_rows, const float* theta_l,

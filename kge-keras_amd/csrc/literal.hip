@@ -122,14 +122,15 @@ __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, c
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t n = m_pos + m_neg;
   const int h = d >> 1;
-  const int width = MODEL == KGE_COMPLEX ? h : d;
+  const int width = MODEL == KGE_COMPLEX || MODEL == KGE_ROTATE ? h : d;
+  const int dr = MODEL == KGE_ROTATE ? h : d;  // width of a relation row (RotatE: h phases, models.py:428-429)
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n; t += (int64_t)gridDim.x * 4) {
     const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
     const int p = tr[1];
     const bool ok = (unsigned)p < (unsigned)R;
     const float* hs = H + t * d;
     const float* ho = H + (n + t) * d;
-    const float* rp = Rel + (int64_t)(ok ? p : 0) * d;
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * dr;
     DropKey kp{0, 0};
     if (DROP) kp = drop_key(seed, t, 1);
     auto mp = [&](int e) { return DROP ? drop_mul(kp, e, thr, dscale) : 1.f; };
@@ -172,6 +173,36 @@ __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, c
         }
       }
       __builtin_amdgcn_wave_barrier();  // (the next triple of this wave overwrites the slice)
+      continue;
+    }
+    if (MODEL == KGE_ROTATE) {
+      // models.py:437-459 on the transformed rows: the rotated subject minus the object, summed with its signs --
+      // S = sum_k (sr c - si s - or) + (sr s + si c - oi), c / s = cos / sin of the (masked) phase; score = gamma - S (gamma > 0) or S.
+      // Linear in s and o: dS/dsr = c + s, dS/dsi = c - s, dS/do = -1; dS/dphase = sr (c - s) - si (c + s).
+      // dP rows are d wide like every model's (the destination sums run on rows of d): the upper half is written as zeros.
+      float acc = 0.f;
+      for (int k = lane; k < h; k += 64) {
+        float sn, cs;
+        sincosf(rp[k] * mp(k), &sn, &cs);
+        acc += (hs[k] * cs - hs[h + k] * sn - ho[k]) + (hs[k] * sn + hs[h + k] * cs - ho[h + k]);
+      }
+      acc = group_sum<64>(acc);
+      if (MODE == 0) {
+        if (lane == 0) scores[t] = ok ? (gamma > 0.f ? gamma - acc : acc) : __builtin_nanf("");
+        continue;
+      }
+      float gi = ok ? g[t] : 0.f;
+      if (!(gi == gi)) gi = 0.f;
+      const float sg = gamma > 0.f ? -gi : gi;
+      for (int k = lane; k < h; k += 64) {
+        const float b = mp(k);
+        float sn, cs;
+        sincosf(rp[k] * b, &sn, &cs);
+        dH[t * d + k] = sg * (cs + sn); dH[t * d + h + k] = sg * (cs - sn);
+        dH[(n + t) * d + k] = -sg; dH[(n + t) * d + h + k] = -sg;
+        dP[t * d + k] = sg * (hs[k] * (cs - sn) - hs[h + k] * (cs + sn)) * b;
+        dP[t * d + h + k] = 0.f;
+      }
       continue;
     }
     float acc = 0.f;
@@ -292,8 +323,9 @@ __global__ __launch_bounds__(256) void lit_compact(const float* __restrict__ dA,
 static int64_t l256(int64_t x) { return align_up(x, 256); }
 
 static int lit_check(const kge_model_desc* md, int L, int act) {
-  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX && md->model != KGE_HOLE)
-    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE, ComplEx and HolE are built)", md->model);
+  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX && md->model != KGE_HOLE && md->model != KGE_ROTATE)
+    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE, ComplEx, HolE and RotatE are built)", md->model);
+  if (md->model == KGE_ROTATE && md->d_e != 2 * md->d_r) return fail(KGE_EINVAL, "literal path under RotatE: d_e must be 2 * d_r");
   if (md->model == KGE_HOLE && md->d_e > kLitHoleMax)
     return fail(KGE_EUNSUPPORTED, "literal path under HolE: rows of at most %d floats (e_dim = %d)", kLitHoleMax, md->d_e);
   if (L <= 0) return fail(KGE_EINVAL, "literal path: literal width %d", L);
@@ -346,7 +378,19 @@ __global__ __launch_bounds__(256) void lit_splitk_sum(const float* __restrict__ 
 int64_t lit_workspace_bytes(const kge_model_desc* md, int L, int64_t m_pos, int64_t m_neg) {
   const int64_t n = m_pos + m_neg, d = md->d_e, K1 = d + L;
   return l256((int64_t)lit_splits(2 * n, d, K1) * d * K1 * 4) + pull_header_bytes(md) + 2 * l256(2 * n * K1 * 4) + 3 * l256(2 * n * d * 4) + 3 * l256(n * d * 4) + 2 * l256(n * 4) +
-         l256(cdiv(2 * n, 64) * d * 4) + pull_workspace_bytes(md, n) + l256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096;
+         l256(cdiv(2 * n, 64) * d * 4) + pull_workspace_bytes(md, n) + l256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096 +
+         (md->model == KGE_ROTATE ? l256((int64_t)md->num_relations * d * 4) : 0);
+}
+
+// RotatE: the relation rows are h = d / 2 wide, the destination sums run on rows of d.  The per-triple rows dP carry zeros in their
+// upper half and are summed into a padded table gRp (R x d, all-zero between steps); this folds its lower half into gR and clears it.
+__global__ __launch_bounds__(256) void lit_fold_rel(float* __restrict__ gRp, float* __restrict__ gR, int R, int d) {
+  const int h = d >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)R * d; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / d), k = (int)(i % d);
+    if (k < h) gR[(int64_t)r * h + k] += gRp[i];
+    gRp[i] = 0.f;
+  }
 }
 
 template <int MODEL, int NORM, int MODE>
@@ -365,6 +409,7 @@ static void launch_rows_model(bool drop, int grid, hipStream_t st, const float* 
   if (md->model == KGE_DISTMULT) launch_rows<KGE_DISTMULT, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->model == KGE_COMPLEX) launch_rows<KGE_COMPLEX, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->model == KGE_HOLE) launch_rows<KGE_HOLE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
+  else if (md->model == KGE_ROTATE) launch_rows<KGE_ROTATE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->norm == 1) launch_rows<KGE_TRANSE, 1, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->norm == 3) launch_rows<KGE_TRANSE, 3, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
   else if (md->norm == 5) launch_rows<KGE_TRANSE, 5, MODE>(drop, grid, st, Rel, pos, m_pos, neg, m_neg, md, H, g, scores, dH, dP, seed);
@@ -383,6 +428,8 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
   char* q = reinterpret_cast<char*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   auto take = [&](int64_t bytes) { char* r = q; q += l256(bytes); return r; };
   void* pull_hdr = take(pull_header_bytes(md));
+  // (RotatE: right behind the header, in the part of the workspace that is zero on entry and left zero -- see lit_fold_rel)
+  float* gRp = md->model == KGE_ROTATE ? (float*)take((int64_t)md->num_relations * md->d_e * 4) : nullptr;
   float* A = (float*)take(2 * n * K1 * 4);
   float* dA = (float*)take(2 * n * K1 * 4);
   float* Zb = (float*)take(2 * n * d * 4);
@@ -445,8 +492,9 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
     if (drop) hipLaunchKernelGGL((lit_compact<true>), dim3(gc), dim3(256), 0, st, dA, n, d, K1, dS, dO, seed, thr, dscale);
     else hipLaunchKernelGGL((lit_compact<false>), dim3(gc), dim3(256), 0, st, dA, n, d, K1, dS, dO, seed, thr, dscale);
     if (int rc = pull2_fill_entries(md, pos, m_pos, neg, m_neg, plan, st)) return rc;
-    if (int rc = cv_rowsum_launch(md, gE, gR, plan, dS, dPb, dO, st)) return rc;
-    if (int rc = pull_finish_launch(md, gE, gR, plan, st)) return rc;
+    if (int rc = cv_rowsum_launch(md, gE, gRp ? gRp : gR, plan, dS, dPb, dO, st)) return rc;
+    if (int rc = pull_finish_launch(md, gE, gRp ? gRp : gR, plan, st)) return rc;
+    if (gRp) hipLaunchKernelGGL(lit_fold_rel, dim3((int)std::min<int64_t>(cdiv((int64_t)md->num_relations * d, 256), 1024)), dim3(256), 0, st, gRp, gR, md->num_relations, d);
   }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;

@@ -180,8 +180,8 @@ class EmbeddingModel:
         self._seed = int(seed) if seed is not None else 0
         self._lit = None
         if literal_activation:  # models.py:114-120: frozen literal table + Dense(e_dim, activation) on [embedding ; literal]
-            if self.MODEL not in ("DistMult", "TransE", "ComplEx", "HolE"):  # (MODEL "TransE" covers TransE with any norm and pRotatE)
-                raise NotImplementedError(f"the literal input path is built for DistMult, TransE, ComplEx, HolE and pRotatE, not {type(self).__name__}")
+            if self.MODEL not in ("DistMult", "TransE", "ComplEx", "HolE", "RotatE"):  # (MODEL "TransE" covers TransE with any norm and pRotatE)
+                raise NotImplementedError(f"the literal input path is built for DistMult, TransE, ComplEx, HolE, pRotatE and RotatE, not {type(self).__name__}")
             act = literal_activation if isinstance(literal_activation, str) else getattr(literal_activation, "__name__", None)
             if act not in ACT_IDS:
                 raise NotImplementedError(f"literal_activation {literal_activation!r}: one of {sorted(k for k in ACT_IDS if k)}")

@@ -69,16 +69,18 @@ def test_literal_train_step_parity(model, kw, loss, act, dp):
         np.testing.assert_allclose(b, Ho["b"], atol=TOL_W_LONG)
 
 
-@pytest.mark.parametrize("model,kw", [("pRotatE", {}), ("pRotatE", dict(gamma=0)), ("TransE", dict(norm=3.5, gamma=12)), ("TransE", dict(norm=1.5, gamma=0))])
+@pytest.mark.parametrize("model,kw", [("pRotatE", {}), ("pRotatE", dict(gamma=0)), ("TransE", dict(norm=3.5, gamma=12)), ("TransE", dict(norm=1.5, gamma=0)),
+                                      ("RotatE", {}), ("RotatE", dict(gamma=0))])
 @pytest.mark.parametrize("dp", [0.0, 0.25])
 def test_literal_under_protate_and_general_p_norm(model, kw, dp):
-    """models.py:152-158 is model agnostic: the literal transform in front of pRotatE's phase distance (:479-489) and of TransE with any
-    positive real tf.norm order (:188) -- two steps (scores, loss, both tables, the Dense) against the oracle, with and without dropout;
-    predict and the 1-vs-all ranks on the transformed table."""
+    """models.py:152-158 is model agnostic: the literal transform in front of pRotatE's phase distance (:479-489), of TransE with any
+    positive real tf.norm order (:188) and of RotatE (:437-459: entity rows -- and the Dense -- 2 e_dim wide, relation rows e_dim phases)
+    -- two steps (scores, loss, both tables, the Dense) against the oracle, with and without dropout; predict on the transformed table;
+    RotatE also the filtered 1-vs-all ranks."""
     N, R, d, L, m = 30, 4, 16, 5, 200
     mdl, E0, R0, lit, H, rs = _mk(model, N, R, d, L, "tanh", seed=4, dp=dp, loss_function="pointwize_logistic", margin=0.5, **kw)
     mdl.compile("adam")
-    norm = mdl.modulus if model == "pRotatE" else kw["norm"]
+    norm = mdl.modulus if model == "pRotatE" else kw.get("norm", 1)
     gamma = kw.get("gamma", 12)
     Eo, Ro, Ho, Lo = E0.astype(np.float64), R0.astype(np.float64), _f64(H), lit.astype(np.float64)
     oo = O.AdamTF()
@@ -98,6 +100,14 @@ def test_literal_under_protate_and_general_p_norm(model, kw, dp):
     s_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 0], "tanh")
     o_, _ = O.literal_transform(Ho, Eo, Lo, t[:, 2], "tanh")
     np.testing.assert_allclose(mdl.predict(t), O.score_rows(model, s_, Ro[t[:, 1]], o_, norm, gamma), atol=TOL, rtol=1e-4)
+    if model == "RotatE":
+        Et, _ = O.literal_transform(Ho, Eo, Lo, np.arange(N), "tanh")
+        test = [tuple(int(v) for v in x) for x in t[:30]]
+        filt = [f for f in (tuple(int(v) for v in x) for x in _tri(rs, 100, N, R)) if f not in set(test)]
+        tr, hr = O.ranks_closed_form("RotatE", Et, Ro, test, filt, norm, gamma)
+        fh, ft = O.build_filters(filt)
+        gt, gh = mdl.rank(test, N, ft, fh)
+        assert np.mean(gt == tr) > 0.95 and np.mean(gh == hr) > 0.95 and np.max(np.abs(gt - tr)) <= 1 and np.max(np.abs(gh - hr)) <= 1
     mdl._raise_on_flag()
 
 
