@@ -146,8 +146,15 @@ class RowShardedTables:
             for buf, per in ((self.bufE[self.cur ^ 1], self.per_e), (self.bufR[self.cur ^ 1], self.per_r)):
                 mine = buf[self.rank * per:(self.rank + 1) * per]
                 if dist.get_backend(self.group) != "nccl":
-                    mine = mine.clone()  # (gloo stages through the host and is not specified for an input inside the output)
-                dist.all_gather_into_tensor(buf, mine, group=self.group)
+                    # gloo (rehearsals, CPU tests): its all-gathers of device tensors are pathologically slow (190 ms for 5.9 MB between two
+                    # ranks on one GPU, tools/rows_probe.py; its all-reduce moves twice the bytes in 4 ms), so the other ranks' slices are
+                    # zeroed and the table is all-reduced: x + 0 is exact
+                    for r in range(self.ws):
+                        if r != self.rank:
+                            buf[r * per:(r + 1) * per].zero_()
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    dist.all_gather_into_tensor(buf, mine, group=self.group)
             if loss is not None:
                 dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
         self.cur ^= 1

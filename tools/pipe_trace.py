@@ -57,12 +57,21 @@ if len(steps_tr) > 8:
     dur = np.median([b - a for a, b in steps_tr])
     s2s = np.median(np.diff([a for a, _b in steps_tr]))
     k1, k2 = conc["train_grads"], conc["opt"]
-    print(f"\naccounting of one training step (medians / averages, us):")
+    chained = os.environ.get("KGE_PIPE_CHAIN", "1") != "0"  # (chained steps: ONE launch per step, the closing launch only ends a run)
+    print(f"\naccounting of one training step (medians / averages, us; {'chained steps: one launch per step' if chained else 'two launches per step'}):")
     print(f"  pace of the un-instrumented pipeline (1000 steps, wall clock)                 {pace:7.1f}")
-    print(f"  step1_kernel beside the producer stages (library hipEvents)                  {k1:7.1f}")
-    print(f"  rel_tail_kernel (library hipEvents)                                          {k2:7.1f}")
-    print(f"  step stage begin -> end with the stage trace armed (both kernels + the gap)  {dur:7.1f}   => stream-order gap step1 -> rel_tail ~ {dur - k1 - k2:5.1f}")
-    print(f"  step stage start-to-start with the stage trace armed                         {s2s:7.1f}   => between two step stages ~ {s2s - dur:5.1f} (record of 'plan consumed', the")
-    print(f"      satisfied wait for the next plan, launch of step1_kernel; the trace's own two event records per stage are inside this number)")
-    print(f"  un-instrumented: pace - step1 - rel_tail = {pace - k1 - k2:5.1f} us of launch gaps and event operations per step (two kernel boundaries of ~3 us on a")
-    print(f"      stream that three other streams run beside + one event record + one event wait)")
+    print(f"  step1_kernel beside the producer stages (library hipEvents)                  {k1:7.1f}" + ("   (closers of the previous step + gate included)" if chained else ""))
+    if chained:
+        print(f"  chain_flush_kernel, once per run (library hipEvents)                         {k2:7.1f}")
+        print(f"  step stage begin -> end with the stage trace armed                           {dur:7.1f}")
+        print(f"  step stage start-to-start with the stage trace armed                         {s2s:7.1f}   => between two step stages ~ {s2s - dur:5.1f} (record of 'plan consumed' behind")
+        print(f"      every second step, the satisfied wait for the next plan, launch of step1_kernel; the trace's own two event records per stage are inside this number)")
+        print(f"  un-instrumented: pace - step1 = {pace - k1:5.1f} us between two launches of step1_kernel (one kernel boundary on a stream that three other streams")
+        print(f"      run beside + the wait for the plan + every second step one event record)")
+    else:
+        print(f"  rel_tail_kernel (library hipEvents)                                          {k2:7.1f}")
+        print(f"  step stage begin -> end with the stage trace armed (both kernels + the gap)  {dur:7.1f}   => stream-order gap step1 -> rel_tail ~ {dur - k1 - k2:5.1f}")
+        print(f"  step stage start-to-start with the stage trace armed                         {s2s:7.1f}   => between two step stages ~ {s2s - dur:5.1f} (record of 'plan consumed', the")
+        print(f"      satisfied wait for the next plan, launch of step1_kernel; the trace's own two event records per stage are inside this number)")
+        print(f"  un-instrumented: pace - step1 - rel_tail = {pace - k1 - k2:5.1f} us of launch gaps and event operations per step (two kernel boundaries of ~3 us on a")
+        print(f"      stream that three other streams run beside + one event record + one event wait)")
