@@ -361,27 +361,22 @@ int kge_train_step_swap_window(const kge_model_desc* md, const kge_loss_desc* ld
                                float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
                                uint64_t seed, void* workspace, int64_t workspace_bytes, const kge_row_window* win, kge_stream_t stream);
 
-/* CHAINED steps between twin tables: a run of kge_train_step_swap steps (parts = 3) whose closing launches are folded into the next
- * step's launch.  The closing launch of a step (relation rows = sums of the forward's partial rows + optimizer, the loss, the step
- * state: ~1 us of work) costs ~10 us plus a ~7 us kernel boundary on the step stream; in a chain the relation rows, loss and step state
- * of step seq are produced by the first workgroups of step seq + 1's launch, and every other wave of that launch waits for them at a
- * gate before its first read of a relation row -- one launch per step.  Same tables, moments, loss sums and step state as the same
- * steps through kge_train_step_swap, bit for bit (the same waves sum in the same order).
- *   kge_train_step_swap_chain(seq = 0, 1, 2, ...): the caller alternates the table pairs exactly as with kge_train_step_swap.  BETWEEN the
- *     calls of a chain Rel_out of the last step issued, *loss_out and the step state are one step behind (entity tables are current);
- *     nothing but the next step of the chain or the flush may touch the relation tables, moments, step state or `workspace`.
- *     From seq = 1 on the call WRITES the rows of Rel_in (they are the previous step's Rel_out), hence no const.
- *     The plan is consumed by its own launch (its counters left zero), as always.
- *   kge_train_step_swap_flush(seq_last): closes the last step issued (Rel_in / Rel_out = THAT step's pair); afterwards everything is as
- *     after the same steps of kge_train_step_swap.  err (may be null): bit 32 is set if a gate wait of the chain gave up (a device
- *     fault -- never observed; the waits are bounded so that such a fault cannot hang the device).
- * No row window, no halves apart.  The workspace must have been zero-filled once before its first chain (like the plan buffers). */
-int kge_train_step_swap_chain(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, float* Rel_in,
+/* CHAINED steps between twin tables: kge_train_step_swap (parts = 3) as ONE launch, for runs of steps.  The closing launch of a step
+ * (relation rows = sums of the forward's partial rows + optimizer, the loss, the step state: ~1 us of work) costs ~10 us plus a ~7 us
+ * kernel boundary on the step stream; here R "closer" workgroups and one "state" workgroup sit late in the step's own grid, wait on
+ * per-workgroup flags of the relation-grouped forward (write-through stores, cache-bypassing loads, no atomics) and do that work while
+ * the rest of the entity role is still running.  Same tables, moments, loss and step state as the same steps through
+ * kge_train_step_swap, bit for bit (the same sums in the same order), and complete after every call.
+ *   seq = 0, 1, 2, ...: the number of the step in the chain; the caller alternates the table pairs exactly as with kge_train_step_swap.
+ *     seq = 0 is preceded by a small launch that copies lr_t of the update from the step state into a ring inside `workspace` (a wave
+ *     of the entity role may read lr_t after the state workgroup has moved the step state on) and clears the flags; a chain must not be
+ *     interleaved with other steps on the same workspace and step state -- end it, then start a new one with seq = 0.
+ *   err_flag (may be null): bit 32 is set if a flag wait gave up (a device fault -- never observed; the waits are bounded so that
+ *     such a fault cannot hang the device).
+ * No row window, no halves apart.  The workspace must have been zero-filled once (like the plan buffers). */
+int kge_train_step_swap_chain(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in,
                               float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
-                              uint64_t seed, void* workspace, int64_t workspace_bytes, int64_t seq, kge_stream_t stream);
-int kge_train_step_swap_flush(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* Rel_in, float* Rel_out,
-                              int64_t m_pos, int64_t m_neg, float* loss_out, void* workspace, int64_t workspace_bytes, int64_t seq_last,
-                              uint32_t* err, kge_stream_t stream);
+                              uint64_t seed, void* workspace, int64_t workspace_bytes, int64_t seq, uint32_t* err_flag, kge_stream_t stream);
 
 /* ---- the reference's loss functions as callables on two score vectors (utils.py:288-319, reduce_mean=True):
  *      *loss_out = loss(true, false, margin, negative_samples); d_true / d_false (optional, may be NULL) receive the

@@ -119,8 +119,7 @@ SIGNATURES = {
     "kge_train_step_swap_supported": (C.c_int, [_MD, _LD, _OD]),
     "kge_train_step_swap": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I32, _P]),
     "kge_train_step_swap_window": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _P, _P]),
-    "kge_train_step_swap_chain": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I64, _P]),
-    "kge_train_step_swap_flush": (C.c_int, [_MD, _LD, _OD, _P, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _P]),
+    "kge_train_step_swap_chain": (C.c_int, [_MD, _LD, _OD, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, C.c_uint64, _P, _I64, _I64, _P, _P]),
     "kge_loss_pairs": (C.c_int, [_LD, _P, _I64, _P, _I64, _P, _I64, _P]),
     "kge_set_grad_mode": (C.c_int, [C.c_int]),
     "kge_set_dedup_mode": (C.c_int, [C.c_int]),

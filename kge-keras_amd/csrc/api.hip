@@ -152,9 +152,8 @@ int l3_value(const float*, int64_t, float, float*, void*, int64_t, hipStream_t);
 int score_dispatch_training(const kge_model_desc*, const float*, const float*, const int32_t*, int64_t, uint64_t, int64_t, float*, uint32_t*, hipStream_t);
 bool step_swap_supported(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*);
 int train_step_swap(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, const float*, const float*, float*, float*, void*, int64_t,
-                    int64_t, float*, uint64_t, void*, int64_t, int, hipStream_t, const kge_row_window* win = nullptr, int64_t chain_seq = -1);
-int train_step_swap_flush(const kge_model_desc*, const kge_loss_desc*, const kge_opt_desc*, const float*, float*, int64_t, int64_t, float*, void*, int64_t,
-                          int64_t, uint32_t*, hipStream_t);
+                    int64_t, float*, uint64_t, void*, int64_t, int, hipStream_t, const kge_row_window* win = nullptr, int64_t chain_seq = -1,
+                    uint32_t* chain_err = nullptr);
 
 int loss_value(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, float*, float*, void*, int64_t, hipStream_t);
 int loss_pairs(const kge_loss_desc*, const float*, int64_t, const float*, int64_t, float*, int64_t, hipStream_t);
@@ -478,9 +477,9 @@ int kge_train_step_swap_window(const kge_model_desc* md, const kge_loss_desc* ld
                          static_cast<hipStream_t>(stream), win);
 }
 
-int kge_train_step_swap_chain(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, float* Rel_in,
+int kge_train_step_swap_chain(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in,
                               float* E_out, float* Rel_out, void* plan, int64_t plan_bytes, int64_t m_pos, int64_t m_neg, float* loss_out,
-                              uint64_t seed, void* workspace, int64_t workspace_bytes, int64_t seq, kge_stream_t stream) {
+                              uint64_t seed, void* workspace, int64_t workspace_bytes, int64_t seq, uint32_t* err_flag, kge_stream_t stream) {
   if (!od) return fail(KGE_EINVAL, "kge_train_step_swap_chain: optimizer descriptor is null");
   if (seq < 0) return fail(KGE_EINVAL, "kge_train_step_swap_chain: seq must be >= 0");
   if (int rc = check_plan("kge_train_step_swap_chain", md, ld, m_pos, m_neg)) return rc;
@@ -491,18 +490,7 @@ int kge_train_step_swap_chain(const kge_model_desc* md, const kge_loss_desc* ld,
   if (plan_bytes < batch_plan_bytes(md, m_pos + m_neg))
     return fail(KGE_EWORKSPACE, "kge_train_step_swap_chain: plan buffer has %lld bytes, needs %lld", (long long)plan_bytes, (long long)batch_plan_bytes(md, m_pos + m_neg));
   return train_step_swap(md, ld, od, E_in, Rel_in, E_out, Rel_out, plan, m_pos, m_neg, loss_out, seed, workspace, workspace_bytes, 3,
-                         static_cast<hipStream_t>(stream), nullptr, seq);
-}
-
-int kge_train_step_swap_flush(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* Rel_in, float* Rel_out,
-                              int64_t m_pos, int64_t m_neg, float* loss_out, void* workspace, int64_t workspace_bytes, int64_t seq_last,
-                              uint32_t* err, kge_stream_t stream) {
-  if (!od) return fail(KGE_EINVAL, "kge_train_step_swap_flush: optimizer descriptor is null");
-  if (seq_last < 0) return fail(KGE_EINVAL, "kge_train_step_swap_flush: seq_last must be >= 0");
-  if (int rc = check_plan("kge_train_step_swap_flush", md, ld, m_pos, m_neg)) return rc;
-  if (!Rel_in || !Rel_out || !loss_out || Rel_in == Rel_out) return fail(KGE_EINVAL, "kge_train_step_swap_flush: null or aliased tables");
-  if (!step_swap_supported(md, ld, od)) return fail(KGE_EUNSUPPORTED, "kge_train_step_swap_flush: needs what kge_train_step_swap needs");
-  return train_step_swap_flush(md, ld, od, Rel_in, Rel_out, m_pos, m_neg, loss_out, workspace, workspace_bytes, seq_last, err, static_cast<hipStream_t>(stream));
+                         static_cast<hipStream_t>(stream), nullptr, seq, err_flag);
 }
 
 int64_t kge_rank_workspace_bytes(const kge_model_desc* md, int64_t n_queries) {

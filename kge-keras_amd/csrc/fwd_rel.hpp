@@ -31,9 +31,9 @@ struct FwdRelArgs {
   float* coef; float* scores; float* rslab;
   uint64_t seed; uint32_t thr; float dscale;
   int rel_lo = 0, rel_hi = 0x7fffffff;  // relation window of an owner-computes step (kge_train_step_swap_window): units of other relations are skipped
-  // chained steps (StepChain, pull.hpp): the relation rows are being written by this launch's closers -- wait for gate[0] >= gate_need
-  // before the first read of one; the rows of a relation come from the list starts (the counters are cleared by this very launch)
-  const uint32_t* gate = nullptr; uint32_t gate_need = 0; uint32_t* gate_to = nullptr; int gate_R = 0;
+  // chained steps (StepChain, pull.hpp): non-zero = the unit's partial row is stored write-through and the wave waits for the
+  // acknowledgement -- a closer workgroup of the same launch sums the rows
+  uint32_t chain_tok = 0;
 };
 
 __device__ __forceinline__ bool rel_in_window(const FwdRelArgs& a, int unit) {
@@ -66,16 +66,14 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
   (void)hc; (void)seed; (void)thr; (void)dscale;
   const int2 pc = rumap[unit];
   const int p = pc.x;
-  const int c = a.gate ? (p + 1 < a.gate_R ? roff[p + 1] : a.rtotal[1]) - roff[p] : a.rcnt[p];
+  const int c = a.rcnt[p];
   const int chunk = rel_chunk_rows(c);
   const int start = roff[p] + pc.y * chunk;
   const int len = min(chunk, c - pc.y * chunk);
   const float* rp = Rel + (int64_t)p * d_e;
   float4 pv[NA], acc[NA];
-  // the first entry is fetched in front of the gate of a chained step (it does not depend on the relation rows)
   int4 e_nx = make_int4(0, 0, 0, 0);
   if (sub < len) e_nx = rentries[start + sub];
-  if (a.gate) rel_gate_wait(a.gate, a.gate_need, a.gate_to);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int ch = lane + j * G;
@@ -176,11 +174,17 @@ __device__ __forceinline__ int fwd_rel_unit(const FwdRelArgs& a, int unit, int R
     for (int j = 0; j < NV; ++j) {
       const int ch = lane + j * G;
       if (ch < nchunk) {
-        *reinterpret_cast<float4*>(dst + ch * 4) = acc[j];
-        if (MODEL == KGE_COMPLEX) *reinterpret_cast<float4*>(dst + h + ch * 4) = acc[NV + j];
+        if (a.chain_tok) {
+          store4_sc1(dst + ch * 4, acc[j]);
+          if (MODEL == KGE_COMPLEX) store4_sc1(dst + h + ch * 4, acc[NV + j]);
+        } else {
+          *reinterpret_cast<float4*>(dst + ch * 4) = acc[j];
+          if (MODEL == KGE_COMPLEX) *reinterpret_cast<float4*>(dst + h + ch * 4) = acc[NV + j];
+        }
       }
     }
   }
+  if (a.chain_tok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row is at the memory side before this workgroup's flag says so
   *len_out = len;
   *c_out = c;
   return p;

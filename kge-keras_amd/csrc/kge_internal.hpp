@@ -105,25 +105,29 @@ __device__ __forceinline__ void step_advance(const StepAdvance& a, float loss) {
   step_state_loss(a.step)[0] += (double)loss;
 }
 
-// The gate of a chained step (StepChain, pull.hpp): `ready` is 64 words on 64 cache lines, all set to the launch's token by the state
-// workgroup once every closer has stored its row; a wave polls the line of its workgroup with relaxed agent-scope loads (they bypass
-// the caches) until it reads the token.  No wave reads a relation row in front of its gate, and the caches were invalidated when
-// the launch began, so behind the gate plain loads see the closers' write-through stores.  Bounded: closers and the state workgroup are
-// the first workgroups of the grid and wait for no reader, so the token always arrives -- if it does not (a fault), the wave carries on
-// and the flush reports it.
-constexpr int kGateLines = 64, kGateStride = 32;  // words
-__device__ __forceinline__ void rel_gate_wait(const uint32_t* ready, uint32_t need, uint32_t* timeouts) {
-  const uint32_t* line = ready + (blockIdx.x & (kGateLines - 1)) * kGateStride;
-  uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  if (v < need) {
-    int spins = 0;
-    do {
-      __builtin_amdgcn_s_sleep(4);
-      v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    } while (v < need && ++spins < (1 << 16));
-    if (v < need && (threadIdx.x & 63) == 0) atomicAdd(timeouts, 1u);
+// Chained steps (StepChain, pull.hpp): results that another workgroup of the SAME launch consumes are stored write-through (sc1: they
+// reach the memory side once acknowledged) and read back with agent-scope loads (which bypass the caches); a flag word per producing
+// workgroup says when.
+__device__ __forceinline__ void store4_sc1(float* p, float4 v) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ float4 load4_agent(const float* p) {
+  return make_float4(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                     __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// All 256 threads of a workgroup: wait until flags[b0 .. b1] all carry `tok`.  Bounded: the producers come earlier in the grid and wait
+// for nothing, so the token always arrives -- if it does not (a fault), the workgroup carries on and the step reports it (bit 32 of
+// the error word).  Returns false when it gave up.
+__device__ __forceinline__ bool flags_wait(const uint32_t* flags, int b0, int b1, uint32_t tok) {
+  for (int spins = 0;; ++spins) {
+    int ok = 1;
+    for (int b = b0 + (int)threadIdx.x; b <= b1; b += 256) ok &= __hip_atomic_load(flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tok;
+    if (__syncthreads_and(ok)) return true;
+    if (spins >= (1 << 16)) return false;
+    __builtin_amdgcn_s_sleep(2);
   }
-  asm volatile("" ::: "memory");
 }
 
 // One extra workgroup of the pull launch reduces the forward's loss partials (fixed order) and advances the step state, when the

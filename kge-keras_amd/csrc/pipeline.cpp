@@ -88,7 +88,7 @@ struct Pipeline {
   uint64_t seed = 0;               // arrays: dropout seed of the last step issued (kge_pipeline_set_seed)
   bool swap = false;               // steps alternate between the caller's tables and their twins (kge_train_step_swap)
   bool chain = false;              // ... as chained steps (kge_train_step_swap_chain: one launch per step); KGE_PIPE_CHAIN=0 keeps the two-launch step
-  int64_t chain_seq = 0;           // steps issued in the running chain (a chain lives inside one kge_pipeline_run)
+  int64_t chain_seq = 0;           // steps issued in the running chain (a chain lives inside one kge_pipeline_run: seq 0 refills the lr ring)
   int parity = 0;                  // swap: 1 = the current tables are the twins
   int stage_mask = 15;  // experiments only (KGE_PIPE_STAGES): bit s clear = stage s is not launched (its events still are recorded)
 };
@@ -152,9 +152,10 @@ int stage_calls(Pipeline* p, int stage, int slot, hipStream_t st) {
       if (p->swap) {  // (the caller moves the parity on; lr_t of the update comes from the device-resident step state)
         const int q = p->parity;
         const int parts = 3;
-        if (p->chain)  // one launch per step: the relation rows of a step are closed inside the next step's launch (kge_pipeline_run ends the chain)
+        if (p->chain)  // one launch per step: relation rows, loss and step state closed by late workgroups of the step's own launch
           return kge_train_step_swap_chain(&d.md, &d.ld, &d.od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin,
-                                           plan_buf, d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, p->chain_seq++, st);
+                                           plan_buf, d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, p->chain_seq++,
+                                           d.err_flag, st);
         return kge_train_step_swap(&d.md, &d.ld, &d.od, q ? d.E_twin : d.E, q ? d.Rel_twin : d.Rel, q ? d.E : d.E_twin, q ? d.Rel : d.Rel_twin, plan_buf,
                                    d.plan_bytes, m, m, d.loss_out, p->arrays ? ++p->seed : 0, d.train_ws, d.train_ws_bytes, parts, st);
       }
@@ -522,16 +523,6 @@ int kge_pipeline_run(void* handle, int64_t n_steps, kge_stream_t stream) {
       p->last_rec_step = step;
     }
     rc = produce(p, p->t + 1);
-  }
-  // the end of the chain: the last step issued is closed (its relation rows, loss, step state) -- also after a failure half way
-  if (p->chain && p->chain_seq > 0) {
-    const kge_pipeline_desc& d = p->d;
-    const int q = p->parity ^ 1;  // the parity the last step ran with
-    const int64_t m = d.B * d.ns;
-    const int frc = kge_train_step_swap_flush(&d.md, &d.ld, &d.od, q ? d.Rel_twin : d.Rel, q ? d.Rel : d.Rel_twin, m, m, d.loss_out, d.train_ws, d.train_ws_bytes,
-                                              p->chain_seq - 1, d.err_flag, main_st);
-    if (frc != KGE_OK && rc == KGE_OK) rc = frc;
-    p->chain_seq = 0;
   }
   // the caller reads (E, Rel) -- also after a failure half way: the steps issued so far must not be left in the twins
   if (p->swap && p->parity) {

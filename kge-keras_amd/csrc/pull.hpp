@@ -41,25 +41,24 @@ struct OptFinish {
 // the optimizer to that row -- parameters read from the step's input tables, written to the twin tables (every other wave still
 // gathers the OLD rows), moments in place -- so neither a gradient table nor an optimizer sweep exists.  lr_t of the update: read from
 // the device-resident step state when the whole step is one call (lr_state / lr_slot), by value (lr_t) when its halves are issued apart.
-// Chained steps (kge_train_step_swap_chain; step1.hip): the closing launch of a step costs ~10 us + a ~7 us kernel boundary on the step
-// stream for ~1 us of work, so inside a run of steps the relation rows of step i are closed by the FIRST workgroups of step i+1's
-// launch ("closers": one per relation row, + one "state" workgroup for the loss and the step state), and every other wave of that
-// launch waits at a gate before its first read of a relation row.  The gate has no atomics and no word that many waves write or that
-// everybody polls: closer r stores the launch's token into its own word flags[r]; the state workgroup -- the only poller of those --
-// sees all R of them and stores the token into 64 words on 64 cache lines; a reader polls one of the 64 (its workgroup's).  (A first
-// version counted one word up with R atomics and let every wave poll that word: 0.140 ms per step against 0.100 without a chain.)
-// Nothing else crosses
-// workgroups inside a launch: partial rows, loss partials, the relation lists' bounds and lr_t all travel from launch i to launch
-// i+1 in buffers picked by the parity of i, i.e. across a kernel boundary.  The chain ends with kge_train_step_swap_flush.
+// Chained steps (kge_train_step_swap_chain; step1.hip): the closing launch of a step does ~1 us of work and costs ~10 us plus a ~7 us
+// kernel boundary on the step stream, so in a run of steps the relation rows, the loss and the step state are produced INSIDE the
+// step's one launch, by R "closer" workgroups (one per relation row) and one "state" workgroup placed late in the grid -- behind the
+// forward workgroups and most of the entity-role ones, so that by the time they are dispatched the forward has long finished and what
+// they do (a few dependent memory round trips) hides behind the rest of the entity role.  The forward workgroups store their partial
+// rows and loss partials write-through and then a flag word each; a closer polls the flags of the workgroups that hold its relation's
+// units (the state workgroup: all of them) and reads the rows with cache-bypassing loads.  No atomics, no word that many waves write
+// or that everybody polls.  Relation rows go to Rel_out, which no wave of the launch reads: the next launch sees them across the
+// kernel boundary like everything else.  lr_t of the update comes from a two-slot ring (a wave may read it after the state workgroup
+// has moved the step state on); the first step of a chain is preceded by a small launch that fills the ring and clears the flags.
+// (Versions that put the closers of step i at the START of step i + 1's launch, with a gate in front of every other wave, measured
+// 6 us more per step; a gate counted up with atomics 40 us more: profiles/r04_experiments.txt.)
 struct StepChain {
-  uint32_t* flags;      // [R] token of the launch in which the closer of relation r last stored its row (null: not chained)
-  uint32_t* ready;      // [64 lines] the gate: the token once all closers of the launch have stored (kge_internal.hpp: rel_gate_wait)
-  uint32_t* timeouts;   // [1] gate waits that gave up (a fault, reported by the flush)
-  float* lr_ring;       // [4] lr_t of update seq in slot seq & 3
-  float* partials[2];   // loss partials of step seq in [seq & 1]
-  float* slab[2];       // partial relation rows of step seq in [seq & 1]
-  int32_t* relmeta[2];  // [2R] {first unit, rows} of every relation of step seq in [seq & 1]
-  int64_t seq;          // number of this step in the chain (0: nothing to close)
+  uint32_t* bflags;     // [forward workgroups] token of the launch whose results the workgroup stored last (null: not chained)
+  uint32_t* timeouts;   // [1] flag waits that gave up (a fault, reported through the error word)
+  float* lr_ring;       // [2] lr_t of update seq in slot seq & 1
+  uint32_t* err;
+  int64_t seq;          // number of this step in the chain
 };
 
 struct StepTail {
@@ -84,7 +83,7 @@ struct StepTail {
   int ent_lo, ent_hi, rel_lo, rel_hi;
   int32_t* ecnt;
   int N;
-  StepChain ch;                // ch.flags non-null: a chained step
+  StepChain ch;                // ch.timeouts non-null: a chained step
 };
 inline void step_tail_whole(StepTail& t, int N, int R) { t.ent_lo = 0; t.ent_hi = N; t.rel_lo = 0; t.rel_hi = R; t.ecnt = nullptr; t.N = N; }
 

@@ -60,9 +60,7 @@ struct Plan2 {
   int32_t* rrank;   // [n]  rank of triple t in its relation list (-1: invalid ids)
   int4* rentries;   // [n]  {s, o, t, 0}
   float* rslab;     // [max_units][d]
-  float* rslab2;    // chained steps (StepChain): the slab of the odd steps, and {first unit, rows} of every relation by step parity
-  int32_t* relmeta[2];
-  uint32_t *gate_flags, *gate_ready;
+  uint32_t* bflags; // chained steps (StepChain): a flag word per forward workgroup
   int max_units;
   // entity side (same meaning as PullPlan, keys = entities only)
   PullPlan ent;
@@ -498,7 +496,7 @@ static int64_t plan_bytes(const Sizes& z) {
 }
 static int64_t scratch_bytes(const Sizes& z, int d_e) {
   return b256(z.max_units * d_e * 4) + b256(z.n * 4) * 2 + b256(2 * z.max_extra * d_e * 4) + 512 +
-         b256(z.max_units * d_e * 4) + 2 * b256(2 * z.R * 4) + b256(z.R * 4) + b256(64 * 128);  // chained steps: second slab of partial relation rows, two relation-bounds tables, the gate
+         b256((z.max_units / 4 + 1) * 4);  // chained steps: a flag word per forward workgroup
 }
 
 int64_t pull2_workspace_bytes(const kge_model_desc* md, int64_t n) {
@@ -555,11 +553,7 @@ static void carve_scratch(void* region, const kge_model_desc* md, int64_t n, Pla
   p->ent.coef = (float*)take(n * 4);
   p->ent.slab = (float*)take(2 * z.max_extra * md->d_e * 4);
   p->dd.uscore = (float*)take(n * 4);
-  p->rslab2 = (float*)take(z.max_units * md->d_e * 4);
-  p->relmeta[0] = (int32_t*)take(2 * z.R * 4);
-  p->relmeta[1] = (int32_t*)take(2 * z.R * 4);
-  p->gate_flags = (uint32_t*)take(z.R * 4);
-  p->gate_ready = (uint32_t*)take(64 * 128);
+  p->bflags = (uint32_t*)take((z.max_units / 4 + 1) * 4);
 }
 
 // kernels of pull.hip reused on the entity keys
@@ -798,8 +792,7 @@ static int plan_exec(const kge_model_desc* md, const kge_loss_desc* ld, const fl
     t.ecnt = p.ent.cnt; t.N = md->num_entities;
     if (t.ch.timeouts) {
       if (windowed) return fail(KGE_EUNSUPPORTED, "chained steps take no row window");
-      t.ch.slab[0] = p.rslab; t.ch.slab[1] = p.rslab2; t.ch.relmeta[0] = p.relmeta[0]; t.ch.relmeta[1] = p.relmeta[1];
-      t.ch.flags = p.gate_flags; t.ch.ready = p.gate_ready;
+      t.ch.bflags = p.bflags;
     }
     const FwdRelArgs fa{E, Rel, m_pos, m_neg, md->d_e, nchunk, md->gamma, md->modulus, ld->margin, p.rcnt, p.roff, p.rtotal, p.rumap, p.rentries, nullptr,
                         nullptr, p.rslab, seed, drop ? drop_thr(md->dropout) : 0u, drop ? 1.f / (1.f - md->dropout) : 1.f};
@@ -915,21 +908,6 @@ int train_grads_planned(const kge_model_desc* md, const kge_loss_desc* ld, const
   carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
   const Src src{nullptr, m_pos, nullptr, m_neg, p.dd.uniq, p.dd.nu};
   return plan_exec(md, ld, E, Rel, gE, gR, m_pos, m_neg, p, src, nullptr, loss_partials, n_partials, loss_out, seed, st, adv, finish, tail, grad_parts);
-}
-
-// step1.hip
-int chain_flush_launch(const StepTail& tail, const float* Rel_in, int rel_blocks, float* loss_out, const StepAdvance& adv, uint32_t* err, hipStream_t st);
-// The end of a chain of steps (kge_train_step_swap_flush): closes step tail.ch.seq, whose relation rows go Rel_in -> tail.Rel_out.
-int train_chain_flush(const kge_model_desc* md, const float* Rel_in, int64_t m_pos, int64_t m_neg, float* loss_out, void* ws, const StepAdvance& adv,
-                      const StepTail& tail, uint32_t* err, hipStream_t st) {
-  const int64_t n = m_pos + m_neg;
-  Plan2 p;
-  carve_scratch((char*)ws + plan_bytes(sizes_of(md, n)), md, n, &p);
-  StepTail t = tail;
-  t.R = md->num_relations; t.d_r = md->d_r;
-  t.ch.slab[0] = p.rslab; t.ch.slab[1] = p.rslab2; t.ch.relmeta[0] = p.relmeta[0]; t.ch.relmeta[1] = p.relmeta[1];
-  t.ch.flags = p.gate_flags; t.ch.ready = p.gate_ready;
-  return chain_flush_launch(t, Rel_in, (int)cdiv(sizes_of(md, n).max_units, 4), loss_out, adv, err, st);
 }
 
 }  // namespace kge

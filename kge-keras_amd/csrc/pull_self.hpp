@@ -18,7 +18,6 @@ struct SelfArgs {
   const float* lr_state;  // non-null: lr_t of this update is read from the device-resident step state (a whole step in one call) ...
   float* lr_keep;         // ... and copied here by the launch's first thread, for the closing launch (rel_tail_kernel)
   float *E_out, *mE, *vE;
-  const uint32_t* gate = nullptr; uint32_t gate_need = 0; uint32_t* gate_to = nullptr;  // chained steps: see FwdRelArgs (fwd_rel.hpp)
 };
 
 // One wave: entity unit `unit` (a destination row, or an extra chunk of a hub row); `mine`: NACC * 16 float4 of LDS of this wave.
@@ -88,7 +87,6 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
 
   int4 e_nx = make_int4(0, 0, 0, 0);
   if (sub < len) e_nx = a.entries[start + sub];
-  if (a.gate) rel_gate_wait(a.gate, a.gate_need, a.gate_to);  // (own row and first entry are on their way: neither depends on the relation rows)
   for (int i = sub; i < len; i += NSUB) {
     asm volatile("" ::: "memory");  // (the own row stays in LDS: without this the compiler hoists its reads into 16 more registers)
     const int4 e = e_nx;

@@ -415,13 +415,12 @@ static int carve(void* ws, int64_t bytes, const kge_model_desc* md, int64_t m_po
   return KGE_OK;
 }
 
-// Chained steps (StepChain, pull.hpp): the words between lr_slot and gbuf hold the lr ring [8..12) and the give-up count [20]; the two
-// partial-sum planes double as the loss partials by step parity (a step between twin tables has no L3 term, so reg_partials is
-// free).  Slabs, relation bounds and the gate: the scratch of pull2.hip (timeouts non-null marks the step as chained until then).
-static void chain_of(const Workspace& ws, int64_t seq, StepChain* ch) {
+// Chained steps (StepChain, pull.hpp): the words between lr_slot and gbuf hold the two-slot lr ring [8..10) and the give-up count [20]; the
+// forward workgroups' flags live in the scratch of pull2.hip (timeouts non-null marks the step as chained until they are attached).
+static void chain_of(const Workspace& ws, int64_t seq, uint32_t* err, StepChain* ch) {
   ch->lr_ring = ws.lr_slot + 8;
   ch->timeouts = reinterpret_cast<uint32_t*>(ws.lr_slot + 20);
-  ch->partials[0] = ws.loss_partials; ch->partials[1] = ws.reg_partials;
+  ch->err = err;
   ch->seq = seq;
 }
 
@@ -851,7 +850,7 @@ bool step_swap_supported(const kge_model_desc* md, const kge_loss_desc* ld, cons
 }
 int train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* E_in, const float* Rel_in, float* E_out,
                     float* Rel_out, void* plan, int64_t m_pos, int64_t m_neg, float* loss_out, uint64_t seed, void* workspace, int64_t wbytes,
-                    int parts, hipStream_t st, const kge_row_window* win, int64_t chain_seq) {
+                    int parts, hipStream_t st, const kge_row_window* win, int64_t chain_seq, uint32_t* chain_err) {
   Workspace ws;
   if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
   int nb = 0;
@@ -864,7 +863,7 @@ int train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge
   t.Rel_out = Rel_out; t.mR = od->mRel; t.vR = od->vRel;
   t.b1 = od->beta1; t.b2 = od->beta2; t.eps = od->eps;
   t.parts = parts;
-  if (chain_seq >= 0) chain_of(ws, chain_seq, &t.ch);
+  if (chain_seq >= 0) chain_of(ws, chain_seq, chain_err, &t.ch);
   if (parts == 3) {
     // the whole step on one stream: lr_t of this update is read from the step state (prepared by the previous update, or by
     // kge_opt_state_init) -- nothing of the step is a host value, so a captured step replays right.  The first launch copies it into
@@ -878,24 +877,6 @@ int train_step_swap(const kge_model_desc* md, const kge_loss_desc* ld, const kge
     t.lr_t = host_lr_t(od);
   }
   return train_grads_planned(md, ld, E_in, Rel_in, nullptr, nullptr, plan, m_pos, m_neg, ws.loss_partials, &nb, loss_out, ws.pull, seed, st, adv, nullptr, &t);
-}
-
-int train_chain_flush(const kge_model_desc* md, const float* Rel_in, int64_t m_pos, int64_t m_neg, float* loss_out, void* ws, const StepAdvance& adv,
-                      const StepTail& tail, uint32_t* err, hipStream_t st);  // pull2.hip
-int train_step_swap_flush(const kge_model_desc* md, const kge_loss_desc* ld, const kge_opt_desc* od, const float* Rel_in, float* Rel_out, int64_t m_pos,
-                          int64_t m_neg, float* loss_out, void* workspace, int64_t wbytes, int64_t seq_last, uint32_t* err, hipStream_t st) {
-  (void)ld;
-  Workspace ws;
-  if (int rc = carve(workspace, wbytes, md, m_pos, m_neg, &ws)) return rc;
-  StepAdvance adv{od->step_dev, nullptr, od->kind, od->lr, od->beta1, od->beta2};
-  StepTail t{};
-  step_tail_whole(t, md->num_entities, md->num_relations);
-  t.kind = od->kind;
-  t.Rel_out = Rel_out; t.mR = od->mRel; t.vR = od->vRel;
-  t.b1 = od->beta1; t.b2 = od->beta2; t.eps = od->eps;
-  t.parts = 3;
-  chain_of(ws, seq_last, &t.ch);
-  return train_chain_flush(md, Rel_in, m_pos, m_neg, loss_out, ws.pull, adv, t, err, st);
 }
 
 int opt_apply_vector(const kge_opt_desc* od, float* w, float* g, int64_t n, float gscale, hipStream_t st) {

@@ -413,13 +413,13 @@ def test_row_shard_trainer_world_of_one_equals_twin_step():
 @pytest.mark.parametrize("model,kw,d", [("DistMult", {}, 200), ("DistMult", {}, 24), ("TransE", dict(norm=2, gamma=12), 64), ("ComplEx", {}, 40),
                                         ("pRotatE", {}, 24)])
 def test_chained_steps_equal_the_same_steps_one_by_one(model, kw, d, opt):
-    """kge_train_step_swap_chain / kge_train_step_swap_flush: the relation rows, loss and step state of step i are produced by the first
-    workgroups of step i + 1's launch (every other wave of that launch waits for them at a gate), the last step by the flush.  Same
-    waves, same summation order: tables, moments, step state (count, next lr_t, loss sum) and the last loss must be BIT-IDENTICAL to the
-    same steps through kge_train_step_swap (list order pinned by the deterministic mode, since the two models build their own plans).
-    Chains of 1, 2 and 5 steps back to back on the same workspace (the flush leaves the gates ready for the next chain); a hub entity, a
-    dominant relation, relations without rows, untouched entities; the plan buffers' counters must be left zero by a chained step
-    (rebuilt with parts | 8)."""
+    """kge_train_step_swap_chain: the relation rows, the loss and the step state of a step are produced by late workgroups of the step's
+    ONE launch (they wait on per-workgroup flags of the relation-grouped forward: write-through stores, cache-bypassing loads).  Same
+    sums in the same order: tables, moments, step state (count, next lr_t, loss sum) and the loss must be BIT-IDENTICAL to the same
+    steps through kge_train_step_swap AFTER EVERY STEP (list order pinned by the deterministic mode, since the two models build their
+    own plans).  Chains of 1, 2 and 5 steps back to back on the same workspace (seq = 0 refills the lr ring and clears the flags); a
+    hub entity, a dominant relation, relations without rows, untouched entities; the plan buffers' counters must be left zero by a
+    chained step (rebuilt with parts | 8)."""
     from kge_keras_amd import _lib, models as M
     C, lib = _lib.C, _lib.lib
     N, R = 301, 9
@@ -445,7 +445,6 @@ def test_chained_steps_equal_the_same_steps_one_by_one(model, kw, d, opt):
         err = torch.zeros(1, dtype=torch.int32, device="cuda")
         k = 0
         for chain_len in (1, 2, 5):
-            last = None
             for seq in range(chain_len):
                 ent = lambda n: np.where(rs.rand(n) < 0.3, 7, rs.randint(0, N - 40, n))  # hub: entity 7; entities N-40.. never touched
                 rel = lambda n: np.where(rs.rand(n) < 0.6, 2, rs.randint(0, R - 2, n))   # relation 2 dominant; relations R-2.. without rows
@@ -457,23 +456,19 @@ def test_chained_steps_equal_the_same_steps_one_by_one(model, kw, d, opt):
                 od = chn._opt_desc()
                 _lib.check(lib.kge_train_step_swap_chain(C.byref(md), C.byref(ld), C.byref(od), cur[0].data_ptr(), cur[1].data_ptr(), nxt[0].data_ptr(),
                                                          nxt[1].data_ptr(), plans[k % 3].buf.data_ptr(), plans[k % 3].buf.numel(), n_pos, n_neg,
-                                                         chn._loss.data_ptr(), 0, chn._ws.data_ptr(), chn._ws.numel(), seq, _lib.stream_ptr()))
-                last = (cur[1], nxt[1])
+                                                         chn._loss.data_ptr(), 0, chn._ws.data_ptr(), chn._ws.numel(), seq, err.data_ptr(), _lib.stream_ptr()))
                 cur, nxt = nxt, cur
                 k += 1
-            od = chn._opt_desc()
-            _lib.check(lib.kge_train_step_swap_flush(C.byref(md), C.byref(ld), C.byref(od), last[0].data_ptr(), last[1].data_ptr(), n_pos, n_neg,
-                                                     chn._loss.data_ptr(), chn._ws.data_ptr(), chn._ws.numel(), chain_len - 1, err.data_ptr(), _lib.stream_ptr()))
-            torch.cuda.synchronize()
-            assert int(err.item()) == 0
-            assert torch.equal(cur[0], ref.E), (chain_len, float((cur[0] - ref.E).abs().max()))
-            assert torch.equal(cur[1], ref.Rel), (chain_len, float((cur[1] - ref.Rel).abs().max()))
-            assert torch.equal(chn._step_dev, ref._step_dev), (chain_len, chn._step_dev, ref._step_dev)
-            assert torch.equal(chn._loss, L_ref.reshape(1)) or float(chn._loss[0]) == float(L_ref)
-            if opt == "adam":
-                for a, b in zip(chn.optimizer.slots, ref.optimizer.slots):
-                    assert torch.equal(a, b)
-            nxt[0].fill_(7.0)
-            nxt[1].fill_(7.0)
+                torch.cuda.synchronize()
+                assert int(err.item()) == 0
+                assert torch.equal(cur[0], ref.E), (chain_len, seq, float((cur[0] - ref.E).abs().max()))
+                assert torch.equal(cur[1], ref.Rel), (chain_len, seq, float((cur[1] - ref.Rel).abs().max()))
+                assert torch.equal(chn._step_dev, ref._step_dev), (chain_len, seq, chn._step_dev, ref._step_dev)
+                assert float(chn._loss[0]) == float(L_ref)
+                if opt == "adam":
+                    for a, b in zip(chn.optimizer.slots, ref.optimizer.slots):
+                        assert torch.equal(a, b)
+                nxt[0].fill_(7.0)
+                nxt[1].fill_(7.0)
     finally:
         lib.kge_set_deterministic(0)

@@ -60,9 +60,8 @@ if len(steps_tr) > 8:
     chained = os.environ.get("KGE_PIPE_CHAIN", "1") != "0"  # (chained steps: ONE launch per step, the closing launch only ends a run)
     print(f"\naccounting of one training step (medians / averages, us; {'chained steps: one launch per step' if chained else 'two launches per step'}):")
     print(f"  pace of the un-instrumented pipeline (1000 steps, wall clock)                 {pace:7.1f}")
-    print(f"  step1_kernel beside the producer stages (library hipEvents)                  {k1:7.1f}" + ("   (closers of the previous step + gate included)" if chained else ""))
+    print(f"  step1_kernel beside the producer stages (library hipEvents)                  {k1:7.1f}" + ("   (write-through partial rows, closers and state workgroup included)" if chained else ""))
     if chained:
-        print(f"  chain_flush_kernel, once per run (library hipEvents)                         {k2:7.1f}")
         print(f"  step stage begin -> end with the stage trace armed                           {dur:7.1f}")
         print(f"  step stage start-to-start with the stage trace armed                         {s2s:7.1f}   => between two step stages ~ {s2s - dur:5.1f} (record of 'plan consumed' behind")
         print(f"      every second step, the satisfied wait for the next plan, launch of step1_kernel; the trace's own two event records per stage are inside this number)")
