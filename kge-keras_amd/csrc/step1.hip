@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void chain_begin_kernel(float* ring, const flo
   if (i == 0) ring[0] = state_lr[0];
 }
 
+// (waves_per_eu: the DistMult d <= 256 instance sits at 93 - 98 registers depending on what else shares the kernel; 97+ rounds up to 104 and
+//  costs every role its fifth wave per SIMD -- 63 -> 66 us alone, 8.4 -> 9.4 ms on the 10 M-entity table -- so the compiler is held to 96 there)
 template <int MODEL, int NORM, int LOSS, int NV, int G, bool DROP>
-__global__ __launch_bounds__(256) void step1_kernel(FwdRelArgs fa, SelfArgs sa, float* __restrict__ loss_partials, int rel_blocks, int R, ChainDev cd) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODEL == KGE_DISTMULT && NV == 4 && !DROP ? 5 : 1))) void step1_kernel(FwdRelArgs fa, SelfArgs sa, float* __restrict__ loss_partials, int rel_blocks, int R, ChainDev cd) {
   constexpr int NACC = MODEL == KGE_COMPLEX ? 2 * NV : NV;
   __shared__ float4 selfrow[4][NACC * G];
   __shared__ float red[16];
