@@ -438,7 +438,10 @@ def hbm_leg(torch, steps, n_entities=HBM_ENTITIES, serial_only=False):
         algo = rows * 16 * d + 24.0 * N * d
         k_live = k_ms / max(1, k_n) * 1e-3
         rp = rocprof_avg_ms("step1_kernel", "*_hbm_kernel_stats.csv")
-        k_avg = max(k_live, rp[0] * 1e-3) if rp is not None else k_live  # the slower of live hipEvents and the committed rocprofv3 average
+        # Live hipEvents of THIS run price the leg; the committed rocprofv3 average of the same command rides along with its own fraction.
+        # (The cache-resident roofline object takes the slower of the two, which agree within a few per cent there; on this 48 GB stream
+        #  the boxes of the pool differ by up to 15 % -- 8.2 .. 9.5 ms -- so a committed figure from another box says little about this one.)
+        k_avg = k_live
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_hbm.json")))
@@ -454,6 +457,7 @@ def hbm_leg(torch, steps, n_entities=HBM_ENTITIES, serial_only=False):
                 "n_entities": N, "table_bytes": N * d * 4,
                 "avg_kernel_ms": k_avg * 1e3, "avg_kernel_ms_live_hipevents": k_live * 1e3, "launches": k_n,
                 "avg_kernel_ms_rocprofv3": rp[0] if rp else None, "rocprofv3_source": f"profiles/{rp[1]}" if rp else None,
+                "frac_at_committed_rocprofv3_avg": (algo / (rp[0] * 1e-3) / HBM_PEAK) if rp else None,
                 "algorithmic_bytes_per_launch": algo,
                 "algorithmic_bytes_note": "24 N d (Keras Adam on every entity row: read w, m, v; write w, m, v) + 16 d per batch row (two entity rows gathered in the "
                                           "forward role, one per list entry = two per row in the entity role); relation rows (L2 resident) and index lists not counted",

@@ -12,8 +12,8 @@ echo "bench lines done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_serial -- python3 $root/bench.py --steps 100 --warmup 5 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval --no-hbm-leg --no-dp02 --serial > $root/gpurun_out/prof_${tag}_serial.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag} -- python3 $root/bench.py --steps 100 --warmup 5 --settle 0 --no-cpu-baseline --no-check --no-sharded-eval --no-hbm-leg --no-dp02 > $root/gpurun_out/prof_${tag}.log 2>&1
-# the HBM leg alone (the benched pipeline on the 10 M entity table, kernel by kernel): step1_kernel's average on THAT shape, + its PMC traffic
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_hbm -- python3 $root/bench.py --leg hbm --serial --steps 20 > $root/gpurun_out/prof_${tag}_hbm.log 2>&1
+# the HBM leg alone, as the bench runs it (the benched pipeline on the 10 M entity table: a pipelined pass, then kernel by kernel): step1_kernel average on THAT shape (a serial pass alone, from cold, reads 6 - 12 % longer), + its PMC traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_hbm -- python3 $root/bench.py --leg hbm --steps 20 > $root/gpurun_out/prof_${tag}_hbm.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/pmc_${tag}_hbm_fetch -- python3 $root/bench.py --leg hbm --serial --steps 6 > $root/gpurun_out/pmc_${tag}_hbm_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/pmc_${tag}_hbm_write -- python3 $root/bench.py --leg hbm --serial --steps 6 > $root/gpurun_out/pmc_${tag}_hbm_write.log 2>&1
 # kernel trace of the concurrent pipeline at the driver's flags: where the time between two step1_kernel launches goes
