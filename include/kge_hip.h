@@ -227,7 +227,7 @@ int kge_hole_spec_adjoint(float* Ghat, int64_t rows, int32_t d, const float* W, 
  *      the 1-vs-all ranking then run the ordinary kernels on it.  kge_lit_train_grads is the gradient half of a train step
  *      (gradients into gradE / gradRel / gtheta_l, zero on entry); built under DistMult, TransE (every norm id, i.e. pRotatE too), ComplEx,
  *      HolE and RotatE (d_e = 2 d_r: the Dense is d_e wide; the workspace must be zero-filled once, a padded relation-gradient table
- *      lives in it); ConvE and HAKE return KGE_EUNSUPPORTED. */
+ *      lives in it); ConvE through kge_lit_conve_train_grads below; HAKE returns KGE_EUNSUPPORTED. */
 int64_t kge_lit_workspace_bytes(const kge_model_desc* md, int32_t L, int64_t m_pos, int64_t m_neg);
 int64_t kge_lit_transform_workspace_bytes(const kge_model_desc* md, int32_t L, int32_t rows);
 int kge_lit_transform(const kge_model_desc* md, int32_t act, const float* E, const float* Lit, int32_t L, int32_t lit_rows, const float* theta_l,
@@ -236,6 +236,15 @@ int kge_lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32
                         int32_t L, int32_t lit_rows, const float* theta_l, float* gradE, float* gradRel, float* gtheta_l, const int32_t* pos,
                         int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* workspace,
                         int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* The same gradient half with ConvE behind the transform (models.py:152-158 in front of ConvE.func, :264-275): the head runs on STAGED
+ * tables -- entity rows = the batch's 2n transformed rows, relation rows = the batch's n relation rows with their dropout masks applied,
+ * triples (t, t, n + t), its own input dropout off (the transform has masked the entity inputs) -- so its per-triple gradient rows are
+ * dL/d(transformed rows), which then go back through the Dense.  theta_c / bn_stats / gtheta_c as in kge_conve_train_grads; the
+ * workspace (kge_lit_workspace_bytes with the ConvE descriptor) must be zero-filled once. */
+int kge_lit_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32_t act, const float* E, const float* Rel, const float* Lit,
+                              int32_t L, int32_t lit_rows, const float* theta_l, const float* theta_c, float* bn_stats, float* gradE, float* gradRel,
+                              float* gtheta_l, float* gtheta_c, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                              float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
 /* ---- HAKE (models.py:362-400; kge_model_desc.model = KGE_HAKE, gamma in the descriptor).  score_t = gamma - (phase_weight * sum_k
  *      |sin((phase_s + phase_p - phase_o) / 2)| + mod_weight * sqrt(sum over ALL rows of the call of M^2)) with phase = row / (embedding_range
  *      / pi), M = mod_s (mod_p + bias) - |mod_o| (1 - bias), bias = clip(bias_p, <= 1) raised to -|mod_p| -- the second term is tf.norm

@@ -173,8 +173,10 @@ int hole_spec_forward(const float*, int64_t, int, const float*, float*, hipStrea
 int hole_spec_adjoint(float*, int64_t, int, const float*, float*, int, hipStream_t);
 int64_t lit_transform_workspace_bytes(const kge_model_desc*, int, int);
 int lit_transform(const kge_model_desc*, int, const float*, const float*, int, int, const float*, int, float*, void*, int64_t, uint32_t*, hipStream_t);
+struct LitConve { const float* theta; float* stats; float* gtheta; };  // literal.hip
 int lit_train_grads(const kge_model_desc*, const kge_loss_desc*, int, const float*, const float*, const float*, int, int, const float*, float*, float*,
-                    float*, const int32_t*, int64_t, const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t);
+                    float*, const int32_t*, int64_t, const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t,
+                    const LitConve* conve = nullptr);
 int64_t rank_sweep_q_workspace_bytes(int64_t, int);
 int rank_sweep_q(const float*, int64_t, int, const float*, int, int, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, int,
                  void*, int64_t, hipStream_t);
@@ -824,6 +826,18 @@ int kge_lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32
   if (!Lit || !theta_l || !gtheta_l || !workspace) return fail(KGE_EINVAL, "kge_lit_train_grads: null pointer");
   return lit_train_grads(md, ld, act, E, Rel, Lit, L, lit_rows, theta_l, gradE, gradRel, gtheta_l, pos, m_pos, neg, m_neg, loss_out, scores_out, seed,
                          workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream));
+}
+
+int kge_lit_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int32_t act, const float* E, const float* Rel, const float* Lit,
+                              int32_t L, int32_t lit_rows, const float* theta_l, const float* theta_c, float* bn_stats, float* gradE, float* gradRel,
+                              float* gtheta_l, float* gtheta_c, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                              float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_train("kge_lit_conve_train_grads", md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, err_flag)) return rc;
+  if (md->model != KGE_CONVE) return fail(KGE_EINVAL, "kge_lit_conve_train_grads: the descriptor is not a ConvE one");
+  if (!Lit || !theta_l || !gtheta_l || !theta_c || !bn_stats || !gtheta_c || !workspace) return fail(KGE_EINVAL, "kge_lit_conve_train_grads: null pointer");
+  const LitConve cv{theta_c, bn_stats, gtheta_c};
+  return lit_train_grads(md, ld, act, E, Rel, Lit, L, lit_rows, theta_l, gradE, gradRel, gtheta_l, pos, m_pos, neg, m_neg, loss_out, scores_out, seed,
+                         workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream), &cv);
 }
 
 // ---- RCCL collectives of the sharded evaluation and of data-parallel training, on a communicator the caller made (ncclComm_t passed

@@ -1065,9 +1065,21 @@ int64_t conve_infer_workspace_bytes(const kge_model_desc* md, int64_t n) {
   return (cv_fast(s) ? 1 : 2) * c256(m * s.F * 4) + 2 * c256(m * s.d * 4) + c256(2 * s.C * 4) + c256(2 * s.d * 4) + c256(cv_psum_floats(s, m) * 4) + 2048;
 }
 
+// rows != null: the per-triple gradient rows are handed out ({dS, dP, dO}, (m_pos + m_neg, d) each, valid until the workspace is used
+// again) instead of being summed into gE / gR -- what the literal path needs: there the "tables" are staged rows of the batch itself.
+int conve_train_grads_rows(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta, float* stats,
+                           float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                           float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st,
+                           const float** rows);
 int conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta, float* stats,
                       float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
                       float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st) {
+  return conve_train_grads_rows(md, ld, E, Rel, theta, stats, gE, gR, gtheta, pos, m_pos, neg, m_neg, loss_out, scores_out, seed, ws, wbytes, err, st, nullptr);
+}
+int conve_train_grads_rows(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta, float* stats,
+                           float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                           float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st,
+                           const float** rows) {
   int64_t nt, ns;
   if (int rc = conve_sizes(md, &nt, &ns)) return rc;
   if (wbytes < conve_workspace_bytes(md, m_pos, m_neg))
@@ -1079,7 +1091,8 @@ int conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const f
   float* sc = scores_out ? scores_out : w.sc;
   // destination lists (ids only)
   PullPlan plan;
-  if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, w.pull_hdr, w.pull_body, st, &plan)) return rc;
+  if (!rows)
+    if (int rc = pull_prepare(md, pos, m_pos, neg, m_neg, w.pull_hdr, w.pull_body, st, &plan)) return rc;
   {
     ProfScope prof(KGE_PROF_FWD, st);
     if (int rc = cv_forward(md, E, Rel, theta, stats, pos, m_pos, 0, true, w.call[0], w.psum, sc, 1, err, seed, st)) return rc;
@@ -1090,6 +1103,11 @@ int conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const f
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
     if (int rc = cv_backward(md, E, Rel, theta, gtheta, pos, m_pos, 0, w.call[0], w, w.g, seed, st)) return rc;
     if (int rc = cv_backward(md, E, Rel, theta, gtheta, neg, m_neg, m_pos, w.call[1], w, w.g + m_pos, seed, st)) return rc;
+    if (rows) {
+      rows[0] = w.dS; rows[1] = w.dP; rows[2] = w.dO;
+      KGE_HIP_TRY(hipGetLastError());
+      return KGE_OK;
+    }
     if (int rc = pull2_fill_entries(md, pos, m_pos, neg, m_neg, plan, st)) return rc;
     const int N = md->num_entities, NK = N + md->num_relations;
     rowsum_dispatch((int)cdiv(NK + plan.max_extra, 4), st, gE, gR, N, NK, md->d_e, plan, w.dS, w.dP, w.dO);

@@ -13,6 +13,14 @@
 namespace kge {
 
 rocblas_handle blas_handle_shared();  // conve.hip
+// conve.hip: ConvE's gradient half with the per-triple rows handed out instead of summed (rows = {dS, dP, dO})
+int conve_train_grads_rows(const kge_model_desc* md, const kge_loss_desc* ld, const float* E, const float* Rel, const float* theta, float* stats,
+                           float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg,
+                           float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err, hipStream_t st,
+                           const float** rows);
+int64_t conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg);
+// ConvE behind the literal transform (lit_train_grads): the head's parameters, moving statistics and parameter gradients
+struct LitConve { const float* theta; float* stats; float* gtheta; };
 int cv_rowsum_launch(const kge_model_desc* md, float* gE, float* gR, const PullPlan& plan, const float* dS, const float* dP, const float* dO,
                      hipStream_t st);  // conve.hip
 int pull2_fill_entries(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p,
@@ -270,6 +278,39 @@ __global__ __launch_bounds__(256) void lit_rows(const float* __restrict__ Rel, c
   }
 }
 
+// ConvE behind the literal transform: the head runs on STAGED tables -- entity rows = the 2n transformed rows of the batch (H), relation
+// rows = the batch's n relation rows with their dropout masks applied (Pm), triples (t, t, n + t) -- so its gradient rows with respect
+// to those tables are dL/d(transformed rows) and dL/d(masked relation rows).  One wave per batch row.
+template <bool DROP>
+__global__ __launch_bounds__(256) void lit_stage_rel(const float* __restrict__ Rel, const int32_t* __restrict__ pos, int64_t m_pos,
+                                                      const int32_t* __restrict__ neg, int64_t m_neg, int R, int d, float* __restrict__ Pm,
+                                                      int32_t* __restrict__ tri, uint64_t seed, uint32_t thr, float dscale, uint32_t* __restrict__ err) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = m_pos + m_neg;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n; t += (int64_t)gridDim.x * 4) {
+    const int32_t* tr = t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos);
+    const int p = tr[1];
+    const bool ok = (unsigned)p < (unsigned)R;
+    if (!ok && lane == 0) atomicOr(err, 1u);
+    const float* rp = Rel + (int64_t)(ok ? p : 0) * d;
+    DropKey kp{0, 0};
+    if (DROP) kp = drop_key(seed, t, 1);
+    for (int k = lane; k < d; k += 64) Pm[t * d + k] = ok ? rp[k] * (DROP ? drop_mul(kp, k, thr, dscale) : 1.f) : 0.f;
+    if (lane == 0) { tri[3 * t] = (int32_t)t; tri[3 * t + 1] = (int32_t)t; tri[3 * t + 2] = (int32_t)(n + t); }
+  }
+}
+// dP[t] = rows[t] * mask(t, role 1): the gradient with respect to the UNMASKED relation row of batch row t
+template <bool DROP>
+__global__ __launch_bounds__(256) void lit_mask_rel(const float* __restrict__ rows, int64_t n, int d, float* __restrict__ dP, uint64_t seed, uint32_t thr,
+                                                     float dscale) {
+  const int64_t total = n * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / d;
+    const int k = (int)(i - t * d);
+    dP[i] = rows[i] * (DROP ? drop_mul(drop_key(seed, t, 1), k, thr, dscale) : 1.f);
+  }
+}
+
 // dZ = dH * act'(Zb) in place; per-block partial column sums (64 rows per block) for the bias gradient.
 __global__ __launch_bounds__(256) void lit_act_bwd(float* __restrict__ dH, const float* __restrict__ Zb, int64_t rows, int d, int act,
                                                     float* __restrict__ psum) {
@@ -323,8 +364,9 @@ __global__ __launch_bounds__(256) void lit_compact(const float* __restrict__ dA,
 static int64_t l256(int64_t x) { return align_up(x, 256); }
 
 static int lit_check(const kge_model_desc* md, int L, int act) {
-  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX && md->model != KGE_HOLE && md->model != KGE_ROTATE)
-    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE, ComplEx, HolE and RotatE are built)", md->model);
+  if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX && md->model != KGE_HOLE && md->model != KGE_ROTATE &&
+      md->model != KGE_CONVE)
+    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE, ComplEx, HolE, RotatE and ConvE are built)", md->model);
   if (md->model == KGE_ROTATE && md->d_e != 2 * md->d_r) return fail(KGE_EINVAL, "literal path under RotatE: d_e must be 2 * d_r");
   if (md->model == KGE_HOLE && md->d_e > kLitHoleMax)
     return fail(KGE_EUNSUPPORTED, "literal path under HolE: rows of at most %d floats (e_dim = %d)", kLitHoleMax, md->d_e);
@@ -375,11 +417,24 @@ __global__ __launch_bounds__(256) void lit_splitk_sum(const float* __restrict__ 
   }
 }
 
+// ConvE behind the transform: its staged descriptor (2n entity rows, n relation rows, input dropout already applied) and what it adds to the workspace
+static kge_model_desc lit_conve_desc(const kge_model_desc* md, int64_t n) {
+  kge_model_desc m2 = *md;
+  m2.num_entities = (int32_t)(2 * n);
+  m2.num_relations = (int32_t)n;
+  m2.dropout = 0.f;
+  return m2;
+}
+static int64_t lit_conve_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
+  const int64_t n = m_pos + m_neg;
+  const kge_model_desc m2 = lit_conve_desc(md, n);
+  return l256(n * md->d_e * 4) + l256(n * 12) + l256(conve_workspace_bytes(&m2, m_pos, m_neg)) + 1024;
+}
 int64_t lit_workspace_bytes(const kge_model_desc* md, int L, int64_t m_pos, int64_t m_neg) {
   const int64_t n = m_pos + m_neg, d = md->d_e, K1 = d + L;
   return l256((int64_t)lit_splits(2 * n, d, K1) * d * K1 * 4) + pull_header_bytes(md) + 2 * l256(2 * n * K1 * 4) + 3 * l256(2 * n * d * 4) + 3 * l256(n * d * 4) + 2 * l256(n * 4) +
          l256(cdiv(2 * n, 64) * d * 4) + pull_workspace_bytes(md, n) + l256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096 +
-         (md->model == KGE_ROTATE ? l256((int64_t)md->num_relations * d * 4) : 0);
+         (md->model == KGE_ROTATE ? l256((int64_t)md->num_relations * d * 4) : 0) + (md->model == KGE_CONVE ? lit_conve_bytes(md, m_pos, m_neg) : 0);
 }
 
 // RotatE: the relation rows are h = d / 2 wide, the destination sums run on rows of d.  The per-triple rows dP carry zeros in their
@@ -419,8 +474,10 @@ static void launch_rows_model(bool drop, int grid, hipStream_t st, const float* 
 int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, const float* E, const float* Rel, const float* Lit, int L,
                     int lit_rows_n, const float* theta, float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos,
                     const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err,
-                    hipStream_t st) {
+                    hipStream_t st, const LitConve* conve) {
   if (int rc = lit_check(md, L, act)) return rc;
+  if ((md->model == KGE_CONVE) != (conve != nullptr)) return fail(KGE_EINVAL, "literal path: ConvE goes through kge_lit_conve_train_grads (and only ConvE)");
+  if (2 * (m_pos + m_neg) > 0x7fffffff) return fail(KGE_EINVAL, "literal path: batch too large");
   if (wbytes < lit_workspace_bytes(md, L, m_pos, m_neg))
     return fail(KGE_EWORKSPACE, "literal path: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)lit_workspace_bytes(md, L, m_pos, m_neg));
   const int64_t n = m_pos + m_neg;
@@ -447,6 +504,18 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
   void* loss_ws = take(loss_ws_bytes);
   const int splits = lit_splits(2 * n, d, K1);
   float* wpart = (float*)take((int64_t)splits * d * K1 * 4);
+  float* Pm = nullptr;
+  int32_t* tri2 = nullptr;
+  void* cws = nullptr;
+  kge_model_desc md2 = *md;
+  int64_t cws_bytes = 0;
+  if (conve) {
+    md2 = lit_conve_desc(md, n);
+    Pm = (float*)take(n * d * 4);
+    tri2 = (int32_t*)take(n * 12);
+    cws_bytes = conve_workspace_bytes(&md2, m_pos, m_neg);
+    cws = take(cws_bytes);
+  }
   float* sc = scores_out ? scores_out : scb;
   const bool drop = md->dropout > 0.f;
   const uint32_t thr = drop_thr(md->dropout);
@@ -466,12 +535,27 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
     KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (rocblas_int)(2 * n), K1, &one, theta, d, A, K1, &zero, Zb, d));
     if (act == kActSoftmax) hipLaunchKernelGGL(lit_softmax_fwd, dim3((int)std::min<int64_t>(cdiv(2 * n, 4), 8192)), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d);
     else hipLaunchKernelGGL(lit_act_fwd, dim3(gel), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d, act);
-    launch_rows_model<0>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, nullptr, sc, nullptr, nullptr, seed);
+    if (!conve) launch_rows_model<0>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, nullptr, sc, nullptr, nullptr, seed);
   }
-  if (int rc = loss_value(ld, sc, m_pos, sc + m_pos, m_neg, loss_out, g, g + m_pos, loss_ws, loss_ws_bytes, st)) return rc;
+  if (conve) {
+    // models.py:152-158 in front of ConvE.func (:264-275): the head (batch statistics, hidden dropout, its own loss call) on the staged rows
+    if (drop) hipLaunchKernelGGL((lit_stage_rel<true>), dim3(gw), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, d, Pm, tri2, seed, thr, dscale, err);
+    else hipLaunchKernelGGL((lit_stage_rel<false>), dim3(gw), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, d, Pm, tri2, seed, thr, dscale, err);
+    const float* rows[3] = {nullptr, nullptr, nullptr};
+    if (int rc = conve_train_grads_rows(&md2, ld, H, Pm, conve->theta, conve->stats, nullptr, nullptr, conve->gtheta, tri2, m_pos, tri2 + 3 * m_pos, m_neg, loss_out,
+                                        sc, seed, cws, cws_bytes, err, st, rows))
+      return rc;
+    KGE_HIP_TRY(hipMemcpyAsync(dH, rows[0], (size_t)n * d * 4, hipMemcpyDeviceToDevice, st));
+    KGE_HIP_TRY(hipMemcpyAsync(dH + n * d, rows[2], (size_t)n * d * 4, hipMemcpyDeviceToDevice, st));
+    const int gm = (int)std::min<int64_t>(cdiv(n * d, 256), 8192);
+    if (drop) hipLaunchKernelGGL((lit_mask_rel<true>), dim3(gm), dim3(256), 0, st, rows[1], n, d, dPb, seed, thr, dscale);
+    else hipLaunchKernelGGL((lit_mask_rel<false>), dim3(gm), dim3(256), 0, st, rows[1], n, d, dPb, seed, thr, dscale);
+  } else if (int rc = loss_value(ld, sc, m_pos, sc + m_pos, m_neg, loss_out, g, g + m_pos, loss_ws, loss_ws_bytes, st)) {
+    return rc;
+  }
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
-    launch_rows_model<1>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, g, nullptr, dH, dPb, seed);
+    if (!conve) launch_rows_model<1>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, g, nullptr, dH, dPb, seed);
     // (softmax: rows first -- dz = h (dh - <dh, h>) -- then the column sums through the linear branch of lit_act_bwd)
     if (act == kActSoftmax) hipLaunchKernelGGL(lit_softmax_bwd_rows, dim3((int)std::min<int64_t>(cdiv(2 * n, 4), 8192)), dim3(256), 0, st, dH, Zb, 2 * n, d);
     hipLaunchKernelGGL(lit_act_bwd, dim3(nb_rows), dim3(256), 0, st, dH, Zb, 2 * n, d, act == kActSoftmax ? 0 : act, psum);

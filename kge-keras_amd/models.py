@@ -180,8 +180,8 @@ class EmbeddingModel:
         self._seed = int(seed) if seed is not None else 0
         self._lit = None
         if literal_activation:  # models.py:114-120: frozen literal table + Dense(e_dim, activation) on [embedding ; literal]
-            if self.MODEL not in ("DistMult", "TransE", "ComplEx", "HolE", "RotatE"):  # (MODEL "TransE" covers TransE with any norm and pRotatE)
-                raise NotImplementedError(f"the literal input path is built for DistMult, TransE, ComplEx, HolE, pRotatE and RotatE, not {type(self).__name__}")
+            if self.MODEL not in ("DistMult", "TransE", "ComplEx", "HolE", "RotatE", "ConvE"):  # (MODEL "TransE" covers TransE with any norm and pRotatE)
+                raise NotImplementedError(f"the literal input path is built for DistMult, TransE, ComplEx, HolE, pRotatE, RotatE and ConvE, not {type(self).__name__}")
             act = literal_activation if isinstance(literal_activation, str) else getattr(literal_activation, "__name__", None)
             if act not in ACT_IDS:
                 raise NotImplementedError(f"literal_activation {literal_activation!r}: one of {sorted(k for k in ACT_IDS if k)}")
@@ -307,9 +307,9 @@ class EmbeddingModel:
 
     def _raise_on_flag(self):
         flag = int(self._err.item())
-        if flag & 32:  # (kge_train_step_swap_flush: bounded gate waits of chained steps -- a device fault, never a data error)
+        if flag & 32:  # (kge_train_step_swap_chain: the bounded flag waits of its closer workgroups -- a device fault, never a data error)
             self._err.zero_()
-            raise RuntimeError("chained training steps: a wave gave up waiting for the relation rows of the previous step (device fault); the tables are not to be trusted")
+            raise RuntimeError("chained training steps: a closer workgroup gave up waiting for the forward's partial rows (device fault); the tables are not to be trusted")
         if flag != 0:
             self._err.zero_()
             raise IndexError("triple ids out of range of the embedding tables (indices[...] is not in [0, N))")
@@ -1240,7 +1240,8 @@ class ConvE(EmbeddingModel):
         n = t.shape[0]
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         md = self._infer_ws(n)
-        check(lib.kge_conve_score(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(),
+        Et = self._eval_table()  # (E itself, or with the literal path the transformed table: models.py:152-158 in inference mode)
+        check(lib.kge_conve_score(C.byref(md), Et.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(),
                                   t.data_ptr(), n, out.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(),
                                   _lib.stream_ptr()))
         return out
@@ -1266,13 +1267,16 @@ class ConvE(EmbeddingModel):
                                   out.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
         return out
 
-    def hidden(self, triples):
-        """x(s, p) of every row in inference mode, (n, dim) on the device; score(s, p, o) = <x, E[o]>."""
+    def hidden(self, triples, Et=None):
+        """x(s, p) of every row in inference mode, (n, dim) on the device; score(s, p, o) = <x, E[o]> (Et: the entity table to read, the
+        literal-transformed one where the literal path is on)."""
         t = as_triples(triples, self.device, self.num_entities, self.num_relations)
         n = t.shape[0]
         out = torch.empty((n, int(self.dim)), dtype=torch.float32, device=self.device)
         md = self._infer_ws(n)
-        check(lib.kge_conve_hidden(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(),
+        if Et is None:
+            Et = self._eval_table()
+        check(lib.kge_conve_hidden(C.byref(md), Et.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(),
                                    t.data_ptr(), n, out.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(),
                                    _lib.stream_ptr()))
         return out
@@ -1290,6 +1294,8 @@ class ConvE(EmbeddingModel):
         if o.kind == "adam" and self._tslots is None:
             self._tslots = (torch.zeros_like(self.theta), torch.zeros_like(self.theta))
         md, ld = self._model_desc(True), self._loss_desc()
+        if self._lit is not None:
+            return self._train_step_literal_conve(pos, neg, md, ld, scores_out)
         need = check(lib.kge_conve_workspace_bytes(C.byref(md), pos.shape[0], neg.shape[0]))
         if self._cws is None or self._cws.numel() < need:
             self._cws = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
@@ -1311,15 +1317,44 @@ class ConvE(EmbeddingModel):
         check(lib.kge_opt_apply_vector(C.byref(odv), self.theta.data_ptr(), self._gtheta.data_ptr(), self.theta.numel(), 1.0, _lib.stream_ptr()))
         return {"loss": self._loss[0]}
 
+    def _train_step_literal_conve(self, pos, neg, md, ld, scores_out):
+        """models.py:152-158 in front of ConvE.func: the gradient half through kge_lit_conve_train_grads (the head on the batch's transformed
+        rows as staged tables), then the optimizer on the four parameter groups (tables, head, Dense)."""
+        lt, o = self._lit, self.optimizer
+        if o.kind == "adam" and lt["slots"] is None:
+            lt["slots"] = (torch.zeros_like(lt["theta"]), torch.zeros_like(lt["theta"]))
+        need = check(lib.kge_lit_workspace_bytes(C.byref(md), lt["L"], pos.shape[0], neg.shape[0]))
+        if lt["ws"] is None or lt["ws"].numel() < need:
+            lt["ws"] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+        o.iterations += 1
+        self._seed += 1
+        check(lib.kge_lit_conve_train_grads(C.byref(md), C.byref(ld), lt["act"], self.E.data_ptr(), self.Rel.data_ptr(), lt["table"].data_ptr(), lt["L"],
+                                            lt["table"].shape[0], lt["theta"].data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(), self._gE.data_ptr(),
+                                            self._gR.data_ptr(), lt["gtheta"].data_ptr(), self._gtheta.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(),
+                                            neg.shape[0], self._loss.data_ptr(), scores_out.data_ptr() if scores_out is not None else None, self._seed,
+                                            lt["ws"].data_ptr(), lt["ws"].numel(), self._err.data_ptr(), _lib.stream_ptr()))
+        od = self._opt_desc()
+        if self._ws is None:
+            need2 = check(lib.kge_train_step_workspace_bytes(C.byref(md), C.byref(ld), 0, 0))
+            self._ws = torch.zeros(int(need2), dtype=torch.uint8, device=self.device)
+        check(lib.kge_opt_apply(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
+                                self._gR.data_ptr(), 1.0, self._loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()))
+        for th, g, sl in ((self.theta, self._gtheta, self._tslots), (lt["theta"], lt["gtheta"], lt["slots"])):
+            ts = [x.data_ptr() for x in sl] if sl else [None, None]
+            odv = OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, o.iterations, ts[0], ts[1], None, None)
+            check(lib.kge_opt_apply_vector(C.byref(odv), th.data_ptr(), g.data_ptr(), th.numel(), 1.0, _lib.stream_ptr()))
+        return {"loss": self._loss[0]}
+
     def _batch_loss_into(self, data, ctx, acc=None, out=None):
         """Forward-only loss of one batch in inference mode (models.py:239-275 with moving statistics and no dropout; tests.py:130-134
         passes validation_data to fit): the scores of both arrays by kge_conve_score, the loss on them by kge_loss_value."""
         pos = as_triples(data[0], self.device, self.num_entities, self.num_relations)
         neg = as_triples(data[1], self.device, self.num_entities, self.num_relations)
         sc = torch.empty(pos.shape[0] + neg.shape[0], dtype=torch.float32, device=self.device)
+        Et = ctx["Et"] if ctx and "Et" in ctx else self._eval_table()
         for t, o_ in ((pos, sc[:pos.shape[0]]), (neg, sc[pos.shape[0]:])):
             md = self._infer_ws(t.shape[0])
-            check(lib.kge_conve_score(C.byref(md), self.E.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(), t.data_ptr(),
+            check(lib.kge_conve_score(C.byref(md), Et.data_ptr(), self.Rel.data_ptr(), self.theta.data_ptr(), self.bn_stats.data_ptr(), t.data_ptr(),
                                       t.shape[0], o_.data_ptr(), self._iws.data_ptr(), self._iws.numel(), self._err.data_ptr(), _lib.stream_ptr()))
         ld = self._loss_desc()
         ws = self._loss_ws(pos.shape[0], neg.shape[0])
@@ -1355,21 +1390,22 @@ class ConvE(EmbeddingModel):
                                        _lib.stream_ptr()))
             return 1 + cnt.cpu().numpy().astype(np.int64)
 
-        Ecand = self.E[:N].contiguous()
+        Et = self._eval_table()  # (with the literal path: the transformed table, built once for the whole evaluation)
+        Ecand = Et[:N].contiguous()
         for a in range(0, len(test), chunk):
             part = test[a:a + chunk]
             fq, fi = filter_coo(part, 0, filt, N)
-            tails[a:a + chunk] = sweep(self.hidden(part), Ecand, part[:, 2], fq, fi)
+            tails[a:a + chunk] = sweep(self.hidden(part, Et), Ecand, part[:, 2], fq, fi)
         ent = np.arange(N, dtype=np.int32)
         for p in np.unique(test[:, 1]):
             idx = np.nonzero(test[:, 1] == p)[0]
             allsp = np.stack([ent, np.full(N, p, dtype=np.int32), np.zeros(N, dtype=np.int32)], 1)
-            Xp = self.hidden(allsp)  # (N, d): candidate matrix of this relation
+            Xp = self.hidden(allsp, Et)  # (N, d): candidate matrix of this relation
             for a in range(0, len(idx), chunk):
                 sel = idx[a:a + chunk]
                 part = test[sel]
                 fq, fi = filter_coo(part, 1, filt, N)
-                Q = self.E.index_select(0, torch.from_numpy(part[:, 2].astype(np.int64)).to(self.device)).contiguous()
+                Q = Et.index_select(0, torch.from_numpy(part[:, 2].astype(np.int64)).to(self.device)).contiguous()
                 heads[sel] = sweep(Q, Xp, part[:, 0], fq, fi)
         self._raise_on_flag()
         return tails, heads

@@ -869,3 +869,52 @@ def literal_train_step(model, H, act, E, Rel, Lit, opt, pos, neg, loss="pointwiz
     opt.apply("lit_W", H["W"], gW)
     opt.apply("lit_b", H["b"], gb)
     return Lv, per[0]["sc"], per[1]["sc"]
+
+
+def literal_conve_train_step(P, H, act, E, Rel, Lit, opt, pos, neg, loss="pointwize_hinge", margin=1, negative_samples=1, dropout=0.0, hidden_dp=0.0,
+                             seed=0):
+    """One Keras train step with the literal path (models.py:152-158) in front of ConvE.func (:264-275): s and o are the Dense's outputs on
+    [dp(E[id]) ; dp(Lit[id])], p = dp(Rel[p]); the head runs once on the positives and once on the negatives in training mode (batch
+    statistics, hidden dropout: conve_forward / conve_backward).  E, Rel, the Dense (H) and the head's trainables (P) are updated in place."""
+    dt = E.dtype
+    pos = np.asarray(pos).reshape(-1, 3).astype(np.int64)
+    neg = np.asarray(neg).reshape(-1, 3).astype(np.int64)
+    d, L = E.shape[1], Lit.shape[1]
+    per = []
+    for t, off in ((pos, 0), (neg, len(pos))):
+        m = len(t)
+        one_e, one_l = np.ones((m, d), dt), np.ones((m, L), dt)
+        if dropout:
+            mk = lambda role, w: dropout_multipliers(seed, m, role, w, dropout, off).astype(dt)  # noqa: E731
+            ms, mp, mo, mls, mlo = mk(0, d), mk(1, Rel.shape[1]), mk(2, d), mk(5, L), mk(6, L)
+        else:
+            ms, mp, mo, mls, mlo = one_e, np.ones((m, Rel.shape[1]), dt), one_e, one_l, one_l
+        s_, cs = literal_transform(H, E, Lit, t[:, 0], act, ms, mls)
+        o_, co = literal_transform(H, E, Lit, t[:, 2], act, mo, mlo)
+        p_ = Rel[t[:, 1]] * mp
+        c = {}
+        _, sc = conve_forward(P, s_, p_, o_, True, hidden_dp, seed, off, c)
+        per.append(dict(t=t, o=o_, cs=cs, co=co, ms=ms, mp=mp, mo=mo, cache=c, sc=sc.astype(dt)))
+    Lv, gt, gf = loss_value_and_grads(loss, per[0]["sc"], per[1]["sc"], margin, negative_samples)
+    gE, gR = np.zeros_like(E), np.zeros_like(Rel)
+    gW, gb = np.zeros_like(H["W"]), np.zeros_like(H["b"])
+    gP = {k: np.zeros_like(P[k]) for k in CONVE_TRAINABLE}
+    for c, g in ((per[0], gt), (per[1], gf)):
+        ds, dp, do, gp = conve_backward(P, c["cache"], c["o"], g.astype(dt))
+        for k in CONVE_TRAINABLE:
+            gP[k] += gp[k]
+        _scatter_add(gR, c["t"][:, 1], (dp * c["mp"]).astype(dt))
+        for dh, cache, mask, col in ((ds, c["cs"], c["ms"], 0), (do, c["co"], c["mo"], 2)):
+            dZ = literal_act_backward(cache, dh)
+            gW += cache["A"].T @ dZ
+            gb += dZ.sum(0)
+            dA = dZ @ H["W"].T
+            _scatter_add(gE, c["t"][:, col], (dA[:, :d] * mask).astype(dt))
+    opt.begin_step()
+    opt.apply("E", E, gE)
+    opt.apply("R", Rel, gR)
+    for k in CONVE_TRAINABLE:
+        opt.apply("conve_" + k, P[k], gP[k])
+    opt.apply("lit_W", H["W"], gW)
+    opt.apply("lit_b", H["b"], gb)
+    return Lv, per[0]["sc"], per[1]["sc"]
