@@ -227,7 +227,7 @@ int kge_hole_spec_adjoint(float* Ghat, int64_t rows, int32_t d, const float* W, 
  *      the 1-vs-all ranking then run the ordinary kernels on it.  kge_lit_train_grads is the gradient half of a train step
  *      (gradients into gradE / gradRel / gtheta_l, zero on entry); built under DistMult, TransE (every norm id, i.e. pRotatE too), ComplEx,
  *      HolE and RotatE (d_e = 2 d_r: the Dense is d_e wide; the workspace must be zero-filled once, a padded relation-gradient table
- *      lives in it); ConvE through kge_lit_conve_train_grads below; HAKE returns KGE_EUNSUPPORTED. */
+ *      lives in it); ConvE and HAKE through kge_lit_conve_train_grads / kge_lit_hake_train_grads below. */
 int64_t kge_lit_workspace_bytes(const kge_model_desc* md, int32_t L, int64_t m_pos, int64_t m_neg);
 int64_t kge_lit_transform_workspace_bytes(const kge_model_desc* md, int32_t L, int32_t rows);
 int kge_lit_transform(const kge_model_desc* md, int32_t act, const float* E, const float* Lit, int32_t L, int32_t lit_rows, const float* theta_l,
@@ -269,6 +269,13 @@ int kge_hake_rank_counts(const float* scores, int64_t n, const int64_t* q_off, i
 int kge_hake_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const kge_hake_params* hp, const float* E, const float* Rel,
                          float* gradE, float* gradRel, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
                          float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
+/* ... and with HAKE behind the transform (LiteralE-style input path above): the same staging -- one call of the model per side on the
+ * staged rows, so the call-wide norm is the side's as in kge_hake_train_grads; its dense accumulators over the staged tables are the
+ * per-row gradients; the relation rows (3h wide, entity rows 2h) are scattered into gradRel by float atomics. */
+int kge_lit_hake_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const kge_hake_params* hp, int32_t act, const float* E,
+                             const float* Rel, const float* Lit, int32_t L, int32_t lit_rows, const float* theta_l, float* gradE, float* gradRel,
+                             float* gtheta_l, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out,
+                             float* scores_out, uint64_t seed, void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream);
 /* Seeds the device-resident step state: od->step_dev := {od->step - 1, lr_t(od->step), 0} (see kge_opt_desc). */
 int kge_opt_state_init(const kge_opt_desc* od, kge_stream_t stream);
 /* Keras optimizer update of one flat fp32 vector (w -= ..., g re-zeroed); od->mE / od->vE are its Adam slots. */

@@ -95,6 +95,7 @@ SIGNATURES = {
     "kge_lit_transform": (C.c_int, [_MD, _I32, _P, _P, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "kge_lit_train_grads": (C.c_int, [_MD, _LD, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
     "kge_lit_conve_train_grads": (C.c_int, [_MD, _LD, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
+    "kge_lit_hake_train_grads": (C.c_int, [_MD, _LD, _P, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _U64, _P, _I64, _P, _P]),
     "kge_hole_spec_width": (_I32, [_I32]),
     "kge_hole_spec_basis": (C.c_int, [_I32, _P, _P, _P]),
     "kge_hole_spec_forward": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),

@@ -176,7 +176,7 @@ int lit_transform(const kge_model_desc*, int, const float*, const float*, int, i
 struct LitConve { const float* theta; float* stats; float* gtheta; };  // literal.hip
 int lit_train_grads(const kge_model_desc*, const kge_loss_desc*, int, const float*, const float*, const float*, int, int, const float*, float*, float*,
                     float*, const int32_t*, int64_t, const int32_t*, int64_t, float*, float*, uint64_t, void*, int64_t, uint32_t*, hipStream_t,
-                    const LitConve* conve = nullptr);
+                    const LitConve* conve = nullptr, const kge_hake_params* hake = nullptr);
 int64_t rank_sweep_q_workspace_bytes(int64_t, int);
 int rank_sweep_q(const float*, int64_t, int, const float*, int, int, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t*, int,
                  void*, int64_t, hipStream_t);
@@ -838,6 +838,17 @@ int kge_lit_conve_train_grads(const kge_model_desc* md, const kge_loss_desc* ld,
   const LitConve cv{theta_c, bn_stats, gtheta_c};
   return lit_train_grads(md, ld, act, E, Rel, Lit, L, lit_rows, theta_l, gradE, gradRel, gtheta_l, pos, m_pos, neg, m_neg, loss_out, scores_out, seed,
                          workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream), &cv);
+}
+
+int kge_lit_hake_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const kge_hake_params* hp, int32_t act, const float* E, const float* Rel,
+                             const float* Lit, int32_t L, int32_t lit_rows, const float* theta_l, float* gradE, float* gradRel, float* gtheta_l,
+                             const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed,
+                             void* workspace, int64_t workspace_bytes, uint32_t* err_flag, kge_stream_t stream) {
+  if (int rc = check_train("kge_lit_hake_train_grads", md, ld, E, Rel, gradE, gradRel, pos, m_pos, neg, m_neg, loss_out, err_flag)) return rc;
+  if (md->model != KGE_HAKE || !hp) return fail(KGE_EINVAL, "kge_lit_hake_train_grads: needs a HAKE descriptor and its parameters");
+  if (!Lit || !theta_l || !gtheta_l || !workspace) return fail(KGE_EINVAL, "kge_lit_hake_train_grads: null pointer");
+  return lit_train_grads(md, ld, act, E, Rel, Lit, L, lit_rows, theta_l, gradE, gradRel, gtheta_l, pos, m_pos, neg, m_neg, loss_out, scores_out, seed,
+                         workspace, workspace_bytes, err_flag, static_cast<hipStream_t>(stream), nullptr, hp);
 }
 
 // ---- RCCL collectives of the sharded evaluation and of data-parallel training, on a communicator the caller made (ncclComm_t passed

@@ -21,6 +21,11 @@ int conve_train_grads_rows(const kge_model_desc* md, const kge_loss_desc* ld, co
 int64_t conve_workspace_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg);
 // ConvE behind the literal transform (lit_train_grads): the head's parameters, moving statistics and parameter gradients
 struct LitConve { const float* theta; float* stats; float* gtheta; };
+// hake.hip: HAKE's gradient half (dense accumulators gE / gR += per-row gradients by float atomics) and its scratch
+int hake_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, const kge_hake_params* hp, const float* E, const float* Rel, float* gE, float* gR,
+                     const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed,
+                     void* workspace, int64_t wbytes, uint32_t* err, hipStream_t st);
+int64_t hake_workspace_bytes(int64_t n, int64_t chunk);
 int cv_rowsum_launch(const kge_model_desc* md, float* gE, float* gR, const PullPlan& plan, const float* dS, const float* dP, const float* dO,
                      hipStream_t st);  // conve.hip
 int pull2_fill_entries(const kge_model_desc* md, const int32_t* pos, int64_t m_pos, const int32_t* neg, int64_t m_neg, const PullPlan& p,
@@ -311,6 +316,23 @@ __global__ __launch_bounds__(256) void lit_mask_rel(const float* __restrict__ ro
   }
 }
 
+// HAKE behind the literal transform (relation rows 3h wide, entity rows 2h: the destination sums of this path run on rows of ONE width):
+// gR[p_t] += rows[t] * mask(t, role 1) by float atomics, like HAKE's own gradient path
+template <bool DROP>
+__global__ __launch_bounds__(256) void lit_scatter_rel(const float* __restrict__ rows, const int32_t* __restrict__ pos, int64_t m_pos,
+                                                        const int32_t* __restrict__ neg, int64_t m_neg, int R, int dr, float* __restrict__ gR, uint64_t seed,
+                                                        uint32_t thr, float dscale) {
+  const int64_t n = m_pos + m_neg, total = n * dr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / dr;
+    const int k = (int)(i - t * dr);
+    const int p = (t < m_pos ? pos + 3 * t : neg + 3 * (t - m_pos))[1];
+    if ((unsigned)p >= (unsigned)R) continue;
+    const float v = rows[i] * (DROP ? drop_mul(drop_key(seed, t, 1), k, thr, dscale) : 1.f);
+    if (v != 0.f) unsafeAtomicAdd(gR + (int64_t)p * dr + k, v);
+  }
+}
+
 // dZ = dH * act'(Zb) in place; per-block partial column sums (64 rows per block) for the bias gradient.
 __global__ __launch_bounds__(256) void lit_act_bwd(float* __restrict__ dH, const float* __restrict__ Zb, int64_t rows, int d, int act,
                                                     float* __restrict__ psum) {
@@ -365,8 +387,8 @@ static int64_t l256(int64_t x) { return align_up(x, 256); }
 
 static int lit_check(const kge_model_desc* md, int L, int act) {
   if (md->model != KGE_DISTMULT && md->model != KGE_TRANSE && md->model != KGE_COMPLEX && md->model != KGE_HOLE && md->model != KGE_ROTATE &&
-      md->model != KGE_CONVE)
-    return fail(KGE_EUNSUPPORTED, "literal path: model %d (DistMult, TransE, ComplEx, HolE, RotatE and ConvE are built)", md->model);
+      md->model != KGE_CONVE && md->model != KGE_HAKE)
+    return fail(KGE_EUNSUPPORTED, "literal path: model %d", md->model);
   if (md->model == KGE_ROTATE && md->d_e != 2 * md->d_r) return fail(KGE_EINVAL, "literal path under RotatE: d_e must be 2 * d_r");
   if (md->model == KGE_HOLE && md->d_e > kLitHoleMax)
     return fail(KGE_EUNSUPPORTED, "literal path under HolE: rows of at most %d floats (e_dim = %d)", kLitHoleMax, md->d_e);
@@ -430,11 +452,16 @@ static int64_t lit_conve_bytes(const kge_model_desc* md, int64_t m_pos, int64_t 
   const kge_model_desc m2 = lit_conve_desc(md, n);
   return l256(n * md->d_e * 4) + l256(n * 12) + l256(conve_workspace_bytes(&m2, m_pos, m_neg)) + 1024;
 }
+static int64_t lit_hake_bytes(const kge_model_desc* md, int64_t m_pos, int64_t m_neg) {
+  const int64_t n = m_pos + m_neg;
+  return 2 * l256(n * md->d_r * 4) + l256(n * 12) + l256(hake_workspace_bytes(n, 0)) + 1024;
+}
 int64_t lit_workspace_bytes(const kge_model_desc* md, int L, int64_t m_pos, int64_t m_neg) {
   const int64_t n = m_pos + m_neg, d = md->d_e, K1 = d + L;
   return l256((int64_t)lit_splits(2 * n, d, K1) * d * K1 * 4) + pull_header_bytes(md) + 2 * l256(2 * n * K1 * 4) + 3 * l256(2 * n * d * 4) + 3 * l256(n * d * 4) + 2 * l256(n * 4) +
          l256(cdiv(2 * n, 64) * d * 4) + pull_workspace_bytes(md, n) + l256(train_workspace_bytes(nullptr, m_pos, m_neg)) + 4096 +
-         (md->model == KGE_ROTATE ? l256((int64_t)md->num_relations * d * 4) : 0) + (md->model == KGE_CONVE ? lit_conve_bytes(md, m_pos, m_neg) : 0);
+         (md->model == KGE_ROTATE || md->model == KGE_HAKE ? l256((int64_t)md->num_relations * d * 4) : 0) +
+         (md->model == KGE_CONVE ? lit_conve_bytes(md, m_pos, m_neg) : 0) + (md->model == KGE_HAKE ? lit_hake_bytes(md, m_pos, m_neg) : 0);
 }
 
 // RotatE: the relation rows are h = d / 2 wide, the destination sums run on rows of d.  The per-triple rows dP carry zeros in their
@@ -443,7 +470,7 @@ __global__ __launch_bounds__(256) void lit_fold_rel(float* __restrict__ gRp, flo
   const int h = d >> 1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)R * d; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / d), k = (int)(i % d);
-    if (k < h) gR[(int64_t)r * h + k] += gRp[i];
+    if (gR && k < h) gR[(int64_t)r * h + k] += gRp[i];
     gRp[i] = 0.f;
   }
 }
@@ -474,9 +501,10 @@ static void launch_rows_model(bool drop, int grid, hipStream_t st, const float* 
 int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, const float* E, const float* Rel, const float* Lit, int L,
                     int lit_rows_n, const float* theta, float* gE, float* gR, float* gtheta, const int32_t* pos, int64_t m_pos,
                     const int32_t* neg, int64_t m_neg, float* loss_out, float* scores_out, uint64_t seed, void* ws, int64_t wbytes, uint32_t* err,
-                    hipStream_t st, const LitConve* conve) {
+                    hipStream_t st, const LitConve* conve, const kge_hake_params* hake) {
   if (int rc = lit_check(md, L, act)) return rc;
   if ((md->model == KGE_CONVE) != (conve != nullptr)) return fail(KGE_EINVAL, "literal path: ConvE goes through kge_lit_conve_train_grads (and only ConvE)");
+  if ((md->model == KGE_HAKE) != (hake != nullptr)) return fail(KGE_EINVAL, "literal path: HAKE goes through kge_lit_hake_train_grads (and only HAKE)");
   if (2 * (m_pos + m_neg) > 0x7fffffff) return fail(KGE_EINVAL, "literal path: batch too large");
   if (wbytes < lit_workspace_bytes(md, L, m_pos, m_neg))
     return fail(KGE_EWORKSPACE, "literal path: workspace has %lld bytes, needs %lld", (long long)wbytes, (long long)lit_workspace_bytes(md, L, m_pos, m_neg));
@@ -486,7 +514,7 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
   auto take = [&](int64_t bytes) { char* r = q; q += l256(bytes); return r; };
   void* pull_hdr = take(pull_header_bytes(md));
   // (RotatE: right behind the header, in the part of the workspace that is zero on entry and left zero -- see lit_fold_rel)
-  float* gRp = md->model == KGE_ROTATE ? (float*)take((int64_t)md->num_relations * md->d_e * 4) : nullptr;
+  float* gRp = md->model == KGE_ROTATE || md->model == KGE_HAKE ? (float*)take((int64_t)md->num_relations * md->d_e * 4) : nullptr;
   float* A = (float*)take(2 * n * K1 * 4);
   float* dA = (float*)take(2 * n * K1 * 4);
   float* Zb = (float*)take(2 * n * d * 4);
@@ -509,11 +537,20 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
   void* cws = nullptr;
   kge_model_desc md2 = *md;
   int64_t cws_bytes = 0;
+  float* dPm = nullptr;
+  const int dr = md->d_r;
   if (conve) {
     md2 = lit_conve_desc(md, n);
     Pm = (float*)take(n * d * 4);
     tri2 = (int32_t*)take(n * 12);
     cws_bytes = conve_workspace_bytes(&md2, m_pos, m_neg);
+    cws = take(cws_bytes);
+  } else if (hake) {
+    md2 = lit_conve_desc(md, n);  // (the same staging: 2n entity rows, n relation rows, input dropout already applied)
+    Pm = (float*)take(n * dr * 4);
+    dPm = (float*)take(n * dr * 4);
+    tri2 = (int32_t*)take(n * 12);
+    cws_bytes = hake_workspace_bytes(n, 0);
     cws = take(cws_bytes);
   }
   float* sc = scores_out ? scores_out : scb;
@@ -535,9 +572,21 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
     KGE_BLAS_TRY(rocblas_sgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (rocblas_int)(2 * n), K1, &one, theta, d, A, K1, &zero, Zb, d));
     if (act == kActSoftmax) hipLaunchKernelGGL(lit_softmax_fwd, dim3((int)std::min<int64_t>(cdiv(2 * n, 4), 8192)), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d);
     else hipLaunchKernelGGL(lit_act_fwd, dim3(gel), dim3(256), 0, st, Zb, H, 2 * n, d, theta + (int64_t)K1 * d, act);
-    if (!conve) launch_rows_model<0>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, nullptr, sc, nullptr, nullptr, seed);
+    if (!conve && !hake) launch_rows_model<0>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, nullptr, sc, nullptr, nullptr, seed);
   }
-  if (conve) {
+  if (hake) {
+    // models.py:152-158 in front of HAKE.func (:383-400): one call of the model per side on the staged rows (the call-wide norm is the
+    // side's, as in HAKE's own train step); its dense accumulators over the staged tables ARE the per-row gradients
+    if (drop) hipLaunchKernelGGL((lit_stage_rel<true>), dim3(gw), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, dr, Pm, tri2, seed, thr, dscale, err);
+    else hipLaunchKernelGGL((lit_stage_rel<false>), dim3(gw), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, dr, Pm, tri2, seed, thr, dscale, err);
+    KGE_HIP_TRY(hipMemsetAsync(dH, 0, (size_t)2 * n * d * 4, st));
+    KGE_HIP_TRY(hipMemsetAsync(dPm, 0, (size_t)n * dr * 4, st));
+    KGE_HIP_TRY(hipMemsetAsync(dPb, 0, (size_t)n * d * 4, st));  // (the relation keys of the destination sums add zeros into the padded table)
+    if (int rc = hake_train_grads(&md2, ld, hake, H, Pm, dH, dPm, tri2, m_pos, tri2 + 3 * m_pos, m_neg, loss_out, sc, seed, cws, cws_bytes, err, st)) return rc;
+    const int gm = (int)std::min<int64_t>(cdiv(n * dr, 256), 8192);
+    if (drop) hipLaunchKernelGGL((lit_scatter_rel<true>), dim3(gm), dim3(256), 0, st, dPm, pos, m_pos, neg, m_neg, md->num_relations, dr, gR, seed, thr, dscale);
+    else hipLaunchKernelGGL((lit_scatter_rel<false>), dim3(gm), dim3(256), 0, st, dPm, pos, m_pos, neg, m_neg, md->num_relations, dr, gR, seed, thr, dscale);
+  } else if (conve) {
     // models.py:152-158 in front of ConvE.func (:264-275): the head (batch statistics, hidden dropout, its own loss call) on the staged rows
     if (drop) hipLaunchKernelGGL((lit_stage_rel<true>), dim3(gw), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, d, Pm, tri2, seed, thr, dscale, err);
     else hipLaunchKernelGGL((lit_stage_rel<false>), dim3(gw), dim3(256), 0, st, Rel, pos, m_pos, neg, m_neg, md->num_relations, d, Pm, tri2, seed, thr, dscale, err);
@@ -555,7 +604,7 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
   }
   {
     ProfScope prof(KGE_PROF_TRAIN_GRADS, st);
-    if (!conve) launch_rows_model<1>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, g, nullptr, dH, dPb, seed);
+    if (!conve && !hake) launch_rows_model<1>(drop, gw, st, Rel, pos, m_pos, neg, m_neg, md, H, g, nullptr, dH, dPb, seed);
     // (softmax: rows first -- dz = h (dh - <dh, h>) -- then the column sums through the linear branch of lit_act_bwd)
     if (act == kActSoftmax) hipLaunchKernelGGL(lit_softmax_bwd_rows, dim3((int)std::min<int64_t>(cdiv(2 * n, 4), 8192)), dim3(256), 0, st, dH, Zb, 2 * n, d);
     hipLaunchKernelGGL(lit_act_bwd, dim3(nb_rows), dim3(256), 0, st, dH, Zb, 2 * n, d, act == kActSoftmax ? 0 : act, psum);
@@ -578,7 +627,7 @@ int lit_train_grads(const kge_model_desc* md, const kge_loss_desc* ld, int act, 
     if (int rc = pull2_fill_entries(md, pos, m_pos, neg, m_neg, plan, st)) return rc;
     if (int rc = cv_rowsum_launch(md, gE, gRp ? gRp : gR, plan, dS, dPb, dO, st)) return rc;
     if (int rc = pull_finish_launch(md, gE, gRp ? gRp : gR, plan, st)) return rc;
-    if (gRp) hipLaunchKernelGGL(lit_fold_rel, dim3((int)std::min<int64_t>(cdiv((int64_t)md->num_relations * d, 256), 1024)), dim3(256), 0, st, gRp, gR, md->num_relations, d);
+    if (gRp) hipLaunchKernelGGL(lit_fold_rel, dim3((int)std::min<int64_t>(cdiv((int64_t)md->num_relations * d, 256), 1024)), dim3(256), 0, st, gRp, hake ? nullptr : gR, md->num_relations, d);
   }
   KGE_HIP_TRY(hipGetLastError());
   return KGE_OK;

@@ -180,8 +180,8 @@ class EmbeddingModel:
         self._seed = int(seed) if seed is not None else 0
         self._lit = None
         if literal_activation:  # models.py:114-120: frozen literal table + Dense(e_dim, activation) on [embedding ; literal]
-            if self.MODEL not in ("DistMult", "TransE", "ComplEx", "HolE", "RotatE", "ConvE"):  # (MODEL "TransE" covers TransE with any norm and pRotatE)
-                raise NotImplementedError(f"the literal input path is built for DistMult, TransE, ComplEx, HolE, pRotatE, RotatE and ConvE, not {type(self).__name__}")
+            if self.MODEL not in ("DistMult", "TransE", "ComplEx", "HolE", "RotatE", "ConvE", "HAKE"):  # (MODEL "TransE" covers TransE with any norm and pRotatE)
+                raise NotImplementedError(f"the literal input path is not built for {type(self).__name__}")
             act = literal_activation if isinstance(literal_activation, str) else getattr(literal_activation, "__name__", None)
             if act not in ACT_IDS:
                 raise NotImplementedError(f"literal_activation {literal_activation!r}: one of {sorted(k for k in ACT_IDS if k)}")
@@ -892,8 +892,6 @@ class HAKE(EmbeddingModel):
         kwargs['e_dim'] = 2 * kwargs['e_dim']  # KeyError if absent, like models.py:371-372
         kwargs['r_dim'] = 3 * kwargs['r_dim']
         super().__init__(name=name, **kwargs)
-        if self._lit is not None:
-            raise NotImplementedError("the literal input path is not built for HAKE")
         self.gamma = gamma
         self.epsilon = epsilon
         self.phase_weight = phase_weight
@@ -917,7 +915,9 @@ class HAKE(EmbeddingModel):
         md, hp = md or self._model_desc(False), self._hake()
         n_seg = 0 if seg_off is None else seg_off.numel() - 1
         ws = self._hake_ws(n, -n_seg if n_seg else (chunk if 0 < chunk < n else n))  # (scoring: no loss scratch; chunk 0 sizes a training batch)
-        check(lib.kge_hake_score(C.byref(md), C.byref(hp), (self.E if E is None else E).data_ptr(), (self.Rel if Rel is None else Rel).data_ptr(),
+        if E is None:
+            E = self._eval_table()  # (E itself, or with the literal path the transformed table: models.py:152-158 in inference mode)
+        check(lib.kge_hake_score(C.byref(md), C.byref(hp), E.data_ptr(), (self.Rel if Rel is None else Rel).data_ptr(),
                                  t.data_ptr(), n, chunk, seg_off.data_ptr() if n_seg else None, n_seg, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                  self._err.data_ptr(), _lib.stream_ptr()))
         return out
@@ -951,8 +951,19 @@ class HAKE(EmbeddingModel):
         return False
 
     def _grads(self, pos, neg, md, ld, scores_out, seed):
-        ws = self._hake_ws(pos.shape[0] + neg.shape[0], 0)
         hp = self._hake()
+        if self._lit is not None:  # models.py:152-158 in front of HAKE.func: the model on the batch's transformed rows as staged tables
+            lt = self._lit
+            need = check(lib.kge_lit_workspace_bytes(C.byref(md), lt["L"], pos.shape[0], neg.shape[0]))
+            if lt["ws"] is None or lt["ws"].numel() < need:
+                lt["ws"] = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+            check(lib.kge_lit_hake_train_grads(C.byref(md), C.byref(ld), C.byref(hp), lt["act"], self.E.data_ptr(), self.Rel.data_ptr(), lt["table"].data_ptr(),
+                                               lt["L"], lt["table"].shape[0], lt["theta"].data_ptr(), self._gE.data_ptr(), self._gR.data_ptr(),
+                                               lt["gtheta"].data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0], self._loss.data_ptr(),
+                                               scores_out.data_ptr() if scores_out is not None else None, seed, lt["ws"].data_ptr(), lt["ws"].numel(),
+                                               self._err.data_ptr(), _lib.stream_ptr()))
+            return
+        ws = self._hake_ws(pos.shape[0] + neg.shape[0], 0)
         check(lib.kge_hake_train_grads(C.byref(md), C.byref(ld), C.byref(hp), self.E.data_ptr(), self.Rel.data_ptr(), self._gE.data_ptr(),
                                        self._gR.data_ptr(), pos.data_ptr(), pos.shape[0], neg.data_ptr(), neg.shape[0], self._loss.data_ptr(),
                                        scores_out.data_ptr() if scores_out is not None else None, seed, ws.data_ptr(), ws.numel(),
@@ -975,6 +986,13 @@ class HAKE(EmbeddingModel):
             data = data[0]
         self.train_grads(data, scores_out)
         self.apply_grads(1.0)
+        if self._lit is not None:  # the Dense of the literal path
+            lt, o = self._lit, self.optimizer
+            if o.kind == "adam" and lt["slots"] is None:
+                lt["slots"] = (torch.zeros_like(lt["theta"]), torch.zeros_like(lt["theta"]))
+            ts = [x.data_ptr() for x in lt["slots"]] if lt["slots"] else [None, None]
+            odv = OptDesc(OPT_IDS[o.kind], o.lr, o.beta_1, o.beta_2, o.epsilon, o.iterations, ts[0], ts[1], None, None)
+            check(lib.kge_opt_apply_vector(C.byref(odv), lt["theta"].data_ptr(), lt["gtheta"].data_ptr(), lt["theta"].numel(), 1.0, _lib.stream_ptr()))
         return {"loss": self._loss[0]}
 
     def _batch_loss_into(self, data, ctx, acc=None, out=None):

@@ -162,3 +162,48 @@ def test_hake_through_the_harness(datasets):
     tes = set(te)
     res = validate(mdl, te, 14, None, filtering_triples=[t for t in tr if t not in tes])
     assert 1.0 <= res["mr"] <= 14.0 and 0.0 < res["mrr"] <= 1.0
+
+
+@pytest.mark.parametrize("loss,act", [("pointwize_logistic", "tanh"), ("pairwize_hinge", "sigmoid")])
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+@pytest.mark.parametrize("dp", [0.0, 0.25])
+def test_literal_path_under_hake(loss, act, opt, dp):
+    """models.py:152-158 is model agnostic: the literal transform (Dense on [entity row ; literal row], 2h wide like the entity rows) in
+    front of HAKE.func (:383-400).  The library runs the model on the batch's transformed rows as staged tables, one call per side
+    (kge_lit_hake_train_grads): the call-wide norm is the side's; two train steps -- scores, loss, both tables, the Dense -- against the
+    oracle's composition, with and without dropout; then model(x) / predict on the transformed table."""
+    N, R, h, L, m = 30, 4, 8, 5, 150
+    from kge_keras_amd import models as M
+    rs = np.random.RandomState(17)
+    rng = (12 + 2) / (2 * h) / 2
+    E0 = np.concatenate([rs.uniform(-rng, rng, (N, h)), rs.uniform(-1.0, 1.0, (N, h))], 1).astype(np.float32)
+    R0 = np.concatenate([rs.uniform(-rng, rng, (R, h)), rs.uniform(-1.0, 1.0, (R, h)), rs.uniform(-1.5, 1.5, (R, h))], 1).astype(np.float32)
+    lit = rs.rand(N, L).astype(np.float32)
+    mdl = M.HAKE(e_dim=h, r_dim=h, num_entities=N, num_relations=R, gamma=12, init_entities=E0, init_relations=R0, literals=lit, literal_activation=act,
+                 dp=dp, loss_function=loss, margin=0.5)
+    prm = O.hake_params(mdl.e_dim, 12, 2, mdl.phase_weight, mdl.mod_weight)
+    H = O.literal_init(2 * h, L, rs)
+    H["b"] += rs.uniform(-0.1, 0.1, 2 * h).astype(np.float32)
+    mdl.set_literal_dense(H["W"], H["b"])
+    mdl.compile(opt)
+    Eo, Ro, Lo_ = E0.astype(np.float64), R0.astype(np.float64), lit.astype(np.float64)
+    Ho = {k: np.asarray(v, dtype=np.float64).copy() for k, v in H.items()}
+    oo = O.make_optimizer(opt)
+    for step in range(2):
+        pos, neg = _triples(rs, m, N, R), _triples(rs, m + 30, N, R)
+        sc = torch.empty(2 * m + 30, dtype=torch.float32, device="cuda")
+        Lg = float(mdl.train_step([pos, neg], scores_out=sc)["loss"].item())
+        Lr, sp, sn = O.literal_train_step("HAKE", Ho, act, Eo, Ro, Lo_, oo, pos, neg, loss, 0.5, 1, prm, 12, dropout=dp, seed=mdl._seed)
+        np.testing.assert_allclose(sc.cpu().numpy(), np.concatenate([sp, sn]), atol=TOL, rtol=1e-4)
+        assert Lg == pytest.approx(Lr, rel=TOL_L_BIG, abs=TOL_LA), (step, Lg, Lr)
+        assert_tables(mdl.E.cpu().numpy(), Eo, atol=TOL_W_LONG)
+        assert_tables(mdl.Rel.cpu().numpy(), Ro, atol=TOL_W_LONG)
+        W, b = mdl.get_literal_dense()
+        assert_tables(W, Ho["W"], atol=TOL_W_LONG)
+        assert_tables(b, Ho["b"], atol=TOL_W_LONG)
+    assert float(mdl._gE.abs().max()) == 0.0 and float(mdl._gR.abs().max()) == 0.0 and float(mdl._lit["gtheta"].abs().max()) == 0.0
+    t = _triples(rs, 100, N, R)
+    Et, _ = O.literal_transform(Ho, Eo, Lo_, np.arange(N), act)
+    np.testing.assert_allclose(mdl(t).cpu().numpy(), O.call("HAKE", Et, Ro, t, prm, 12), atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(mdl.predict(t), O.call("HAKE", Et, Ro, t, prm, 12, chunk=32), atol=TOL, rtol=1e-4)
+    mdl._raise_on_flag()
