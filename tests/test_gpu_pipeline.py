@@ -403,13 +403,15 @@ def test_python_loop_with_captured_twin_step(datasets, opt):
     np.testing.assert_allclose(h.history["loss"], losses, rtol=1e-4)
 
 
-@pytest.mark.parametrize("halves", [True, False])
+@pytest.mark.parametrize("halves,loop", [(True, "native"), (False, "native"), (True, "python")])
 @pytest.mark.parametrize("model,opt", [("DistMult", "adam"), ("TransE", "sgd")])
-def test_native_data_parallel_step_on_a_one_rank_communicator(datasets, model, opt, halves, monkeypatch):
+def test_native_data_parallel_step_on_a_one_rank_communicator(datasets, model, opt, halves, loop, monkeypatch):
     """kge_pipeline_desc.comm: the data-parallel step inside the native driver -- entity half of the gradients, all-reduce of its
     table on the communicator's own stream beside the relation half, all-reduce of the rest, optimizer half with scale 1 / world.
     One GPU allows a one-rank RCCL communicator (every collective the identity), which exercises everything but the wire: with it an
-    epoch must equal the host generator + the oracle's steps, with the gradient halves apart and in one piece."""
+    epoch must equal the host generator + the oracle's steps, with the gradient halves apart and in one piece.  loop = "python": the
+    same communicator under the Python loop (serial launches) -- the comm branch of its step stage, which must never be captured into a
+    graph (a collective inside a hipGraph): graph_stages leaves the step out whenever comm is set."""
     from kge_keras_amd import dist as D
     from kge_keras_amd.harness import DataGenerator, DeviceDataGenerator, build_model
     from kge_keras_amd.pipeline import TrainPipeline
@@ -425,10 +427,13 @@ def test_native_data_parallel_step_on_a_one_rank_communicator(datasets, model, o
     comm, destroy = D.make_rccl_comm()
     try:
         pipe = TrainPipeline(mdl, gen.kg, gen.n, gen.batch_size, gen.ns, gen.num_e, gen.sampler, comm=comm, world=1)
+        assert "T" not in pipe.graph_stages
+        if loop == "python":
+            pipe.serial = True
         gen._upload_global()
         tot = float(pipe.run_epoch(gen.index, list(range(len(gen)))).item())
         gen.release_global()
-        assert pipe._h is not None and pipe._twins is None and mdl.optimizer.iterations == len(gen)
+        assert (pipe._h is not None) == (loop == "native") and pipe._twins is None and mdl.optimizer.iterations == len(gen)
         pipe.close()
     finally:
         destroy()
