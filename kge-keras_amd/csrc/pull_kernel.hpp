@@ -13,6 +13,13 @@ template <> struct V<4> {
   static __device__ __forceinline__ T ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
   static __device__ __forceinline__ void st(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
   static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  // Non-temporal forms for streams with no reuse inside a step, on tables past the caches (pull_self.hpp: SelfArgs.stream_nt)
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ T ld_nt(const float* p) {
+    const v4f_ x = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(p));
+    return make_float4(x.x, x.y, x.z, x.w);
+  }
+  static __device__ __forceinline__ void st_nt(float* p, T v) { __builtin_nontemporal_store(v4f_{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_*>(p)); }
 };
 template <> struct V<1> {
   using T = float;

@@ -18,6 +18,10 @@ struct SelfArgs {
   const float* lr_state;  // non-null: lr_t of this update is read from the device-resident step state (a whole step in one call) ...
   float* lr_keep;         // ... and copied here by the launch's first thread, for the closing launch (rel_tail_kernel)
   float *E_out, *mE, *vE;
+  // 1: Adam's moment rows (read once, written once per step) go non-temporal; 2: also the parameter rows of entities no triple touches.
+  // For tables past the Infinity Cache: there the streams only push each other out of the caches (10 M entities: 9.14 -> 8.74 ms with 1);
+  // on a table that fits (the FB15k-237 bench: 47 MB with moments) they cost 5 % instead, so the host sets this by size.
+  int stream_nt = 0;
 };
 
 // One wave: entity unit `unit` (a destination row, or an extra chunk of a hub row); `mine`: NACC * 16 float4 of LDS of this wave.
@@ -61,11 +65,17 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
       const int ch = lane + (i % NV) * G;
       if (i < NACC && ch < nchunk) {
         const int at = (i / NV) * h + ch * 4;
-        float4 w = L::ld(self + at), m = L::zero(), v = L::zero();
-        if (a.kind == KGE_OPT_ADAM_TF) { m = L::ld(mrow0 + at); v = L::ld(vrow0 + at); }
+        float4 w = a.stream_nt > 1 ? L::ld_nt(self + at) : L::ld(self + at), m = L::zero(), v = L::zero();
+        if (a.kind == KGE_OPT_ADAM_TF) {
+          if (a.stream_nt) { m = L::ld_nt(mrow0 + at); v = L::ld_nt(vrow0 + at); }
+          else { m = L::ld(mrow0 + at); v = L::ld(vrow0 + at); }
+        }
         tail_upd(a.kind, lr0, a.b1, a.b2, a.eps, w, L::zero(), m, v);
-        L::st(wout0 + at, w);
-        if (a.kind == KGE_OPT_ADAM_TF) { L::st(mrow0 + at, m); L::st(vrow0 + at, v); }
+        if (a.stream_nt > 1) L::st_nt(wout0 + at, w); else L::st(wout0 + at, w);
+        if (a.kind == KGE_OPT_ADAM_TF) {
+          if (a.stream_nt) { L::st_nt(mrow0 + at, m); L::st_nt(vrow0 + at, v); }
+          else { L::st(mrow0 + at, m); L::st(vrow0 + at, v); }
+        }
       }
     }
     return;
@@ -213,10 +223,16 @@ __device__ __forceinline__ void pull_self_unit(const SelfArgs& a, int unit, floa
       const int at = (i / NV) * h + ch * 4;
       if (a.kind < 0) { L::st(wout + at, L::ld(wout + at) + g); continue; }  // (accumulates, like every gradient path of the library)
       float4 w = mine[i * G + lane], m = L::zero(), v = L::zero();
-      if (a.kind == KGE_OPT_ADAM_TF) { m = L::ld(mrow + at); v = L::ld(vrow + at); }
+      if (a.kind == KGE_OPT_ADAM_TF) {
+        if (a.stream_nt) { m = L::ld_nt(mrow + at); v = L::ld_nt(vrow + at); }
+        else { m = L::ld(mrow + at); v = L::ld(vrow + at); }
+      }
       tail_upd(a.kind, a.lr_state ? a.lr_state[0] : a.lr, a.b1, a.b2, a.eps, w, g, m, v);
       L::st(wout + at, w);
-      if (a.kind == KGE_OPT_ADAM_TF) { L::st(mrow + at, m); L::st(vrow + at, v); }
+      if (a.kind == KGE_OPT_ADAM_TF) {
+        if (a.stream_nt) { L::st_nt(mrow + at, m); L::st_nt(vrow + at, v); }
+        else { L::st(mrow + at, m); L::st(vrow + at, v); }
+      }
     }
   }
 }

@@ -71,6 +71,8 @@ void self_args_of(const kge_model_desc* md, const kge_loss_desc* ld, const float
   a.kind = tail.kind; a.lr = lr_t; a.lr_state = nullptr; a.lr_keep = nullptr; a.b1 = tail.b1; a.b2 = tail.b2; a.eps = tail.eps;
   a.E_out = tail.E_out; a.mE = tail.mE; a.vE = tail.vE;
   a.row_lo = tail.ent_lo; a.row_n = tail.ent_hi - tail.ent_lo;
+  // tables + moments past the 256 MB Infinity Cache: their streams go non-temporal (SelfArgs.stream_nt)
+  a.stream_nt = (int64_t)md->num_entities * md->d_e * 4 * 3 > (256ll << 20) ? 1 : 0;  // (2 -- the parameter rows too -- measured no different from 1)
 }
 
 // Entity half: every entity row of E_out, moments in place, entity counters of the plan left zero.  lr_t by value.
