@@ -962,7 +962,7 @@ def main():
                          "launch": (("the library's native loop (kge_pipeline_run: one C call for the K timed steps) launches every stage's kernels on four streams (generator rounds | draw | plan | step); the step is ONE launch between twin tables (chained steps: step1_kernel with its closer workgroups; KGE_PIPE_CHAIN=0: step1_kernel + rel_tail_kernel)" if not dist_on else
                                      ("the library's native loop issues every stage on its streams; the step is the data-parallel one (entity half of the gradients, all-reduce of its table on an RCCL communicator of the library's own beside the relation half, all-reduce of the rest, optimizer half)" if comm is not None else
                                       "draw and plan stages replayed from hipGraphs on their streams; the step (gradient half, all-reduce, optimizer half) launched kernel by kernel from Python over torch.distributed" + (f" [{dp_native_note}]" if dp_native_note else "")))
-                                    + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap; the two-launch form of the step: step1_kernel without its closers, then rel_tail_kernel)"
+                                    + "; kernel durations above come from a second pass of the same steps launched kernel by kernel on one stream (no overlap; the same one-launch form of the step: kge_train_step_swap_chain from the Python loop)"
                                     if pipe is not None
                                     else "kernel-by-kernel stream launches"),
                          "plan": ("ids-only half of the step (fold + gradient lists) built 1-2 batches ahead on its own stream, inside the timed region"

@@ -403,6 +403,16 @@ class EmbeddingModel:
         od = self._opt_desc()
         tw = getattr(self, "_step_twins", None)  # (E twin, Rel twin) lent by a TrainPipeline: the step closed by its pull launch
         if tw is not None and od.step_dev and lib.kge_train_step_swap_supported(C.byref(md), C.byref(ld), C.byref(od)) == 1:
+            seq = getattr(self, "_chain_seq", None)  # (a TrainPipeline's serial pass: the one-launch form of the step, like its native driver)
+            if seq is not None:
+                check(lib.kge_train_step_swap_chain(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(), tw[0].data_ptr(),
+                                                    tw[1].data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), plan.m_pos, plan.m_neg,
+                                                    self._loss.data_ptr(), self._seed, self._ws.data_ptr(), self._ws.numel(), seq, self._err.data_ptr(),
+                                                    _lib.stream_ptr()))
+                self._chain_seq = seq + 1
+                self.E.copy_(tw[0])
+                self.Rel.copy_(tw[1])
+                return {"loss": self._loss[0]}
             check(lib.kge_train_step_swap(C.byref(md), C.byref(ld), C.byref(od), self.E.data_ptr(), self.Rel.data_ptr(), tw[0].data_ptr(),
                                           tw[1].data_ptr(), plan.buf.data_ptr(), plan.buf.numel(), plan.m_pos, plan.m_neg,
                                           self._loss.data_ptr(), self._seed, self._ws.data_ptr(), self._ws.numel(), 3, _lib.stream_ptr()))

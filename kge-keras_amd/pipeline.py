@@ -380,8 +380,17 @@ class TrainPipeline:
             self._on_native(lambda: _lib.check(_lib.lib.kge_pipeline_run(self._h, n, _lib.stream_ptr())), join)
             self.t += n
             return
-        for _ in range(n):
-            self.tick()
+        # Kernel-by-kernel launches (serial = a profiling pass) of the step between twin tables: as chained steps, i.e. the SAME one-launch
+        # form the native driver issues (closers inside step1_kernel), so that what such a pass times is the kernel of the timed region
+        chain = self.serial and not self.use_graphs and getattr(self.model, "_step_twins", None) is not None
+        if chain:
+            self.model._chain_seq = 0
+        try:
+            for _ in range(n):
+                self.tick()
+        finally:
+            if chain:
+                self.model._chain_seq = None
 
     # ------------------------------------------------------------------ driving
     def load_epoch(self, index, order):
